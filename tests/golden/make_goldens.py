@@ -1,0 +1,440 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors by running the REFERENCE itself.
+
+Runs only in the build container, where /root/reference is mounted read-only:
+it imports the reference's modules with the 3-line shim of SURVEY.md Appendix C
+(random-init HF configs instead of from_pretrained, enc_dec_mask on CPU, an
+explicit args namespace), fills every parameter with the closed-form synthetic
+weights of ``msmd_amd.synth`` and records inputs/outputs as small ``.npz``
+files next to this script.  No reference source is copied: the fixtures are
+data (inputs, expected outputs).  ``infer_coeffs`` lives in a script that
+cannot be imported here (needs cv2/librosa); its function object is built from
+the reference file's AST at generation time only.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_goldens.py [names...]
+"""
+from __future__ import annotations
+
+import argparse
+import ast
+import math
+import os
+import pickle
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+sys.path.insert(0, REF)
+
+import torch  # noqa: E402
+import transformers  # noqa: E402
+
+from msmd_amd import synth, shapes  # noqa: E402
+from msmd_amd.config import default_args  # noqa: E402
+
+torch.set_grad_enabled(False)
+VERSIONS = f"torch={torch.__version__};transformers={transformers.__version__};numpy={np.__version__}"
+
+
+# --------------------------------------------------------------------------- shim
+def import_reference():
+    import utils.wav2vec2 as w2
+    import utils.hubert as hb
+    import utils.model_common as mc
+    from transformers import Wav2Vec2Config, HubertConfig
+    w2.Wav2Vec2Model.from_pretrained = classmethod(
+        lambda cls, name, **kw: cls(Wav2Vec2Config(attn_implementation="eager")))
+    hb.HubertModel.from_pretrained = classmethod(
+        lambda cls, name, **kw: cls(HubertConfig(attn_implementation="eager")))
+    import model as M
+    import style_encoder as SE
+    orig = mc.enc_dec_mask
+    M.enc_dec_mask = lambda T, S, fw=2, ex=0, device="cpu": orig(T, S, fw, ex, device="cpu")
+    return M, SE, mc
+
+
+def ref_args(**kw):
+    a = default_args(**kw)
+    return a
+
+
+def build_ref_model(M, audio_model="wav2vec2", **kw):
+    args = ref_args(audio_model=audio_model, **kw)
+    model = M.get_diffusion_model(args, device="cpu").eval()
+    synth.load_synthetic(model)
+    return model, args
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    arrays["_versions"] = np.array(VERSIONS)
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+# --------------------------------------------------------------------------- G1 index maths
+def g1_index(M, SE, mc):
+    out = {}
+    for L in (31999, 32000, 32001, 32081, 32320, 64000, 64001, 64079, 64080, 64081, 160000):
+        x = torch.arange(L, dtype=torch.float32)[None]
+        y = mc.pad_audio(x)[0].numpy()
+        out[f"pad_len_{L}"] = np.int64(y.shape[0])
+        out[f"pad_head_{L}"] = y[:48].astype(np.int64)
+        out[f"pad_tail_{L}"] = y[-48:].astype(np.int64)
+    # conv length chain from the real HF module
+    import utils.wav2vec2 as w2
+    enc = w2.Wav2Vec2Model.from_pretrained("x")
+    for S in (32080, 64080, 160080):
+        out[f"conv_T_{S}"] = np.int64(enc._get_feat_extract_output_lengths(torch.tensor(S)).item())
+    # crop + interpolate tables, obtained by pushing index ramps through the reference's function
+    for fps, frame_num, T50 in ((25, 200, 200), (30, 200, 400), (25, 500, 500), (25, 100, 100), (30, 120, 250)):
+        crop = round(frame_num * 50 / fps)
+        x = torch.arange(T50, dtype=torch.float32)[None, None, :crop]
+        y = w2.linear_interpolation(x, 50, fps, output_len=frame_num)[0, 0].numpy()
+        out[f"crop_{fps}_{frame_num}"] = np.int64(crop)
+        out[f"interp_{fps}_{frame_num}_{T50}"] = y
+    import torch.nn.functional as F
+    y = F.interpolate(torch.arange(200, dtype=torch.float32)[None, None], size=100, align_corners=False, mode="linear")
+    out["interp_200_to_100"] = y[0, 0].numpy()
+    # infer_coeffs window plan
+    for S in (32000, 64000, 100000, 200001, 64001, 63999):
+        clip_len = int(S / 16000 * 25)
+        n_sub = 1 if clip_len <= 100 else math.ceil(clip_len / 100)
+        n_pad = round(640.0 * 100) * n_sub - S
+        out[f"plan_{S}"] = np.array([clip_len, n_sub, n_pad, math.ceil(n_pad / 640.0)], dtype=np.int64)
+    save("g1_index", **out)
+
+
+# --------------------------------------------------------------------------- G2 schedule
+def g2_schedule(M, SE, mc):
+    out = {}
+    for T in (5, 500):
+        for mode in ("linear", "quadratic", "sigmoid", "cosine"):
+            s = M.DiffusionSchedule(T, mode)
+            for k in ("betas", "alphas", "alpha_bars", "sigmas_flex", "sigmas_inflex"):
+                out[f"{mode}_{T}_{k}"] = getattr(s, k).numpy()
+    out["enc_dec_mask_110_1_0"] = mc.enc_dec_mask(110, 110, 1, 0, device="cpu").numpy()
+    out["enc_dec_mask_110_1_1"] = mc.enc_dec_mask(110, 110, 1, 1, device="cpu").numpy()
+    pe = mc.PositionalEncoding(512, max_len=501)
+    out["pe_512_501_rows"] = pe.pe[0, [0, 1, 7, 250, 500]].numpy()
+    save("g2_schedule", **out)
+
+
+# --------------------------------------------------------------------------- G3 network blocks
+def g3_audio(M, SE, mc):
+    for am in ("wav2vec2", "hubert"):
+        model, args = build_ref_model(M, am)
+        enc = model.audio_encoder
+        B = 2
+        audio = synth.audio_clips(B, 64000)
+        grabs = {}
+
+        def hook(name):
+            def fn(mod, inp, outp):
+                o = outp[0] if isinstance(outp, tuple) else outp
+                grabs[name] = o.detach().numpy().copy()
+            return fn
+        hs = [enc.feature_extractor.conv_layers[0].register_forward_hook(hook("conv0")),
+              enc.feature_extractor.register_forward_hook(hook("conv")),
+              enc.feature_projection.register_forward_hook(hook("proj")),
+              enc.encoder.pos_conv_embed.register_forward_hook(hook("posconv")),
+              enc.encoder.layers[0].register_forward_hook(hook("layer0")),
+              enc.encoder.layers[11].register_forward_hook(hook("layer11"))]
+        feat = model.extract_audio_feature(t(audio)).numpy()
+        feat768 = model.extract_audio_768_feature(t(audio)).numpy()
+        for h in hs:
+            h.remove()
+        out = dict(
+            conv0=grabs["conv0"].transpose(0, 2, 1)[:, ::61, ::7],      # (B, 12815, 512) channels-last, subsampled
+            conv=grabs["conv"].transpose(0, 2, 1)[:, ::3, ::5],        # (B, 200, 512)
+            proj=grabs["proj"][:, ::3, ::5],
+            posconv=grabs["posconv"][:, ::3, ::5],                      # GELU(conv)[:, :-1] (B,200,768)
+            layer0=grabs["layer0"][:, ::3, ::5],
+            layer11=grabs["layer11"][:, ::3, ::5],
+            feat768=feat768[:, ::2, ::3],
+            feat=feat,
+        )
+        # 2 s clip at 30 fps exercises the non-trivial crop/interp path of the wrapper
+        a2 = synth.audio_clips(1, 32000, tag="audio30")
+        y = enc(mc.pad_audio(t(a2)), 30, frame_num=60).last_hidden_state.numpy()
+        out["hidden_fps30_60"] = y
+        save(f"g3_audio_{am}", **out)
+        if am == "wav2vec2":
+            keys = list(model.state_dict().keys())
+            shp = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+            mine = shapes.msmd_shapes(args)
+            for k, v in mine.items():
+                kk = k.replace("weight_g", "parametrizations.weight.original0").replace(
+                    "weight_v", "parametrizations.weight.original1")
+                assert shp[kk] == tuple(v), (k, shp[kk], v)
+            extra = [k for k in keys if synth.canonical_name(k) not in mine and not synth.is_computed_buffer(k)]
+            assert not extra, extra
+            n_params = sum(int(np.prod(v)) for v in mine.values())
+            save("g0_keys", keys=np.array(keys), n_params=np.int64(n_params),
+                 style_keys=np.array(list(SE.get_style_encoder(args, "vae2").state_dict().keys())))
+
+
+def denoiser_inputs(B, args, tag="dn"):
+    d = args.feature_dim
+    return dict(
+        motion=synth.normalish(f"{tag}/motion", (B, 100, 67)),
+        audio_feat=synth.normalish(f"{tag}/audio_feat", (B, 100, d)),
+        shape=(0.3 * synth.normalish(f"{tag}/shape", (B, 100))).astype(np.float32),
+        style=synth.normalish(f"{tag}/style", (B, args.d_style)),
+        prev_motion=synth.normalish(f"{tag}/prev_motion", (B, 10, 67)),
+        prev_audio=synth.normalish(f"{tag}/prev_audio", (B, 10, d)),
+        indicator=np.concatenate([np.ones((B, 80), np.float32), np.zeros((B, 20), np.float32)], axis=1),
+    )
+
+
+def g3_denoiser(M, SE, mc):
+    model, args = build_ref_model(M)
+    B = 2
+    x = denoiser_inputs(B, args)
+    step = torch.tensor([7, 433])
+    person = torch.cat([t(x["shape"])[:, None], t(x["style"])[:, None]], dim=-1)
+    out = {}
+    for width in (1, 2):
+        if width != 1:
+            model2, _ = build_ref_model(M, align_mask_width=width)
+            net = model2.denoising_net
+        else:
+            net = model.denoising_net
+        y = net(t(x["motion"]), t(x["audio_feat"]), person, t(x["style"])[:, None], t(x["prev_motion"]),
+                t(x["prev_audio"]), step, t(x["indicator"]))
+        out[f"target_w{width}"] = y.numpy()
+    dyn, stat, al = model.denoising_net(t(x["motion"]), t(x["audio_feat"]), person, t(x["style"])[:, None],
+                                        t(x["prev_motion"]), t(x["prev_audio"]), step, t(x["indicator"]),
+                                        keep_separate=True)
+    out["dynamic"], out["static"], out["alphas"] = dyn.numpy(), stat.numpy()[:, :2], al.numpy()
+    out["step"] = step.numpy()
+    save("g3_denoiser", **out)
+
+
+def g3_forward(M, SE, mc):
+    model, args = build_ref_model(M)
+    B = 2
+    x = denoiser_inputs(B, args, tag="fw")
+    audio = synth.audio_clips(B, 64000, tag="fw_audio")
+    out = {}
+    # (a) raw audio, start tokens, no CFG masking
+    torch.manual_seed(11)
+    eps, target, _, afeat = model(t(x["motion"]), t(audio), t(x["shape"]), t(x["style"]), time_step=[3, 499],
+                                  indicator=t(x["indicator"]), train_with_CFG=False)
+    out.update(a_eps=eps.numpy(), a_target=target.numpy(), a_audio_feat=afeat.numpy()[:, ::2, ::3])
+    # (b) feature input + prev frames + CFG masking on (replay the single rand draw)
+    torch.manual_seed(12)
+    flag = torch.rand(B)
+    torch.manual_seed(12)
+    eps, target, _, _ = model(t(x["motion"]), t(x["audio_feat"]), t(x["shape"]), t(x["style"]),
+                              t(x["prev_motion"]), t(x["prev_audio"]), time_step=[250, 1],
+                              indicator=t(x["indicator"]), train_with_CFG=True)
+    out.update(b_eps=eps.numpy(), b_target=target.numpy(), b_flag=flag.numpy())
+    save("g3_forward", **out)
+
+
+def g3_style(M, SE, mc):
+    args = ref_args()
+    enc = SE.get_style_encoder(args, "vae2").eval()
+    synth.load_synthetic(enc)
+    out = {}
+    for B, T in ((2, 100), (1, 60)):
+        m = synth.motion_clips(B, T, tag="style_in")
+        torch.manual_seed(5)
+        z, mu, logvar = enc(t(m))
+        torch.manual_seed(5)
+        eps = torch.randn_like(mu)
+        out[f"mu_{B}_{T}"], out[f"logvar_{B}_{T}"] = mu.numpy(), logvar.numpy()
+        out[f"z_{B}_{T}"], out[f"eps_{B}_{T}"] = z.numpy(), eps.numpy()
+    save("g3_style", **out)
+
+
+def g3_sample(M, SE, mc):
+    model, args = build_ref_model(M)
+    B = 2
+    x = denoiser_inputs(B, args, tag="sm")
+    out = {}
+    T = 3
+    model.diffusion_sched = M.DiffusionSchedule(T, "cosine")
+    xT = synth.normalish("sm/xT", (B, 100, 67))
+    cases = {
+        "inc": dict(cfg_mode="incremental", cfg_scale=1.15),
+        "ind": dict(cfg_mode="independent", cfg_scale=[1.3, 0.9]),
+        "audio_only": dict(cfg_cond=["audio"], cfg_scale=2.0),
+        "nocfg": dict(cfg_cond=[]),
+        "dt": dict(cfg_mode="incremental", cfg_scale=1.4, dynamic_threshold=(0.9, 0.5, 2.0)),
+        "flex": dict(cfg_mode="incremental", cfg_scale=1.15, flexibility=0.5),
+    }
+    for seed, (name, kw) in enumerate(cases.items()):
+        torch.manual_seed(100 + seed)
+        zs = [torch.randn(B, 100, 67) for _ in range(T - 1)]  # draws for t = T..2, in order
+        torch.manual_seed(100 + seed)
+        y, _, _ = model.sample(t(x["audio_feat"]), t(x["shape"]), t(x["style"]), t(x["prev_motion"]),
+                               t(x["prev_audio"]), motion_at_T=t(xT), indicator=t(x["indicator"]), **kw)
+        out[f"{name}_x0"] = y.numpy()
+        out[f"{name}_z"] = np.stack([z.numpy() for z in zs])  # index 0 -> t=T
+    # target='noise' variant
+    model_n, _ = build_ref_model(M, target="noise")
+    model_n.diffusion_sched = M.DiffusionSchedule(T, "linear")
+    torch.manual_seed(321)
+    zs = [torch.randn(B, 100, 67) for _ in range(T - 1)]
+    torch.manual_seed(321)
+    y, _, _ = model_n.sample(t(x["audio_feat"]), t(x["shape"]), t(x["style"]), motion_at_T=t(xT), cfg_scale=1.15,
+                             indicator=t(x["indicator"]))
+    out["noise_x0"], out["noise_z"] = y.numpy(), np.stack([z.numpy() for z in zs])
+    save("g3_sample", **out)
+
+
+def _load_infer_coeffs():
+    """Build the reference's infer_coeffs function object from its file's AST (this container only)."""
+    src = open(os.path.join(REF, "inference.py")).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "infer_coeffs"][0]
+    mod = ast.Module(body=[fn], type_ignores=[])
+    import torch.nn.functional as F
+    ns = dict(torch=torch, F=F, math=math)
+    exec(compile(mod, "<reference inference.py:infer_coeffs>", "exec"), ns)
+    return ns["infer_coeffs"]
+
+
+def g3_infer(M, SE, mc):
+    infer_coeffs = _load_infer_coeffs()
+    model, args = build_ref_model(M)
+    T = 2
+    model.diffusion_sched = M.DiffusionSchedule(T, "cosine")
+    out = {}
+    for S in (100000, 32000):
+        audio = synth.audio_clips(1, S, tag="infer")[0]
+        style = synth.normalish("infer/style", (1, args.d_style))
+        shape = np.zeros((1, 1, 100), np.float32)
+        # Record the reference's own normal draws in call order (window 0: x_T then one z per step
+        # t>1; window i>0: z per step only).  HF's encoder also consumes torch.rand([]) per layer
+        # (LayerDrop coin, drawn even in eval mode), so replay-by-reseeding would be fragile.
+        draws = []
+        orig_randn, orig_randn_like = torch.randn, torch.randn_like
+
+        def rec_randn(*a, **k):
+            r = orig_randn(*a, **k)
+            draws.append(r.clone())
+            return r
+
+        def rec_randn_like(*a, **k):
+            r = orig_randn_like(*a, **k)
+            draws.append(r.clone())
+            return r
+        torch.manual_seed(77)
+        torch.randn, torch.randn_like = rec_randn, rec_randn_like
+        try:
+            y = infer_coeffs(model, args, t(audio), t(shape), 640.0, t(style), cfg_scale=1.4, dynamic_threshold=None)
+        finally:
+            torch.randn, torch.randn_like = orig_randn, orig_randn_like
+        out[f"coef_{S}"] = y.numpy()
+        out[f"draws_{S}"] = np.stack([d.numpy() for d in draws])
+    save("g3_infer", **out)
+
+
+# --------------------------------------------------------------------------- G4 FLAME / rotations
+def write_flame_asset(tmpdir):
+    a = synth.flame_asset()
+    pkl = os.path.join(tmpdir, "generic_model.pkl")
+    with open(pkl, "wb") as f:
+        pickle.dump({k: a[k] for k in ("f", "v_template", "shapedirs", "posedirs", "J_regressor",
+                                       "kintree_table", "weights")}, f)
+    lmk = dict(a["lmk"])
+    lmk["dynamic_lmk_faces_idx"] = torch.from_numpy(lmk["dynamic_lmk_faces_idx"])
+    lmk["dynamic_lmk_bary_coords"] = torch.from_numpy(lmk["dynamic_lmk_bary_coords"])
+    npy = os.path.join(tmpdir, "landmark_embedding.npy")
+    np.save(npy, lmk, allow_pickle=True)
+    return pkl, npy
+
+
+def flame_inputs(B, tag="flame"):
+    return dict(shape=(0.5 * synth.normalish(f"{tag}/shape", (B, 100))).astype(np.float32),
+                exp=(0.5 * synth.normalish(f"{tag}/exp", (B, 50))).astype(np.float32),
+                pose=(0.4 * synth.normalish(f"{tag}/pose", (B, 6))).astype(np.float32))
+
+
+def g4_flame(M, SE, mc):
+    from utils import flame as FL, lbs as LBS
+    with tempfile.TemporaryDirectory() as td:
+        pkl, npy = write_flame_asset(td)
+        cfg = FL.FLAMEConfig
+        cfg.flame_model_path, cfg.flame_lmk_embedding_path = pkl, npy
+        fl = FL.FLAME(cfg).eval()
+    B = 8
+    x = flame_inputs(B)
+    x["pose"][0] = 0.0            # zero rotation (eps placement of batch_rodrigues)
+    x["pose"][1, :3] = [0.0, 1.2, 0.0]   # large yaw -> dynamic landmark LUT > 39 clamp
+    x["pose"][2, :3] = [0.0, -1.2, 0.0]  # negative yaw branch
+    x["pose"][3, :3] = [0.0, -0.3, 0.0]
+    v, lm2d, lm3d = fl(t(x["shape"]), t(x["exp"]), t(x["pose"]))
+    v_nog, _, _ = fl(t(x["shape"]), t(x["exp"]), t(x["pose"]), ignore_global_rot=True, return_lm2d=False,
+                     return_lm3d=False)
+    vn = v.numpy()
+    out = dict(pose=x["pose"], verts_sub=vn[:, ::79], verts_sum=vn.sum(axis=1, dtype=np.float64),
+               verts_abs_sum=np.abs(vn).sum(axis=1, dtype=np.float64), lm2d=lm2d.numpy(), lm3d=lm3d.numpy(),
+               verts_nog_sub=v_nog.numpy()[:, ::79])
+    rv = np.concatenate([np.zeros((1, 3), np.float32), np.array([[math.pi, 0, 0], [0, 0, 1e-9], [1e-4, -2e-4, 3e-4]],
+                        np.float32), (1.5 * synth.normalish("rodrigues", (12, 3))).astype(np.float32)])
+    out["rodrigues_in"], out["rodrigues_out"] = rv, LBS.batch_rodrigues(t(rv)).numpy()
+    save("g4_flame", **out)
+
+
+def g4_rotations(M, SE, mc):
+    from utils import rotation_conversions as RC
+    n = 32
+    aa = (1.2 * synth.normalish("rot/aa", (n, 3))).astype(np.float32)
+    aa[0] = 0.0
+    aa[1] = [1e-7, -2e-7, 1e-7]       # small-angle Taylor branch
+    aa[2] = [math.pi, 0.0, 0.0]
+    q = synth.normalish("rot/q", (n, 4))
+    q2 = synth.normalish("rot/q2", (n, 4))
+    pts = synth.normalish("rot/pts", (n, 3))
+    d6 = synth.normalish("rot/d6", (n, 6))
+    eul = (1.0 * synth.normalish("rot/eul", (n, 3))).astype(np.float32)
+    out = dict(aa=aa, q=q, q2=q2, pts=pts, d6=d6, eul=eul)
+    R = RC.axis_angle_to_matrix(t(aa))
+    out["axis_angle_to_matrix"] = R.numpy()
+    out["axis_angle_to_quaternion"] = RC.axis_angle_to_quaternion(t(aa)).numpy()
+    out["quaternion_to_matrix"] = RC.quaternion_to_matrix(t(q)).numpy()
+    out["matrix_to_quaternion"] = RC.matrix_to_quaternion(R).numpy()
+    out["quaternion_to_axis_angle"] = RC.quaternion_to_axis_angle(t(q)).numpy()
+    out["matrix_to_axis_angle"] = RC.matrix_to_axis_angle(R).numpy()
+    out["rotation_6d_to_matrix"] = RC.rotation_6d_to_matrix(t(d6)).numpy()
+    out["matrix_to_rotation_6d"] = RC.matrix_to_rotation_6d(R).numpy()
+    out["axis_angle_to_rotation_6d"] = RC.axis_angle_to_rotation_6d(t(aa)).numpy()
+    out["quaternion_raw_multiply"] = RC.quaternion_raw_multiply(t(q), t(q2)).numpy()
+    out["quaternion_multiply"] = RC.quaternion_multiply(t(q), t(q2)).numpy()
+    out["quaternion_invert"] = RC.quaternion_invert(t(q)).numpy()
+    out["quaternion_apply"] = RC.quaternion_apply(t(q), t(pts)).numpy()
+    out["standardize_quaternion"] = RC.standardize_quaternion(t(q)).numpy()
+    for conv in ("XYZ", "ZYX", "YXZ", "XYX", "ZXZ"):
+        Re = RC.euler_angles_to_matrix(t(eul), conv)
+        out[f"euler_angles_to_matrix_{conv}"] = Re.numpy()
+        out[f"matrix_to_euler_angles_{conv}"] = RC.matrix_to_euler_angles(Re, conv).numpy()
+    save("g4_rotations", **out)
+
+
+ALL = dict(g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
+           g3_forward=g3_forward, g3_style=g3_style, g3_sample=g3_sample, g3_infer=g3_infer,
+           g4_flame=g4_flame, g4_rotations=g4_rotations)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("names", nargs="*", default=list(ALL))
+    ns = ap.parse_args()
+    torch.set_num_threads(8)
+    mods = import_reference()
+    for n in ns.names:
+        print("==", n)
+        ALL[n](*mods)

@@ -1,0 +1,254 @@
+"""Pin the numpy oracle against vectors produced by the imported reference
+(tests/golden/make_goldens.py).  Index maths bit-exact; fp32 tolerances stated per test."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import audio_encoder as oa, diffusion as od, flame as ofl, infer as oi, nn as onn, rotations as orot
+from oracle import style as ost
+from msmd_amd import synth
+
+from conftest import load_golden
+from helpers import denoiser_inputs, flame_inputs, maxabs, msmd_state_dict, style_state_dict
+
+
+# ----------------------------------------------------------------------------- G1 index maths (bit-exact)
+def test_pad_audio_index_bit_exact():
+    g = load_golden("g1_index")
+    for L in (31999, 32000, 32001, 32081, 32320, 64000, 64001, 64079, 64080, 64081, 160000):
+        idx = oa.pad_audio_gather_index(L)
+        assert idx.shape[0] == int(g[f"pad_len_{L}"]), L
+        assert np.array_equal(idx[:48], g[f"pad_head_{L}"]), L
+        assert np.array_equal(idx[-48:], g[f"pad_tail_{L}"]), L
+
+
+def test_conv_length_chain():
+    g = load_golden("g1_index")
+    for S, T in ((32080, 100), (64080, 200), (160080, 500)):
+        assert oa.conv_out_lengths(S)[-1] == int(g[f"conv_T_{S}"]) == T
+    assert oa.conv_out_lengths(64080) == [12815, 6407, 3203, 1601, 800, 400, 200]
+
+
+def test_crop_and_interp_tables_bit_exact():
+    g = load_golden("g1_index")
+    for fps, frame_num, T50 in ((25, 200, 200), (30, 200, 400), (25, 500, 500), (25, 100, 100), (30, 120, 250)):
+        crop = oa.crop_len(frame_num, fps)
+        assert crop == int(g[f"crop_{fps}_{frame_num}"])
+        ramp = np.arange(T50, dtype=np.float32)[None, :crop, None]
+        y = onn.interp_linear_cl(ramp, frame_num)[0, :, 0]
+        assert np.array_equal(y, g[f"interp_{fps}_{frame_num}_{T50}"]), (fps, frame_num)
+    y = onn.interp_linear_cl(np.arange(200, dtype=np.float32)[None, :, None], 100)[0, :, 0]
+    assert np.array_equal(y, g["interp_200_to_100"])
+    # 200 -> 100 is exactly the pairwise mean
+    i0, i1, w1 = onn.interp_linear_table(200, 100)
+    assert np.array_equal(i0, np.arange(100) * 2) and np.array_equal(i1, i0 + 1) and np.all(w1 == 0.5)
+
+
+def test_infer_window_plan():
+    g = load_golden("g1_index")
+    for S in (32000, 64000, 100000, 200001, 64001, 63999):
+        p = oi.window_plan(S)
+        assert [p["clip_len"], p["n_subdivision"], p["n_padding_audio_samples"], p["n_padding_frames"]] == \
+            g[f"plan_{S}"].tolist()
+
+
+# ----------------------------------------------------------------------------- G2 schedule
+def test_diffusion_schedule():
+    g = load_golden("g2_schedule")
+    for T in (5, 500):
+        for mode in ("linear", "quadratic", "sigmoid", "cosine"):
+            s = od.diffusion_schedule(T, mode)
+            for k, v in s.items():
+                ref = g[f"{mode}_{T}_{k}"]
+                assert v.shape == ref.shape
+                # fp32 libm (cos/exp/log) ulp differences between torch and numpy, amplified by the
+                # 1 - ab[i]/ab[i-1] cancellation: <= 1e-5 absolute on values in [0, 1]
+                assert maxabs(v, ref) <= 1e-5, (mode, T, k, maxabs(v, ref))
+
+
+def test_masks_and_pe():
+    g = load_golden("g2_schedule")
+    assert np.array_equal(od.enc_dec_mask(110, 110, 1, 0), g["enc_dec_mask_110_1_0"])
+    assert np.array_equal(od.enc_dec_mask(110, 110, 1, 1), g["enc_dec_mask_110_1_1"])
+    m = od.alignment_mask(10, 100, 1)
+    assert m.shape == (111, 110) and not m[0].any()
+    assert all(np.flatnonzero(~m[i]).tolist() == [i - 1] for i in range(1, 111))
+    pe = onn.sinusoid_table(501, 512)
+    assert maxabs(pe[0, [0, 1, 7, 250, 500]], g["pe_512_501_rows"]) <= 1e-4  # 1-ulp exp() differences x position 500
+
+
+# ----------------------------------------------------------------------------- G3 blocks
+@pytest.mark.parametrize("am", ["wav2vec2", "hubert"])
+def test_audio_encoder(am):
+    g = load_golden(f"g3_audio_{am}")
+    sd, args = msmd_state_dict(am)
+    audio = synth.audio_clips(2, 64000)
+    h, st = oa.audio_encoder(sd, "audio_encoder.", oa.pad_audio(audio), 25, frame_num=200, return_stages=True)
+    assert maxabs(st["conv"][:, ::3, ::5], g["conv"]) <= 2e-5
+    assert maxabs(st["proj"][:, ::3, ::5], g["proj"]) <= 5e-5
+    assert maxabs(st["layer0"][:, ::3, ::5], g["layer0"]) <= 1e-4
+    assert maxabs(st["layer11"][:, ::3, ::5], g["layer11"]) <= 1e-4
+    feat768 = onn.interp_linear_cl(h, 100)
+    assert maxabs(feat768[:, ::2, ::3], g["feat768"]) <= 1e-4
+    feat = onn.linear(feat768, sd["audio_feature_map.weight"], sd["audio_feature_map.bias"])
+    assert maxabs(feat, g["feat"]) <= 1e-4
+    # 30 fps crop/interp path, 2 s clip
+    a2 = synth.audio_clips(1, 32000, tag="audio30")
+    y = oa.audio_encoder(sd, "audio_encoder.", oa.pad_audio(a2), 30, frame_num=60)
+    assert maxabs(y, g["hidden_fps30_60"]) <= 1e-4
+
+
+def test_conv0_groupnorm_slice():
+    """conv0 + GroupNorm(512,512) + GELU slice (the hook captured the whole first conv layer)."""
+    g = load_golden("g3_audio_wav2vec2")
+    sd, _ = msmd_state_dict("wav2vec2")
+    audio = oa.pad_audio(synth.audio_clips(2, 64000))
+    p = "audio_encoder.feature_extractor.conv_layers.0."
+    x = onn.conv1d_cl(audio[:, :, None], sd[p + "conv.weight"], None, 5)
+    assert x.shape == (2, 12815, 512)
+    mean = x.mean(axis=1, keepdims=True, dtype=np.float64)
+    var = x.var(axis=1, keepdims=True, dtype=np.float64)
+    y = onn.gelu(((x - mean) / np.sqrt(var + 1e-5)).astype(np.float32) * sd[p + "layer_norm.weight"]
+                 + sd[p + "layer_norm.bias"])
+    assert maxabs(y[:, ::61, ::7], g["conv0"]) <= 1e-5
+
+
+def test_state_dict_keys_match_reference():
+    g = load_golden("g0_keys")
+    sd, _ = msmd_state_dict("wav2vec2")
+    ref_keys = {synth.canonical_name(str(k)) for k in g["keys"]}
+    learnable = {k for k in ref_keys if not synth.is_computed_buffer(k)}
+    assert learnable == set(sd.keys())
+    assert int(g["n_params"]) == 130_017_905
+    ssd, _ = style_state_dict()
+    assert {str(k) for k in g["style_keys"] if "PE.pe" not in str(k)} == set(ssd.keys())
+
+
+def test_denoiser():
+    g = load_golden("g3_denoiser")
+    sd, args = msmd_state_dict("wav2vec2")
+    x = denoiser_inputs(2, args)
+    person = np.concatenate([x["shape"][:, None], x["style"][:, None]], axis=-1)
+    for width in (1, 2):
+        y = od.denoising_net(sd, x["motion"], x["audio_feat"], person, x["style"][:, None], x["prev_motion"],
+                             x["prev_audio"], g["step"], x["indicator"], align_mask_width=width)
+        assert y.shape == (2, 110, 67)
+        assert maxabs(y, g[f"target_w{width}"]) <= 5e-5, width
+    dyn, stat, al = od.denoising_net(sd, x["motion"], x["audio_feat"], person, x["style"][:, None], x["prev_motion"],
+                                     x["prev_audio"], g["step"], x["indicator"], keep_separate=True)
+    assert maxabs(dyn, g["dynamic"]) <= 5e-5 and maxabs(al, g["alphas"]) <= 5e-5
+    assert maxabs(stat[:, :2], g["static"]) <= 5e-5
+
+
+def test_msmd_forward():
+    g = load_golden("g3_forward")
+    sd, args = msmd_state_dict("wav2vec2")
+    sched = od.diffusion_schedule(500, "cosine")
+    x = denoiser_inputs(2, args, tag="fw")
+    audio = synth.audio_clips(2, 64000, tag="fw_audio")
+    _, target, afeat = od.msmd_forward(sd, sched, x["motion"], audio, x["shape"], x["style"], [3, 499], g["a_eps"],
+                                       indicator=x["indicator"])
+    assert maxabs(afeat[:, ::2, ::3], g["a_audio_feat"]) <= 1e-4
+    assert maxabs(target, g["a_target"]) <= 1e-4
+    flag = g["b_flag"]
+    _, target, _ = od.msmd_forward(sd, sched, x["motion"], x["audio_feat"], x["shape"], x["style"], [250, 1],
+                                   g["b_eps"], x["prev_motion"], x["prev_audio"], x["indicator"],
+                                   null_style_mask=flag > 0.55, null_audio_mask=flag > 0.9)
+    assert maxabs(target, g["b_target"]) <= 1e-4
+
+
+def test_style_encoder():
+    g = load_golden("g3_style")
+    sd, _ = style_state_dict()
+    for B, T in ((2, 100), (1, 60)):
+        m = synth.motion_clips(B, T, tag="style_in")
+        mu, logvar = ost.style_encoder_mu_logvar(sd, m)
+        assert maxabs(mu, g[f"mu_{B}_{T}"]) <= 2e-5 and maxabs(logvar, g[f"logvar_{B}_{T}"]) <= 2e-5
+        assert maxabs(ost.reparam(mu, logvar, g[f"eps_{B}_{T}"]), g[f"z_{B}_{T}"]) <= 5e-5
+
+
+def test_sampler():
+    g = load_golden("g3_sample")
+    sd, args = msmd_state_dict("wav2vec2")
+    x = denoiser_inputs(2, args, tag="sm")
+    T = 3
+    sched = od.diffusion_schedule(T, "cosine")
+    xT = synth.normalish("sm/xT", (2, 100, 67))
+    cases = {
+        "inc": dict(cfg_mode="incremental", cfg_scale=1.15),
+        "ind": dict(cfg_mode="independent", cfg_scale=[1.3, 0.9]),
+        "audio_only": dict(cfg_cond=["audio"], cfg_scale=2.0),
+        "nocfg": dict(cfg_cond=[]),
+        "dt": dict(cfg_mode="incremental", cfg_scale=1.4, dynamic_threshold=(0.9, 0.5, 2.0)),
+        "flex": dict(cfg_mode="incremental", cfg_scale=1.15, flexibility=0.5),
+    }
+    for name, kw in cases.items():
+        z = g[f"{name}_z"]
+        z_list = {T - i: z[i] for i in range(T - 1)}
+        y = od.sample(sd, sched, x["audio_feat"], x["shape"], x["style"], xT, z_list, x["prev_motion"],
+                      x["prev_audio"], x["indicator"], **kw)
+        assert maxabs(y, g[f"{name}_x0"]) <= 1e-4, (name, maxabs(y, g[f"{name}_x0"]))
+    z = g["noise_z"]
+    y = od.sample(sd, od.diffusion_schedule(T, "linear"), x["audio_feat"], x["shape"], x["style"], xT,
+                  {T - i: z[i] for i in range(T - 1)}, indicator=x["indicator"], target="noise")
+    assert maxabs(y, g["noise_x0"]) <= 2e-4
+
+
+def test_infer_coeffs():
+    g = load_golden("g3_infer")
+    sd, args = msmd_state_dict("wav2vec2")
+    T = 2
+    sched = od.diffusion_schedule(T, "cosine")
+    for S in (100000, 32000):
+        audio = synth.audio_clips(1, S, tag="infer")[0]
+        style = synth.normalish("infer/style", (1, args.d_style))
+        shape = np.zeros((1, 1, 100), np.float32)
+        draws = g[f"draws_{S}"]
+        n_sub = oi.window_plan(S)["n_subdivision"]
+        z_lists = [{2: draws[1 + i]} for i in range(n_sub)]
+        y = oi.infer_coeffs(sd, sched, audio, shape, style, draws[0], z_lists, cfg_scale=1.4)
+        assert y.shape == g[f"coef_{S}"].shape
+        assert maxabs(y, g[f"coef_{S}"]) <= 1e-4, S
+
+
+# ----------------------------------------------------------------------------- G4 FLAME / rotations
+def test_flame_lbs_and_landmarks():
+    g = load_golden("g4_flame")
+    fl = ofl.FlameOracle(synth.flame_asset())
+    x = flame_inputs(8)
+    pose = g["pose"]
+    v, lm2d, lm3d = fl.forward(x["shape"], x["exp"], pose)
+    assert v.shape == (8, 5023, 3)
+    assert maxabs(v[:, ::79], g["verts_sub"]) <= 2e-6
+    assert maxabs(v.sum(axis=1, dtype=np.float64), g["verts_sum"]) <= 2e-3  # sum of 5023 fp32 values
+    assert maxabs(lm2d, g["lm2d"]) <= 2e-6 and maxabs(lm3d, g["lm3d"]) <= 2e-6
+    v2, _, _ = fl.forward(x["shape"], x["exp"], pose, ignore_global_rot=True, return_lm2d=False, return_lm3d=False)
+    assert maxabs(v2[:, ::79], g["verts_nog_sub"]) <= 2e-6
+    assert maxabs(ofl.batch_rodrigues(g["rodrigues_in"]), g["rodrigues_out"]) <= 1e-6
+
+
+def test_rotation_conversions():
+    g = load_golden("g4_rotations")
+    aa, q, q2, pts, d6, eul = (g[k] for k in ("aa", "q", "q2", "pts", "d6", "eul"))
+    R = orot.axis_angle_to_matrix(aa)
+    checks = dict(
+        axis_angle_to_matrix=R, axis_angle_to_quaternion=orot.axis_angle_to_quaternion(aa),
+        quaternion_to_matrix=orot.quaternion_to_matrix(q), matrix_to_quaternion=orot.matrix_to_quaternion(g["axis_angle_to_matrix"]),
+        quaternion_to_axis_angle=orot.quaternion_to_axis_angle(q),
+        matrix_to_axis_angle=orot.matrix_to_axis_angle(g["axis_angle_to_matrix"]),
+        rotation_6d_to_matrix=orot.rotation_6d_to_matrix(d6), matrix_to_rotation_6d=orot.matrix_to_rotation_6d(g["axis_angle_to_matrix"]),
+        axis_angle_to_rotation_6d=orot.axis_angle_to_rotation_6d(aa),
+        quaternion_raw_multiply=orot.quaternion_raw_multiply(q, q2), quaternion_multiply=orot.quaternion_multiply(q, q2),
+        quaternion_invert=orot.quaternion_invert(q), quaternion_apply=orot.quaternion_apply(q, pts),
+        standardize_quaternion=orot.standardize_quaternion(q))
+    for k, v in checks.items():
+        # outputs up to ~6 in magnitude (angle * axis of un-normalised quaternions): a few fp32 ulps
+        tol = 2e-5 if k in ("matrix_to_axis_angle", "quaternion_apply", "matrix_to_quaternion",
+                            "quaternion_to_axis_angle") else 2e-6
+        assert maxabs(v, g[k]) <= tol, (k, maxabs(v, g[k]))
+    for conv in ("XYZ", "ZYX", "YXZ", "XYX", "ZXZ"):
+        Re = orot.euler_angles_to_matrix(eul, conv)
+        assert maxabs(Re, g[f"euler_angles_to_matrix_{conv}"]) <= 2e-6
+        assert maxabs(orot.matrix_to_euler_angles(g[f"euler_angles_to_matrix_{conv}"], conv),
+                      g[f"matrix_to_euler_angles_{conv}"]) <= 2e-5

@@ -1,0 +1,40 @@
+"""Explicit model configuration.
+
+The reference's ``training_script.py`` parser (reference training_script.py:448-515)
+never defines a dozen attributes that ``MSMD`` / ``DenoisingNetwork_MSMD`` /
+the losses read (reference model.py:78-129, 843-849; utils/common.py:220,245).
+SURVEY.md §5.6 records the upstream DiffPoseTalk defaults; this module ships
+them as one explicit namespace so that the reference's CLI flag names keep
+working and nothing is left undefined.
+"""
+from __future__ import annotations
+
+import argparse
+
+DEFAULTS = dict(
+    # model
+    target="sample", architecture="decoder", style_enc_ckpt=None, d_style=256, fps=25,
+    n_motions=100, n_prev_motions=10, audio_model="wav2vec2", feature_dim=512,
+    n_diff_steps=500, diff_schedule="cosine", cfg_mode="incremental",
+    guiding_conditions="audio,style", num_of_basis=4, style_enc_model_style="vae2",
+    dataset_type="ravdess+celebv-text-medium", rot_repr="aa", no_head_pose=False,
+    use_indicator=True, n_heads=8, n_layers=8, mlp_ratio=4, align_mask_width=1,
+    no_use_learnable_pe=False, regularize_alpha="None",
+    # losses (reference training_script.py:476-486, utils/common.py)
+    criterion="l2", no_constrain_prev=False, l_vert=1.0, l_vel=0.5, l_smooth=10.0,
+    l_head_angle=1.0, l_head_vel=0.5, l_head_smooth=0.5, l_head_trans=0.5,
+    l_kl_div=1e-7, use_vertex_space=False,
+    # training (reference training_script.py:488-513, training_specs.sh)
+    lr=2e-5, warm_iter=5000, batch_size=16, max_iter=2_000_000,
+    gradient_accumulation_steps=1, trunc_prob1=0.5, trunc_prob2=0.4,
+    prob_cross_style=0.3, use_cross_style=True,
+    # engine (new in this build)
+    compute_dtype="bf16",       # "bf16" speed mode | "fp32" parity mode
+    encoder_layers=None,        # override HF num_hidden_layers (tests use 1-2)
+)
+
+
+def default_args(**overrides) -> argparse.Namespace:
+    cfg = dict(DEFAULTS)
+    cfg.update(overrides)
+    return argparse.Namespace(**cfg)
