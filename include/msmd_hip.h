@@ -1,0 +1,209 @@
+/*
+ * msmd_hip.h -- C ABI of libmsmd_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * audio -> motion-coefficient hot path of ubisoft/ubisoft-laforge-msmd.
+ *
+ * The reference has no FFI/plugin layer: the path sits behind Python nn.Module calls
+ * (SURVEY.md section 8b).  Each entry point below replaces the implicit torch/cuDNN/cuBLAS/HF
+ * device ops issued by the cited reference lines.  Conventions:
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory owned by the caller;
+ *   - no hidden allocation, no host synchronisation (graph-capturable); workspaces are passed in;
+ *   - re-entrant per stream; `stream` is a hipStream_t passed as void*;
+ *   - returns a hipError_t-compatible int (0 = success); argument errors return hipErrorInvalidValue (1);
+ *   - activations are channels-last, row-major (rows, cols); `dtype` selects fp32 (parity mode)
+ *     or bf16 storage with fp32 accumulation (speed mode).  Biases / norm affine params / statistics
+ *     are always fp32.
+ */
+#ifndef MSMD_HIP_H
+#define MSMD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSMD_F32 0
+#define MSMD_BF16 1
+
+#define MSMD_ACT_NONE 0
+#define MSMD_ACT_GELU 1 /* exact erf GELU */
+#define MSMD_ACT_ELU 2  /* alpha = 1 */
+
+typedef void* msmd_stream_t; /* hipStream_t */
+
+/* Library / device probe: returns the ABI version; safe to call without a GPU. */
+int msmd_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense contraction on MFMA:  C = act(A . W^T + bias) + residual
+ *   A: (M, K) activations, row m at  A + (m / rows_per_batch) * a_batch_stride + (m % rows_per_batch) * lda
+ *      (elements).  With rows_per_batch = T_out, lda = stride*C_in, a_batch_stride = T_in*C_in and
+ *      K = k*C_in this IS a strided Conv1d over a channels-last signal with no im2col buffer.
+ *   W: (N, K) row-major, leading dimension ldw (torch Linear layout; conv weights repacked (N, k*C_in)).
+ *   bias: fp32 (N) or NULL.  residual: (M, N) ld ldr or NULL.  C: (M, N) ld ldc.
+ *   in_dtype: dtype of A and W.  out_dtype: dtype of C and residual.
+ *   batch > 1 launches independent problems with the given element strides (grouped conv).
+ *   Requirements: K % (16 / sizeof(in)) == 0, lda/ldw/a_batch_stride/strideA/strideW multiples of the same.
+ * Replaces: nn.Linear / nn.Conv1d / nn.MultiheadAttention projections at reference model.py:115,856-906,
+ *   style_encoder.py:135-175, utils/wav2vec2.py:79,95,111 (HF conv stack, projection, pos-conv, encoder FFN).
+ */
+int msmd_gemm(const void* A, const void* W, const float* bias, const void* residual, void* C,
+              int M, int N, int K, int in_dtype, int out_dtype,
+              long lda, int rows_per_batch, long a_batch_stride, long ldw, long ldc, long ldr, int act,
+              int batch, long strideA, long strideW, long strideC, long strideBias, long strideR,
+              msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * y = LayerNorm(act(x + residual)) * gamma + beta + post_add      (row-wise over `cols`)
+ *   residual, post_add (fp32, cols) may be NULL.  eps as torch (1e-5).  Biased variance.
+ * Replaces: nn.LayerNorm at reference style_encoder.py:142,150,170; HF feature_projection.layer_norm,
+ *   encoder.layer_norm, layers.N.{layer_norm,final_layer_norm}; decoder norm1-3 (model.py:874-878).
+ */
+int msmd_layernorm(const void* x, const void* residual, const float* gamma, const float* beta,
+                   const float* post_add, void* y, int rows, int cols, float eps, int act,
+                   int in_dtype, int out_dtype, msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused softmax attention for short sequences (Tk <= 512), head_dim 64:
+ *   O[b, t, h*64:(h+1)*64] = softmax(scale * Q_h K_h^T  (masked -> -inf)) V_h
+ *   Q/K/V/O rows are addressed as base + b*bstride + t*tstride + h*64 (elements).
+ *   mask: (Tq, Tk) bytes, nonzero = masked out, or NULL.
+ * Replaces: HF Wav2Vec2Attention (called from utils/wav2vec2.py:111), nn.MultiheadAttention inside
+ *   nn.TransformerDecoderLayer (model.py:874-878,956) and nn.TransformerEncoderLayer (style_encoder.py:158).
+ */
+int msmd_attention(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
+                   long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
+                   long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
+                   int dtype, msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Audio front end.  pad plan = (reflect_len applied twice per side, replicate_len 0/1), computed on
+ * the host exactly as reference utils/model_common.py:110-123.
+ */
+/* out (B, L + 4*reflect_len + 2*replicate_len) fp32 = pad_audio(audio (B, L)). */
+int msmd_pad_audio(const float* audio, float* out, int B, int L, int reflect_len, int replicate_len,
+                   msmd_stream_t stream);
+
+/* conv0 (1->C, k=10, s=5, no bias) statistics for GroupNorm(C groups): stats (B, C, 2) = {mean, rstd}
+ * over the T0 = (Lp - 10)/5 + 1 output frames, reading the UNPADDED audio through the pad map.
+ * w0: (C, 10) fp32.  Replaces HF Wav2Vec2GroupNormConvLayer (called at utils/wav2vec2.py:79). */
+#define MSMD_CONV0_SPLITS 16 /* ws: (B, MSMD_CONV0_SPLITS, C, 2) fp32 partial (mean, M2), merged with Chan's formula */
+int msmd_conv0_stats(const float* audio, const float* w0, float* stats, float* ws, int B, int L, int reflect_len,
+                     int replicate_len, int C, float eps, msmd_stream_t stream);
+
+/* out (B, T0, C) = GELU(GroupNorm(conv0(pad(audio)))) with the statistics above. */
+int msmd_conv0_gn_gelu(const float* audio, const float* w0, const float* stats, const float* gamma,
+                       const float* beta, void* out, int B, int L, int reflect_len, int replicate_len,
+                       int C, int out_dtype, msmd_stream_t stream);
+
+/* Linear resample along time of a channels-last tensor with F.interpolate(mode='linear',
+ * align_corners=False) semantics: y (B, T_out, C) from the first T_crop frames of x (B, T_in, C).
+ * Replaces utils/wav2vec2.py:57-63,82-84 and model.py:260. */
+int msmd_interp_linear(const void* x, void* y, int B, int T_in, int T_crop, int T_out, int C, int dtype,
+                       msmd_stream_t stream);
+
+/* Regroup (B, T, G*Cg) channels-last into the zero-padded group-major layout (B, G, T + 2*pad, Cg)
+ * the positional grouped conv reads as G windowed GEMMs. */
+int msmd_group_pad(const void* x, void* y, int B, int T, int G, int Cg, int pad, int dtype, msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Denoiser glue (reference model.py:931-951, 961-996, 231-236, 404-432).
+ */
+/* feats (N, 1+Lp+L, Kpad): row 0 is left to the caller (person token); rows 1.. = [prev_motion ; motion]
+ * (dm cols) ++ indicator col (0 for prev rows) ++ zero pad up to Kpad.  motion: (N, L, dm), prev: (N, Lp, dm),
+ * indicator (N, L) fp32 or NULL.  x_t = c0[n]*motion + c1[n]*eps when eps != NULL (q-sample, model.py:231-236). */
+int msmd_denoiser_pack_input(const float* motion, const float* eps, const float* c0, const float* c1,
+                             const float* prev_motion, const float* indicator, void* feats, int N, int L,
+                             int Lp, int dm, int Kpad, int motion_batch, int out_dtype, msmd_stream_t stream);
+
+/* x (N, T, d) += pe (T, d) (learned PE, model.py:949); row 0 additionally += tok0 (N, d) (person + step emb). */
+int msmd_add_pe_token(void* x, const float* pe, const void* tok0, int N, int T, int d, int dtype,
+                      msmd_stream_t stream);
+
+/* out (N, L, dm) fp32 = dyn[:, :, :dm] + sum_b alpha_b * static_b (face dims) / sum_b static_b (last 3 dims)
+ * dec: (N, L, dm+nb) decoder head output (row stride ld_dec); stat: (Ns, nb, dm) static bases, Ns in {N, N/entries}.
+ * (model.py:961-996, use_head_alpha=False.) */
+int msmd_heads_static_mix(const void* dec, long ld_dec, const void* stat, float* out, int N, int L, int dm,
+                          int nb, int stat_batch, int use_head_alpha, int dtype, msmd_stream_t stream);
+
+/* One CFG + DDPM ancestral update (model.py:396-432), in place on x (B, L, dm) fp32.
+ * res: (n_entries*B, Lp+L, dm) fp32 denoiser outputs; scales[n_entries-1]; coefficients on the host
+ * (c0, c1, sigma) as the reference computes them; z (B, L, dm) or NULL for the last step.
+ * mode: 0 = incremental, 1 = independent (in-place accumulation order of the reference). target: 0 sample, 1 noise. */
+int msmd_cfg_ddpm_step(float* x, const float* res, const float* z, const float* scales, int n_entries,
+                       int B, int L, int Lp, int dm, int mode, int target, float c0, float c1, float sigma,
+                       msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * FLAME: blendshapes + pose correctives + joint regression + Rodrigues + kinematic chain + skinning
+ * (reference utils/lbs.py:141-223, utils/flame.py:180-217) in two launches.
+ *
+ * One-time host-side packing (frame-invariant model constants, done by the caller at load time):
+ *   JS   (NB+1, J*3): JS[0] = J_regressor . v_template, JS[1+l] = J_regressor . shapedirs[:, :, l]
+ *                     (joint regression is linear in the shape, utils/lbs.py:185-189);
+ *   dirs (3, Kp, Vp): dirs[c][k][v] = shapedirs[v][c][k] for k < NB, posedirs[k-NB][3v+c] for the next
+ *                     (J-1)*9 rows, 0 beyond (Kp = 192, Vp = V rounded up to 64);
+ *   v_template (3, Vp) and lbs_weights (J, Vp) as coordinate / joint planes.
+ *
+ * msmd_lbs_prepare: per frame, coef (B, Kp) = [betas | pose_feature = (R[1:] - I) | 0], the relative rigid
+ *   transforms A (B, J, 12) (3x4 row-major) and optionally the posed joints (B, J, 3).
+ *   pose: (B, J*3) axis-angle, or (B, J*9) rotation matrices when pose_is_matrix != 0.
+ * msmd_lbs_skin: verts (B, V, 3) = sum_j w[v][j] A[b][j] . [v_template + coef . dirs ; 1].
+ */
+int msmd_lbs_prepare(const float* betas, const float* pose, const float* JS, const int* parents,
+                     float* coef, float* A, float* joints, int B, int NB, int J, int Kp, int pose_is_matrix,
+                     msmd_stream_t stream);
+int msmd_lbs_skin(const float* coef, const float* A, const float* v_template, const float* dirs,
+                  const float* lbs_weights, float* verts, int B, int J, int V, int Vp, int Kp,
+                  msmd_stream_t stream);
+
+/* Landmarks by barycentric interpolation (utils/lbs.py:102-138): out (B, L, 3).
+ * faces (F,3) int32; lmk_faces_idx (B or 1, L) int32 with batch stride idx_bstride (0 = shared);
+ * bary (B or 1, L, 3) with batch stride bary_bstride. */
+int msmd_landmarks(const float* verts, const int* faces, const int* lmk_faces_idx, long idx_bstride,
+                   const float* bary, long bary_bstride, float* out, int B, int V, int L, msmd_stream_t stream);
+
+/* Dynamic-contour LUT row (utils/flame.py:126-172): row (B) int32 from the neck-chain yaw. */
+int msmd_dynamic_lmk_row(const float* full_pose, const int* neck_chain, int n_chain, int* row, int B, int J,
+                         msmd_stream_t stream);
+
+/* batch_rodrigues (utils/lbs.py:270-301): R (N, 3, 3) from rot_vecs (N, 3). */
+int msmd_batch_rodrigues(const float* rot_vecs, float* R, int N, msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rotation conversions (reference utils/rotation_conversions.py:38-569), elementwise over n items.
+ * op codes below; `conv` packs an Euler convention as 3 axis indices (X=0,Y=1,Z=2): a0 | a1<<2 | a2<<4.
+ */
+#define MSMD_ROT_QUAT_TO_MAT 0
+#define MSMD_ROT_MAT_TO_QUAT 1
+#define MSMD_ROT_AA_TO_QUAT 2
+#define MSMD_ROT_QUAT_TO_AA 3
+#define MSMD_ROT_AA_TO_MAT 4
+#define MSMD_ROT_MAT_TO_AA 5
+#define MSMD_ROT_6D_TO_MAT 6
+#define MSMD_ROT_MAT_TO_6D 7
+#define MSMD_ROT_AA_TO_6D 8
+#define MSMD_ROT_EULER_TO_MAT 9
+#define MSMD_ROT_MAT_TO_EULER 10
+#define MSMD_ROT_QUAT_STANDARDIZE 11
+#define MSMD_ROT_QUAT_INVERT 12
+#define MSMD_ROT_QUAT_RAW_MUL 13 /* in2 = second quaternion */
+#define MSMD_ROT_QUAT_MUL 14
+#define MSMD_ROT_QUAT_APPLY 15 /* in2 = points (n,3) */
+int msmd_rotation_convert(int op, const float* in, const float* in2, float* out, long n, int conv,
+                          msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small utilities.
+ */
+int msmd_cast(const void* x, void* y, long n, int in_dtype, int out_dtype, msmd_stream_t stream);
+/* y (rows, cols_out) = x (rows, cols_in) zero-padded / truncated per row (dtype convert allowed). */
+int msmd_pad_cols(const void* x, void* y, long rows, int cols_in, int cols_out, int in_dtype, int out_dtype,
+                  msmd_stream_t stream);
+/* y[r, :] = mean over T of x[b, t, :]  (B, T, C) -> (B, C) fp32 (style_encoder.py:189). */
+int msmd_mean_time(const void* x, float* y, int B, int T, int C, int dtype, msmd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSMD_HIP_H */

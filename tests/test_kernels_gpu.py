@@ -1,0 +1,281 @@
+"""GPU parity tests of the individual HIP kernels through the C ABI (ctypes) against the numpy oracle.
+
+fp32 parity mode: tolerances are absolute fp32 noise for O(1) values (stated per test).
+bf16 speed mode: inputs are rounded to bf16 first so that only accumulation order / output rounding differ;
+tolerance 2^-7 relative to the output scale (one bf16 ulp of the largest value)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import audio_encoder as oa, diffusion as od, flame as ofl, nn as onn, rotations as orot
+from msmd_amd import synth
+
+from conftest import load_golden
+from helpers import flame_inputs, maxabs
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def ops():
+    from msmd_amd import ops as _ops
+    return _ops
+
+
+def dev(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    return t.to(dtype) if dtype is not None else t
+
+
+def bf16_round(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(torch.bfloat16).float().numpy()
+
+
+def test_library_shares_torch_hip_runtime():
+    """A pointer allocated by torch must be usable by our kernels on torch's current stream."""
+    o = ops()
+    x = torch.arange(4096, device=DEV, dtype=torch.float32).reshape(4, 1024)
+    y = o.pad_cols(x, 1024, torch.float32)
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 200, 96), (37, 71, 256), (1000, 512, 1536), (64, 48, 6144),
+                                   (5, 512, 360)])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gemm_matches_oracle(M, N, K, dtype):
+    o = ops()
+    a = synth.normalish(f"gemm/a/{M}x{K}", (M, K))
+    w = synth.uniform(f"gemm/w/{N}x{K}", (N, K), -1, 1) / math.sqrt(K)
+    b = synth.uniform(f"gemm/b/{N}", (N,), -0.5, 0.5)
+    r = synth.normalish(f"gemm/r/{M}x{N}", (M, N))
+    if dtype == "bf16":
+        a, w, r = bf16_round(a), bf16_round(w), bf16_round(r)
+        td = torch.bfloat16
+    else:
+        td = torch.float32
+    for act, use_r in ((0, False), (1, True), (2, False)):
+        ref = onn.linear(a, w, b)
+        ref = onn.gelu(ref) if act == 1 else (onn.elu(ref) if act == 2 else ref)
+        if use_r:
+            ref = ref + r
+        out = o.gemm(dev(a, td), dev(w, td), dev(b), dev(r, td) if use_r else None, act)
+        torch.cuda.synchronize()
+        got = out.float().cpu().numpy()
+        tol = 2e-5 if dtype == "fp32" else 2 ** -7 * max(1.0, float(np.abs(ref).max()))
+        assert maxabs(got, ref) <= tol, (M, N, K, dtype, act, maxabs(got, ref))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gemm_is_strided_conv1d(dtype):
+    """Windowed-A addressing == nn.Conv1d(k=3, s=2) / (k=2, s=2) over a channels-last signal."""
+    o = ops()
+    B, T, C, Co = 3, 101, 64, 80
+    x = synth.normalish("conv/x", (B, T, C))
+    td = torch.float32
+    if dtype == "bf16":
+        x, td = bf16_round(x), torch.bfloat16
+    for k, s in ((3, 2), (2, 2), (3, 1)):
+        w = synth.uniform(f"conv/w{k}", (Co, C, k)) / math.sqrt(C * k)
+        if dtype == "bf16":
+            w = bf16_round(w)
+        ref = onn.gelu(onn.conv1d_cl(x, w, None, stride=s))
+        wp = np.ascontiguousarray(w.transpose(0, 2, 1).reshape(Co, k * C))
+        out = o.conv1d_cl(dev(x, td), dev(wp, td), None, kernel=k, stride=s, act=1)
+        torch.cuda.synchronize()
+        assert out.shape == ref.shape
+        tol = 2e-5 if dtype == "fp32" else 2 ** -7
+        assert maxabs(out.float().cpu().numpy(), ref) <= tol, (k, s, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_layernorm(dtype):
+    o = ops()
+    for rows, cols in ((7, 512), (33, 768), (5, 256), (3, 1024)):
+        x = synth.normalish(f"ln/x{rows}x{cols}", (rows, cols)) * 2 + 0.3
+        r = synth.normalish(f"ln/r{rows}x{cols}", (rows, cols))
+        g = 1 + 0.1 * synth.uniform(f"ln/g{cols}", (cols,))
+        b = 0.1 * synth.uniform(f"ln/b{cols}", (cols,))
+        post = synth.uniform(f"ln/p{cols}", (cols,))
+        td = torch.float32
+        if dtype == "bf16":
+            x, r, td = bf16_round(x), bf16_round(r), torch.bfloat16
+        ref = onn.layer_norm(onn.elu(x + r), g, b) + post
+        out = o.layernorm(dev(x, td), dev(g), dev(b), residual=dev(r, td), post_add=dev(post), act=2)
+        torch.cuda.synchronize()
+        tol = 1e-5 if dtype == "fp32" else 2 ** -6
+        assert maxabs(out.float().cpu().numpy(), ref) <= tol, (rows, cols, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,H,Tq,Tk,masked", [(2, 12, 200, 200, False), (3, 8, 111, 110, True), (1, 8, 111, 111, False),
+                                              (1, 2, 500, 500, False), (2, 8, 100, 100, False)])
+def test_attention(dtype, B, H, Tq, Tk, masked):
+    o = ops()
+    d = H * 64
+    q = synth.normalish(f"att/q{B}{H}{Tq}", (B, Tq, d))
+    k = synth.normalish(f"att/k{B}{H}{Tk}", (B, Tk, d))
+    v = synth.normalish(f"att/v{B}{H}{Tk}", (B, Tk, d))
+    td = torch.float32
+    if dtype == "bf16":
+        q, k, v, td = bf16_round(q), bf16_round(k), bf16_round(v), torch.bfloat16
+    mask = od.alignment_mask(10, 100, 1) if masked else None
+    qh = q.reshape(B, Tq, H, 64).transpose(0, 2, 1, 3)
+    kh = k.reshape(B, Tk, H, 64).transpose(0, 2, 1, 3)
+    vh = v.reshape(B, Tk, H, 64).transpose(0, 2, 1, 3)
+    s = np.matmul(qh, kh.transpose(0, 1, 3, 2)) * np.float32(0.125)
+    if mask is not None:
+        s = np.where(mask[None, None], -np.inf, s)
+    ref = np.matmul(onn.softmax(s), vh).transpose(0, 2, 1, 3).reshape(B, Tq, d)
+    # packed QKV layout exercises the stride arguments
+    qkv = torch.cat([dev(q, td), dev(k, td), dev(v, td)], dim=-1) if Tq == Tk else None
+    if qkv is not None:
+        out = o.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, 0.125)
+    else:
+        out = o.attention(dev(q, td), dev(k, td), dev(v, td), H, 0.125, mask=dev(mask) if mask is not None else None)
+    torch.cuda.synchronize()
+    tol = 2e-5 if dtype == "fp32" else 2 ** -6
+    assert maxabs(out.float().cpu().numpy(), ref) <= tol, (dtype, B, H, Tq, Tk, maxabs(out.float().cpu().numpy(), ref))
+
+
+def test_pad_audio_bit_exact():
+    o = ops()
+    for L in (31999, 32000, 32001, 32081, 64000, 64079, 160000):
+        r, rep = oa.pad_audio_plan(L)
+        x = np.arange(2 * L, dtype=np.float32).reshape(2, L)
+        got = o.pad_audio(dev(x), r, rep).cpu().numpy()
+        assert np.array_equal(got, oa.pad_audio(x)), L
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_conv0_groupnorm_gelu(dtype):
+    o = ops()
+    g = load_golden("g3_audio_wav2vec2")
+    from helpers import msmd_state_dict
+    sd, _ = msmd_state_dict("wav2vec2")
+    p = "audio_encoder.feature_extractor.conv_layers.0."
+    audio = synth.audio_clips(2, 64000)
+    r, rep = oa.pad_audio_plan(64000)
+    w0 = np.ascontiguousarray(sd[p + "conv.weight"].reshape(512, 10))
+    out = o.conv0_gn_gelu(dev(audio), dev(w0), dev(sd[p + "layer_norm.weight"]), dev(sd[p + "layer_norm.bias"]), r, rep,
+                          torch.float32 if dtype == "fp32" else torch.bfloat16)
+    torch.cuda.synchronize()
+    assert out.shape == (2, 12815, 512)
+    got = out.float().cpu().numpy()
+    tol = 2e-5 if dtype == "fp32" else 2 ** -7 * 4
+    assert maxabs(got[:, ::61, ::7], g["conv0"]) <= tol  # golden = reference's conv0+GN+GELU output
+
+
+def test_interp_linear_bit_exact_index_and_weights():
+    o = ops()
+    g = load_golden("g1_index")
+    for fps, frame_num, T50 in ((25, 200, 200), (30, 200, 400), (25, 500, 500), (30, 120, 250)):
+        crop = oa.crop_len(frame_num, fps)
+        ramp = np.arange(T50, dtype=np.float32)[None, :, None] * np.ones((1, 1, 4), np.float32)
+        got = o.interp_linear(dev(ramp), frame_num, crop).cpu().numpy()[0, :, 0]
+        assert np.array_equal(got, g[f"interp_{fps}_{frame_num}_{T50}"]), (fps, frame_num)
+    x = synth.normalish("interp/x", (2, 200, 768))
+    got = o.interp_linear(dev(x), 100).cpu().numpy()
+    assert np.array_equal(got, onn.interp_linear_cl(x, 100))  # exact pairwise mean
+
+
+def test_group_pad():
+    o = ops()
+    x = synth.normalish("gp/x", (2, 50, 96))
+    y = o.group_pad(dev(x), 2, 8).cpu().numpy()
+    assert y.shape == (2, 2, 66, 48)
+    assert np.all(y[:, :, :8] == 0) and np.all(y[:, :, 58:] == 0)
+    assert np.array_equal(y[:, 1, 8:58], x[:, :, 48:])
+
+
+def test_flame_lbs_matches_oracle_and_golden():
+    from msmd_amd.utils.flame import FLAME, FLAMEConfig
+    from types import SimpleNamespace
+    g = load_golden("g4_flame")
+    asset = synth.flame_asset()
+    cfg = SimpleNamespace(**vars(FLAMEConfig))
+    cfg.asset = asset
+    fl = FLAME(cfg).to(DEV)
+    x = flame_inputs(8)
+    pose = g["pose"]
+    v, lm2d, lm3d = fl(dev(x["shape"]), dev(x["exp"]), dev(pose))
+    torch.cuda.synchronize()
+    v = v.cpu().numpy()
+    assert v.shape == (8, 5023, 3)
+    # FLAME vertex coordinates are O(0.1); fp32 accumulation-order noise only
+    assert maxabs(v[:, ::79], g["verts_sub"]) <= 5e-6
+    assert maxabs(lm2d.cpu().numpy(), g["lm2d"]) <= 5e-6 and maxabs(lm3d.cpu().numpy(), g["lm3d"]) <= 5e-6
+    orc = ofl.FlameOracle(asset)
+    vo, _, _ = orc.forward(x["shape"], x["exp"], pose, return_lm2d=False, return_lm3d=False)
+    assert maxabs(v, vo) <= 5e-6
+    v2, _, _ = fl(dev(x["shape"]), dev(x["exp"]), dev(pose), ignore_global_rot=True, return_lm2d=False,
+                  return_lm3d=False)
+    assert maxabs(v2.cpu().numpy()[:, ::79], g["verts_nog_sub"]) <= 5e-6
+    # dynamic-contour LUT row: bit-exact integers
+    row = ops().dynamic_lmk_row(dev(orc.full_pose(pose)), dev(orc.neck_kin_chain.astype(np.int32)))
+    assert np.array_equal(row.cpu().numpy(), ofl.dynamic_lmk_index(orc.full_pose(pose), orc.neck_kin_chain))
+    # ragged frame counts (not a multiple of the 16-frame tile) and a large batch
+    for B in (1, 17, 100):
+        xi = flame_inputs(B, tag=f"flame{B}")
+        vi, _, _ = fl(dev(xi["shape"]), dev(xi["exp"]), dev(xi["pose"]), return_lm2d=False, return_lm3d=False)
+        vr, _, _ = orc.forward(xi["shape"], xi["exp"], xi["pose"], return_lm2d=False, return_lm3d=False)
+        assert maxabs(vi.cpu().numpy(), vr) <= 5e-6, B
+
+
+def test_batch_rodrigues():
+    from msmd_amd.utils.lbs import batch_rodrigues
+    g = load_golden("g4_flame")
+    got = batch_rodrigues(dev(g["rodrigues_in"])).cpu().numpy()
+    assert maxabs(got, g["rodrigues_out"]) <= 1e-6
+
+
+def test_rotation_conversions():
+    from msmd_amd.utils import rotation_conversions as RC
+    g = load_golden("g4_rotations")
+    aa, q, q2, pts, d6, eul = (dev(g[k]) for k in ("aa", "q", "q2", "pts", "d6", "eul"))
+    R = dev(g["axis_angle_to_matrix"])
+    got = dict(
+        axis_angle_to_matrix=RC.axis_angle_to_matrix(aa), axis_angle_to_quaternion=RC.axis_angle_to_quaternion(aa),
+        quaternion_to_matrix=RC.quaternion_to_matrix(q), matrix_to_quaternion=RC.matrix_to_quaternion(R),
+        quaternion_to_axis_angle=RC.quaternion_to_axis_angle(q), matrix_to_axis_angle=RC.matrix_to_axis_angle(R),
+        rotation_6d_to_matrix=RC.rotation_6d_to_matrix(d6), matrix_to_rotation_6d=RC.matrix_to_rotation_6d(R),
+        axis_angle_to_rotation_6d=RC.axis_angle_to_rotation_6d(aa),
+        quaternion_raw_multiply=RC.quaternion_raw_multiply(q, q2), quaternion_multiply=RC.quaternion_multiply(q, q2),
+        quaternion_invert=RC.quaternion_invert(q), quaternion_apply=RC.quaternion_apply(q, pts),
+        standardize_quaternion=RC.standardize_quaternion(q))
+    for k, v in got.items():
+        tol = 2e-5 if k in ("matrix_to_axis_angle", "quaternion_apply", "matrix_to_quaternion",
+                            "quaternion_to_axis_angle") else 2e-6
+        assert v.shape == g[k].shape, k
+        assert maxabs(v.cpu().numpy(), g[k]) <= tol, (k, maxabs(v.cpu().numpy(), g[k]))
+    for conv in ("XYZ", "ZYX", "YXZ", "XYX", "ZXZ"):
+        assert maxabs(RC.euler_angles_to_matrix(eul, conv).cpu().numpy(), g[f"euler_angles_to_matrix_{conv}"]) <= 2e-6
+        assert maxabs(RC.matrix_to_euler_angles(dev(g[f"euler_angles_to_matrix_{conv}"]), conv).cpu().numpy(),
+                      g[f"matrix_to_euler_angles_{conv}"]) <= 2e-5
+    with pytest.raises(ValueError):
+        RC.euler_angles_to_matrix(eul, "XXY")
+    with pytest.raises(ValueError):
+        RC.matrix_to_quaternion(torch.zeros(2, 3, 4, device=DEV))
+
+
+def test_cfg_ddpm_step_matches_reference_inplace_semantics():
+    o = ops()
+    B, L, Lp, dm = 2, 100, 10, 67
+    for mode, name in ((0, "incremental"), (1, "independent")):
+        res = synth.normalish(f"cfg/res{mode}", (3 * B, Lp + L, dm))
+        x = synth.normalish("cfg/x", (B, L, dm))
+        z = synth.normalish("cfg/z", (B, L, dm))
+        scales = np.array([1.3, 0.9], np.float32)
+        r = [c.copy() for c in np.split(res, 3, axis=0)]
+        theta = r[0][:, -L:]
+        for i in range(2):
+            theta += scales[i] * (r[i + 1][:, -L:] - (r[0] if mode == 1 else r[i])[:, -L:])
+        c0, c1, sg = np.float32(0.7), np.float32(0.25), np.float32(0.1)
+        ref = c0 * x + c1 * theta + sg * z
+        xt = dev(x).clone()
+        o.cfg_ddpm_step(xt, dev(res), dev(z), dev(scales), 3, Lp, mode, 0, c0, c1, sg)
+        torch.cuda.synchronize()
+        assert maxabs(xt.cpu().numpy(), ref) <= 2e-6, name

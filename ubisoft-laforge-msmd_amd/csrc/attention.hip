@@ -1,0 +1,208 @@
+// Fused softmax attention, head_dim 64, any Tq/Tk (flash-style online softmax over 64-key tiles).
+//
+// Workgroup = 4 waves = 64 query rows of one (batch, head); each wave owns 16 queries.
+// S is computed SWAPPED (S^T = K . Q^T) so that the query sits on the MFMA lane (l & 15) and the keys
+// in the accumulator registers: row max / row sum are lane-local plus two cross-lane steps (xor 16, 32),
+// and P^T is already the B operand of the second product O^T = V^T . P^T with no LDS round trip.
+// K-slot permutation: the PV MFMA consumes keys in the order the S accumulators hold them
+// (slot (q, e) = key 16 f + 4 q + e); the V^T operand is fetched in that same order
+//   bf16: ds_read_b64_tr_b16 transposed reads from a row-major [key][d] LDS image (no transpose pass),
+//   fp32: ds_read_b32 from a padded [key][d] image (parity mode, exact fp32 MFMA 16x16x4).
+#include "common.h"
+
+struct AttnArgs {
+  const void* Q; const void* K; const void* V; void* O;
+  int B, H, Tq, Tk;
+  long qb, qt, kb, kt, vb, vt, ob, ot;
+  float scale;
+  const uint8_t* mask;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr int KROW = BF ? 128 : 256;  // bytes per K row in LDS (64 elements)
+  constexpr int VROW = BF ? 128 : 272;  // fp32 V rows padded to 68 floats
+  constexpr int NCH = BF ? 8 : 16;      // 16-B chunks per 64-element row
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * KROW + 64 * VROW];
+  unsigned char* sK = smem;
+  unsigned char* sV = smem + 64 * KROW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int query = blockIdx.x * 64 + wid * 16 + fr;
+  const int qrow = query < p.Tq ? query : p.Tq - 1;
+  const T* Qp = (const T*)p.Q + (long)b * p.qb + (long)qrow * p.qt + h * 64;
+  const T* Kb = (const T*)p.K + (long)b * p.kb + h * 64;
+  const T* Vb = (const T*)p.V + (long)b * p.vb + h * 64;
+
+  // Q fragments (B operand of S^T = K Q^T): chunk (4g + fq) of the lane's query row
+  u32x4 qf[BF ? 2 : 4];
+#pragma unroll
+  for (int g = 0; g < (BF ? 2 : 4); ++g) qf[g] = *(const u32x4*)(Qp + (BF ? 32 : 16) * g + (BF ? 8 : 4) * fq);
+
+  f32x4 acc_o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) acc_o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int kv0 = 0; kv0 < p.Tk; kv0 += 64) {
+    __syncthreads();
+    // ---- stage K and V tiles (rows beyond Tk are zero-filled)
+#pragma unroll
+    for (int i = 0; i < NCH / 4; ++i) {
+      const int c = tid + i * 256;
+      const int row = c / NCH, ch = c % NCH;
+      const int key = kv0 + row;
+      u32x4 kk = u32x4{0, 0, 0, 0}, vv = u32x4{0, 0, 0, 0};
+      if (key < p.Tk) {
+        kk = *(const u32x4*)(Kb + (long)key * p.kt + ch * (16 / sizeof(T)));
+        vv = *(const u32x4*)(Vb + (long)key * p.vt + ch * (16 / sizeof(T)));
+      }
+      if constexpr (BF) {
+        *(u32x4*)(sK + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kk;
+        *(u32x4*)(sV + row * 128 + ((((ch >> 1) ^ ((row >> 1) & 3)) << 5) + ((ch & 1) << 4))) = vv;
+      } else {
+        *(u32x4*)(sK + row * 256 + ((ch ^ (row & 15)) << 4)) = kk;
+        *(u32x4*)(sV + row * 272 + (ch << 4)) = vv;
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T tile: 4 fragments of 16 keys x 16 queries
+    f32x4 s[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      s[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int row = 16 * f + fr;
+      if constexpr (BF) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const u32x4 a = *(const u32x4*)(sK + row * 128 + (((4 * g + fq) ^ ((row >> 1) & 7)) << 4));
+          s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                         __builtin_bit_cast(bf16x8, qf[g]), s[f], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const u32x4 a = *(const u32x4*)(sK + row * 256 + (((4 * g + fq) ^ (row & 15)) << 4));
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            s[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(qf[g][e]), s[f], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- scale, mask, online softmax (query = lane & 15; keys 16 f + 4 fq + e)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = kv0 + 16 * f + 4 * fq + e;
+        float v = s[f][e] * p.scale;
+        bool dead = key >= p.Tk;
+        if (p.mask && !dead) dead = p.mask[(long)qrow * p.Tk + key] != 0;
+        v = dead ? -INFINITY : v;
+        s[f][e] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = (m_run == -INFINITY) ? 0.f : (BF ? __expf(m_run - m_use) : expf(m_run - m_use));
+    float ps = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pv = BF ? __expf(s[f][e] - m_use) : expf(s[f][e] - m_use);
+        s[f][e] = pv;
+        ps += pv;
+      }
+    ps += __shfl_xor(ps, 16, 64);
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc_o[d][e] *= alpha;
+
+    // ---- O^T += V^T . P^T
+    if constexpr (BF) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const int f0 = 2 * pr, f1 = 2 * pr + 1;
+        const bf16x8 pb = bf16x8{(bf16_t)s[f0][0], (bf16_t)s[f0][1], (bf16_t)s[f0][2], (bf16_t)s[f0][3],
+                                 (bf16_t)s[f1][0], (bf16_t)s[f1][1], (bf16_t)s[f1][2], (bf16_t)s[f1][3]};
+        // transposed read: lane i = 4 q' + p' of each 16-lane group addresses row key0 + q', cols d0 + 4 p'
+        const int qp = fr >> 2, pp = fr & 3;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const int r0 = 16 * f0 + 4 * fq + qp, r1 = 16 * f1 + 4 * fq + qp;
+          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(sV + r0 * 128 + ((d ^ ((r0 >> 1) & 3)) << 5) + pp * 8));
+          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(sV + r1 * 128 + ((d ^ ((r1 >> 1) & 3)) << 5) + pp * 8));
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          const s16x8 va = s16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          acc_o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va), pb, acc_o[d], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int krow = 16 * f + 4 * fq + e;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const float a = *(const float*)(sV + krow * 272 + (16 * d + fr) * 4);
+            acc_o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, s[f][e], acc_o[d], 0, 0, 0);
+          }
+        }
+    }
+  }
+
+  if (query < p.Tq) {
+    const float inv = 1.0f / l_run;
+    T* Op = (T*)p.O + (long)b * p.ob + (long)query * p.ot + h * 64;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = acc_o[d][e] * inv;
+      if constexpr (BF)
+        *(bf16x4*)(Op + 16 * d + 4 * fq) = bf16x4{(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+      else
+        *(f32x4*)(Op + 16 * d + 4 * fq) = f32x4{o[0], o[1], o[2], o[3]};
+    }
+  }
+}
+
+extern "C" int msmd_attention(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
+                              long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
+                              long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
+                              int dtype, msmd_stream_t stream) {
+  if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || !Q || !K || !V || !O) return 1;
+  const int E = dtype == MSMD_BF16 ? 8 : 4;
+  if (q_tstride % E || k_tstride % E || v_tstride % E || o_tstride % 4 || q_bstride % E || k_bstride % E ||
+      v_bstride % E || o_bstride % 4)
+    return 1;
+  if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)V & 15) || ((uintptr_t)O & 15)) return 1;
+  AttnArgs p{Q, K, V, O, B, H, Tq, Tk, q_bstride, q_tstride, k_bstride, k_tstride, v_bstride, v_tstride,
+             o_bstride, o_tstride, scale, mask};
+  dim3 grid((Tq + 63) / 64, H, B), block(256);
+  if (dtype == MSMD_BF16)
+    hipLaunchKernelGGL(attn_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);
+  else if (dtype == MSMD_F32)
+    hipLaunchKernelGGL(attn_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
+  else
+    return 1;
+  MSMD_RETURN_LAST();
+}

@@ -1,0 +1,180 @@
+// Denoiser glue and the CFG + DDPM update: small elementwise kernels (HBM/launch-bound), written so
+// that one sampler step is a fixed sequence of launches with no host round trip (hipGraph-capturable).
+#include "common.h"
+
+// feats rows 1.. = [prev_motion ; x_t] ++ indicator ++ zero pad; row 0 (person token slot) is zero-filled.
+template <typename TO>
+__global__ void pack_input_kernel(const float* __restrict__ motion, const float* __restrict__ eps,
+                                  const float* __restrict__ c0, const float* __restrict__ c1,
+                                  const float* __restrict__ prev, const float* __restrict__ ind,
+                                  TO* __restrict__ feats, int L, int Lp, int dm, int Kpad, int motion_batch) {
+  const int n = blockIdx.y;
+  const int Tn = 1 + Lp + L;
+  const int nm = n % motion_batch;  // CFG entries share one x_t (reference model.py:389)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Tn * Kpad; i += gridDim.x * blockDim.x) {
+    const int r = i / Kpad - 1, k = i % Kpad;  // r == -1: person-token row, zero-filled here
+    float v = 0.f;
+    if (r >= 0 && r < Lp) {
+      if (k < dm) v = prev[((long)n * Lp + r) * dm + k];
+    } else if (r >= Lp) {
+      const int t = r - Lp;
+      if (k < dm) {
+        v = motion[((long)nm * L + t) * dm + k];
+        if (eps) v = c0[nm] * v + c1[nm] * eps[((long)nm * L + t) * dm + k];
+      } else if (k == dm && ind) {
+        v = ind[(long)n * L + t];
+      }
+    }
+    feats[(long)n * Tn * Kpad + i] = from_f32<TO>(v);
+  }
+}
+
+extern "C" int msmd_denoiser_pack_input(const float* motion, const float* eps, const float* c0, const float* c1,
+                                        const float* prev_motion, const float* indicator, void* feats, int N, int L,
+                                        int Lp, int dm, int Kpad, int motion_batch, int out_dtype,
+                                        msmd_stream_t stream) {
+  if (N <= 0 || L <= 0 || Lp < 0 || dm <= 0 || Kpad < dm + (indicator ? 1 : 0) || motion_batch <= 0) return 1;
+  dim3 grid(((1 + Lp + L) * Kpad + 255) / 256, N), block(256);
+  if (out_dtype == MSMD_F32)
+    hipLaunchKernelGGL(pack_input_kernel<float>, grid, block, 0, (hipStream_t)stream, motion, eps, c0, c1, prev_motion,
+                       indicator, (float*)feats, L, Lp, dm, Kpad, motion_batch);
+  else
+    hipLaunchKernelGGL(pack_input_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, motion, eps, c0, c1,
+                       prev_motion, indicator, (bf16_t*)feats, L, Lp, dm, Kpad, motion_batch);
+  MSMD_RETURN_LAST();
+}
+
+// x (N, T, d) += pe (T, d); row 0 = tok0 (N, d) + pe[0]   (row 0 of x is overwritten, not accumulated)
+template <typename T>
+__global__ void add_pe_token_kernel(T* __restrict__ x, const float* __restrict__ pe, const T* __restrict__ tok0,
+                                    int Tn, int d) {
+  const int n = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Tn * d; i += gridDim.x * blockDim.x) {
+    const int t = i / d, c = i % d;
+    const float base = (t == 0) ? to_f32(tok0[(long)n * d + c]) : to_f32(x[(long)n * Tn * d + i]);
+    x[(long)n * Tn * d + i] = from_f32<T>(base + pe[i]);
+  }
+}
+
+extern "C" int msmd_add_pe_token(void* x, const float* pe, const void* tok0, int N, int T, int d, int dtype,
+                                 msmd_stream_t stream) {
+  if (N <= 0 || T <= 0 || d <= 0 || !tok0) return 1;
+  dim3 grid((T * d + 255) / 256, N), block(256);
+  if (dtype == MSMD_F32)
+    hipLaunchKernelGGL(add_pe_token_kernel<float>, grid, block, 0, (hipStream_t)stream, (float*)x, pe,
+                       (const float*)tok0, T, d);
+  else
+    hipLaunchKernelGGL(add_pe_token_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (bf16_t*)x, pe,
+                       (const bf16_t*)tok0, T, d);
+  MSMD_RETURN_LAST();
+}
+
+// out = dyn + sum_b alpha_b * static_b (dims < dm-3, or all dims when use_head_alpha) ; + sum_b static_b (last 3 dims)
+template <typename T>
+__global__ void heads_mix_kernel(const T* __restrict__ dec, long ld_dec, const T* __restrict__ stat,
+                                 float* __restrict__ out, int L, int dm, int nb, int stat_batch, int use_head_alpha) {
+  const int n = blockIdx.y;
+  const int ns = n % stat_batch;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L * dm; i += gridDim.x * blockDim.x) {
+    const int t = i / dm, k = i % dm;
+    const T* row = dec + ((long)n * L + t) * ld_dec;
+    float v = 0.f;
+    const bool weighted = use_head_alpha || (k < dm - 3);
+    for (int b = 0; b < nb; ++b) {
+      const float s = to_f32(stat[((long)ns * nb + b) * dm + k]);
+      v += weighted ? s * to_f32(row[dm + b]) : s;
+    }
+    out[((long)n * L + t) * dm + k] = to_f32(row[k]) + v;
+  }
+}
+
+extern "C" int msmd_heads_static_mix(const void* dec, long ld_dec, const void* stat, float* out, int N, int L, int dm,
+                                     int nb, int stat_batch, int use_head_alpha, int dtype, msmd_stream_t stream) {
+  if (N <= 0 || L <= 0 || dm <= 3 || nb <= 0 || stat_batch <= 0) return 1;
+  dim3 grid((L * dm + 255) / 256, N), block(256);
+  if (dtype == MSMD_F32)
+    hipLaunchKernelGGL(heads_mix_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)dec, ld_dec,
+                       (const float*)stat, out, L, dm, nb, stat_batch, use_head_alpha);
+  else
+    hipLaunchKernelGGL(heads_mix_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dec, ld_dec,
+                       (const bf16_t*)stat, out, L, dm, nb, stat_batch, use_head_alpha);
+  MSMD_RETURN_LAST();
+}
+
+// CFG combine + DDPM posterior step, in place on x (B, L, dm).  The reference accumulates theta IN PLACE
+// into entry 0's slice (model.py:407-415): `results[0]` IS the running theta, so
+//   incremental: theta += s_e * (r[e+1] - r[e])   with r[0] := running theta when e == 0,
+//   independent: theta += s_e * (r[e+1] - theta)  (later terms see the already-updated entry 0).
+__global__ void cfg_ddpm_kernel(float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ z,
+                                const float* __restrict__ scales, int n_entries, int B, int L, int Lp, int dm,
+                                int mode, int target, float c0, float c1, float sigma) {
+  const long total = (long)B * L * dm;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / ((long)L * dm));
+    const int rem = (int)(i % ((long)L * dm));
+    const int t = rem / dm, k = rem % dm;
+    const long stride_e = (long)B * (Lp + L) * dm;
+    const long off = ((long)b * (Lp + L) + Lp + t) * dm + k;
+    float theta = res[off];
+    for (int e = 0; e < n_entries - 1; ++e) {
+      const float hi = res[(e + 1) * stride_e + off];
+      const float lo = (mode == 1 || e == 0) ? theta : res[e * stride_e + off];
+      theta += scales[e] * (hi - lo);
+    }
+    const float xt = x[i];
+    const float zz = z ? z[i] : 0.f;
+    x[i] = (target == 0) ? (c0 * xt + c1 * theta + sigma * zz) : (c0 * (xt - c1 * theta) + sigma * zz);
+  }
+}
+
+extern "C" int msmd_cfg_ddpm_step(float* x, const float* res, const float* z, const float* scales, int n_entries,
+                                  int B, int L, int Lp, int dm, int mode, int target, float c0, float c1, float sigma,
+                                  msmd_stream_t stream) {
+  if (B <= 0 || L <= 0 || dm <= 0 || n_entries < 1 || (n_entries > 1 && !scales)) return 1;
+  const long total = (long)B * L * dm;
+  dim3 grid((unsigned)min((total + 255) / 256, (long)2048)), block(256);
+  hipLaunchKernelGGL(cfg_ddpm_kernel, grid, block, 0, (hipStream_t)stream, x, res, z, scales, n_entries, B, L, Lp, dm,
+                     mode, target, c0, c1, sigma);
+  MSMD_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ void pad_cols_kernel(const TI* __restrict__ x, TO* __restrict__ y, long rows, int ci, int co) {
+  const long total = rows * co;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / co;
+    const int c = (int)(i % co);
+    y[i] = from_f32<TO>(c < ci ? to_f32(x[r * ci + c]) : 0.f);
+  }
+}
+
+extern "C" int msmd_pad_cols(const void* x, void* y, long rows, int cols_in, int cols_out, int in_dtype, int out_dtype,
+                             msmd_stream_t stream) {
+  if (rows <= 0 || cols_in <= 0 || cols_out <= 0) return 1;
+  const long total = rows * cols_out;
+  dim3 grid((unsigned)min((total + 255) / 256, (long)4096)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (in_dtype == MSMD_F32 && out_dtype == MSMD_F32)
+    hipLaunchKernelGGL((pad_cols_kernel<float, float>), grid, block, 0, st, (const float*)x, (float*)y, rows, cols_in,
+                       cols_out);
+  else if (in_dtype == MSMD_F32 && out_dtype == MSMD_BF16)
+    hipLaunchKernelGGL((pad_cols_kernel<float, bf16_t>), grid, block, 0, st, (const float*)x, (bf16_t*)y, rows,
+                       cols_in, cols_out);
+  else if (in_dtype == MSMD_BF16 && out_dtype == MSMD_F32)
+    hipLaunchKernelGGL((pad_cols_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)x, (float*)y, rows,
+                       cols_in, cols_out);
+  else if (in_dtype == MSMD_BF16 && out_dtype == MSMD_BF16)
+    hipLaunchKernelGGL((pad_cols_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, rows,
+                       cols_in, cols_out);
+  else
+    return 1;
+  MSMD_RETURN_LAST();
+}
+
+extern "C" int msmd_cast(const void* x, void* y, long n, int in_dtype, int out_dtype, msmd_stream_t stream) {
+  if (n <= 0 || n > 0x7fffffffL) return 1;
+  return msmd_pad_cols(x, y, 1, (int)n, (int)n, in_dtype, out_dtype, stream);
+}
+
+extern "C" int msmd_abi_version(void) { return 1; }

@@ -1,0 +1,302 @@
+// FLAME vertex pass: blendshapes + pose correctives + skinning fused in ONE kernel, plus the tiny
+// per-frame kinematics, landmarks and the dynamic-contour LUT row.
+// Reference: utils/lbs.py:141-371, utils/flame.py:126-244.
+//
+// Skinning kernel (the HBM-relevant one): per frame it must write 5023*3 fp32 (60 276 B) and read 186
+// coefficients; everything else (dirs 11.6 MB, weights, template) is frame-invariant and cache resident.
+// The contraction v_posed = template + coef(186) . dirs(186 x 15069) runs on the exact-fp32 MFMA
+// (v_mfma_f32_16x16x4_f32): a workgroup owns 64 vertices (16 per wave), keeps their three coordinate
+// planes of `dirs` in REGISTERS (3 x 48 VGPRs per lane, loaded once) and streams frame tiles of 16
+// through it, so the reference's materialised (B, V, 4, 4) transforms, W.expand and homogeneous
+// coordinates (about 10x the algorithmic bytes) never exist.  The vertex sits on the MFMA lane, so the
+// per-vertex blend T = sum_j w_j A_j and the 3x4 transform are lane-local; 16 lanes store 16 consecutive
+// vertices (192 contiguous bytes) per frame.
+#include "common.h"
+
+__device__ __forceinline__ void rodrigues(const float* r, float* R) {
+  // reference utils/lbs.py:285-300: angle = ||r + 1e-8||, dir = r / angle (un-shifted r)
+  const float x = r[0] + 1e-8f, y = r[1] + 1e-8f, z = r[2] + 1e-8f;
+  const float angle = sqrtf(x * x + y * y + z * z);
+  const float rx = r[0] / angle, ry = r[1] / angle, rz = r[2] / angle;
+  const float s = sinf(angle), c1 = 1.0f - cosf(angle);
+  // K = [[0,-rz,ry],[rz,0,-rx],[-ry,rx,0]];  R = I + s K + (1-c) K K
+  const float K[9] = {0.f, -rz, ry, rz, 0.f, -rx, -ry, rx, 0.f};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float kk = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) kk += K[i * 3 + k] * K[k * 3 + j];
+      R[i * 3 + j] = (i == j ? 1.0f : 0.0f) + s * K[i * 3 + j] + c1 * kk;
+    }
+}
+
+__global__ void rodrigues_kernel(const float* __restrict__ rv, float* __restrict__ R, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float r[3] = {rv[i * 3], rv[i * 3 + 1], rv[i * 3 + 2]}, o[9];
+  rodrigues(r, o);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[(long)i * 9 + k] = o[k];
+}
+
+extern "C" int msmd_batch_rodrigues(const float* rot_vecs, float* R, int N, msmd_stream_t stream) {
+  if (N <= 0) return 1;
+  hipLaunchKernelGGL(rodrigues_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, rot_vecs, R, N);
+  MSMD_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Per-frame kinematics: one wavefront per frame.
+#define LBS_MAXJ 8
+__global__ __launch_bounds__(64) void lbs_prepare_kernel(const float* __restrict__ betas,
+                                                         const float* __restrict__ pose,
+                                                         const float* __restrict__ JS,
+                                                         const int* __restrict__ parents, float* __restrict__ coef,
+                                                         float* __restrict__ A, float* __restrict__ joints_out,
+                                                         int NB, int J, int Kp, int pose_is_matrix) {
+  __shared__ float sJ[LBS_MAXJ * 3];
+  __shared__ float sR[LBS_MAXJ * 9];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* be = betas + (long)b * NB;
+  // joints = J_regressor . (template + sum_l beta_l shapedirs_l): linear, so use the precomputed JS table
+  if (t < J * 3) {
+    float acc = JS[t];
+    for (int l = 0; l < NB; ++l) acc = fmaf(be[l], JS[(long)(1 + l) * J * 3 + t], acc);
+    sJ[t] = acc;
+  }
+  if (t < J) {
+    float R[9];
+    if (pose_is_matrix) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R[k] = pose[((long)b * J + t) * 9 + k];
+    } else {
+      const float r[3] = {pose[((long)b * J + t) * 3], pose[((long)b * J + t) * 3 + 1], pose[((long)b * J + t) * 3 + 2]};
+      rodrigues(r, R);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sR[t * 9 + k] = R[k];
+  }
+  __syncthreads();
+  // coefficient row = [betas | pose_feature = (R[1:] - I) | 0 pad]
+  float* crow = coef + (long)b * Kp;
+  for (int k = t; k < Kp; k += 64) {
+    float v = 0.f;
+    if (k < NB) v = be[k];
+    else if (k < NB + (J - 1) * 9) {
+      const int pf = k - NB, j = 1 + pf / 9, rc = pf % 9;
+      v = sR[j * 9 + rc] - ((rc == 0 || rc == 4 || rc == 8) ? 1.0f : 0.0f);
+    }
+    crow[k] = v;
+  }
+  if (t == 0) {
+    // kinematic chain (utils/lbs.py:317-371): T_0 = [R_0 | J_0]; T_i = T_parent . [R_i | J_i - J_parent]
+    float Tm[LBS_MAXJ][12];
+    for (int i = 0; i < J; ++i) {
+      float loc[12];
+      const int pa = i == 0 ? -1 : parents[i];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) loc[r * 4 + c] = sR[i * 9 + r * 3 + c];
+        loc[r * 4 + 3] = sJ[i * 3 + r] - (pa >= 0 ? sJ[pa * 3 + r] : 0.f);
+      }
+      if (pa < 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Tm[i][k] = loc[k];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float v = Tm[pa][r * 4 + 0] * loc[0 * 4 + c] + Tm[pa][r * 4 + 1] * loc[1 * 4 + c] +
+                      Tm[pa][r * 4 + 2] * loc[2 * 4 + c];
+            if (c == 3) v += Tm[pa][r * 4 + 3];
+            Tm[i][r * 4 + c] = v;
+          }
+        }
+      }
+    }
+    for (int i = 0; i < J; ++i) {
+      float* Ao = A + ((long)b * J + i) * 12;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float tj = Tm[i][r * 4] * sJ[i * 3] + Tm[i][r * 4 + 1] * sJ[i * 3 + 1] + Tm[i][r * 4 + 2] * sJ[i * 3 + 2];
+        Ao[r * 4 + 0] = Tm[i][r * 4 + 0];
+        Ao[r * 4 + 1] = Tm[i][r * 4 + 1];
+        Ao[r * 4 + 2] = Tm[i][r * 4 + 2];
+        Ao[r * 4 + 3] = Tm[i][r * 4 + 3] - tj;
+        if (joints_out) joints_out[((long)b * J + i) * 3 + r] = Tm[i][r * 4 + 3];
+      }
+    }
+  }
+}
+
+extern "C" int msmd_lbs_prepare(const float* betas, const float* pose, const float* JS, const int* parents,
+                                float* coef, float* A, float* joints, int B, int NB, int J, int Kp,
+                                int pose_is_matrix, msmd_stream_t stream) {
+  if (B <= 0 || NB <= 0 || J <= 0 || J > LBS_MAXJ || Kp < NB + (J - 1) * 9) return 1;
+  hipLaunchKernelGGL(lbs_prepare_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, betas, pose, JS, parents, coef, A,
+                     joints, NB, J, Kp, pose_is_matrix);
+  MSMD_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused blendshape + skinning.  KS = Kp / 4 MFMA steps; lane (q = l>>4, i = l&15) owns k = q*KS + s at
+// step s for BOTH operands (a K permutation leaves the contraction unchanged).
+template <int KS, int J>
+__global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__ coef, const float* __restrict__ A,
+                                                       const float* __restrict__ tmpl, const float* __restrict__ dirs,
+                                                       const float* __restrict__ wts, float* __restrict__ verts, int B,
+                                                       int V, int Vp, int frames_per_block) {
+  constexpr int Kp = KS * 4;
+  __shared__ __attribute__((aligned(16))) float sA[16 * J * 12];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int v = blockIdx.x * 64 + wid * 16 + i;  // < Vp by construction
+  const int f_begin = blockIdx.y * frames_per_block;
+  const int f_end = min(B, f_begin + frames_per_block);
+
+  // frame-invariant operands -> registers
+  float d[3][KS];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) d[c][s] = dirs[((long)c * Kp + q * KS + s) * Vp + v];
+  float t3[3], w[J];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) t3[c] = tmpl[(long)c * Vp + v];
+#pragma unroll
+  for (int j = 0; j < J; ++j) w[j] = wts[(long)j * Vp + v];
+
+  for (int f0 = f_begin; f0 < f_end; f0 += 16) {
+    __syncthreads();
+    for (int k = tid; k < 16 * J * 12; k += 256) {
+      const int f = f0 + k / (J * 12);
+      sA[k] = f < f_end ? A[(long)f * J * 12 + k % (J * 12)] : 0.f;
+    }
+    // A operand: row = frame f0 + i, k = q*KS + s  (16-B loads, 4 steps each)
+    const int fa = min(f0 + i, B - 1);
+    const float* crow = coef + (long)fa * Kp + q * KS;
+    f32x4 acc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < KS / 4; ++s4) {
+      const f32x4 a = *(const f32x4*)(crow + s4 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], d[c][s4 * 4 + e], acc[c], 0, 0, 0);
+    }
+    __syncthreads();
+    // epilogue: lane = vertex v, frames f0 + 4q + e
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int fl = 4 * q + e, f = f0 + fl;
+      float T[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) T[k] = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const f32x4* ap = (const f32x4*)(sA + (fl * J + j) * 12);
+        const f32x4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          T[k] = fmaf(w[j], a0[k], T[k]);
+          T[4 + k] = fmaf(w[j], a1[k], T[4 + k]);
+          T[8 + k] = fmaf(w[j], a2[k], T[8 + k]);
+        }
+      }
+      const float px = t3[0] + acc[0][e], py = t3[1] + acc[1][e], pz = t3[2] + acc[2][e];
+      if (f < f_end && v < V) {
+        float* o = verts + ((long)f * V + v) * 3;
+        o[0] = T[0] * px + T[1] * py + T[2] * pz + T[3];
+        o[1] = T[4] * px + T[5] * py + T[6] * pz + T[7];
+        o[2] = T[8] * px + T[9] * py + T[10] * pz + T[11];
+      }
+    }
+  }
+}
+
+extern "C" int msmd_lbs_skin(const float* coef, const float* A, const float* v_template, const float* dirs,
+                             const float* lbs_weights, float* verts, int B, int J, int V, int Vp, int Kp,
+                             msmd_stream_t stream) {
+  if (B <= 0 || V <= 0 || Vp < V || (Vp & 63) || J != 5 || Kp != 192) return 1;  // FLAME2020 geometry
+  // enough frame splits to fill 256 CUs, at least 64 frames per workgroup to amortise the dirs load
+  const int vt = Vp / 64;
+  int splits = max(1, min((B + 63) / 64, (2048 + vt - 1) / vt));
+  int fpb = (((B + splits - 1) / splits) + 15) / 16 * 16;
+  splits = (B + fpb - 1) / fpb;
+  dim3 grid(vt, splits), block(256);
+  hipLaunchKernelGGL((lbs_skin_kernel<48, 5>), grid, block, 0, (hipStream_t)stream, coef, A, v_template, dirs,
+                     lbs_weights, verts, B, V, Vp, fpb);
+  MSMD_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void landmarks_kernel(const float* __restrict__ verts, const int* __restrict__ faces,
+                                 const int* __restrict__ idx, long idx_bs, const float* __restrict__ bary, long bary_bs,
+                                 float* __restrict__ out, int B, int V, int L) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * L) return;
+  const int b = t / L, l = t % L;
+  const int face = idx[b * idx_bs + l];
+  const float* bc = bary + b * bary_bs + (long)l * 3;
+  float o[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int f = 0; f < 3; ++f) {
+    const int vi = faces[(long)face * 3 + f];
+    const float* vp = verts + ((long)b * V + vi) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] += vp[c] * bc[f];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[(long)t * 3 + c] = o[c];
+}
+
+extern "C" int msmd_landmarks(const float* verts, const int* faces, const int* lmk_faces_idx, long idx_bstride,
+                              const float* bary, long bary_bstride, float* out, int B, int V, int L,
+                              msmd_stream_t stream) {
+  if (B <= 0 || V <= 0 || L <= 0) return 1;
+  hipLaunchKernelGGL(landmarks_kernel, dim3((B * L + 255) / 256), dim3(256), 0, (hipStream_t)stream, verts, faces,
+                     lmk_faces_idx, idx_bstride, bary, bary_bstride, out, B, V, L);
+  MSMD_RETURN_LAST();
+}
+
+// LUT row of utils/flame.py:126-172 (pose2rot=True): relative neck rotation -> yaw degrees -> row in [0, 78]
+__global__ void dyn_lmk_row_kernel(const float* __restrict__ full_pose, const int* __restrict__ chain, int n_chain,
+                                   int* __restrict__ row, int B, int J) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float rel[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+  for (int n = 0; n < n_chain; ++n) {
+    const int j = chain[n];
+    const float r[3] = {full_pose[((long)b * J + j) * 3], full_pose[((long)b * J + j) * 3 + 1],
+                        full_pose[((long)b * J + j) * 3 + 2]};
+    float R[9], o[9];
+    rodrigues(r, R);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) o[i * 3 + k] = R[i * 3] * rel[k] + R[i * 3 + 1] * rel[3 + k] + R[i * 3 + 2] * rel[6 + k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rel[k] = o[k];
+  }
+  const float sy = sqrtf(rel[0] * rel[0] + rel[3] * rel[3]);
+  const float ang = atan2f(-rel[6], sy) * 180.0f / 3.14159265358979323846f;
+  long y = (long)rintf(fminf(ang, 39.0f));  // torch.round = round-half-to-even
+  const long neg = y < 0 ? 1 : 0, m = y < -39 ? 1 : 0;
+  const long neg_vals = m * 78 + (1 - m) * (39 - y);
+  row[b] = (int)(neg * neg_vals + (1 - neg) * y);
+}
+
+extern "C" int msmd_dynamic_lmk_row(const float* full_pose, const int* neck_chain, int n_chain, int* row, int B, int J,
+                                    msmd_stream_t stream) {
+  if (B <= 0 || n_chain <= 0) return 1;
+  hipLaunchKernelGGL(dyn_lmk_row_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, full_pose,
+                     neck_chain, n_chain, row, B, J);
+  MSMD_RETURN_LAST();
+}

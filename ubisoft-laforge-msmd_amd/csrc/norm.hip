@@ -1,0 +1,143 @@
+// Row-wise LayerNorm and small reductions (HBM-bound; one wavefront per row, values kept in registers).
+#include "common.h"
+
+template <typename T> __device__ __forceinline__ void load4(const T* p, float* v);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float* v) {
+  const f32x4 t = *(const f32x4*)p;
+  v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float* v) {
+  const bf16x4 t = *(const bf16x4*)p;
+  v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float* v);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float* v) {
+  *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float* v) {
+  *(bf16x4*)p = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+}
+
+// cols % 4 == 0, cols <= 4 * 64 * MAXC
+template <typename TI, typename TO, int MAXC>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, const TI* __restrict__ res,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        const float* __restrict__ post, TO* __restrict__ y, int rows,
+                                                        int cols, float eps, int act) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = cols >> 2;
+  float v[MAXC][4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nchunk) {
+      load4<TI>(x + (long)row * cols + c * 4, v[i]);
+      if (res) {
+        float r[4];
+        load4<TI>(res + (long)row * cols + c * 4, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] += r[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[i][e] = apply_act(v[i][e], act);
+        s += v[i][e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cols + eps);
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nchunk) {
+      float g[4], b[4], o[4];
+      load4<float>(gamma + c * 4, g);
+      load4<float>(beta + c * 4, b);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+      if (post) {
+        float pa[4];
+        load4<float>(post + c * 4, pa);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += pa[e];
+      }
+      store4<TO>(y + (long)row * cols + c * 4, o);
+    }
+  }
+}
+
+template <typename TI, typename TO>
+static int launch_ln(const void* x, const void* res, const float* g, const float* b, const float* post, void* y,
+                     int rows, int cols, float eps, int act, hipStream_t st) {
+  dim3 grid((rows + 3) / 4), block(256);
+  if (cols <= 4 * 64 * 2)
+    hipLaunchKernelGGL((layernorm_kernel<TI, TO, 2>), grid, block, 0, st, (const TI*)x, (const TI*)res, g, b, post,
+                       (TO*)y, rows, cols, eps, act);
+  else if (cols <= 4 * 64 * 4)
+    hipLaunchKernelGGL((layernorm_kernel<TI, TO, 4>), grid, block, 0, st, (const TI*)x, (const TI*)res, g, b, post,
+                       (TO*)y, rows, cols, eps, act);
+  else if (cols <= 4 * 64 * 16)
+    hipLaunchKernelGGL((layernorm_kernel<TI, TO, 16>), grid, block, 0, st, (const TI*)x, (const TI*)res, g, b, post,
+                       (TO*)y, rows, cols, eps, act);
+  else
+    return 1;
+  MSMD_RETURN_LAST();
+}
+
+extern "C" int msmd_layernorm(const void* x, const void* residual, const float* gamma, const float* beta,
+                              const float* post_add, void* y, int rows, int cols, float eps, int act, int in_dtype,
+                              int out_dtype, msmd_stream_t stream) {
+  if (rows <= 0 || cols <= 0 || (cols & 3) || !x || !y || !gamma || !beta) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (in_dtype == MSMD_F32 && out_dtype == MSMD_F32)
+    return launch_ln<float, float>(x, residual, gamma, beta, post_add, y, rows, cols, eps, act, st);
+  if (in_dtype == MSMD_BF16 && out_dtype == MSMD_BF16)
+    return launch_ln<bf16_t, bf16_t>(x, residual, gamma, beta, post_add, y, rows, cols, eps, act, st);
+  if (in_dtype == MSMD_BF16 && out_dtype == MSMD_F32)
+    return launch_ln<bf16_t, float>(x, residual, gamma, beta, post_add, y, rows, cols, eps, act, st);
+  if (in_dtype == MSMD_F32 && out_dtype == MSMD_BF16)
+    return launch_ln<float, bf16_t>(x, residual, gamma, beta, post_add, y, rows, cols, eps, act, st);
+  return 1;
+}
+
+// mean over time of a channels-last (B, T, C) tensor -> (B, C) fp32
+template <typename T>
+__global__ void mean_time_kernel(const T* __restrict__ x, float* __restrict__ y, int Tn, int C) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const T* p = x + (long)b * Tn * C + c;
+  float s = 0.f;
+  for (int t = 0; t < Tn; ++t) s += to_f32(p[(long)t * C]);
+  y[(long)b * C + c] = s / (float)Tn;
+}
+
+extern "C" int msmd_mean_time(const void* x, float* y, int B, int T, int C, int dtype, msmd_stream_t stream) {
+  if (B <= 0 || T <= 0 || C <= 0) return 1;
+  dim3 grid((C + 255) / 256, B), block(256);
+  if (dtype == MSMD_F32)
+    hipLaunchKernelGGL(mean_time_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)x, y, T, C);
+  else
+    hipLaunchKernelGGL(mean_time_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, y, T, C);
+  MSMD_RETURN_LAST();
+}

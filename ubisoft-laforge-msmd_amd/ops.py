@@ -1,0 +1,281 @@
+"""Tensor-level shims over the C ABI (include/msmd_hip.h).
+
+PyTorch is plumbing here: it owns device memory (caching allocator, so no
+hipMalloc in steady state) and the current HIP stream; every op below hands raw
+device pointers + sizes to a hand-written gfx950 kernel.  All ops launch on
+``torch.cuda.current_stream()`` and never synchronise, so sequences of them can
+be captured in a hipGraph (torch.cuda.CUDAGraph).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_ELU = 0, 1, 2
+CONV0_SPLITS = 16
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("msmd_amd ops need tensors on the MI355X (cuda) device; there is no CPU path")
+
+
+def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None, *, M=None, K=None, lda=None,
+         rows_per_batch=0, a_batch_stride=0, batch=1, strideA=0, strideW=0, strideC=0, strideBias=0, strideR=0,
+         N=None, ldw=None, ldc=None):
+    """C = act(A @ W^T + bias) + residual.  a: (..., K) contiguous unless M/K/lda describe a windowed view;
+    w: (N, K) (or (batch, N, K) with strideW).  Returns C with a's leading dims + (N,)."""
+    _need_cuda(a, w, bias, residual)
+    lib = _lib.load()
+    if K is None:
+        K = a.shape[-1]
+    if M is None:
+        M = a.numel() // K
+    if N is None:
+        N = w.shape[-2]
+    if lda is None:
+        lda = K
+    if ldw is None:
+        ldw = w.shape[-1]
+    out_dtype = out_dtype or a.dtype
+    if out is None:
+        lead = a.shape[:-1] if a.numel() // a.shape[-1] == M and batch == 1 else (M,)
+        out = torch.empty(*lead, N, device=a.device, dtype=out_dtype)
+    if ldc is None:
+        ldc = N
+    ldr = residual.stride(-2) if residual is not None and residual.dim() >= 2 else N
+    if bias is not None and bias.dtype != torch.float32:
+        raise TypeError("bias must be fp32")
+    _lib.check(lib.msmd_gemm(_p(a), _p(w), _p(bias), _p(residual), _p(out), M, N, K, _dt(a), _dt(out), lda,
+                             rows_per_batch, a_batch_stride, ldw, ldc, ldr, act, batch, strideA, strideW, strideC,
+                             strideBias, strideR, _stream()), "msmd_gemm")
+    return out
+
+
+def conv1d_cl(x, w_packed, bias=None, *, kernel, stride, act=ACT_NONE, out_dtype=None):
+    """Strided Conv1d over a channels-last (B, T, C) signal as ONE windowed GEMM (no im2col).
+    w_packed: (Cout, kernel*C) with K index = kk*C + c."""
+    B, T, C = x.shape
+    T_out = (T - kernel) // stride + 1
+    out = torch.empty(B, T_out, w_packed.shape[0], device=x.device, dtype=out_dtype or x.dtype)
+    gemm(x, w_packed, bias, None, act, out=out, M=B * T_out, K=kernel * C, lda=stride * C, rows_per_batch=T_out,
+         a_batch_stride=T * C)
+    return out
+
+
+def layernorm(x, gamma, beta, residual=None, post_add=None, act=ACT_NONE, eps=1e-5, out_dtype=None):
+    _need_cuda(x, gamma, beta)
+    lib = _lib.load()
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    y = torch.empty(x.shape, device=x.device, dtype=out_dtype or x.dtype)
+    _lib.check(lib.msmd_layernorm(_p(x), _p(residual), _p(gamma), _p(beta), _p(post_add), _p(y), rows, cols, eps, act,
+                                  _dt(x), _dt(y), _stream()), "msmd_layernorm")
+    return y
+
+
+def attention(q, k, v, n_heads, scale, mask=None, out=None):
+    """q: (B, Tq, H*64) view, k/v: (B, Tk, H*64) views (last dim contiguous; may be slices of a packed QKV)."""
+    _need_cuda(q, k, v)
+    lib = _lib.load()
+    B, Tq, d = q.shape
+    Tk = k.shape[1]
+    assert d == n_heads * 64 and q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1
+    if out is None:
+        out = torch.empty(B, Tq, d, device=q.device, dtype=q.dtype)
+    m = None
+    if mask is not None:
+        assert mask.dtype in (torch.bool, torch.uint8) and mask.shape == (Tq, Tk) and mask.is_contiguous()
+        m = mask
+    _lib.check(lib.msmd_attention(_p(q), _p(k), _p(v), _p(out), B, n_heads, Tq, Tk, q.stride(0), q.stride(1),
+                                  k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),
+                                  float(scale), _p(m), _dt(q), _stream()), "msmd_attention")
+    return out
+
+
+def pad_audio(audio, reflect_len, replicate_len):
+    lib = _lib.load()
+    B, L = audio.shape
+    out = torch.empty(B, L + 4 * reflect_len + 2 * replicate_len, device=audio.device, dtype=torch.float32)
+    _lib.check(lib.msmd_pad_audio(_p(audio), _p(out), B, L, reflect_len, replicate_len, _stream()), "msmd_pad_audio")
+    return out
+
+
+def conv0_gn_gelu(audio, w0, gamma, beta, reflect_len, replicate_len, out_dtype, eps=1e-5):
+    """GELU(GroupNorm(conv0(pad_audio(audio)))) -> (B, T0, C) channels-last."""
+    lib = _lib.load()
+    B, L = audio.shape
+    C = w0.shape[0]
+    Lp = L + 4 * reflect_len + 2 * replicate_len
+    T0 = (Lp - 10) // 5 + 1
+    stats = torch.empty(B, C, 2, device=audio.device, dtype=torch.float32)
+    ws = torch.empty(B, CONV0_SPLITS, C, 2, device=audio.device, dtype=torch.float32)
+    _lib.check(lib.msmd_conv0_stats(_p(audio), _p(w0), _p(stats), _p(ws), B, L, reflect_len, replicate_len, C, eps,
+                                    _stream()), "msmd_conv0_stats")
+    out = torch.empty(B, T0, C, device=audio.device, dtype=out_dtype)
+    _lib.check(lib.msmd_conv0_gn_gelu(_p(audio), _p(w0), _p(stats), _p(gamma), _p(beta), _p(out), B, L, reflect_len,
+                                      replicate_len, C, _dt(out), _stream()), "msmd_conv0_gn_gelu")
+    return out
+
+
+def interp_linear(x, t_out, t_crop=None):
+    lib = _lib.load()
+    B, T, C = x.shape
+    t_crop = T if t_crop is None else min(int(t_crop), T)  # slicing past the end clamps (utils/wav2vec2.py:83)
+    y = torch.empty(B, t_out, C, device=x.device, dtype=x.dtype)
+    _lib.check(lib.msmd_interp_linear(_p(x), _p(y), B, T, t_crop, t_out, C, _dt(x), _stream()), "msmd_interp_linear")
+    return y
+
+
+def group_pad(x, groups, pad):
+    lib = _lib.load()
+    B, T, C = x.shape
+    y = torch.empty(B, groups, T + 2 * pad, C // groups, device=x.device, dtype=x.dtype)
+    _lib.check(lib.msmd_group_pad(_p(x), _p(y), B, T, groups, C // groups, pad, _dt(x), _stream()), "msmd_group_pad")
+    return y
+
+
+def denoiser_pack_input(motion, prev_motion, indicator, feats, eps=None, c0=None, c1=None):
+    lib = _lib.load()
+    N, Tn, Kpad = feats.shape
+    L, dm = motion.shape[1], motion.shape[2]
+    Lp = prev_motion.shape[1]
+    assert Tn == 1 + Lp + L
+    _lib.check(lib.msmd_denoiser_pack_input(_p(motion), _p(eps), _p(c0), _p(c1), _p(prev_motion), _p(indicator),
+                                            _p(feats), N, L, Lp, dm, Kpad, motion.shape[0], _dt(feats), _stream()),
+               "msmd_denoiser_pack_input")
+    return feats
+
+
+def add_pe_token(x, pe, tok0):
+    lib = _lib.load()
+    N, T, d = x.shape
+    _lib.check(lib.msmd_add_pe_token(_p(x), _p(pe), _p(tok0), N, T, d, _dt(x), _stream()), "msmd_add_pe_token")
+    return x
+
+
+def heads_static_mix(dec, stat, L, dm, nb, use_head_alpha=False):
+    lib = _lib.load()
+    N = dec.shape[0]
+    out = torch.empty(N, L, dm, device=dec.device, dtype=torch.float32)
+    _lib.check(lib.msmd_heads_static_mix(_p(dec), dec.stride(1), _p(stat), _p(out), N, L, dm, nb, stat.shape[0],
+                                         int(use_head_alpha), _dt(dec), _stream()), "msmd_heads_static_mix")
+    return out
+
+
+def cfg_ddpm_step(x, res, z, scales, n_entries, Lp, mode, target, c0, c1, sigma):
+    lib = _lib.load()
+    B, L, dm = x.shape
+    _lib.check(lib.msmd_cfg_ddpm_step(_p(x), _p(res), _p(z), _p(scales), n_entries, B, L, Lp, dm, mode, target,
+                                      float(c0), float(c1), float(sigma), _stream()), "msmd_cfg_ddpm_step")
+    return x
+
+
+def pad_cols(x, cols_out, out_dtype=None):
+    lib = _lib.load()
+    cols_in = x.shape[-1]
+    rows = x.numel() // cols_in
+    y = torch.empty(*x.shape[:-1], cols_out, device=x.device, dtype=out_dtype or x.dtype)
+    _lib.check(lib.msmd_pad_cols(_p(x), _p(y), rows, cols_in, cols_out, _dt(x), _dt(y), _stream()), "msmd_pad_cols")
+    return y
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    return pad_cols(x.contiguous(), x.shape[-1], dtype)
+
+
+def mean_time(x):
+    lib = _lib.load()
+    B, T, C = x.shape
+    y = torch.empty(B, C, device=x.device, dtype=torch.float32)
+    _lib.check(lib.msmd_mean_time(_p(x), _p(y), B, T, C, _dt(x), _stream()), "msmd_mean_time")
+    return y
+
+
+# ----------------------------------------------------------------------------- FLAME
+def lbs_prepare(betas, pose, JS, parents, Kp=192, pose_is_matrix=False, want_joints=True):
+    lib = _lib.load()
+    B, NB = betas.shape
+    J = parents.shape[0]
+    coef = torch.empty(B, Kp, device=betas.device, dtype=torch.float32)
+    A = torch.empty(B, J, 12, device=betas.device, dtype=torch.float32)
+    joints = torch.empty(B, J, 3, device=betas.device, dtype=torch.float32) if want_joints else None
+    _lib.check(lib.msmd_lbs_prepare(_p(betas), _p(pose), _p(JS), _p(parents), _p(coef), _p(A), _p(joints), B, NB, J,
+                                    Kp, int(pose_is_matrix), _stream()), "msmd_lbs_prepare")
+    return coef, A, joints
+
+
+def lbs_skin(coef, A, v_template_planes, dirs, weight_planes, V):
+    lib = _lib.load()
+    B, Kp = coef.shape
+    J = A.shape[1]
+    Vp = dirs.shape[-1]
+    verts = torch.empty(B, V, 3, device=coef.device, dtype=torch.float32)
+    _lib.check(lib.msmd_lbs_skin(_p(coef), _p(A), _p(v_template_planes), _p(dirs), _p(weight_planes), _p(verts), B, J,
+                                 V, Vp, Kp, _stream()), "msmd_lbs_skin")
+    return verts
+
+
+def landmarks(verts, faces_i32, lmk_faces_idx_i32, bary):
+    """lmk_faces_idx: (L,) / (1, L) shared or (B, L) per frame; bary likewise (.., L, 3)."""
+    lib = _lib.load()
+    B, V, _ = verts.shape
+    idx = lmk_faces_idx_i32.reshape(-1, lmk_faces_idx_i32.shape[-1])
+    bc = bary.reshape(-1, bary.shape[-2], 3)
+    L = idx.shape[1]
+    out = torch.empty(B, L, 3, device=verts.device, dtype=torch.float32)
+    _lib.check(lib.msmd_landmarks(_p(verts), _p(faces_i32), _p(idx), L if idx.shape[0] > 1 else 0, _p(bc),
+                                  L * 3 if bc.shape[0] > 1 else 0, _p(out), B, V, L, _stream()), "msmd_landmarks")
+    return out
+
+
+def dynamic_lmk_row(full_pose, neck_chain_i32):
+    lib = _lib.load()
+    B = full_pose.shape[0]
+    J = full_pose.shape[1] // 3
+    row = torch.empty(B, device=full_pose.device, dtype=torch.int32)
+    _lib.check(lib.msmd_dynamic_lmk_row(_p(full_pose), _p(neck_chain_i32), neck_chain_i32.shape[0], _p(row), B, J,
+                                        _stream()), "msmd_dynamic_lmk_row")
+    return row
+
+
+def batch_rodrigues(rot_vecs):
+    lib = _lib.load()
+    N = rot_vecs.shape[0]
+    R = torch.empty(N, 3, 3, device=rot_vecs.device, dtype=torch.float32)
+    _lib.check(lib.msmd_batch_rodrigues(_p(rot_vecs), _p(R), N, _stream()), "msmd_batch_rodrigues")
+    return R
+
+
+def rotation_convert(op, x, in_width, out_shape_tail, x2=None, conv=0):
+    """Generic elementwise rotation conversion: x (..., in_width[, in_width2]) -> (..., *out_shape_tail)."""
+    lib = _lib.load()
+    x = x.contiguous().float()
+    n = x.numel() // in_width
+    lead = x.shape[:-1] if in_width in (3, 4, 6) else x.shape[:-2]
+    out = torch.empty(*lead, *out_shape_tail, device=x.device, dtype=torch.float32)
+    if x2 is not None:
+        x2 = x2.contiguous().float()
+    _lib.check(lib.msmd_rotation_convert(op, _p(x), _p(x2), _p(out), n, conv, _stream()), "msmd_rotation_convert")
+    return out

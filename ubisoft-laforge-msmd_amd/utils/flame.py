@@ -1,0 +1,131 @@
+"""FLAME head model on the MI355X (drop-in surface of reference utils/flame.py:59-244)."""
+from __future__ import annotations
+
+import pickle
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import lbs as _lbs
+
+FLAMEConfig = SimpleNamespace(
+    flame_model_path="/code/models/flame_data/FLAME2020/generic_model.pkl",
+    n_shape=100, n_exp=50, n_tex=50, tex_type="BFM",
+    tex_path="/code/models/flame_data/FLAME2020/FLAME_albedo_from_BFM.npz",
+    flame_lmk_embedding_path="/code/models/flame_data/landmark_embedding.npy",
+)
+
+
+def _np(a, dtype=np.float32):
+    if "scipy.sparse" in str(type(a)):
+        a = a.todense()
+    return np.array(a, dtype=dtype)
+
+
+class FLAME(nn.Module):
+    """Same buffers, constructor argument and forward signature as the reference class.
+    ``config`` may also carry ``asset`` (a dict with the pickle's arrays + 'lmk') so tests can
+    build the module from the synthetic asset without touching the filesystem."""
+
+    def __init__(self, config):
+        super().__init__()
+        asset = getattr(config, "asset", None)
+        if asset is None:
+            with open(config.flame_model_path, "rb") as f:
+                asset = dict(pickle.load(f, encoding="latin1"))
+            lmk = np.load(config.flame_lmk_embedding_path, allow_pickle=True, encoding="latin1")[()]
+        else:
+            lmk = asset["lmk"]
+        self.dtype = torch.float32
+        self.register_buffer("faces_tensor", torch.tensor(_np(asset["f"], np.int64), dtype=torch.long))
+        self.register_buffer("v_template", torch.tensor(_np(asset["v_template"])))
+        sd = torch.tensor(_np(asset["shapedirs"]))
+        sd = torch.cat([sd[:, :, :config.n_shape], sd[:, :, 300:300 + config.n_exp]], 2)
+        self.register_buffer("shapedirs", sd)
+        npb = asset["posedirs"].shape[-1]
+        self.register_buffer("posedirs", torch.tensor(_np(np.reshape(asset["posedirs"], [-1, npb]).T)))
+        self.register_buffer("J_regressor", torch.tensor(_np(asset["J_regressor"])))
+        parents = torch.tensor(_np(asset["kintree_table"][0], np.int64)).long()
+        parents[0] = -1
+        self.register_buffer("parents", parents)
+        self.register_buffer("lbs_weights", torch.tensor(_np(asset["weights"])))
+        self.register_parameter("eye_pose", nn.Parameter(torch.zeros(1, 6), requires_grad=False))
+        self.register_parameter("eye_pose_mat", nn.Parameter(torch.eye(3).view(1, 9).repeat(1, 2), requires_grad=False))
+        self.register_parameter("neck_pose", nn.Parameter(torch.zeros(1, 3), requires_grad=False))
+        self.register_parameter("neck_pose_mat", nn.Parameter(torch.eye(3).view(1, 9), requires_grad=False))
+
+        def _t(x, dt):
+            return (x if torch.is_tensor(x) else torch.from_numpy(np.asarray(x))).to(dt)
+        self.register_buffer("lmk_faces_idx", _t(lmk["static_lmk_faces_idx"], torch.long))
+        self.register_buffer("lmk_bary_coords", _t(lmk["static_lmk_bary_coords"], torch.float32))
+        self.register_buffer("dynamic_lmk_faces_idx", _t(lmk["dynamic_lmk_faces_idx"], torch.long))
+        self.register_buffer("dynamic_lmk_bary_coords", _t(lmk["dynamic_lmk_bary_coords"], torch.float32))
+        self.register_buffer("full_lmk_faces_idx", _t(lmk["full_lmk_faces_idx"], torch.long))
+        self.register_buffer("full_lmk_bary_coords", _t(lmk["full_lmk_bary_coords"], torch.float32))
+        chain, cur = [], 1
+        while cur != -1:
+            chain.append(cur)
+            cur = int(parents[cur])
+        self.register_buffer("neck_kin_chain", torch.tensor(chain, dtype=torch.long))
+        self._packed = None
+
+    def _pack(self):
+        if self._packed is None or self._packed["dev"] != self.v_template.device:
+            self._packed = dict(
+                dev=self.v_template.device,
+                lbs=_lbs.LbsConstants(self.v_template, self.shapedirs, self.posedirs, self.J_regressor, self.parents,
+                                      self.lbs_weights),
+                faces=self.faces_tensor.to(torch.int32).contiguous(),
+                chain=self.neck_kin_chain.to(torch.int32).contiguous(),
+                static_idx=self.lmk_faces_idx.to(torch.int32).contiguous(),
+                dyn_idx=self.dynamic_lmk_faces_idx.to(torch.int32).contiguous(),
+                full_idx=self.full_lmk_faces_idx.to(torch.int32).contiguous(),
+            )
+        return self._packed
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def seletec_3d68(self, vertices):
+        p = self._pack()
+        return ops.landmarks(vertices.float().contiguous(), p["faces"], p["full_idx"], self.full_lmk_bary_coords)
+
+    def forward(self, shape_params=None, expression_params=None, pose_params=None, eye_pose_params=None,
+                pose2rot=True, ignore_global_rot=False, return_lm2d=True, return_lm3d=True):
+        """reference utils/flame.py:180-244."""
+        p = self._pack()
+        B = shape_params.shape[0]
+        betas = torch.cat([shape_params, expression_params], dim=1).float().contiguous()
+        if pose2rot:
+            if pose_params is None:
+                pose_params = self.eye_pose.expand(B, -1)
+            if eye_pose_params is None:
+                eye_pose_params = self.eye_pose.expand(B, -1)
+            head = pose_params[:, :3] if not ignore_global_rot else torch.zeros_like(pose_params[:, :3])
+            full_pose = torch.cat([head, self.neck_pose.expand(B, -1), pose_params[:, 3:], eye_pose_params], dim=1)
+        else:
+            if pose_params is None:
+                pose_params = self.eye_pose_mat.expand(B, -1)
+            if eye_pose_params is None:
+                eye_pose_params = self.eye_pose_mat.expand(B, -1)
+            head = pose_params[:, :9] if not ignore_global_rot else self.eye_pose_mat.expand(B, -1)[:, :9]
+            full_pose = torch.cat([head, self.neck_pose_mat.expand(B, -1), pose_params[:, 9:], eye_pose_params], dim=1)
+        full_pose = full_pose.float().contiguous()
+        vertices, _ = _lbs.lbs(betas, full_pose, self.v_template, self.shapedirs, self.posedirs, self.J_regressor,
+                               self.parents, self.lbs_weights, pose2rot, self.dtype, constants=p["lbs"])
+        landmarks2d = landmarks3d = None
+        if return_lm2d:
+            if not pose2rot:
+                raise NotImplementedError("dynamic landmarks from rotation-matrix poses are not built yet")
+            row = ops.dynamic_lmk_row(full_pose, p["chain"]).long()
+            idx = torch.cat([p["dyn_idx"][row], p["static_idx"].unsqueeze(0).expand(B, -1)], 1).contiguous()
+            bary = torch.cat([self.dynamic_lmk_bary_coords[row], self.lmk_bary_coords.unsqueeze(0).expand(B, -1, -1)],
+                             1).contiguous()
+            landmarks2d = ops.landmarks(vertices, p["faces"], idx, bary)
+        if return_lm3d:
+            landmarks3d = ops.landmarks(vertices, p["faces"], p["full_idx"], self.full_lmk_bary_coords)
+        return vertices, landmarks2d, landmarks3d

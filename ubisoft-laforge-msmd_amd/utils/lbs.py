@@ -1,0 +1,90 @@
+"""Linear blend skinning on the MI355X (drop-in surface of reference utils/lbs.py).
+
+``lbs(...)`` keeps the reference signature (utils/lbs.py:141) but runs as two HIP launches
+(csrc/flame.hip): a per-frame kinematics kernel and one fused blendshape+skinning kernel; the
+reference's (B, V, 4, 4) transforms and homogeneous coordinates are never materialised.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+
+KP = 192  # 150 shape/expression coefficients + 36 pose-corrective features, padded to a multiple of 16
+
+
+class LbsConstants:
+    """Frame-invariant FLAME tensors repacked once for the kernels (plumbing, load time)."""
+
+    def __init__(self, v_template, shapedirs, posedirs, J_regressor, parents, lbs_weights):
+        dev = v_template.device
+        V = v_template.shape[0]
+        NB = shapedirs.shape[2]
+        J = J_regressor.shape[0]
+        assert NB + (J - 1) * 9 <= KP
+        Vp = (V + 63) // 64 * 64
+        self.V, self.Vp, self.NB, self.J = V, Vp, NB, J
+        vt = v_template.float()
+        sd = shapedirs.float()
+        Jr = J_regressor.float()
+        # joint regression table: rows [template ; each blendshape] -> (NB+1, J*3)
+        js0 = (Jr @ vt).reshape(1, J * 3)
+        jsl = torch.einsum("ji,ikl->ljk", Jr, sd).reshape(NB, J * 3)
+        self.JS = torch.cat([js0, jsl], 0).contiguous()
+        dirs = torch.zeros(3, KP, Vp, device=dev, dtype=torch.float32)
+        dirs[:, :NB, :V] = sd.permute(1, 2, 0)                      # (3, NB, V)
+        pd = posedirs.float().reshape(-1, V, 3)                      # (P, V, 3)
+        dirs[:, NB:NB + pd.shape[0], :V] = pd.permute(2, 0, 1)
+        self.dirs = dirs.contiguous()
+        tp = torch.zeros(3, Vp, device=dev, dtype=torch.float32)
+        tp[:, :V] = vt.t()
+        self.template_planes = tp.contiguous()
+        wp = torch.zeros(J, Vp, device=dev, dtype=torch.float32)
+        wp[:, :V] = lbs_weights.float().t()
+        self.weight_planes = wp.contiguous()
+        par = parents.to(torch.int32).clone()
+        par[0] = -1
+        self.parents = par.contiguous()
+
+
+_CACHE = {}
+
+
+def _constants(v_template, shapedirs, posedirs, J_regressor, parents, lbs_weights):
+    key = (v_template.data_ptr(), shapedirs.data_ptr(), posedirs.data_ptr(), lbs_weights.data_ptr())
+    c = _CACHE.get(key)
+    if c is None:
+        vt = v_template[0] if v_template.dim() == 3 else v_template
+        c = _CACHE[key] = LbsConstants(vt, shapedirs, posedirs, J_regressor, parents, lbs_weights)
+    return c
+
+
+def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_weights, pose2rot=True,
+        dtype=torch.float32, constants: LbsConstants = None):
+    """reference utils/lbs.py:141-223.  Returns (verts (B, V, 3), posed joints (B, J, 3))."""
+    if dtype != torch.float32:
+        raise TypeError("lbs runs in fp32")
+    c = constants or _constants(v_template, shapedirs, posedirs, J_regressor, parents, lbs_weights)
+    B = max(betas.shape[0], pose.shape[0])
+    betas = betas.float().expand(B, -1).contiguous()
+    pose = pose.float().reshape(pose.shape[0], -1).expand(B, -1).contiguous()
+    coef, A, joints = ops.lbs_prepare(betas, pose, c.JS, c.parents, KP, pose_is_matrix=not pose2rot)
+    verts = ops.lbs_skin(coef, A, c.template_planes, c.dirs, c.weight_planes, c.V)
+    return verts, joints
+
+
+def batch_rodrigues(rot_vecs, epsilon=1e-8, dtype=torch.float32):
+    """reference utils/lbs.py:270-301."""
+    return ops.batch_rodrigues(rot_vecs.float().contiguous())
+
+
+def vertices2landmarks(vertices, faces, lmk_faces_idx, lmk_bary_coords):
+    """reference utils/lbs.py:102-138."""
+    return ops.landmarks(vertices.float().contiguous(), faces.to(torch.int32).contiguous(),
+                         lmk_faces_idx.to(torch.int32).contiguous(), lmk_bary_coords.float().contiguous())
+
+
+def rot_mat_to_euler(rot_mats):
+    """reference utils/lbs.py:26-32 (host-side helper on tiny tensors; the LUT path uses the fused kernel)."""
+    sy = torch.sqrt(rot_mats[:, 0, 0] * rot_mats[:, 0, 0] + rot_mats[:, 1, 0] * rot_mats[:, 1, 0])
+    return torch.atan2(-rot_mats[:, 2, 0], sy)
