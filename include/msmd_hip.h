@@ -116,9 +116,10 @@ int msmd_denoiser_pack_input(const float* motion, const float* eps, const float*
                              const float* prev_motion, const float* indicator, void* feats, int N, int L,
                              int Lp, int dm, int Kpad, int motion_batch, int out_dtype, msmd_stream_t stream);
 
-/* x (N, T, d) += pe (T, d) (learned PE, model.py:949); row 0 additionally += tok0 (N, d) (person + step emb). */
-int msmd_add_pe_token(void* x, const float* pe, const void* tok0, int N, int T, int d, int dtype,
-                      msmd_stream_t stream);
+/* x (N, T, d) += pe (T, d) (learned PE, model.py:949); row 0 is REPLACED by tok0[n] + row0_add + pe[0]
+ * (tok0 (N, d) = person projection (+ step embedding); row0_add (d) optional shared step embedding). */
+int msmd_add_pe_token(void* x, const float* pe, const void* tok0, const void* row0_add, int N, int T, int d,
+                      int dtype, msmd_stream_t stream);
 
 /* out (N, L, dm) fp32 = dyn[:, :, :dm] + sum_b alpha_b * static_b (face dims) / sum_b static_b (last 3 dims)
  * dec: (N, L, dm+nb) decoder head output (row stride ld_dec); stat: (Ns, nb, dm) static bases, Ns in {N, N/entries}.

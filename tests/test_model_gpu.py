@@ -1,0 +1,217 @@
+"""GPU parity of the model-level call surface (MSMD / DenoisingNetwork_MSMD / StyleEncoder_VAE2 / infer_coeffs)
+against the goldens produced by the imported reference (tests/golden/make_goldens.py).
+
+fp32 parity mode: max-abs-err < 1e-4 on the motion coefficients (BASELINE.json north_star).
+bf16 speed mode: reported with its own tolerance (stated in test_bf16_mode_tolerance)."""
+from unittest import mock
+
+import numpy as np
+import pytest
+import torch
+
+from msmd_amd import synth
+from msmd_amd.config import default_args
+
+from conftest import load_golden
+from helpers import denoiser_inputs, maxabs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+_MODELS = {}
+
+
+def get_model(audio_model="wav2vec2", dtype="fp32", **kw):
+    from msmd_amd.model import get_diffusion_model
+    key = (audio_model, dtype, tuple(sorted(kw.items())))
+    if key not in _MODELS:
+        _MODELS.clear()  # keep one model resident
+        args = default_args(audio_model=audio_model, compute_dtype=dtype, **kw)
+        _MODELS[key] = (get_diffusion_model(args, DEV).eval(), args)
+    return _MODELS[key]
+
+
+@pytest.mark.parametrize("am", ["wav2vec2", "hubert"])
+def test_extract_audio_feature_fp32(am):
+    g = load_golden(f"g3_audio_{am}")
+    model, args = get_model(am, "fp32")
+    audio = dev(synth.audio_clips(2, 64000))
+    feat = model.extract_audio_feature(audio)
+    f768 = model.extract_audio_768_feature(audio)
+    torch.cuda.synchronize()
+    assert feat.shape == (2, 100, 512) and feat.dtype == torch.float32
+    assert maxabs(f768.cpu().numpy()[:, ::2, ::3], g["feat768"]) < 1e-4
+    assert maxabs(feat.cpu().numpy(), g["feat"]) < 1e-4
+    # wrapper surface (already padded audio, 30 fps crop + interpolation path)
+    from msmd_amd.utils.model_common import pad_audio
+    a2 = dev(synth.audio_clips(1, 32000, tag="audio30"))
+    y = model.audio_encoder(pad_audio(a2), 30, frame_num=60).last_hidden_state
+    assert maxabs(y.cpu().numpy(), g["hidden_fps30_60"]) < 1e-4
+
+
+def test_encoder_stages_fp32():
+    g = load_golden("g3_audio_wav2vec2")
+    model, _ = get_model("wav2vec2", "fp32")
+    enc = model.audio_encoder
+    audio = dev(synth.audio_clips(2, 64000))
+    x = enc.feature_extractor_cl(audio, torch.float32, 20, 0)
+    assert x.shape == (2, 200, 512)
+    assert maxabs(x.cpu().numpy()[:, ::3, ::5], g["conv"]) < 5e-5
+
+
+def test_denoiser_fp32():
+    g = load_golden("g3_denoiser")
+    for width in (1, 2):
+        model, args = get_model("wav2vec2", "fp32", align_mask_width=width)
+        x = denoiser_inputs(2, args)
+        person = torch.cat([dev(x["shape"])[:, None], dev(x["style"])[:, None]], dim=-1)
+        y = model.denoising_net(dev(x["motion"]), dev(x["audio_feat"]), person, dev(x["style"])[:, None],
+                                dev(x["prev_motion"]), dev(x["prev_audio"]), dev(g["step"]), dev(x["indicator"]))
+        assert y.shape == (2, 110, 67) and y.dtype == torch.float32
+        assert maxabs(y.cpu().numpy(), g[f"target_w{width}"]) < 1e-4, width
+    model, args = get_model("wav2vec2", "fp32")
+    x = denoiser_inputs(2, args)
+    person = torch.cat([dev(x["shape"])[:, None], dev(x["style"])[:, None]], dim=-1)
+    dyn, stat, al = model.denoising_net(dev(x["motion"]), dev(x["audio_feat"]), person, dev(x["style"])[:, None],
+                                        dev(x["prev_motion"]), dev(x["prev_audio"]), dev(g["step"]),
+                                        dev(x["indicator"]), keep_separate=True)
+    assert maxabs(dyn.cpu().numpy(), g["dynamic"]) < 1e-4 and maxabs(al.cpu().numpy(), g["alphas"]) < 1e-4
+    assert maxabs(stat.cpu().numpy()[:, :2], g["static"]) < 1e-4
+    with pytest.raises(TypeError):  # reference model.py:944 fails the same way without an indicator
+        model.denoising_net(dev(x["motion"]), dev(x["audio_feat"]), person, dev(x["style"])[:, None],
+                            dev(x["prev_motion"]), dev(x["prev_audio"]), dev(g["step"]), None)
+
+
+def test_msmd_forward_fp32():
+    g = load_golden("g3_forward")
+    model, args = get_model("wav2vec2", "fp32")
+    x = denoiser_inputs(2, args, tag="fw")
+    audio = dev(synth.audio_clips(2, 64000, tag="fw_audio"))
+    eps, target, m_det, afeat = model(dev(x["motion"]), audio, dev(x["shape"]), dev(x["style"]), time_step=[3, 499],
+                                      indicator=dev(x["indicator"]), train_with_CFG=False, eps=dev(g["a_eps"]))
+    assert target.shape == (2, 110, 67) and afeat.shape == (2, 100, 512)
+    assert maxabs(afeat.cpu().numpy()[:, ::2, ::3], g["a_audio_feat"]) < 1e-4
+    assert maxabs(target.cpu().numpy(), g["a_target"]) < 1e-4
+    # feature input + previous window + CFG masking with the reference's recorded coin flips
+    flag = dev(g["b_flag"])
+    with mock.patch("torch.rand", return_value=flag):
+        _, target, _, _ = model(dev(x["motion"]), dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]),
+                                dev(x["prev_motion"]), dev(x["prev_audio"]), time_step=[250, 1],
+                                indicator=dev(x["indicator"]), train_with_CFG=True, eps=dev(g["b_eps"]))
+    assert maxabs(target.cpu().numpy(), g["b_target"]) < 1e-4
+    with pytest.raises(AssertionError):
+        model(dev(x["motion"]), audio[:, :100], dev(x["shape"]), dev(x["style"]))
+    with pytest.raises(ValueError):
+        model(dev(x["motion"]), audio[0, :1], dev(x["shape"]), dev(x["style"]))
+
+
+def test_style_encoder_fp32():
+    from msmd_amd.style_encoder import get_style_encoder
+    g = load_golden("g3_style")
+    enc = get_style_encoder(default_args(compute_dtype="fp32"), "vae2").to(DEV).eval()
+    assert get_style_encoder(default_args(), "other") is None
+    for B, T in ((2, 100), (1, 60)):
+        m = dev(synth.motion_clips(B, T, tag="style_in"))
+        mu, logvar = enc.mu_logvar(m)
+        assert maxabs(mu.cpu().numpy(), g[f"mu_{B}_{T}"]) < 5e-5 and maxabs(logvar.cpu().numpy(), g[f"logvar_{B}_{T}"]) < 5e-5
+        with mock.patch("torch.randn_like", return_value=dev(g[f"eps_{B}_{T}"])):
+            z, mu2, lv2 = enc(m)
+        assert maxabs(z.cpu().numpy(), g[f"z_{B}_{T}"]) < 1e-4
+        assert enc.sample(m).shape == (B, 256)
+
+
+def test_sampler_fp32():
+    from msmd_amd.model import DiffusionSchedule
+    g = load_golden("g3_sample")
+    model, args = get_model("wav2vec2", "fp32")
+    x = denoiser_inputs(2, args, tag="sm")
+    T = 3
+    old = model.diffusion_sched
+    model.diffusion_sched = DiffusionSchedule(T, "cosine").to(DEV)
+    xT = dev(synth.normalish("sm/xT", (2, 100, 67)))
+    cases = {
+        "inc": dict(cfg_mode="incremental", cfg_scale=1.15),
+        "ind": dict(cfg_mode="independent", cfg_scale=[1.3, 0.9]),
+        "audio_only": dict(cfg_cond=["audio"], cfg_scale=2.0),
+        "nocfg": dict(cfg_cond=[]),
+        "dt": dict(cfg_mode="incremental", cfg_scale=1.4, dynamic_threshold=(0.9, 0.5, 2.0)),
+        "flex": dict(cfg_mode="incremental", cfg_scale=1.15, flexibility=0.5),
+    }
+    try:
+        for name, kw in cases.items():
+            z = g[f"{name}_z"]
+            noise = {T - i: dev(z[i]) for i in range(T - 1)}
+            y, xT_out, af = model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]), dev(x["prev_motion"]),
+                                         dev(x["prev_audio"]), motion_at_T=xT, indicator=dev(x["indicator"]),
+                                         noise=noise, **kw)
+            assert maxabs(y.cpu().numpy(), g[f"{name}_x0"]) < 1e-4, (name, maxabs(y.cpu().numpy(), g[f"{name}_x0"]))
+        traj, _, _ = model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]), motion_at_T=xT,
+                                  indicator=dev(x["indicator"]), ret_traj=True)
+        assert sorted(traj) == [0, 1, 2, 3]
+        with pytest.raises(NotImplementedError):
+            model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]), motion_at_T=xT,
+                         indicator=dev(x["indicator"]), cfg_mode="bogus")
+    finally:
+        model.diffusion_sched = old
+
+
+def test_sampler_target_noise_fp32():
+    from msmd_amd.model import DiffusionSchedule
+    g = load_golden("g3_sample")
+    model, args = get_model("wav2vec2", "fp32", target="noise")
+    x = denoiser_inputs(2, args, tag="sm")
+    T = 3
+    model.diffusion_sched = DiffusionSchedule(T, "linear").to(DEV)
+    z = g["noise_z"]
+    y, _, _ = model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]),
+                           motion_at_T=dev(synth.normalish("sm/xT", (2, 100, 67))), cfg_scale=1.15,
+                           indicator=dev(x["indicator"]), noise={T - i: dev(z[i]) for i in range(T - 1)})
+    assert maxabs(y.cpu().numpy(), g["noise_x0"]) < 2e-4
+
+
+def test_infer_coeffs_fp32():
+    from msmd_amd.inference import infer_coeffs, window_plan
+    from msmd_amd.model import DiffusionSchedule
+    g = load_golden("g3_infer")
+    gi = load_golden("g1_index")
+    model, args = get_model("wav2vec2", "fp32")
+    T = 2
+    old = model.diffusion_sched
+    model.diffusion_sched = DiffusionSchedule(T, "cosine").to(DEV)
+    try:
+        for S in (100000, 32000):
+            clip_len, _, n_sub, n_pad, n_pad_frames = window_plan(S, args.fps, args.n_motions, 640.0)
+            assert [clip_len, n_sub, n_pad, n_pad_frames] == gi[f"plan_{S}"].tolist()
+            audio = dev(synth.audio_clips(1, S, tag="infer")[0])
+            style = dev(synth.normalish("infer/style", (1, args.d_style)))
+            shape = torch.zeros(1, 1, 100, device=DEV)
+            draws = g[f"draws_{S}"]
+            noise = dict(xT=dev(draws[0]), z=[{2: dev(draws[1 + i])} for i in range(n_sub)])
+            y = infer_coeffs(model, args, audio, shape, 640.0, style, cfg_scale=1.4, dynamic_threshold=None, noise=noise)
+            assert y.shape == g[f"coef_{S}"].shape
+            assert maxabs(y.cpu().numpy(), g[f"coef_{S}"]) < 1e-4, S
+    finally:
+        model.diffusion_sched = old
+
+
+def test_bf16_mode_tolerance():
+    """Speed mode (bf16 storage, fp32 accumulate).  Stated tolerance vs the fp32 reference goldens:
+    max-abs-err <= 0.08 on O(1) outputs after 12 encoder + 8 decoder layers (about 2^-4 relative)."""
+    g = load_golden("g3_forward")
+    ga = load_golden("g3_audio_wav2vec2")
+    model, args = get_model("wav2vec2", "bf16")
+    x = denoiser_inputs(2, args, tag="fw")
+    audio = dev(synth.audio_clips(2, 64000, tag="fw_audio"))
+    eps, target, _, afeat = model(dev(x["motion"]), audio, dev(x["shape"]), dev(x["style"]), time_step=[3, 499],
+                                  indicator=dev(x["indicator"]), train_with_CFG=False, eps=dev(g["a_eps"]))
+    e_t = maxabs(target.cpu().numpy(), g["a_target"])
+    e_a = maxabs(afeat.cpu().numpy()[:, ::2, ::3], g["a_audio_feat"])
+    print(f"bf16 mode: target err {e_t:.4f}, audio feat err {e_a:.4f}, |target| max {np.abs(g['a_target']).max():.2f}")
+    assert e_t <= 0.08 and e_a <= 0.08
+    feat = model.extract_audio_feature(dev(synth.audio_clips(2, 64000)))
+    assert maxabs(feat.cpu().numpy(), ga["feat"]) <= 0.08

@@ -44,28 +44,34 @@ extern "C" int msmd_denoiser_pack_input(const float* motion, const float* eps, c
   MSMD_RETURN_LAST();
 }
 
-// x (N, T, d) += pe (T, d); row 0 = tok0 (N, d) + pe[0]   (row 0 of x is overwritten, not accumulated)
+// x (N, T, d) += pe (T, d); row 0 = tok0 (N, d) + row0_add (d, optional) + pe[0]  (row 0 of x is overwritten)
 template <typename T>
 __global__ void add_pe_token_kernel(T* __restrict__ x, const float* __restrict__ pe, const T* __restrict__ tok0,
-                                    int Tn, int d) {
+                                    const T* __restrict__ row0_add, int Tn, int d) {
   const int n = blockIdx.y;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Tn * d; i += gridDim.x * blockDim.x) {
     const int t = i / d, c = i % d;
-    const float base = (t == 0) ? to_f32(tok0[(long)n * d + c]) : to_f32(x[(long)n * Tn * d + i]);
+    float base;
+    if (t == 0) {
+      base = to_f32(tok0[(long)n * d + c]);
+      if (row0_add) base += to_f32(row0_add[c]);
+    } else {
+      base = to_f32(x[(long)n * Tn * d + i]);
+    }
     x[(long)n * Tn * d + i] = from_f32<T>(base + pe[i]);
   }
 }
 
-extern "C" int msmd_add_pe_token(void* x, const float* pe, const void* tok0, int N, int T, int d, int dtype,
-                                 msmd_stream_t stream) {
+extern "C" int msmd_add_pe_token(void* x, const float* pe, const void* tok0, const void* row0_add, int N, int T, int d,
+                                 int dtype, msmd_stream_t stream) {
   if (N <= 0 || T <= 0 || d <= 0 || !tok0) return 1;
   dim3 grid((T * d + 255) / 256, N), block(256);
   if (dtype == MSMD_F32)
     hipLaunchKernelGGL(add_pe_token_kernel<float>, grid, block, 0, (hipStream_t)stream, (float*)x, pe,
-                       (const float*)tok0, T, d);
+                       (const float*)tok0, (const float*)row0_add, T, d);
   else
     hipLaunchKernelGGL(add_pe_token_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (bf16_t*)x, pe,
-                       (const bf16_t*)tok0, T, d);
+                       (const bf16_t*)tok0, (const bf16_t*)row0_add, T, d);
   MSMD_RETURN_LAST();
 }
 

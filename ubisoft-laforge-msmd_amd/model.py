@@ -1,0 +1,489 @@
+"""MSMD diffusion model on the MI355X: drop-in call surface of reference model.py.
+
+Same class names, constructor arguments, method signatures, attributes, exceptions and state_dict
+keys as the reference (model.py:7-17, 20-71, 73-440, 820-996); the arithmetic runs in hand-written
+gfx950 HIP kernels reached through the C ABI in include/msmd_hip.h.  PyTorch supplies device
+memory, streams and host-side RNG only.
+
+Compute dtype: ``args.compute_dtype`` = "bf16" (speed mode: bf16 storage, fp32 accumulation, fp32
+LayerNorm/softmax/GELU maths) or "fp32" (parity mode, exact-fp32 MFMA).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import ops, shapes, synth
+from .utils.model_common import ParamTree, enc_dec_mask, sinusoid_table  # noqa: F401  (enc_dec_mask re-exported)
+
+
+def _cd(args) -> torch.dtype:
+    name = getattr(args, "compute_dtype", "bf16")
+    if name in ("bf16", torch.bfloat16):
+        return torch.bfloat16
+    if name in ("fp32", "float32", torch.float32):
+        return torch.float32
+    raise ValueError(f"Unknown compute dtype {name}!")
+
+
+def get_diffusion_model(args, device="cuda"):
+    """reference model.py:7-17."""
+    if not hasattr(args, "style_enc_ckpt"):
+        args.style_enc_ckpt = None
+    regularizer = getattr(args, "regularize_alpha", "None")
+    return MSMD(args, device, True, use_head_alpha=False, regularize_alpha=regularizer)
+
+
+class DiffusionSchedule(nn.Module):
+    """reference model.py:20-71.  Init-time host maths with the reference's torch op order, so the
+    five (T+1,) buffers are bit-identical to the reference's on the same torch build."""
+
+    def __init__(self, num_steps, mode="linear", beta_1=1e-4, beta_T=0.02, s=0.008):
+        super().__init__()
+        if mode == "linear":
+            betas = torch.linspace(beta_1, beta_T, num_steps)
+        elif mode == "quadratic":
+            betas = torch.linspace(beta_1 ** 0.5, beta_T ** 0.5, num_steps) ** 2
+        elif mode == "sigmoid":
+            betas = torch.sigmoid(torch.linspace(-5, 5, num_steps)) * (beta_T - beta_1) + beta_1
+        elif mode == "cosine":
+            x = torch.linspace(0, num_steps, num_steps + 1)
+            alpha_bars = torch.cos(((x / num_steps) + s) / (1 + s) * torch.pi * 0.5) ** 2
+            alpha_bars = alpha_bars / alpha_bars[0]
+            betas = torch.clip(1 - (alpha_bars[1:] / alpha_bars[:-1]), 0.0001, 0.999)
+        else:
+            raise ValueError(f"Unknown diffusion schedule {mode}!")
+        betas = torch.cat([torch.zeros(1), betas], dim=0)
+        alphas = 1 - betas
+        log_alphas = torch.log(alphas)
+        for i in range(1, log_alphas.shape[0]):
+            log_alphas[i] += log_alphas[i - 1]
+        alpha_bars = log_alphas.exp()
+        sigmas_flex = torch.sqrt(betas)
+        sigmas_inflex = torch.zeros_like(sigmas_flex)
+        for i in range(1, sigmas_flex.shape[0]):
+            sigmas_inflex[i] = ((1 - alpha_bars[i - 1]) / (1 - alpha_bars[i])) * betas[i]
+        sigmas_inflex = torch.sqrt(sigmas_inflex)
+        self.num_steps = num_steps
+        self.register_buffer("betas", betas)
+        self.register_buffer("alphas", alphas)
+        self.register_buffer("alpha_bars", alpha_bars)
+        self.register_buffer("sigmas_flex", sigmas_flex)
+        self.register_buffer("sigmas_inflex", sigmas_inflex)
+        self._host = None
+
+    def host_tables(self):
+        """CPU copies for the sampler's per-step scalar coefficients (no device sync inside the loop)."""
+        if self._host is None:
+            self._host = {k: getattr(self, k).detach().float().cpu() for k in
+                          ("betas", "alphas", "alpha_bars", "sigmas_flex", "sigmas_inflex")}
+        return self._host
+
+    def _apply(self, fn, *a, **k):
+        self._host = None
+        return super()._apply(fn, *a, **k)
+
+    def uniform_sample_t(self, batch_size):
+        ts = torch.randint(1, self.num_steps + 1, (batch_size,))
+        return ts.tolist()
+
+    def get_sigmas(self, t, flexibility=0):
+        assert 0 <= flexibility <= 1
+        return self.sigmas_flex[t] * flexibility + self.sigmas_inflex[t] * (1 - flexibility)
+
+
+class _TE(nn.Module):
+    """Holds the `TE.pe` buffer under the reference's key (denoising_net.TE.pe)."""
+
+    def __init__(self, d_model, max_len):
+        super().__init__()
+        self.register_buffer("pe", sinusoid_table(d_model, max_len))
+
+
+class DenoisingNetwork_MSMD(nn.Module):
+    """reference model.py:820-996 (architecture='decoder')."""
+
+    def __init__(self, args, device="cuda", motion_feat_dim=50, use_head_alpha=True, regularize_alpha="None"):
+        super().__init__()
+        self.regularize_alpha = regularize_alpha
+        self.use_head_alpha = use_head_alpha
+        self.num_of_basis = int(args.num_of_basis)
+        self.use_style = args.style_enc_ckpt is not None or not args.style_enc_model_style == "diffposetalk"
+        self.motion_feat_dim = motion_feat_dim
+        if (args.dataset_type[:9] == "HDTF_TFHP" or args.dataset_type == "flame_mead_ravdess") and motion_feat_dim == 50:
+            if args.rot_repr == "aa":
+                self.motion_feat_dim += 1 if args.no_head_pose else 4
+            else:
+                raise ValueError(f"Unknown rotation representation {args.rot_repr}!")
+        self.shape_feat_dim = 100
+        if self.use_style:
+            self.style_feat_dim = args.d_style
+            self.person_feat_dim = self.shape_feat_dim + self.style_feat_dim
+        else:
+            self.person_feat_dim = self.shape_feat_dim
+        self.use_indicator = args.use_indicator
+        self.architecture = args.architecture
+        self.feature_dim = args.feature_dim
+        self.n_heads = args.n_heads
+        self.n_layers = args.n_layers
+        self.mlp_ratio = args.mlp_ratio
+        self.align_mask_width = args.align_mask_width
+        self.use_learnable_pe = not args.no_use_learnable_pe
+        self.n_prev_motions = args.n_prev_motions
+        self.n_motions = args.n_motions
+        self.n_diff_steps = args.n_diff_steps
+        self.compute_dtype = _cd(args)
+        if self.architecture != "decoder":
+            raise ValueError(f"Unknown architecture: {self.architecture}")
+        if not self.use_learnable_pe:
+            raise NotImplementedError("only the learnable PE (reference default) is built")
+        if self.feature_dim // self.n_heads != 64:
+            raise NotImplementedError("attention kernels are specialised for head_dim 64")
+        if self.regularize_alpha == "sigmoid":
+            raise NotImplementedError("regularize_alpha='sigmoid' is not built (reference default is 'None')")
+
+        self.TE = _TE(self.feature_dim, args.n_diff_steps + 1)
+        tree = ParamTree(shapes.denoiser_shapes(args, self.motion_feat_dim))
+        for name, p in tree._parameters.items():
+            self.register_parameter(name, p)
+        for name, m in tree._modules.items():
+            self.add_module(name, m)
+        if self.align_mask_width > 0:
+            motion_len = self.n_prev_motions + self.n_motions
+            mask = enc_dec_mask(motion_len, motion_len, 1, self.align_mask_width - 1, device="cpu")
+            mask = torch.nn.functional.pad(mask, (0, 0, 1, 0), value=False)
+            self.register_buffer("alignment_mask", mask)
+        else:
+            self.alignment_mask = None
+        self._packed = None
+        self._packed_dtype = None
+        self.to(device)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def _load_from_state_dict(self, state_dict, prefix, *a, **k):
+        self._packed = None
+        return super()._load_from_state_dict(state_dict, prefix, *a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def pack(self, dtype):
+        if self._packed is not None and self._packed_dtype == dtype:
+            return self._packed
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        d, nb, dm = self.feature_dim, self.num_of_basis, self.motion_feat_dim
+        f32 = lambda t: t.float().contiguous()
+        cd = lambda t: t.to(dtype).contiguous()
+
+        def padk(w, mult=8):
+            K = w.shape[1]
+            Kp = (K + mult - 1) // mult * mult
+            out = torch.zeros(w.shape[0], Kp, device=w.device, dtype=torch.float32)
+            out[:, :K] = w.float()
+            return cd(out)
+        P = SimpleNamespace()
+        P.te = f32(sd["TE.pe"][0])
+        P.pe = f32(sd["PE"][0])
+        P.ds0 = (cd(sd["diff_step_map.0.weight"]), f32(sd["diff_step_map.0.bias"]))
+        P.ds2 = (cd(sd["diff_step_map.2.weight"]), f32(sd["diff_step_map.2.bias"]))
+        P.pp = (padk(sd["person_proj.weight"]), f32(sd["person_proj.bias"]))
+        P.fp = (padk(sd["feature_proj.weight"]), f32(sd["feature_proj.bias"]))
+        P.kp_person, P.kp_feat = P.pp[0].shape[1], P.fp[0].shape[1]
+        P.mask = self.alignment_mask.to(torch.uint8).contiguous() if self.alignment_mask is not None else None
+        P.layers = []
+        for n in range(self.n_layers):
+            p = f"transformer.layers.{n}."
+            L = SimpleNamespace()
+            L.sa_w, L.sa_b = cd(sd[p + "self_attn.in_proj_weight"]), f32(sd[p + "self_attn.in_proj_bias"])
+            L.sa_ow, L.sa_ob = cd(sd[p + "self_attn.out_proj.weight"]), f32(sd[p + "self_attn.out_proj.bias"])
+            w, b = sd[p + "multihead_attn.in_proj_weight"], sd[p + "multihead_attn.in_proj_bias"]
+            L.ca_qw, L.ca_qb = cd(w[:d]), f32(b[:d])
+            L.ca_kvw, L.ca_kvb = cd(w[d:]), f32(b[d:])
+            L.ca_ow, L.ca_ob = cd(sd[p + "multihead_attn.out_proj.weight"]), f32(sd[p + "multihead_attn.out_proj.bias"])
+            L.l1 = (cd(sd[p + "linear1.weight"]), f32(sd[p + "linear1.bias"]))
+            L.l2 = (cd(sd[p + "linear2.weight"]), f32(sd[p + "linear2.bias"]))
+            L.n1 = (f32(sd[p + "norm1.weight"]), f32(sd[p + "norm1.bias"]))
+            L.n2 = (f32(sd[p + "norm2.weight"]), f32(sd[p + "norm2.bias"]))
+            L.n3 = (f32(sd[p + "norm3.weight"]), f32(sd[p + "norm3.bias"]))
+            P.layers.append(L)
+        P.md0 = (cd(sd["motion_dec.0.weight"]), f32(sd["motion_dec.0.bias"]))
+        P.md2 = (cd(sd["motion_dec.2.weight"]), f32(sd["motion_dec.2.bias"]))
+        # static bases: first linears stacked (nb*d, d_style); second linears batched (nb, dm, d)
+        P.st0 = (cd(torch.cat([sd[f"static_feature_mapping.{b}.0.weight"] for b in range(nb)], 0)),
+                 f32(torch.cat([sd[f"static_feature_mapping.{b}.0.bias"] for b in range(nb)], 0)))
+        P.st2 = (cd(torch.stack([sd[f"static_feature_mapping.{b}.2.weight"] for b in range(nb)], 0)),
+                 f32(torch.stack([sd[f"static_feature_mapping.{b}.2.bias"] for b in range(nb)], 0)))
+        self._packed, self._packed_dtype = P, dtype
+        return P
+
+    # ------------------------------------------------------------------ pieces (shared with the sampler)
+    def static_bases(self, static_style_feat, dtype):
+        """(Ns, 1, d_style) -> (Ns, nb, dm): the 4 style->static-pose MLPs (model.py:964-971); step-invariant."""
+        P = self.pack(dtype)
+        nb, dm, d = self.num_of_basis, self.motion_feat_dim, self.feature_dim
+        s = ops.cast(static_style_feat.reshape(-1, static_style_feat.shape[-1]).contiguous(), dtype)
+        Ns = s.shape[0]
+        h = ops.gemm(s, *P.st0, act=ops.ACT_GELU)  # (Ns, nb*d)
+        stat = torch.empty(Ns, nb, dm, device=s.device, dtype=dtype)
+        ops.gemm(h, P.st2[0], P.st2[1], None, out=stat, M=Ns, N=dm, K=d, lda=nb * d, ldw=d, ldc=nb * dm, batch=nb,
+                 strideA=d, strideW=dm * d, strideC=dm, strideBias=dm)
+        return stat
+
+    def person_token(self, person_feat, step, dtype):
+        """person_proj(person_feat) + diff_step_map(TE.pe[0, step]) -> (N, d) (model.py:931-933)."""
+        P = self.pack(dtype)
+        te = ops.cast(P.te[step].contiguous(), dtype)
+        emb = ops.gemm(ops.gemm(te, *P.ds0, act=ops.ACT_GELU), *P.ds2)
+        pf = ops.pad_cols(person_feat.reshape(person_feat.shape[0], -1).float().contiguous(), P.kp_person, dtype)
+        return ops.gemm(pf, *P.pp, residual=emb)
+
+    def memory_kv(self, mem, dtype):
+        """Cross-attention K/V projections of the audio memory for every layer: step-invariant in the
+        sampler (hoisted out of the T x n_entries loop)."""
+        P = self.pack(dtype)
+        return [ops.gemm(mem, L.ca_kvw, L.ca_kvb) for L in P.layers]
+
+    def trunk(self, feats, tok0, mem, dtype, kv_list=None, row0_add=None):
+        """feature_proj + PE + 8 post-LN decoder layers + motion_dec head.  feats: packed (N, 111, Kpad);
+        tok0 (N, d); mem (N, 110, d).  Returns dec (N, 110, dm+nb) fp32."""
+        P = self.pack(dtype)
+        d, H = self.feature_dim, self.n_heads
+        N, Tn, _ = feats.shape
+        x = ops.gemm(feats, *P.fp)
+        ops.add_pe_token(x, P.pe, tok0, row0_add)
+        scale = (d // H) ** -0.5
+        for li, L in enumerate(P.layers):
+            qkv = ops.gemm(x, L.sa_w, L.sa_b)
+            a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale)
+            x = ops.layernorm(ops.gemm(a, L.sa_ow, L.sa_ob, residual=x), *L.n1)
+            q = ops.gemm(x, L.ca_qw, L.ca_qb)
+            kv = kv_list[li] if kv_list is not None else ops.gemm(mem, L.ca_kvw, L.ca_kvb)
+            c = ops.attention(q, kv[..., :d], kv[..., d:], H, scale, mask=P.mask)
+            x = ops.layernorm(ops.gemm(c, L.ca_ow, L.ca_ob, residual=x), *L.n2)
+            f = ops.gemm(x, *L.l1, act=ops.ACT_GELU)
+            x = ops.layernorm(ops.gemm(f, *L.l2, residual=x), *L.n3)
+        # motion_dec on rows 1.. (windowed view of x, no copy)
+        Lm = Tn - 1
+        h = torch.empty(N, Lm, d // 2, device=x.device, dtype=dtype)
+        ops.gemm(x[:, 1:], *P.md0, None, ops.ACT_GELU, out=h, M=N * Lm, K=d, lda=d, rows_per_batch=Lm,
+                 a_batch_stride=Tn * d)
+        return ops.gemm(h, *P.md2, out_dtype=torch.float32)
+
+    def forward(self, motion_feat, audio_feat, person_feat, static_style_feat, prev_motion_feat, prev_audio_feat, step,
+                indicator=None, keep_separate=False, dtype=None, _qsample=None):
+        """reference model.py:914-996.  Returns (N, L_p + L, d_motion) fp32."""
+        dtype = dtype or getattr(self, "compute_dtype", torch.float32)
+        if self.use_indicator and indicator is None:
+            raise TypeError("expected Tensor as element 1 in argument 0, but got NoneType")  # reference model.py:944
+        P = self.pack(dtype)
+        N = person_feat.shape[0]
+        L, Lp, dm, nb = motion_feat.shape[1], prev_motion_feat.shape[1], self.motion_feat_dim, self.num_of_basis
+        step = torch.as_tensor(step, device=self.device, dtype=torch.long)
+        tok0 = self.person_token(person_feat, step, dtype)
+        feats = torch.empty(N, 1 + Lp + L, P.kp_feat, device=self.device, dtype=dtype)
+        eps, c0, c1 = _qsample if _qsample is not None else (None, None, None)
+        ops.denoiser_pack_input(motion_feat.float().contiguous(), prev_motion_feat.float().contiguous(),
+                                indicator.float().contiguous() if self.use_indicator else None, feats, eps, c0, c1)
+        mem = torch.cat([ops.cast(prev_audio_feat.contiguous(), dtype), ops.cast(audio_feat.contiguous(), dtype)], dim=1)
+        dec = self.trunk(feats, tok0, mem, dtype)
+        stat = self.static_bases(static_style_feat, torch.float32 if dtype == torch.float32 else dtype)
+        if keep_separate:
+            dynamic = dec[:, :, :dm]
+            alphas = dec[:, :, dm:]
+            static = stat.float()[:, None].expand(-1, Lp + L, -1, -1)
+            if static.shape[0] != N:
+                static = static.repeat(N // static.shape[0], 1, 1, 1)
+            return dynamic, static, alphas
+        return ops.heads_static_mix(dec, stat.float().contiguous(), Lp + L, dm, nb, self.use_head_alpha)
+
+
+class MSMD(nn.Module):
+    """reference model.py:73-818."""
+
+    def __init__(self, args, device="cuda", vae_style=False, conditioned=True, denoisingnset_version=1,
+                 use_head_alpha=True, regularize_alpha="None"):
+        super().__init__()
+        self.target = args.target
+        self.regularize_alpha = regularize_alpha
+        self.architecture = args.architecture
+        self.use_style = (args.style_enc_ckpt is not None) or vae_style
+        self.conditioned = conditioned
+        self.motion_feat_dim = 67
+        self.denoisingnset_version = denoisingnset_version
+        self.use_head_alpha = use_head_alpha
+        self.fps = args.fps
+        self.n_motions = args.n_motions
+        self.n_prev_motions = args.n_prev_motions
+        self.compute_dtype = _cd(args)
+        if self.use_style:
+            self.style_feat_dim = args.d_style
+        self.audio_model = args.audio_model
+        enc_cfg = dict(num_hidden_layers=getattr(args, "encoder_layers", None) or 12)
+        if self.audio_model == "wav2vec2":
+            from .utils.wav2vec2 import Wav2Vec2Model
+            self.audio_encoder = Wav2Vec2Model.from_pretrained("facebook/wav2vec2-base-960h", config=enc_cfg)
+            frozen = ("feature_extractor",)
+        elif self.audio_model == "hubert":
+            from .utils.hubert import HubertModel
+            self.audio_encoder = HubertModel.from_pretrained("facebook/hubert-base-ls960", config=enc_cfg)
+            frozen = ("feature_extractor", "feature_projection", "encoder.layers.0.", "encoder.layers.1.")
+        else:
+            raise ValueError(f"Unknown audio model {self.audio_model}!")
+        for name, p in self.audio_encoder.named_parameters():  # model.py:97,101-110
+            if name.startswith(frozen):
+                p.requires_grad = False
+        if args.architecture == "decoder":
+            self.audio_feature_map = ParamTree({"weight": (args.feature_dim, 768), "bias": (args.feature_dim,)})
+            self.start_audio_feat = nn.Parameter(torch.zeros(1, self.n_prev_motions, args.feature_dim))
+        else:
+            raise ValueError(f"Unknown architecture {args.architecture}!")
+        self.start_motion_feat = nn.Parameter(torch.zeros(1, self.n_prev_motions, self.motion_feat_dim))
+        self.denoising_net = DenoisingNetwork_MSMD(args, "cpu", motion_feat_dim=self.motion_feat_dim,
+                                                   use_head_alpha=self.use_head_alpha,
+                                                   regularize_alpha=self.regularize_alpha)
+        self.diffusion_sched = DiffusionSchedule(args.n_diff_steps, args.diff_schedule)
+        self.cfg_mode = args.cfg_mode
+        guiding_conditions = args.guiding_conditions.split(",") if args.guiding_conditions else []
+        self.guiding_conditions = [cond for cond in guiding_conditions if cond in ["style", "audio"]]
+        if "style" in self.guiding_conditions:
+            if not self.use_style:
+                raise ValueError("Cannot use style guiding without enabling it!")
+            self.null_style_feat = nn.Parameter(torch.zeros(1, 1, self.style_feat_dim))
+        if "audio" in self.guiding_conditions:
+            self.null_audio_feat = nn.Parameter(torch.zeros(1, 1, args.feature_dim))
+        synth.load_synthetic(self)  # deterministic init (no pretrained assets offline); checkpoints overwrite it
+        self._afm = None
+        self.to(device)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def _apply(self, fn, *a, **k):
+        self._afm = None
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, state_dict, prefix, *a, **k):
+        self._afm = None
+        return super()._load_from_state_dict(state_dict, prefix, *a, **k)
+
+    def set_compute_dtype(self, dtype):
+        self.compute_dtype = _cd(SimpleNamespace(compute_dtype=dtype))
+        self.denoising_net.compute_dtype = self.compute_dtype
+        return self
+
+    def _afm_packed(self, dtype):
+        if self._afm is None or self._afm[0] != dtype:
+            self._afm = (dtype, self.audio_feature_map.weight.detach().to(dtype).contiguous(),
+                         self.audio_feature_map.bias.detach().float().contiguous())
+        return self._afm[1], self._afm[2]
+
+    # ------------------------------------------------------------------ audio features
+    def _audio_768(self, audio, frame_num, dtype):
+        h = self.audio_encoder.encode(audio, self.fps, frame_num=frame_num * 2, dtype=dtype, pad=True)  # (N, 2L, 768)
+        return ops.interp_linear(h, frame_num)  # 2:1 linear resample == exact pairwise mean (model.py:260)
+
+    def _audio_feat(self, audio, frame_num, dtype):
+        w, b = self._afm_packed(dtype)
+        return ops.gemm(self._audio_768(audio, frame_num, dtype), w, b)
+
+    @torch.no_grad()
+    def extract_audio_feature(self, audio, frame_num=None):
+        """reference model.py:250-264 -> (N, L, feature_dim) fp32."""
+        frame_num = frame_num or self.n_motions
+        return self._audio_feat(audio, frame_num, self.compute_dtype).float()
+
+    @torch.no_grad()
+    def extract_audio_768_feature(self, audio, frame_num=None):
+        """reference model.py:266-280."""
+        frame_num = frame_num or self.n_motions
+        return self._audio_768(audio, frame_num, self.compute_dtype).float()
+
+    # ------------------------------------------------------------------ training-forward semantics
+    @torch.no_grad()
+    def forward(self, motion_feat, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=None,
+                prev_audio_feat=None, time_step=None, indicator=None, train_with_CFG=True, keep_separate=False,
+                eps=None):
+        """reference model.py:146-248 (inference-mode arithmetic; the autograd path is the next build row).
+        ``eps`` may be injected for deterministic replay (the reference draws torch.randn_like)."""
+        dtype = self.compute_dtype
+        if self.use_style:
+            assert style_feat is not None, "Missing style features!"
+        batch_size = motion_feat.shape[0]
+        if audio_or_feat.ndim == 2:
+            assert audio_or_feat.shape[1] == 16000 * self.n_motions / self.fps, \
+                f"Incorrect audio length {audio_or_feat.shape[1]}"
+            audio_feat_saved = self._audio_feat(audio_or_feat, self.n_motions, dtype).float()
+        elif audio_or_feat.ndim == 3:
+            assert audio_or_feat.shape[1] == self.n_motions, f"Incorrect audio feature length {audio_or_feat.shape[1]}"
+            audio_feat_saved = audio_or_feat
+        else:
+            raise ValueError(f"Incorrect audio input shape {audio_or_feat.shape}")
+        audio_feat = audio_feat_saved
+        if shape_feat.ndim == 2:
+            shape_feat = shape_feat.unsqueeze(1)
+        if style_feat is not None and style_feat.ndim == 2:
+            style_feat = style_feat.unsqueeze(1)
+        if prev_motion_feat is None:
+            prev_motion_feat = self.start_motion_feat.expand(batch_size, -1, -1)
+        if prev_audio_feat is None:
+            prev_audio_feat = self.start_audio_feat.expand(batch_size, -1, -1)
+        # classifier-free guidance masking (model.py:190-218)
+        if len(self.guiding_conditions) > 0 and train_with_CFG:
+            assert len(self.guiding_conditions) <= 2, "Only support 1 or 2 CFG conditions!"
+            if len(self.guiding_conditions) == 1 or self.cfg_mode == "independent":
+                null_cond_prob = 0.5 if len(self.guiding_conditions) >= 2 else 0.1
+                if "style" in self.guiding_conditions:
+                    mask_style = torch.rand(batch_size, device=self.device) < null_cond_prob
+                    style_feat = torch.where(mask_style.view(-1, 1, 1),
+                                             self.null_style_feat.expand(batch_size, -1, -1), style_feat)
+                if "audio" in self.guiding_conditions:
+                    mask_audio = torch.rand(batch_size, device=self.device) < null_cond_prob
+                    audio_feat = torch.where(mask_audio.view(-1, 1, 1),
+                                             self.null_audio_feat.expand(batch_size, self.n_motions, -1), audio_feat)
+            else:
+                mask_flag = torch.rand(batch_size, device=self.device)
+                if "style" in self.guiding_conditions:
+                    style_feat = torch.where((mask_flag > 0.55).view(-1, 1, 1),
+                                             self.null_style_feat.expand(batch_size, -1, -1), style_feat)
+                if "audio" in self.guiding_conditions:
+                    audio_feat = torch.where((mask_flag > 0.9).view(-1, 1, 1),
+                                             self.null_audio_feat.expand(batch_size, self.n_motions, -1), audio_feat)
+        person_feat = shape_feat if style_feat is None else torch.cat([shape_feat, style_feat], dim=-1)
+        if time_step is None:
+            time_step = self.diffusion_sched.uniform_sample_t(batch_size)
+        ts = torch.as_tensor(time_step, device=self.device, dtype=torch.long)
+        alpha_bar = self.diffusion_sched.alpha_bars[ts]
+        c0 = torch.sqrt(alpha_bar).float().contiguous()
+        c1 = torch.sqrt(1 - alpha_bar).float().contiguous()
+        if eps is None:
+            eps = torch.randn_like(motion_feat)
+        eps = eps.float().contiguous()
+        # q-sample is fused into the denoiser's input packing kernel (model.py:231-236)
+        out = self.denoising_net(motion_feat, audio_feat, person_feat, style_feat, prev_motion_feat, prev_audio_feat,
+                                 ts, indicator, keep_separate=keep_separate, dtype=dtype, _qsample=(eps, c0, c1))
+        if keep_separate:
+            dyn, stat, alpha_t = out
+            if self.use_head_alpha:
+                target = dyn + (alpha_t.unsqueeze(-1) * stat).sum(dim=2)
+            else:
+                target = dyn + torch.cat([(alpha_t.unsqueeze(-1) * stat[..., :-3]).sum(2), stat[..., -3:].sum(2)], -1)
+            return eps, target, motion_feat.detach(), audio_feat_saved.detach(), dyn, stat, alpha_t
+        return eps, out, motion_feat.detach(), audio_feat_saved.detach()
+
+    # ------------------------------------------------------------------ sampler
+    @torch.no_grad()
+    def sample(self, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=None, prev_audio_feat=None,
+               motion_at_T=None, indicator=None, cfg_mode=None, cfg_cond=None, cfg_scale=1.15, flexibility=0,
+               dynamic_threshold=None, ret_traj=False, noise=None):
+        """reference model.py:283-440: DDPM ancestral sampling with 1-3-way classifier-free guidance.
+        ``noise``: optional dict {t: z_t} of injected draws (deterministic replay); default torch.randn_like."""
+        from .sampler import sample as _sample
+        return _sample(self, audio_or_feat, shape_feat, style_feat, prev_motion_feat, prev_audio_feat, motion_at_T,
+                       indicator, cfg_mode, cfg_cond, cfg_scale, flexibility, dynamic_threshold, ret_traj, noise)

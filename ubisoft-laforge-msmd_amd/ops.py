@@ -166,10 +166,11 @@ def denoiser_pack_input(motion, prev_motion, indicator, feats, eps=None, c0=None
     return feats
 
 
-def add_pe_token(x, pe, tok0):
+def add_pe_token(x, pe, tok0, row0_add=None):
     lib = _lib.load()
     N, T, d = x.shape
-    _lib.check(lib.msmd_add_pe_token(_p(x), _p(pe), _p(tok0), N, T, d, _dt(x), _stream()), "msmd_add_pe_token")
+    _lib.check(lib.msmd_add_pe_token(_p(x), _p(pe), _p(tok0), _p(row0_add), N, T, d, _dt(x), _stream()),
+               "msmd_add_pe_token")
     return x
 
 

@@ -1,0 +1,149 @@
+"""CFG + DDPM ancestral sampler (reference model.py:283-440) driven from the host, arithmetic in HIP.
+
+Per step the device runs: pack x_t into the denoiser input -> decoder trunk -> heads/static mix ->
+one fused CFG-combine + DDPM-posterior kernel that updates x_t in place.  Step-invariant work is
+hoisted out of the T x n_entries loop: cross-attention K/V projections of
+the audio memory for all layers, the static-style bases, the person projection and ALL T step
+embeddings (one GEMM pair).  Nothing is copied to the host inside the loop (the reference moves
+traj[t] to the CPU every step, model.py:433); per-step scalars come from host copies of the schedule.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+def _entries(cfg_cond, cfg_mode):
+    """(use_audio, use_style) per CFG entry in batch order; entry 0 is the null entry (model.py:340-366)."""
+    ent = [("audio" not in cfg_cond, "style" not in cfg_cond)]
+    for cond in cfg_cond:
+        if cond == "audio":
+            ent.append((True, "style" not in cfg_cond))
+        elif cond == "style":
+            if cfg_mode == "independent":
+                ent.append(("audio" not in cfg_cond, True))
+            elif cfg_mode == "incremental":
+                ent.append((True, True))
+            else:
+                raise NotImplementedError(f"Unknown cfg_mode {cfg_mode}")
+    return ent
+
+
+def sample(model, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=None, prev_audio_feat=None,
+           motion_at_T=None, indicator=None, cfg_mode=None, cfg_cond=None, cfg_scale=1.15, flexibility=0,
+           dynamic_threshold=None, ret_traj=False, noise=None):
+    net = model.denoising_net
+    dtype = model.compute_dtype
+    dev = model.device
+    batch_size = audio_or_feat.shape[0]
+    if cfg_mode is None:
+        cfg_mode = model.cfg_mode
+    if cfg_cond is None:
+        cfg_cond = model.guiding_conditions
+    cfg_cond = [c for c in cfg_cond if c in ["audio", "style"]]
+    if not isinstance(cfg_scale, list):
+        cfg_scale = [cfg_scale] * len(cfg_cond)
+    if len(cfg_cond) > 0:
+        cfg_cond, cfg_scale = zip(*sorted(zip(cfg_cond, cfg_scale), key=lambda x: ["audio", "style"].index(x[0])))
+    else:
+        cfg_cond, cfg_scale = [], []
+    if cfg_mode not in ("incremental", "independent") and len(cfg_cond) > 0:
+        raise NotImplementedError(f"Unknown cfg_mode {cfg_mode}")
+    if model.target not in ("sample", "noise"):
+        raise ValueError("Unknown target type: {}".format(model.target))
+    if "style" in cfg_cond:
+        assert model.use_style and style_feat is not None
+    if model.use_style:
+        if style_feat is None:
+            style_feat = model.null_style_feat.expand(batch_size, -1, -1)
+    else:
+        assert style_feat is None, "This model does not support style feature input!"
+
+    if audio_or_feat.ndim == 2:
+        assert audio_or_feat.shape[1] == 16000 * model.n_motions / model.fps, \
+            f"Incorrect audio length {audio_or_feat.shape[1]}"
+        audio_feat = model._audio_feat(audio_or_feat, model.n_motions, dtype).float()
+    elif audio_or_feat.ndim == 3:
+        assert audio_or_feat.shape[1] == model.n_motions, f"Incorrect audio feature length {audio_or_feat.shape[1]}"
+        audio_feat = audio_or_feat
+    else:
+        raise ValueError(f"Incorrect audio input shape {audio_or_feat.shape}")
+    if shape_feat.ndim == 2:
+        shape_feat = shape_feat.unsqueeze(1)
+    if style_feat is not None and style_feat.ndim == 2:
+        style_feat = style_feat.unsqueeze(1)
+    if shape_feat.shape[0] != batch_size:
+        shape_feat = shape_feat.expand(batch_size, -1, -1)
+    if prev_motion_feat is None:
+        prev_motion_feat = model.start_motion_feat.expand(batch_size, -1, -1)
+    if prev_audio_feat is None:
+        prev_audio_feat = model.start_audio_feat.expand(batch_size, -1, -1)
+    if motion_at_T is None:
+        motion_at_T = torch.randn((batch_size, model.n_motions, model.motion_feat_dim)).to(dev)
+
+    L, Lp, dm, nb = model.n_motions, model.n_prev_motions, net.motion_feat_dim, net.num_of_basis
+    null_audio = model.null_audio_feat.expand(batch_size, L, -1) if "audio" in cfg_cond else audio_feat
+    audio_in, person_in = [], []
+    for use_a, use_s in _entries(cfg_cond, cfg_mode):
+        audio_in.append(audio_feat if use_a else null_audio)
+        st = style_feat if (use_s or "style" not in cfg_cond) else model.null_style_feat.expand(batch_size, -1, -1)
+        person_in.append(torch.cat([shape_feat, st], dim=-1) if model.use_style else shape_feat)
+    n_entries = len(audio_in)
+    N = n_entries * batch_size
+    audio_in = torch.cat(audio_in, dim=0)
+    person_in = torch.cat(person_in, dim=0)
+    prev_m = torch.cat([prev_motion_feat] * n_entries, dim=0).float().contiguous()
+    prev_a = torch.cat([prev_audio_feat] * n_entries, dim=0)
+    ind_in = torch.cat([indicator] * n_entries, dim=0).float().contiguous() if indicator is not None else None
+    if net.use_indicator and ind_in is None:
+        raise TypeError("expected Tensor as element 1 in argument 0, but got NoneType")  # reference model.py:944
+
+    # ---- step-invariant work, hoisted
+    P = net.pack(dtype)
+    T = model.diffusion_sched.num_steps
+    tab = model.diffusion_sched.host_tables()
+    mem = torch.cat([ops.cast(prev_a.contiguous(), dtype), ops.cast(audio_in.contiguous(), dtype)], dim=1)
+    kv_list = net.memory_kv(mem, dtype)
+    stat = net.static_bases(style_feat, dtype).float().contiguous()  # real style for every entry (model.py:374)
+    pf = ops.pad_cols(person_in.reshape(N, -1).float().contiguous(), P.kp_person, dtype)
+    tok_person = ops.gemm(pf, *P.pp)                                   # (N, d) without the step embedding
+    te_all = ops.cast(P.te[: T + 1].contiguous(), dtype)
+    emb_all = ops.gemm(ops.gemm(te_all, *P.ds0, act=ops.ACT_GELU), *P.ds2)  # (T+1, d)
+    scales = torch.tensor(list(cfg_scale), device=dev, dtype=torch.float32) if n_entries > 1 else None
+    feats = torch.empty(N, 1 + Lp + L, P.kp_feat, device=dev, dtype=dtype)
+
+    x = motion_at_T.float().clone().contiguous()
+    traj = {T: motion_at_T} if ret_traj else None
+    mode = 1 if cfg_mode == "independent" else 0
+    target = 0 if model.target == "sample" else 1
+    for t in range(T, 0, -1):
+        if t > 1:
+            z = noise[t].float().contiguous() if noise is not None else torch.randn_like(x)
+        else:
+            z = None
+        alpha = tab["alphas"][t]
+        alpha_bar = tab["alpha_bars"][t]
+        alpha_bar_prev = tab["alpha_bars"][t - 1]
+        sigma = tab["sigmas_flex"][t] * flexibility + tab["sigmas_inflex"][t] * (1 - flexibility)
+        if target == 1:
+            c0 = 1 / torch.sqrt(alpha)
+            c1 = (1 - alpha) / torch.sqrt(1 - alpha_bar)
+        else:
+            c0 = (1 - alpha_bar_prev) * torch.sqrt(alpha) / (1 - alpha_bar)
+            c1 = (1 - alpha) * torch.sqrt(alpha_bar_prev) / (1 - alpha_bar)
+        ops.denoiser_pack_input(x, prev_m, ind_in, feats)
+        dec = net.trunk(feats, tok_person, mem, dtype, kv_list=kv_list, row0_add=emb_all[t])
+        res = ops.heads_static_mix(dec, stat, Lp + L, dm, nb, net.use_head_alpha)
+        if dynamic_threshold:
+            # optional K15 (off in the reference's inference driver, inference.py:272): host-library quantile
+            dt_ratio, dt_min, dt_max = dynamic_threshold
+            s = torch.quantile(res[:, -L:].reshape(N, -1).abs(), dt_ratio, dim=1)
+            s = torch.clamp(s, min=dt_min, max=dt_max)[..., None, None]
+            res = torch.clamp(res, min=-s, max=s).contiguous()
+        ops.cfg_ddpm_step(x, res, z, scales, n_entries, Lp, mode, target, float(c0), float(c1), float(sigma))
+        if ret_traj:
+            traj[t - 1] = x.clone()
+    if ret_traj:
+        return traj, motion_at_T, audio_feat
+    return x, motion_at_T, audio_feat

@@ -1,0 +1,181 @@
+"""wav2vec 2.0 / HuBERT-base audio encoder on the MI355X.
+
+Drop-in surface of reference utils/wav2vec2.py:66-119 (``Wav2Vec2Model.forward(input_values,
+output_fps, frame_num=...)`` -> object with ``.last_hidden_state``) with HF's state_dict key names,
+but no dependency on ``transformers``: the conv feature extractor, feature projection, positional
+grouped conv and the post-LN transformer layers are hand-written HIP kernels (csrc/*.hip) driven
+from here.  Activations are channels-last (B, T, C) end to end; every Conv1d is a windowed MFMA
+GEMM over that layout, so nothing is transposed or im2col'ed.
+
+Differences from the reference that are deliberate:
+  * attention maps are never materialised (the reference forces output_attentions=True and keeps
+    737 MB of them alive per batch-32 forward for nothing);
+  * SpecAugment / LayerDrop / dropout are training-time noise; the inference path here is eval-mode.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from .. import ops, shapes, synth
+from .model_common import ParamTree, pad_audio_plan
+
+CONV_KERNEL = shapes.CONV_KERNEL
+CONV_STRIDE = shapes.CONV_STRIDE
+
+
+def linear_interpolation(features, input_fps, output_fps, output_len=None):
+    """reference utils/wav2vec2.py:57-63 on a channels-last (N, L, C) tensor."""
+    seq_len = features.shape[1] / float(input_fps)
+    if output_len is None:
+        output_len = int(seq_len * output_fps)
+    return ops.interp_linear(features, output_len)
+
+
+class Wav2Vec2Model(nn.Module):
+    """HF-key-compatible parameter tree + HIP forward.  ``config`` carries num_hidden_layers etc."""
+
+    model_type = "wav2vec2"
+
+    def __init__(self, config=None):
+        super().__init__()
+        cfg = dict(num_hidden_layers=12, hidden_size=768, intermediate_size=3072, num_attention_heads=12,
+                   conv_dim=512, num_conv_pos_embeddings=128, num_conv_pos_embedding_groups=16,
+                   layer_norm_eps=1e-5, output_attentions=False)
+        if config is not None:
+            cfg.update(config if isinstance(config, dict) else vars(config))
+        self.config = SimpleNamespace(**cfg)
+        c = self.config
+        tree = ParamTree(shapes.audio_encoder_shapes(c.num_hidden_layers, c.hidden_size, c.intermediate_size,
+                                                     c.conv_dim, c.num_conv_pos_embeddings,
+                                                     c.num_conv_pos_embedding_groups))
+        # adopt the tree's children so state_dict keys carry no extra prefix
+        for name, p in tree._parameters.items():
+            self.register_parameter(name, p)
+        for name, m in tree._modules.items():
+            self.add_module(name, m)
+        self._packed = None
+        self._packed_dtype = None
+
+    @classmethod
+    def from_pretrained(cls, name=None, cache_dir=None, **kw):
+        """No network and no HF cache in this environment: returns the architecture with the
+        deterministic synthetic weights (msmd_amd.synth); real weights arrive via load_state_dict."""
+        m = cls(kw.get("config"))
+        synth.load_synthetic(m, prefix="audio_encoder.")
+        return m
+
+    def _load_from_state_dict(self, state_dict, prefix, *a, **k):
+        self._packed = None
+        return super()._load_from_state_dict(state_dict, prefix, *a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    # ------------------------------------------------------------------ weight packing (load time)
+    def pack(self, dtype):
+        if self._packed is not None and self._packed_dtype == dtype:
+            return self._packed
+        c = self.config
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        P = SimpleNamespace()
+        f32 = lambda t: t.float().contiguous()
+        cd = lambda t: t.to(dtype).contiguous()
+        fe = "feature_extractor.conv_layers."
+        P.w0 = f32(sd[fe + "0.conv.weight"].reshape(c.conv_dim, CONV_KERNEL[0]))
+        P.gn_g, P.gn_b = f32(sd[fe + "0.layer_norm.weight"]), f32(sd[fe + "0.layer_norm.bias"])
+        # conv i>=1: (Cout, Cin, k) -> (Cout, k*Cin), K index = kk*Cin + cin (channels-last window)
+        P.conv_w = [cd(sd[fe + f"{i}.conv.weight"].permute(0, 2, 1).reshape(c.conv_dim, -1))
+                    for i in range(1, len(CONV_KERNEL))]
+        P.fp_ln = (f32(sd["feature_projection.layer_norm.weight"]), f32(sd["feature_projection.layer_norm.bias"]))
+        P.fp_w, P.fp_b = cd(sd["feature_projection.projection.weight"]), f32(sd["feature_projection.projection.bias"])
+        # positional conv: fold weight norm (dim=2): w = g * v / ||v||_{dims 0,1}
+        g, v = sd["encoder.pos_conv_embed.conv.weight_g"].float(), sd["encoder.pos_conv_embed.conv.weight_v"].float()
+        w = v * (g / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+        G = c.num_conv_pos_embedding_groups
+        cg = c.hidden_size // G
+        kpos = c.num_conv_pos_embeddings
+        P.pos_w = cd(w.reshape(G, cg, cg, kpos).permute(0, 1, 3, 2).reshape(G, cg, kpos * cg))  # K = kk*cg + ci
+        P.pos_b = f32(sd["encoder.pos_conv_embed.conv.bias"])
+        P.enc_ln = (f32(sd["encoder.layer_norm.weight"]), f32(sd["encoder.layer_norm.bias"]))
+        P.layers = []
+        for n in range(c.num_hidden_layers):
+            p = f"encoder.layers.{n}."
+            L = SimpleNamespace()
+            L.wqkv = cd(torch.cat([sd[p + f"attention.{x}_proj.weight"] for x in ("q", "k", "v")], 0))
+            L.bqkv = f32(torch.cat([sd[p + f"attention.{x}_proj.bias"] for x in ("q", "k", "v")], 0))
+            L.wo, L.bo = cd(sd[p + "attention.out_proj.weight"]), f32(sd[p + "attention.out_proj.bias"])
+            L.ln1 = (f32(sd[p + "layer_norm.weight"]), f32(sd[p + "layer_norm.bias"]))
+            L.w1, L.b1 = cd(sd[p + "feed_forward.intermediate_dense.weight"]), f32(sd[p + "feed_forward.intermediate_dense.bias"])
+            L.w2, L.b2 = cd(sd[p + "feed_forward.output_dense.weight"]), f32(sd[p + "feed_forward.output_dense.bias"])
+            L.ln2 = (f32(sd[p + "final_layer_norm.weight"]), f32(sd[p + "final_layer_norm.bias"]))
+            P.layers.append(L)
+        self._packed, self._packed_dtype = P, dtype
+        return P
+
+    # ------------------------------------------------------------------ forward pieces
+    def feature_extractor_cl(self, audio, dtype, reflect_len=None, replicate_len=None):
+        """HF Wav2Vec2FeatureEncoder on UNPADDED audio (B, L) with pad_audio fused into conv0's loads.
+        Returns (B, T50, 512) channels-last."""
+        P = self.pack(dtype)
+        if reflect_len is None:
+            reflect_len, replicate_len = 0, 0
+        x = ops.conv0_gn_gelu(audio.float().contiguous(), P.w0, P.gn_g, P.gn_b, reflect_len, replicate_len, dtype,
+                              self.config.layer_norm_eps)
+        for i, w in enumerate(P.conv_w):
+            x = ops.conv1d_cl(x, w, None, kernel=CONV_KERNEL[i + 1], stride=CONV_STRIDE[i + 1], act=ops.ACT_GELU)
+        return x
+
+    def encode_features(self, x, dtype):
+        """feature projection + positional conv + transformer layers on (B, T, 512) -> (B, T, 768)."""
+        P = self.pack(dtype)
+        c = self.config
+        B, T, _ = x.shape
+        H = c.num_attention_heads
+        d = c.hidden_size
+        h = ops.layernorm(x, *P.fp_ln, eps=c.layer_norm_eps)
+        h = ops.gemm(h, P.fp_w, P.fp_b)
+        # positional grouped conv (k=128, pad=64, drop last frame) as G windowed GEMMs + GELU + residual
+        G, cg, kpos = c.num_conv_pos_embedding_groups, d // c.num_conv_pos_embedding_groups, c.num_conv_pos_embeddings
+        xp = ops.group_pad(h, G, kpos // 2)  # (B, G, T + kpos, cg)
+        Tp = T + kpos
+        y = torch.empty_like(h)
+        ops.gemm(xp, P.pos_w, P.pos_b, h, ops.ACT_GELU, out=y, M=B * T, N=cg, K=kpos * cg, lda=cg, rows_per_batch=T,
+                 a_batch_stride=G * Tp * cg, ldw=kpos * cg, ldc=d, batch=G, strideA=Tp * cg, strideW=cg * kpos * cg,
+                 strideC=cg, strideBias=cg, strideR=cg)
+        h = ops.layernorm(y, *P.enc_ln, eps=c.layer_norm_eps)
+        for L in P.layers:
+            qkv = ops.gemm(h, L.wqkv, L.bqkv)
+            a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, (d // H) ** -0.5)
+            h = ops.layernorm(ops.gemm(a, L.wo, L.bo, residual=h), *L.ln1, eps=c.layer_norm_eps)
+            f = ops.gemm(h, L.w1, L.b1, act=ops.ACT_GELU)
+            h = ops.layernorm(ops.gemm(f, L.w2, L.b2, residual=h), *L.ln2, eps=c.layer_norm_eps)
+        return h
+
+    def encode(self, audio, output_fps=25, frame_num=None, dtype=torch.bfloat16, pad=True):
+        """Whole encoder from raw (B, L) audio; pad=True applies the reference's pad_audio plan
+        (model.py:257 passes pad_audio(audio)) inside conv0.  Returns (B, frame_num, 768) in `dtype`."""
+        r, rep = pad_audio_plan(audio.shape[1]) if pad else (0, 0)
+        x = self.feature_extractor_cl(audio, dtype, r, rep)
+        T50 = x.shape[1]
+        if frame_num is not None:
+            crop = min(round(frame_num * 50 / output_fps), T50)   # Python banker's round, utils/wav2vec2.py:82
+            out_len = frame_num
+        else:
+            crop = T50
+            out_len = int(T50 / 50.0 * output_fps)
+        if not (crop == T50 and out_len == T50):                   # 50 fps -> 2*25 fps is the identity
+            x = ops.interp_linear(x, out_len, crop)
+        return self.encode_features(x, dtype)
+
+    def forward(self, input_values, output_fps=25, attention_mask=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None, frame_num=None, dtype=None):
+        """reference utils/wav2vec2.py:71-119 / utils/hubert.py:13-51 (input is ALREADY padded audio)."""
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask is never passed on the reference's path (model.py:257)")
+        dtype = dtype or torch.float32
+        h = self.encode(input_values, output_fps, frame_num, dtype, pad=False)
+        return SimpleNamespace(last_hidden_state=h, hidden_states=None, attentions=None)
