@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Headline benchmark: motion frames/s of the audio -> motion-coefficient forward on MI355X.
+
+Workload (BASELINE.json configs[1]): one step = MSMD.forward on a batch of 32 synthetic 4 s / 16 kHz clips
+(raw audio -> wav2vec2-base encoder -> audio_feature_map -> q-sample -> 8-layer denoiser -> heads), bf16
+storage with fp32 accumulation, eval-mode arithmetic, random-init (closed-form synthetic) weights.
+100 motion frames per clip, so one step produces 3200 frames per GPU.  N > 1: one process per GPU,
+clips are independent (no data-path collective), weak scaling.
+
+Prints ONE JSON line (rank 0) with the contract fields plus:
+  roofline     -- the dominant kernel (bf16 MFMA GEMM, csrc/gemm.hip, 128x128 tile): algorithmic FLOPs
+                  (2*M*N*K per launch, summed over the launches of one step) / their summed durations, measured
+                  live with HIP events on the launch stream in a separate traced pass.
+  cpu_baseline -- the numpy oracle (a parity-checked port of the reference's CPU path) timed on this host's
+                  cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+FLOP_PER_FRAME = 0.6512e9  # MSMD.forward from raw audio = 65.12 GFLOP / 100-frame clip
+
+
+def synth_batch(B, rank, device):
+    """SURVEY.md section 8(d) inputs: z-normalised pseudo-gaussian audio, motion, zero shape, style, ones indicator."""
+    from msmd_amd import synth
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
+    return dict(
+        audio=t(synth.audio_clips(B, 64000, tag=f"bench_audio_r{rank}")),
+        motion=t(synth.motion_clips(B, tag=f"bench_motion_r{rank}")),
+        shape=torch.zeros(B, 100, device=device),
+        style=t(synth.normalish(f"bench_style_r{rank}", (B, 256))),
+        indicator=torch.ones(B, 100, device=device),
+        eps=t(synth.normalish(f"bench_eps_r{rank}", (B, 100, 67))),
+        time_step=[(37 * i + 11) % 500 + 1 for i in range(B)],
+    )
+
+
+def step(model, b):
+    return model(b["motion"], b["audio"], b["shape"], b["style"], time_step=b["time_step"], indicator=b["indicator"],
+                 train_with_CFG=False, eps=b["eps"])
+
+
+def roofline_leg(model, b, steps=3):
+    """Per-launch HIP-event timing of every msmd_gemm launch (the dominant kernel family) over `steps` steps."""
+    from msmd_amd import ops
+    step(model, b)
+    torch.cuda.synchronize()
+    ops.GEMM_TRACE = []
+    for _ in range(steps):
+        step(model, b)
+    torch.cuda.synchronize()
+    trace, ops.GEMM_TRACE = ops.GEMM_TRACE, None
+    flops = 0.0
+    ms = 0.0
+    n_launch = 0
+    big_f = big_ms = 0.0
+    big_n = 0
+    for (M, N, K, batch, dt, e0, e1) in trace:
+        f = 2.0 * M * N * K * batch
+        d = e0.elapsed_time(e1)
+        flops += f
+        ms += d
+        n_launch += 1
+        tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
+        if N > 64 and tiles >= 128:  # launches that run the 128x128 kernel (see csrc/gemm.hip launch_gemm)
+            big_f += f
+            big_ms += d
+            big_n += 1
+    achieved = big_f / (big_ms * 1e-3) / 1e12 if big_ms > 0 else 0.0
+    return dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
+                kernel="gemm_kernel<bf16,bf16,128,128> (csrc/gemm.hip)",
+                launches_per_step=big_n // steps, gflop_per_step=round(big_f / steps / 1e9, 1),
+                ms_per_step_in_kernel=round(big_ms / steps, 3),
+                all_gemm_tflops=round(flops / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
+                all_gemm_launches_per_step=n_launch // steps, all_gemm_ms_per_step=round(ms / steps, 3))
+
+
+def cpu_baseline_leg(B=4):
+    """Numpy oracle (parity-pinned port of the reference CPU path) on this host: MSMD.forward on B clips."""
+    from msmd_amd import shapes, synth
+    from msmd_amd.config import default_args
+    from oracle import diffusion as od
+    args = default_args()
+    sd = synth.fill_state_dict(shapes.msmd_shapes(args))
+    sched = od.diffusion_schedule(500, "cosine")
+    audio = synth.audio_clips(B, 64000, tag="bench_audio_r0")
+    motion = synth.motion_clips(B, tag="bench_motion_r0")
+    style = synth.normalish("bench_style_r0", (B, 256))
+    eps = synth.normalish("bench_eps_r0", (B, 100, 67))
+    ts = [(37 * i + 11) % 500 + 1 for i in range(B)]
+    t0 = time.time()
+    od.msmd_forward(sd, sched, motion, audio, np.zeros((B, 100), np.float32), style, ts, eps,
+                    indicator=np.ones((B, 100), np.float32))
+    dt = time.time() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return dict(value=round(B * 100 / dt, 1), unit="frames/s", cores=int(cores), kind="port",
+                sample=f"oracle.diffusion.msmd_forward (numpy fp32) on {B} clips of the same synthetic workload, "
+                       f"{dt:.1f} s wall")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    from msmd_amd import dp
+    dp.init("nccl", device)
+
+    from msmd_amd.config import default_args
+    from msmd_amd.model import get_diffusion_model
+    args = default_args(compute_dtype=a.dtype)
+    model = get_diffusion_model(args, device).eval()
+    b = synth_batch(a.batch, rank, device)
+    elapsed = dp.timed_steps(lambda: step(model, b), a.steps, a.warmup, sync=torch.cuda.synchronize, device=device)
+
+    if rank == 0:
+        n = max(world, a.gpus) if dist else 1
+        frames = a.batch * 100 * a.steps * n
+        value = frames / elapsed
+        out = {
+            "metric": "FLAME frames/sec on 4s@16kHz clips (whole job; MSMD.forward motion-coefficient frames)",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": n, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "configs[1]: MSMD.forward, batch=32 x 4 s clips per GPU, wav2vec2-base encoder + "
+                                   "8-layer motion decoder, eval-mode, synthetic closed-form weights",
+                       "batch_per_gpu": a.batch, "clip_seconds": 4, "frames_per_clip": 100,
+                       "parallelism": f"dp{n} (independent clips, no collective)"},
+            "end_to_end_tflops": round(value * FLOP_PER_FRAME / 1e12 / n, 1),
+        }
+        if not a.no_roofline:
+            out["roofline"] = roofline_leg(model, b)
+        if not a.no_cpu_baseline and n == 1:
+            out["cpu_baseline"] = cpu_baseline_leg()
+        print(json.dumps(out), flush=True)
+    if dist:
+        import torch.distributed as td
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,10 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_ELU = 0, 1, 2
 CONV0_SPLITS = 16
 
+# Optional per-launch timing of the dominant kernel (bench.py roofline leg): when a list is installed
+# here, every msmd_gemm launch is bracketed by HIP events recorded on the launch stream.
+GEMM_TRACE = None
+
 
 def _dt(t: torch.Tensor) -> int:
     if t.dtype == torch.float32:
@@ -65,9 +69,15 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
     ldr = residual.stride(-2) if residual is not None and residual.dim() >= 2 else N
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("bias must be fp32")
+    if GEMM_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(lib.msmd_gemm(_p(a), _p(w), _p(bias), _p(residual), _p(out), M, N, K, _dt(a), _dt(out), lda,
                              rows_per_batch, a_batch_stride, ldw, ldc, ldr, act, batch, strideA, strideW, strideC,
                              strideBias, strideR, _stream()), "msmd_gemm")
+    if GEMM_TRACE is not None:
+        e1.record()
+        GEMM_TRACE.append((M, N, K, batch, _dt(a), e0, e1))
     return out
 
 
