@@ -33,6 +33,9 @@ typedef void* msmd_stream_t; /* hipStream_t */
 
 /* Library / device probe: returns the ABI version; safe to call without a GPU. */
 int msmd_abi_version(void);
+/* Developer knob: key 0 = force a bf16 GEMM kernel variant (0 = built-in heuristic, -1 = register-staged v1
+ * kernels only).  Used by tools/bench_gemm.py; not part of the drop-in surface. */
+int msmd_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense contraction on MFMA:  C = act(A . W^T + bias) + residual
@@ -87,7 +90,9 @@ int msmd_pad_audio(const float* audio, float* out, int B, int L, int reflect_len
 /* conv0 (1->C, k=10, s=5, no bias) statistics for GroupNorm(C groups): stats (B, C, 2) = {mean, rstd}
  * over the T0 = (Lp - 10)/5 + 1 output frames, reading the UNPADDED audio through the pad map.
  * w0: (C, 10) fp32.  Replaces HF Wav2Vec2GroupNormConvLayer (called at utils/wav2vec2.py:79). */
-#define MSMD_CONV0_SPLITS 16 /* ws: (B, MSMD_CONV0_SPLITS, C, 2) fp32 partial (mean, M2), merged with Chan's formula */
+#define MSMD_CONV0_SPLITS 16 /* ws: (B, MSMD_CONV0_SPLITS, 66) fp32 partial signal moments (sum, S[10], R[55]); at least
+                              * B*16*66 floats.  The conv response is linear in the signal, so per-channel mean / variance
+                              * follow from these 66 numbers per clip. */
 int msmd_conv0_stats(const float* audio, const float* w0, float* stats, float* ws, int B, int L, int reflect_len,
                      int replicate_len, int C, float eps, msmd_stream_t stream);
 

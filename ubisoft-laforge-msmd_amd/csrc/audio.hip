@@ -35,87 +35,96 @@ extern "C" int msmd_pad_audio(const float* audio, float* out, int B, int L, int 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// conv0 statistics: partial (mean, M2) per (batch, time split, channel), merged with Chan's formula.
+// conv0 statistics for GroupNorm(C groups, C channels) WITHOUT evaluating the conv per channel:
+// y_c[t] = sum_k w_c[k] x[5t+k] is linear in x, so over the T0 frames of a clip
+//   sum_t y_c     = w_c . S          S[k]     = sum_t xc[5t+k]
+//   sum_t y_c^2   = w_c^T R w_c      R[k][k'] = sum_t xc[5t+k] xc[5t+k']      (10 + 55 numbers per clip)
+// with xc = x - mu the clip-centred signal (a constant shift leaves the variance unchanged and removes the
+// E[y^2] - mean^2 cancellation for signals with a DC offset).  190x fewer FLOPs than the direct form; the
+// partial sums are fp32 per thread over <= 64 frames, then fp64 across threads/splits.
 #define C0_K 10
 #define C0_S 5
 #define C0_SPLITS 16
+#define C0_NMOM 66  // 1 (sum x) + 10 (S) + 55 (upper triangle of R)
 
-__global__ __launch_bounds__(256) void conv0_stats_partial(const float* __restrict__ audio,
-                                                           const float* __restrict__ w0, float* __restrict__ ws,
-                                                           int L, int r, int rep, int C, int T0) {
-  // block = 64 channels x 4 time lanes; blockIdx = (channel group, split, batch)
-  __shared__ float xs[4096];
-  __shared__ float red[4][64][2];
-  const int b = blockIdx.z, split = blockIdx.y, cg = blockIdx.x;
-  const int c = cg * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+__global__ __launch_bounds__(256) void conv0_moments_partial(const float* __restrict__ audio, float* __restrict__ ws,
+                                                             int L, int r, int rep, int T0, int pass) {
+  // pass 0: ws[b][split][0] = sum of padded samples (for mu).  pass 1: S and R of the centred signal.
+  __shared__ double red[4][C0_NMOM];
+  const int b = blockIdx.y, split = blockIdx.x;
   const int per = (T0 + C0_SPLITS - 1) / C0_SPLITS;
   const int t_begin = split * per, t_end = min(T0, t_begin + per);
-  float w[C0_K];
+  const int Lp = L + 4 * r + 2 * rep;
+  float* out = ws + ((long)b * C0_SPLITS + split) * C0_NMOM;
+  const float* xa = audio + (long)b * L;
+  if (pass == 0) {
+    // samples [5*t_begin, 5*t_end) partition the first 5*T0 samples; the last split adds the 5-sample tail
+    // the split that owns the last frame also owns the (k - s)-sample tail; empty splits own nothing
+    const int s0 = t_begin * C0_S;
+    const int s1 = (t_begin >= T0) ? s0 : (t_end == T0 ? min(Lp, T0 * C0_S + C0_K - C0_S) : t_end * C0_S);
+    double acc = 0.0;
+    for (int i = s0 + threadIdx.x; i < s1; i += 256) acc += (double)xa[pad_src(i, L, r, rep)];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][0] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)(red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+    return;
+  }
+  // mu from pass 0 (all splits)
+  double tot = 0.0;
+  for (int s = 0; s < C0_SPLITS; ++s) tot += (double)ws[((long)b * C0_SPLITS + s) * C0_NMOM];
+  const int n_used = T0 * C0_S + C0_K - C0_S;
+  const float mu = (float)(tot / (double)n_used);
+  float m[C0_NMOM];
 #pragma unroll
-  for (int k = 0; k < C0_K; ++k) w[k] = (c < C) ? w0[c * C0_K + k] : 0.f;
-  // Welford-free two-pass inside the split, processed in LDS chunks of 800 frames (4005 samples)
-  const int CH = 800;
-  float sum = 0.f;
-  int n = 0;
-  for (int pass = 0; pass < 2; ++pass) {
-    float acc = 0.f;
-    float mean = 0.f;
-    if (pass == 1) {
-      // combine the four time lanes' sums -> split mean (all lanes of a channel see the same value)
-      __syncthreads();
-      red[sl][threadIdx.x & 63][0] = sum;
-      __syncthreads();
-      const int cnt = t_end - t_begin;
-      mean = (red[0][threadIdx.x & 63][0] + red[1][threadIdx.x & 63][0] + red[2][threadIdx.x & 63][0] +
-              red[3][threadIdx.x & 63][0]) / (float)max(cnt, 1);
-    }
-    for (int t0 = t_begin; t0 < t_end; t0 += CH) {
-      const int nt = min(CH, t_end - t0);
-      const int ns = nt * C0_S + (C0_K - C0_S);
-      __syncthreads();
-      for (int i = threadIdx.x; i < ns; i += 256) xs[i] = audio[(long)b * L + pad_src(t0 * C0_S + i, L, r, rep)];
-      __syncthreads();
-      for (int t = sl; t < nt; t += 4) {
-        float y = 0.f;
+  for (int i = 0; i < C0_NMOM; ++i) m[i] = 0.f;
+  for (int t = t_begin + threadIdx.x; t < t_end; t += 256) {
+    float x[C0_K];
 #pragma unroll
-        for (int k = 0; k < C0_K; ++k) y = fmaf(w[k], xs[t * C0_S + k], y);
-        if (pass == 0) acc += y; else { const float d = y - mean; acc = fmaf(d, d, acc); }
-      }
-    }
-    if (pass == 0) sum = acc;
-    else {
-      __syncthreads();
-      red[sl][threadIdx.x & 63][1] = acc;
-      __syncthreads();
-      if (sl == 0 && c < C) {
-        const float m2 = red[0][threadIdx.x][1] + red[1][threadIdx.x][1] + red[2][threadIdx.x][1] + red[3][threadIdx.x][1];
-        float* o = ws + (((long)b * C0_SPLITS + split) * C + c) * 2;
-        o[0] = mean;
-        o[1] = m2;
+    for (int k = 0; k < C0_K; ++k) x[k] = xa[pad_src(t * C0_S + k, L, r, rep)] - mu;
+#pragma unroll
+    for (int k = 0; k < C0_K; ++k) {
+      m[1 + k] += x[k];
+#pragma unroll
+      for (int k2 = k; k2 < C0_K; ++k2) {
+        const int idx = 1 + C0_K + k * C0_K - (k * (k - 1)) / 2 + (k2 - k);  // upper-triangle index, compile time
+        m[idx] = fmaf(x[k], x[k2], m[idx]);
       }
     }
   }
-  (void)n;
+#pragma unroll
+  for (int i = 1; i < C0_NMOM; ++i) {
+    double v = (double)m[i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 1 && threadIdx.x < C0_NMOM)
+    out[threadIdx.x] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-__global__ void conv0_stats_merge(const float* __restrict__ ws, float* __restrict__ stats, int C, int T0, float eps) {
+__global__ void conv0_stats_finish(const float* __restrict__ ws, const float* __restrict__ w0,
+                                   float* __restrict__ stats, int C, int T0, float eps) {
+  __shared__ double mom[C0_NMOM];
   const int b = blockIdx.y;
+  if (threadIdx.x < C0_NMOM) {
+    double v = 0.0;
+    for (int s = 0; s < C0_SPLITS; ++s) v += (double)ws[((long)b * C0_SPLITS + s) * C0_NMOM + threadIdx.x];
+    mom[threadIdx.x] = v;
+  }
+  __syncthreads();
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const int per = (T0 + C0_SPLITS - 1) / C0_SPLITS;
-  double n = 0.0, mean = 0.0, m2 = 0.0;
-  for (int s = 0; s < C0_SPLITS; ++s) {
-    const int cnt = min(T0, (s + 1) * per) - min(T0, s * per);
-    if (cnt <= 0) continue;
-    const float* p = ws + (((long)b * C0_SPLITS + s) * C + c) * 2;
-    const double mb = p[0], m2b = p[1], nb = cnt;
-    const double delta = mb - mean, tot = n + nb;
-    mean += delta * nb / tot;
-    m2 += m2b + delta * delta * n * nb / tot;
-    n = tot;
-  }
-  stats[((long)b * C + c) * 2 + 0] = (float)mean;
-  stats[((long)b * C + c) * 2 + 1] = (float)(1.0 / sqrt(m2 / n + (double)eps));
+  const double n_used = (double)(T0 * C0_S + C0_K - C0_S), mu = mom[0] / n_used;
+  double w[C0_K], wsum = 0.0, ws1 = 0.0, q = 0.0;
+  for (int k = 0; k < C0_K; ++k) { w[k] = (double)w0[c * C0_K + k]; wsum += w[k]; ws1 += w[k] * mom[1 + k]; }
+  int idx = 1 + C0_K;
+  for (int k = 0; k < C0_K; ++k)
+    for (int k2 = k; k2 < C0_K; ++k2) q += (k2 == k ? 1.0 : 2.0) * w[k] * w[k2] * mom[idx++];
+  const double mc = ws1 / T0;                 // mean of the centred response
+  const double var = q / T0 - mc * mc;
+  stats[((long)b * C + c) * 2 + 0] = (float)(mc + mu * wsum);
+  stats[((long)b * C + c) * 2 + 1] = (float)(1.0 / sqrt(fmax(var, 0.0) + (double)eps));
 }
 
 extern "C" int msmd_conv0_stats(const float* audio, const float* w0, float* stats, float* ws, int B, int L,
@@ -124,11 +133,11 @@ extern "C" int msmd_conv0_stats(const float* audio, const float* w0, float* stat
   const int Lp = L + 4 * reflect_len + 2 * replicate_len;
   const int T0 = (Lp - C0_K) / C0_S + 1;
   if (T0 <= 0) return 1;
-  dim3 grid((C + 63) / 64, C0_SPLITS, B);
-  hipLaunchKernelGGL(conv0_stats_partial, grid, dim3(256), 0, (hipStream_t)stream, audio, w0, ws, L, reflect_len,
-                     replicate_len, C, T0);
-  hipLaunchKernelGGL(conv0_stats_merge, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, ws, stats, C,
-                     T0, eps);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(C0_SPLITS, B);
+  hipLaunchKernelGGL(conv0_moments_partial, grid, dim3(256), 0, st, audio, ws, L, reflect_len, replicate_len, T0, 0);
+  hipLaunchKernelGGL(conv0_moments_partial, grid, dim3(256), 0, st, audio, ws, L, reflect_len, replicate_len, T0, 1);
+  hipLaunchKernelGGL(conv0_stats_finish, dim3((C + 255) / 256, B), dim3(256), 0, st, ws, w0, stats, C, T0, eps);
   MSMD_RETURN_LAST();
 }
 
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
         float y = 0.f;
 #pragma unroll
         for (int k = 0; k < C0_K; ++k) y = fmaf(w[e][k], xs[t * C0_S + k], y);
-        o[e] = gelu_erf(fmaf(y, sc[e], sh[e]));
+        o[e] = sizeof(TO) == 2 ? gelu_fast(fmaf(y, sc[e], sh[e])) : gelu_erf(fmaf(y, sc[e], sh[e]));
       }
       TO* op = out + ((long)b * T0 + t0 + t) * C + c0;
       if constexpr (sizeof(TO) == 4) *(f32x4*)op = f32x4{o[0], o[1], o[2], o[3]};

@@ -30,6 +30,18 @@ template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return
 // Exact erf GELU (HF ACT2FN['gelu'] / torch F.gelu(approximate='none')).
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): 1 rcp + 1 exp + 6 FMA instead of libm's branchy erff.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float y = 1.0f - poly * t * __expf(-ax * ax);
+  return copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float apply_act(float x, int act) {
   if (act == MSMD_ACT_GELU) return gelu_erf(x);

@@ -19,7 +19,7 @@ struct GemmArgs {
   const void* A; const void* W; const float* bias; const void* R; void* C;
   int M, N, K;
   long lda; int rows_per_batch; long a_batch_stride; long ldw, ldc, ldr;
-  int act; int vec_ok;
+  int act; int vec_ok; float inv_rpb;
   long strideA, strideW, strideC, strideBias, strideR;
   int mt, nt;
 };
@@ -44,6 +44,121 @@ template <> struct Mfma<float> {
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// Row m of the (possibly windowed) A operand -> element offset.  Plain GEMMs skip the division; windowed
+// (conv) rows use an fp32 reciprocal with an exact fix-up (m < 2^24), not a 40-instruction integer divide.
+__device__ __forceinline__ long a_row_offset(const GemmArgs& p, int m) {
+  if (p.rows_per_batch >= p.M) return (long)m * p.lda;
+  int q = (int)((float)m * p.inv_rpb);
+  int r = m - q * p.rows_per_batch;
+  if (r < 0) { q -= 1; r += p.rows_per_batch; }
+  if (r >= p.rows_per_batch) { q += 1; r -= p.rows_per_batch; }
+  return (long)q * p.a_batch_stride + (long)r * p.lda;
+}
+
+// Epilogue shared by both kernels: lane holds row m = ..+fr, columns n = ..+fq*4 + {0..3} of each 16x16 fragment.
+template <typename TO> __device__ __forceinline__ float act_out(float x, int act) {
+  // bf16 outputs keep 8 significant bits: the cheap erf (|err| < 1.5e-7) is far below half an ulp there;
+  // fp32 outputs (parity mode) use the exact erff.
+  if (act == MSMD_ACT_GELU) return sizeof(TO) == 2 ? gelu_fast(x) : gelu_erf(x);
+  if (act == MSMD_ACT_ELU) return elu1(x);
+  return x;
+}
+
+// Interior tiles (fully inside M x N, vector-aligned): straight-line code, no per-element bounds checks.
+template <typename TO, int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int z, int m_base,
+                                                       int n_base, int fr, int fq) {
+  TO* __restrict__ C = (TO*)p.C + z * p.strideC + (long)(m_base + fr) * p.ldc + n_base + fq * 4;
+  const TO* __restrict__ R = p.R ? (const TO*)p.R + z * p.strideR + (long)(m_base + fr) * p.ldr + n_base + fq * 4 : nullptr;
+  const float* __restrict__ bias = p.bias ? p.bias + z * p.strideBias + n_base + fq * 4 : nullptr;
+  f32x4 bv[FN];
+#pragma unroll
+  for (int i = 0; i < FN; ++i) bv[i] = bias ? *(const f32x4*)(bias + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    TO* crow = C + (long)j * 16 * p.ldc;
+    const TO* rrow = R ? R + (long)j * 16 * p.ldr : nullptr;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = act_out<TO>(acc[i][j][e] + bv[i][e], p.act);
+      if (rrow) {
+        if constexpr (sizeof(TO) == 4) {
+          const f32x4 r = *(const f32x4*)(rrow + i * 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += r[e];
+        } else {
+          const bf16x4 r = *(const bf16x4*)(rrow + i * 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+        }
+      }
+      if constexpr (sizeof(TO) == 4) *(f32x4*)(crow + i * 16) = f32x4{v[0], v[1], v[2], v[3]};
+      else *(bf16x4*)(crow + i * 16) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    }
+  }
+}
+
+template <typename TO, int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int z, int m_base,
+                                              int n_base, int fr, int fq) {
+  if (p.vec_ok && m_base + FM * 16 <= p.M && n_base + FN * 16 <= p.N) {
+    gemm_epilogue_interior<TO, FM, FN>(p, acc, z, m_base, n_base, fr, fq);
+    return;
+  }
+  TO* __restrict__ C = (TO*)p.C + z * p.strideC;
+  const TO* __restrict__ R = p.R ? (const TO*)p.R + z * p.strideR : nullptr;
+  const float* __restrict__ bias = p.bias ? p.bias + z * p.strideBias : nullptr;
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+    const int n = n_base + i * 16 + fq * 4;
+    if (n >= p.N) continue;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = (n + e < p.N) ? bias[n + e] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = m_base + j * 16 + fr;
+      if (m >= p.M) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = act_out<TO>(acc[i][j][e] + bv[e], p.act);
+      TO* cp = C + (long)m * p.ldc + n;
+      if (p.vec_ok && n + 3 < p.N) {
+        if (R) {
+          const TO* rp = R + (long)m * p.ldr + n;
+          if constexpr (sizeof(TO) == 4) {
+            const f32x4 r = *(const f32x4*)rp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += r[e];
+          } else {
+            const bf16x4 r = *(const bf16x4*)rp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+          }
+        }
+        if constexpr (sizeof(TO) == 4) {
+          *(f32x4*)cp = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+          *(bf16x4*)cp = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n + e < p.N) {
+            float o = v[e];
+            if (R) o += to_f32(R[(long)m * p.ldr + n + e]);
+            cp[e] = from_f32<TO>(o);
+          }
+        }
+      }
+    }
+  }
+}
 
 template <typename T, typename TO, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
@@ -75,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int m = m0 + row;
     a_ok[i] = m < p.M;
     const int mm = a_ok[i] ? m : 0;
-    a_ptr[i] = A + (long)(mm / p.rows_per_batch) * p.a_batch_stride + (long)(mm % p.rows_per_batch) * p.lda + cc * E;
+    a_ptr[i] = A + a_row_offset(p, mm) + cc * E;
     a_lds[i] = lds_off(row, cc);
   }
 #pragma unroll
@@ -138,56 +253,134 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     __syncthreads();
   }
 
-  // epilogue: lane holds row m = ..+fr, columns n = ..+fq*4 + {0..3}
-  TO* __restrict__ C = (TO*)p.C + z * p.strideC;
-  const TO* __restrict__ R = p.R ? (const TO*)p.R + z * p.strideR : nullptr;
-  const float* __restrict__ bias = p.bias ? p.bias + z * p.strideBias : nullptr;
+  gemm_epilogue<TO, FM, FN>(p, acc, z, m0 + wm, n0 + wn, fr, fq);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bf16 kernel v2: LDS-DMA staging (global_load_lds, 16 B/lane) into an NSTAGE-deep LDS ring, counted
+// s_waitcnt vmcnt so NSTAGE-2 K tiles stay in flight ACROSS the (single, raw) barrier of each K step.
+// Same LDS image / swizzle / fragment reads / epilogue as v1; the swizzle moves to the per-lane SOURCE
+// address because an LDS-DMA wave-instruction writes 1 KiB linearly (cdna_hip_programming.md rule 21).
+// Requires K % 64 == 0 (no K tail: LDS-DMA cannot zero-fill); out-of-range rows are clamped to a valid
+// row (their products are never stored).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const GemmArgs p) {
+  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int LPT = (BM + BN) * 8 / NT;  // LDS-DMA instructions per thread per K tile
+  constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+  static_assert((BM + BN) * 8 % NT == 0, "tile chunks must divide over the threads");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int pid = blockIdx.x;
+  const int xcd = pid & 7, slot = pid >> 3;
+  const int m_tile = (slot / p.nt) * 8 + xcd, n_tile = slot % p.nt;
+  if (m_tile >= p.mt) return;
+  const int z = blockIdx.z;
+  const bf16_t* __restrict__ A = (const bf16_t*)p.A + z * p.strideA;
+  const bf16_t* __restrict__ W = (const bf16_t*)p.W + z * p.strideW;
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+  const bf16_t* src[LPT];
 #pragma unroll
-  for (int i = 0; i < FN; ++i) {
-    const int n = n0 + wn + i * 16 + fq * 4;
-    if (n >= p.N) continue;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bv[e] = (n + e < p.N) ? bias[n + e] : 0.f;
+  for (int i = 0; i < LPT; ++i) {
+    const int id = (i * NW + wid) * 64 + lane;  // 16-B slot of the tile image
+    const int row = id >> 3, phys = id & 7;
+    const int c = phys ^ ((row >> 1) & 7);      // logical chunk stored at this physical slot
+    if (row < BM) {
+      const int m = min(m0 + row, p.M - 1);
+      src[i] = A + a_row_offset(p, m) + c * 8;
+    } else {
+      const int n = min(n0 + row - BM, p.N - 1);
+      src[i] = W + (long)n * p.ldw + c * 8;
     }
+  }
+  auto issue = [&](int kt, int stage) {
 #pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      const int m = m0 + wm + j * 16 + fr;
-      if (m >= p.M) continue;
-      float v[4];
+    for (int i = 0; i < LPT; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[i] + kt * 64),
+                                       (lds_void_t*)(smem + stage * STAGE + (i * NW + wid) * 1024), 16, 0, 0);
+  };
+
+  const int wm = (wid / WN) * (BM / WM), wn = (wid % WN) * (BN / WN);
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4 acc[FN][FM];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][e] + bv[e], p.act);
-      TO* cp = C + (long)m * p.ldc + n;
-      if (p.vec_ok && n + 3 < p.N) {
-        if (R) {
-          const TO* rp = R + (long)m * p.ldr + n;
-          if constexpr (sizeof(TO) == 4) {
-            const f32x4 r = *(const f32x4*)rp;
+  for (int i = 0; i < FN; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += r[e];
-          } else {
-            const bf16x4 r = *(const bf16x4*)rp;
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / 64;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-          }
-        }
-        if constexpr (sizeof(TO) == 4) {
-          *(f32x4*)cp = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-          *(bf16x4*)cp = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-        }
-      } else {
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) issue(s, s);
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + NSTAGE - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, (stage + NSTAGE - 1) % NSTAGE);
+    const unsigned char* sa = smem + stage * STAGE;
+    const unsigned char* sw = sa + BM * 128;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (n + e < p.N) {
-            float o = v[e];
-            if (R) o += to_f32(R[(long)m * p.ldr + n + e]);
-            cp[e] = from_f32<TO>(o);
-          }
-        }
-      }
+    for (int g = 0; g < 2; ++g) {
+      u32x4 fx[FM], fw[FN];
+#pragma unroll
+      for (int j = 0; j < FM; ++j) fx[j] = *(const u32x4*)(sa + lds_off(wm + j * 16 + fr, g * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < FN; ++i) fw[i] = *(const u32x4*)(sw + lds_off(wn + i * 16 + fr, g * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) Mfma<bf16_t>::run(fw[i], fx[j], acc[i][j]);
     }
+    stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
+  }
+  gemm_epilogue<TO, FM, FN>(p, acc, z, m0 + wm, n0 + wn, fr, fq);
+}
+
+static int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" int msmd_set_tuning(int key, int value) {
+  if (key < 0 || key >= 8) return 1;
+  g_tuning[key] = value;
+  return 0;
+}
+
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE>
+static int launch_gemm2(GemmArgs& p, int batch, hipStream_t st) {
+  constexpr int lds = NSTAGE * (BM + BN) * 128;
+  static bool attr_done = false;
+  auto kfn = gemm2_kernel<TO, BM, BN, WM, WN, NSTAGE>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  p.mt = (p.M + BM - 1) / BM; p.nt = (p.N + BN - 1) / BN;
+  dim3 grid(((p.mt + 7) / 8) * 8 * p.nt, 1, batch);
+  hipLaunchKernelGGL(kfn, grid, dim3(WM * WN * 64), lds, st, p);
+  MSMD_RETURN_LAST();
+}
+
+template <typename TO>
+static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
+  switch (variant) {
+    case 1: return launch_gemm2<TO, 128, 128, 2, 2, 2>(p, batch, st);
+    case 2: return launch_gemm2<TO, 128, 128, 2, 2, 3>(p, batch, st);
+    case 3: return launch_gemm2<TO, 128, 128, 2, 2, 4>(p, batch, st);
+    case 4: return launch_gemm2<TO, 256, 128, 4, 2, 3>(p, batch, st);
+    case 5: return launch_gemm2<TO, 256, 256, 2, 4, 2>(p, batch, st);
+    case 6: return launch_gemm2<TO, 128, 256, 2, 4, 3>(p, batch, st);
+    case 7: return launch_gemm2<TO, 64, 128, 1, 4, 4>(p, batch, st);
+    case 8: return launch_gemm2<TO, 128, 64, 4, 1, 4>(p, batch, st);
+    case 9: return launch_gemm2<TO, 64, 64, 2, 2, 4>(p, batch, st);
+    case 10: return launch_gemm2<TO, 128, 64, 2, 2, 3>(p, batch, st);
+    case 11: return launch_gemm2<TO, 64, 128, 2, 2, 3>(p, batch, st);
+    case 12: return launch_gemm2<TO, 64, 64, 2, 2, 2>(p, batch, st);
+    default: return -1;
   }
 }
 
@@ -221,11 +414,25 @@ extern "C" int msmd_gemm(const void* A, const void* W, const float* bias, const 
   p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.rows_per_batch = rows_per_batch; p.a_batch_stride = a_batch_stride;
   p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.act = act;
+  p.inv_rpb = 1.0f / (float)rows_per_batch;
   p.strideA = strideA; p.strideW = strideW; p.strideC = strideC; p.strideBias = strideBias; p.strideR = strideR;
   const int osz = out_dtype == MSMD_BF16 ? 2 : 4;
   p.vec_ok = (ldc % 4 == 0) && (strideC % 4 == 0) && (((uintptr_t)C % (4 * osz)) == 0) &&
              (!residual || ((ldr % 4 == 0) && (strideR % 4 == 0) && (((uintptr_t)residual % (4 * osz)) == 0)));
   hipStream_t st = (hipStream_t)stream;
+  if (in_dtype == MSMD_BF16 && (K % 64) == 0 && g_tuning[0] >= 0) {
+    // Measured on MI355X (tools/bench_gemm.py): the 128x128 LDS-DMA kernel wins once the grid fills the
+    // chip at 2 workgroups per CU; below that, 64x64 tiles (deep ring for long K) keep more CUs busy.
+    int variant = g_tuning[0];
+    if (variant == 0) {
+      const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+      if (N > 64 && tiles128 >= 192) variant = 1;
+      else variant = (K >= 1024) ? 9 : 12;
+    }
+    const int r = out_dtype == MSMD_BF16 ? dispatch_gemm2<bf16_t>(p, batch, st, variant)
+                                         : dispatch_gemm2<float>(p, batch, st, variant);
+    if (r >= 0) return r;
+  }
   if (in_dtype == MSMD_BF16 && out_dtype == MSMD_BF16) return launch_gemm<bf16_t, bf16_t>(p, batch, st);
   if (in_dtype == MSMD_BF16 && out_dtype == MSMD_F32) return launch_gemm<bf16_t, float>(p, batch, st);
   if (in_dtype == MSMD_F32 && out_dtype == MSMD_F32) return launch_gemm<float, float>(p, batch, st);

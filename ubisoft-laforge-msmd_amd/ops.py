@@ -138,7 +138,7 @@ def conv0_gn_gelu(audio, w0, gamma, beta, reflect_len, replicate_len, out_dtype,
     Lp = L + 4 * reflect_len + 2 * replicate_len
     T0 = (Lp - 10) // 5 + 1
     stats = torch.empty(B, C, 2, device=audio.device, dtype=torch.float32)
-    ws = torch.empty(B, CONV0_SPLITS, C, 2, device=audio.device, dtype=torch.float32)
+    ws = torch.empty(B, CONV0_SPLITS, 66, device=audio.device, dtype=torch.float32)
     _lib.check(lib.msmd_conv0_stats(_p(audio), _p(w0), _p(stats), _p(ws), B, L, reflect_len, replicate_len, C, eps,
                                     _stream()), "msmd_conv0_stats")
     out = torch.empty(B, T0, C, device=audio.device, dtype=out_dtype)
