@@ -82,7 +82,7 @@ def roofline_leg(model, b, steps=3):
     achieved = big_f / (big_ms * 1e-3) / 1e12 if big_ms > 0 else 0.0
     return dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                 frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
-                kernel="gemm2_kernel<bf16,128,128,2,2,2> (csrc/gemm.hip)",
+                kernel="gemm2_kernel<bf16,128,128,4,2,2> (csrc/gemm.hip)",
                 launches_per_step=big_n // steps, gflop_per_step=round(big_f / steps / 1e9, 1),
                 ms_per_step_in_kernel=round(big_ms / steps, 3),
                 all_gemm_tflops=round(flops / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,

@@ -191,13 +191,17 @@ def test_group_pad():
     assert np.array_equal(y[:, 1, 8:58], x[:, :, 48:])
 
 
-def test_flame_lbs_matches_oracle_and_golden():
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_flame_lbs_matches_oracle_and_golden(precision):
+    """fp32: exact-fp32 MFMA.  bf16x3: split-bf16 products with fp32 accumulation -- same 5e-6 tolerance on
+    FLAME-scale (|v| ~ 0.1) vertices."""
     from msmd_amd.utils.flame import FLAME, FLAMEConfig
     from types import SimpleNamespace
     g = load_golden("g4_flame")
     asset = synth.flame_asset()
     cfg = SimpleNamespace(**vars(FLAMEConfig))
     cfg.asset = asset
+    cfg.lbs_precision = precision
     fl = FLAME(cfg).to(DEV)
     x = flame_inputs(8)
     pose = g["pose"]

@@ -215,3 +215,41 @@ def test_bf16_mode_tolerance():
     assert e_t <= 0.08 and e_a <= 0.08
     feat = model.extract_audio_feature(dev(synth.audio_clips(2, 64000)))
     assert maxabs(feat.cpu().numpy(), ga["feat"]) <= 0.08
+
+
+def test_sampler_hip_graph_matches_eager():
+    """The captured-step (hipGraph, device-side step counter) loop must equal the eager loop bit for bit when
+    both draw the same noise (zeros here: torch.randn_like is patched before capture)."""
+    from msmd_amd.model import DiffusionSchedule
+    model, args = get_model("wav2vec2", "fp32")
+    x = denoiser_inputs(2, args, tag="sm")
+    T = 6
+    old = model.diffusion_sched
+    model.diffusion_sched = DiffusionSchedule(T, "cosine").to(DEV)
+    xT = dev(synth.normalish("sm/xT", (2, 100, 67)))
+    try:
+        zeros = {t: torch.zeros(2, 100, 67, device=DEV) for t in range(2, T + 1)}
+        for kw in (dict(cfg_scale=1.15), dict(cfg_mode="independent", cfg_scale=[1.3, 0.9], flexibility=0.3)):
+            eager, _, _ = model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]), dev(x["prev_motion"]),
+                                       dev(x["prev_audio"]), motion_at_T=xT, indicator=dev(x["indicator"]), noise=zeros,
+                                       **kw)
+            model.__dict__.pop("_step_graphs", None)
+            with mock.patch("torch.randn_like", side_effect=lambda t: torch.zeros_like(t)):
+                graph, _, _ = model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]),
+                                           dev(x["prev_motion"]), dev(x["prev_audio"]), motion_at_T=xT,
+                                           indicator=dev(x["indicator"]), **kw)
+            assert torch.equal(eager, graph), kw
+        # second call re-uses the cached graph with new operands
+        with mock.patch("torch.randn_like", side_effect=lambda t: torch.zeros_like(t)):
+            again, _, _ = model.sample(dev(x["audio_feat"]) * 0.5, dev(x["shape"]), dev(x["style"]), dev(x["prev_motion"]),
+                                       dev(x["prev_audio"]), motion_at_T=xT, indicator=dev(x["indicator"]), **kw)
+        ref, _, _ = model.sample(dev(x["audio_feat"]) * 0.5, dev(x["shape"]), dev(x["style"]), dev(x["prev_motion"]),
+                                 dev(x["prev_audio"]), motion_at_T=xT, indicator=dev(x["indicator"]), noise=zeros, **kw)
+        assert torch.equal(again, ref)
+        # real noise: finite, and different from the zero-noise trajectory
+        rnd, _, _ = model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]), motion_at_T=xT,
+                                 indicator=dev(x["indicator"]))
+        assert torch.isfinite(rnd).all() and not torch.equal(rnd, eager)
+    finally:
+        model.diffusion_sched = old
+        model.__dict__.pop("_step_graphs", None)

@@ -145,6 +145,67 @@ extern "C" int msmd_cfg_ddpm_step(float* x, const float* res, const float* z, co
 }
 
 // ---------------------------------------------------------------------------------------------------
+// hipGraph support for the sampler: the captured step body must not take per-step host scalars, so the step
+// index lives on the device.  step_select copies row t of the step-embedding table and the (c0, c1, sigma)
+// triple of step t into fixed buffers and then decrements t; cfg_ddpm_dev reads the triple from there.
+template <typename T>
+__global__ void step_select_kernel(const T* __restrict__ emb_all, const float* __restrict__ coef_table,
+                                   int* __restrict__ t_dev, T* __restrict__ emb_row, float* __restrict__ coefs, int d) {
+  const int t = *t_dev;
+  __syncthreads();
+  for (int i = threadIdx.x; i < d; i += blockDim.x) emb_row[i] = emb_all[(long)t * d + i];
+  if (threadIdx.x < 3) coefs[threadIdx.x] = coef_table[t * 3 + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) *t_dev = t - 1;
+}
+
+extern "C" int msmd_sampler_step_select(const void* emb_all, const float* coef_table, int* t_dev, void* emb_row,
+                                        float* coefs, int d, int dtype, msmd_stream_t stream) {
+  if (d <= 0 || !emb_all || !coef_table || !t_dev || !emb_row || !coefs) return 1;
+  if (dtype == MSMD_F32)
+    hipLaunchKernelGGL(step_select_kernel<float>, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)emb_all,
+                       coef_table, t_dev, (float*)emb_row, coefs, d);
+  else
+    hipLaunchKernelGGL(step_select_kernel<bf16_t>, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)emb_all,
+                       coef_table, t_dev, (bf16_t*)emb_row, coefs, d);
+  MSMD_RETURN_LAST();
+}
+
+__global__ void cfg_ddpm_dev_kernel(float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ z,
+                                    const float* __restrict__ scales, const float* __restrict__ coefs, int n_entries,
+                                    int B, int L, int Lp, int dm, int mode, int target) {
+  const float c0 = coefs[0], c1 = coefs[1], sigma = coefs[2];
+  const long total = (long)B * L * dm;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / ((long)L * dm));
+    const int rem = (int)(i % ((long)L * dm));
+    const int t = rem / dm, k = rem % dm;
+    const long stride_e = (long)B * (Lp + L) * dm;
+    const long off = ((long)b * (Lp + L) + Lp + t) * dm + k;
+    float theta = res[off];
+    for (int e = 0; e < n_entries - 1; ++e) {
+      const float hi = res[(e + 1) * stride_e + off];
+      const float lo = (mode == 1 || e == 0) ? theta : res[e * stride_e + off];
+      theta += scales[e] * (hi - lo);
+    }
+    const float xt = x[i];
+    const float zz = z ? z[i] : 0.f;
+    x[i] = (target == 0) ? (c0 * xt + c1 * theta + sigma * zz) : (c0 * (xt - c1 * theta) + sigma * zz);
+  }
+}
+
+extern "C" int msmd_cfg_ddpm_step_dev(float* x, const float* res, const float* z, const float* scales,
+                                      const float* coefs, int n_entries, int B, int L, int Lp, int dm, int mode,
+                                      int target, msmd_stream_t stream) {
+  if (B <= 0 || L <= 0 || dm <= 0 || n_entries < 1 || (n_entries > 1 && !scales) || !coefs) return 1;
+  const long total = (long)B * L * dm;
+  dim3 grid((unsigned)min((total + 255) / 256, (long)2048)), block(256);
+  hipLaunchKernelGGL(cfg_ddpm_dev_kernel, grid, block, 0, (hipStream_t)stream, x, res, z, scales, coefs, n_entries, B,
+                     L, Lp, dm, mode, target);
+  MSMD_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------------
 template <typename TI, typename TO>
 __global__ void pad_cols_kernel(const TI* __restrict__ x, TO* __restrict__ y, long rows, int ci, int co) {
   const long total = rows * co;

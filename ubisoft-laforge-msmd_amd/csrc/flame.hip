@@ -54,8 +54,9 @@ __global__ __launch_bounds__(64) void lbs_prepare_kernel(const float* __restrict
                                                          const float* __restrict__ pose,
                                                          const float* __restrict__ JS,
                                                          const int* __restrict__ parents, float* __restrict__ coef,
-                                                         float* __restrict__ A, float* __restrict__ joints_out,
-                                                         int NB, int J, int Kp, int pose_is_matrix) {
+                                                         bf16_t* __restrict__ coef_hl, float* __restrict__ A,
+                                                         float* __restrict__ joints_out, int NB, int J, int Kp,
+                                                         int pose_is_matrix) {
   __shared__ float sJ[LBS_MAXJ * 3];
   __shared__ float sR[LBS_MAXJ * 9];
   const int b = blockIdx.x, t = threadIdx.x;
@@ -89,6 +90,11 @@ __global__ __launch_bounds__(64) void lbs_prepare_kernel(const float* __restrict
       v = sR[j * 9 + rc] - ((rc == 0 || rc == 4 || rc == 8) ? 1.0f : 0.0f);
     }
     crow[k] = v;
+    if (coef_hl) {  // bf16 hi/lo split for the 3-product MFMA form: v ~= hi + lo with 16 significant bits
+      const bf16_t hi = (bf16_t)v;
+      coef_hl[((long)b * 2 + 0) * Kp + k] = hi;
+      coef_hl[((long)b * 2 + 1) * Kp + k] = (bf16_t)(v - (float)hi);
+    }
   }
   if (t == 0) {
     // kinematic chain (utils/lbs.py:317-371): T_0 = [R_0 | J_0]; T_i = T_parent . [R_i | J_i - J_parent]
@@ -134,11 +140,11 @@ __global__ __launch_bounds__(64) void lbs_prepare_kernel(const float* __restrict
 }
 
 extern "C" int msmd_lbs_prepare(const float* betas, const float* pose, const float* JS, const int* parents,
-                                float* coef, float* A, float* joints, int B, int NB, int J, int Kp,
+                                float* coef, void* coef_hl, float* A, float* joints, int B, int NB, int J, int Kp,
                                 int pose_is_matrix, msmd_stream_t stream) {
   if (B <= 0 || NB <= 0 || J <= 0 || J > LBS_MAXJ || Kp < NB + (J - 1) * 9) return 1;
-  hipLaunchKernelGGL(lbs_prepare_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, betas, pose, JS, parents, coef, A,
-                     joints, NB, J, Kp, pose_is_matrix);
+  hipLaunchKernelGGL(lbs_prepare_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, betas, pose, JS, parents, coef,
+                     (bf16_t*)coef_hl, A, joints, NB, J, Kp, pose_is_matrix);
   MSMD_RETURN_LAST();
 }
 
@@ -233,6 +239,107 @@ extern "C" int msmd_lbs_skin(const float* coef, const float* A, const float* v_t
   dim3 grid(vt, splits), block(256);
   hipLaunchKernelGGL((lbs_skin_kernel<48, 5>), grid, block, 0, (hipStream_t)stream, coef, A, v_template, dirs,
                      lbs_weights, verts, B, V, Vp, fpb);
+  MSMD_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused blendshape + skinning, split-bf16 form: coef = c_hi + c_lo, dirs = d_hi + d_lo (bf16 each), and
+//   coef . dirs ~= c_hi.d_hi + c_hi.d_lo + c_lo.d_hi      (the dropped lo.lo term is 2^-16 relative)
+// on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: 54 MFMAs x 16 cycles per 16x16 tile instead of 144 x 32 on
+// the fp32 MFMA, which moves the kernel from matrix-bound to the epilogue / HBM-write side.  Same register
+// residency of dirs (144 VGPRs), same lane-local epilogue.  dirs_hl: (2, 3, Kp/8, Vp, 8) bf16.
+template <int KG, int J>  // KG = Kp / 32 MFMA K groups
+__global__ __launch_bounds__(256) void lbs_skin_bf16x3_kernel(const bf16_t* __restrict__ coef_hl,
+                                                              const float* __restrict__ A,
+                                                              const float* __restrict__ tmpl,
+                                                              const bf16_t* __restrict__ dirs_hl,
+                                                              const float* __restrict__ wts, float* __restrict__ verts,
+                                                              int B, int V, int Vp, int frames_per_block) {
+  constexpr int Kp = KG * 32;
+  __shared__ __attribute__((aligned(16))) float sA[16 * J * 12];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int v = blockIdx.x * 64 + wid * 16 + i;
+  const int f_begin = blockIdx.y * frames_per_block;
+  const int f_end = min(B, f_begin + frames_per_block);
+
+  u32x4 dh[3][KG], dl[3][KG];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      const long off = (((long)c * (Kp / 8) + 4 * g + q) * Vp + v) * 8;
+      dh[c][g] = *(const u32x4*)(dirs_hl + off);
+      dl[c][g] = *(const u32x4*)(dirs_hl + (long)3 * (Kp / 8) * Vp * 8 + off);
+    }
+  float t3[3], w[J];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) t3[c] = tmpl[(long)c * Vp + v];
+#pragma unroll
+  for (int j = 0; j < J; ++j) w[j] = wts[(long)j * Vp + v];
+
+  for (int f0 = f_begin; f0 < f_end; f0 += 16) {
+    __syncthreads();
+    for (int k = tid; k < 16 * J * 12; k += 256) {
+      const int f = f0 + k / (J * 12);
+      sA[k] = f < f_end ? A[(long)f * J * 12 + k % (J * 12)] : 0.f;
+    }
+    const int fa = min(f0 + i, B - 1);
+    const bf16_t* ch = coef_hl + ((long)fa * 2) * Kp + 8 * q;
+    f32x4 acc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4*)(ch + 32 * g));
+      const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4*)(ch + Kp + 32 * g));
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8, dh[c][g]), acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, dl[c][g]), acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, dh[c][g]), acc[c], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int fl = 4 * q + e, f = f0 + fl;
+      float T[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) T[k] = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const f32x4* ap = (const f32x4*)(sA + (fl * J + j) * 12);
+        const f32x4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          T[k] = fmaf(w[j], a0[k], T[k]);
+          T[4 + k] = fmaf(w[j], a1[k], T[4 + k]);
+          T[8 + k] = fmaf(w[j], a2[k], T[8 + k]);
+        }
+      }
+      const float px = t3[0] + acc[0][e], py = t3[1] + acc[1][e], pz = t3[2] + acc[2][e];
+      if (f < f_end && v < V) {
+        float* o = verts + ((long)f * V + v) * 3;
+        o[0] = T[0] * px + T[1] * py + T[2] * pz + T[3];
+        o[1] = T[4] * px + T[5] * py + T[6] * pz + T[7];
+        o[2] = T[8] * px + T[9] * py + T[10] * pz + T[11];
+      }
+    }
+  }
+}
+
+extern "C" int msmd_lbs_skin_bf16x3(const void* coef_hl, const float* A, const float* v_template, const void* dirs_hl,
+                                    const float* lbs_weights, float* verts, int B, int J, int V, int Vp, int Kp,
+                                    msmd_stream_t stream) {
+  if (B <= 0 || V <= 0 || Vp < V || (Vp & 63) || J != 5 || Kp != 192) return 1;
+  const int vt = Vp / 64;
+  int splits = max(1, min((B + 63) / 64, (2048 + vt - 1) / vt));
+  int fpb = (((B + splits - 1) / splits) + 15) / 16 * 16;
+  splits = (B + fpb - 1) / fpb;
+  dim3 grid(vt, splits), block(256);
+  hipLaunchKernelGGL((lbs_skin_bf16x3_kernel<6, 5>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)coef_hl, A,
+                     v_template, (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb);
   MSMD_RETURN_LAST();
 }
 

@@ -380,6 +380,10 @@ static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
     case 10: return launch_gemm2<TO, 128, 64, 2, 2, 3>(p, batch, st);
     case 11: return launch_gemm2<TO, 64, 128, 2, 2, 3>(p, batch, st);
     case 12: return launch_gemm2<TO, 64, 64, 2, 2, 2>(p, batch, st);
+    case 13: return launch_gemm2<TO, 128, 128, 4, 2, 2>(p, batch, st);
+    case 14: return launch_gemm2<TO, 128, 64, 2, 2, 2>(p, batch, st);
+    case 15: return launch_gemm2<TO, 64, 128, 2, 2, 2>(p, batch, st);
+    case 16: return launch_gemm2<TO, 128, 128, 2, 4, 2>(p, batch, st);
     default: return -1;
   }
 }
@@ -426,7 +430,7 @@ extern "C" int msmd_gemm(const void* A, const void* W, const float* bias, const 
     int variant = g_tuning[0];
     if (variant == 0) {
       const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
-      if (N > 64 && tiles128 >= 192) variant = 1;
+      if (N > 64 && tiles128 >= 192) variant = 13;  // 128x128, 8 waves (4x2), 2-stage ring, 2 workgroups/CU
       else variant = (K >= 1024) ? 9 : 12;
     }
     const int r = out_dtype == MSMD_BF16 ? dispatch_gemm2<bf16_t>(p, batch, st, variant)

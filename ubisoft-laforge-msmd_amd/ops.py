@@ -201,6 +201,20 @@ def cfg_ddpm_step(x, res, z, scales, n_entries, Lp, mode, target, c0, c1, sigma)
     return x
 
 
+def sampler_step_select(emb_all, coef_table, t_dev, emb_row, coefs):
+    lib = _lib.load()
+    _lib.check(lib.msmd_sampler_step_select(_p(emb_all), _p(coef_table), _p(t_dev), _p(emb_row), _p(coefs),
+                                            emb_all.shape[-1], _dt(emb_all), _stream()), "msmd_sampler_step_select")
+
+
+def cfg_ddpm_step_dev(x, res, z, scales, coefs, n_entries, Lp, mode, target):
+    lib = _lib.load()
+    B, L, dm = x.shape
+    _lib.check(lib.msmd_cfg_ddpm_step_dev(_p(x), _p(res), _p(z), _p(scales), _p(coefs), n_entries, B, L, Lp, dm, mode,
+                                          target, _stream()), "msmd_cfg_ddpm_step_dev")
+    return x
+
+
 def pad_cols(x, cols_out, out_dtype=None):
     lib = _lib.load()
     cols_in = x.shape[-1]
@@ -225,16 +239,17 @@ def mean_time(x):
 
 
 # ----------------------------------------------------------------------------- FLAME
-def lbs_prepare(betas, pose, JS, parents, Kp=192, pose_is_matrix=False, want_joints=True):
+def lbs_prepare(betas, pose, JS, parents, Kp=192, pose_is_matrix=False, want_joints=True, want_split=False):
     lib = _lib.load()
     B, NB = betas.shape
     J = parents.shape[0]
     coef = torch.empty(B, Kp, device=betas.device, dtype=torch.float32)
+    coef_hl = torch.empty(B, 2, Kp, device=betas.device, dtype=torch.bfloat16) if want_split else None
     A = torch.empty(B, J, 12, device=betas.device, dtype=torch.float32)
     joints = torch.empty(B, J, 3, device=betas.device, dtype=torch.float32) if want_joints else None
-    _lib.check(lib.msmd_lbs_prepare(_p(betas), _p(pose), _p(JS), _p(parents), _p(coef), _p(A), _p(joints), B, NB, J,
-                                    Kp, int(pose_is_matrix), _stream()), "msmd_lbs_prepare")
-    return coef, A, joints
+    _lib.check(lib.msmd_lbs_prepare(_p(betas), _p(pose), _p(JS), _p(parents), _p(coef), _p(coef_hl), _p(A), _p(joints),
+                                    B, NB, J, Kp, int(pose_is_matrix), _stream()), "msmd_lbs_prepare")
+    return coef, coef_hl, A, joints
 
 
 def lbs_skin(coef, A, v_template_planes, dirs, weight_planes, V):
@@ -245,6 +260,17 @@ def lbs_skin(coef, A, v_template_planes, dirs, weight_planes, V):
     verts = torch.empty(B, V, 3, device=coef.device, dtype=torch.float32)
     _lib.check(lib.msmd_lbs_skin(_p(coef), _p(A), _p(v_template_planes), _p(dirs), _p(weight_planes), _p(verts), B, J,
                                  V, Vp, Kp, _stream()), "msmd_lbs_skin")
+    return verts
+
+
+def lbs_skin_bf16x3(coef_hl, A, v_template_planes, dirs_hl, weight_planes, V):
+    lib = _lib.load()
+    B, _, Kp = coef_hl.shape
+    J = A.shape[1]
+    Vp = dirs_hl.shape[-2]
+    verts = torch.empty(B, V, 3, device=A.device, dtype=torch.float32)
+    _lib.check(lib.msmd_lbs_skin_bf16x3(_p(coef_hl), _p(A), _p(v_template_planes), _p(dirs_hl), _p(weight_planes),
+                                        _p(verts), B, J, V, Vp, Kp, _stream()), "msmd_lbs_skin_bf16x3")
     return verts
 
 

@@ -111,17 +111,10 @@ def sample(model, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=N
     te_all = ops.cast(P.te[: T + 1].contiguous(), dtype)
     emb_all = ops.gemm(ops.gemm(te_all, *P.ds0, act=ops.ACT_GELU), *P.ds2)  # (T+1, d)
     scales = torch.tensor(list(cfg_scale), device=dev, dtype=torch.float32) if n_entries > 1 else None
-    feats = torch.empty(N, 1 + Lp + L, P.kp_feat, device=dev, dtype=dtype)
-
-    x = motion_at_T.float().clone().contiguous()
-    traj = {T: motion_at_T} if ret_traj else None
     mode = 1 if cfg_mode == "independent" else 0
     target = 0 if model.target == "sample" else 1
-    for t in range(T, 0, -1):
-        if t > 1:
-            z = noise[t].float().contiguous() if noise is not None else torch.randn_like(x)
-        else:
-            z = None
+
+    def coefficients(t):
         alpha = tab["alphas"][t]
         alpha_bar = tab["alpha_bars"][t]
         alpha_bar_prev = tab["alpha_bars"][t - 1]
@@ -132,6 +125,24 @@ def sample(model, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=N
         else:
             c0 = (1 - alpha_bar_prev) * torch.sqrt(alpha) / (1 - alpha_bar)
             c1 = (1 - alpha) * torch.sqrt(alpha_bar_prev) / (1 - alpha_bar)
+        return float(c0), float(c1), float(sigma)
+
+    use_graph = (noise is None and not dynamic_threshold and not ret_traj and getattr(model, "use_hip_graph", True)
+                 and T > 1)
+    if use_graph:
+        x = _graph_loop(model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, motion_at_T, prev_m,
+                        ind_in, mem, kv_list, stat, tok_person, emb_all, scales, coefficients)
+        return x, motion_at_T, audio_feat
+
+    x = motion_at_T.float().clone().contiguous()
+    traj = {T: motion_at_T} if ret_traj else None
+    feats = torch.empty(N, 1 + Lp + L, P.kp_feat, device=dev, dtype=dtype)
+    for t in range(T, 0, -1):
+        if t > 1:
+            z = noise[t].float().contiguous() if noise is not None else torch.randn_like(x)
+        else:
+            z = None
+        c0, c1, sigma = coefficients(t)
         ops.denoiser_pack_input(x, prev_m, ind_in, feats)
         dec = net.trunk(feats, tok_person, mem, dtype, kv_list=kv_list, row0_add=emb_all[t])
         res = ops.heads_static_mix(dec, stat, Lp + L, dm, nb, net.use_head_alpha)
@@ -141,9 +152,84 @@ def sample(model, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=N
             s = torch.quantile(res[:, -L:].reshape(N, -1).abs(), dt_ratio, dim=1)
             s = torch.clamp(s, min=dt_min, max=dt_max)[..., None, None]
             res = torch.clamp(res, min=-s, max=s).contiguous()
-        ops.cfg_ddpm_step(x, res, z, scales, n_entries, Lp, mode, target, float(c0), float(c1), float(sigma))
+        ops.cfg_ddpm_step(x, res, z, scales, n_entries, Lp, mode, target, c0, c1, sigma)
         if ret_traj:
             traj[t - 1] = x.clone()
     if ret_traj:
         return traj, motion_at_T, audio_feat
     return x, motion_at_T, audio_feat
+
+
+class _StepGraph:
+    """One captured denoise step (hipGraph): device-side step counter, static operand buffers."""
+
+    def __init__(self, model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, like):
+        B = N // n_entries
+        self.x = torch.zeros(B, L, dm, device=dev, dtype=torch.float32)
+        self.prev_m = torch.zeros_like(like["prev_m"])
+        self.ind = torch.zeros_like(like["ind_in"]) if like["ind_in"] is not None else None
+        self.mem = torch.zeros_like(like["mem"])
+        self.kv = [torch.zeros_like(k) for k in like["kv_list"]]
+        self.stat = torch.zeros_like(like["stat"])
+        self.tok = torch.zeros_like(like["tok_person"])
+        self.emb_all = torch.zeros_like(like["emb_all"])
+        self.scales = torch.zeros_like(like["scales"]) if like["scales"] is not None else None
+        self.coef_table = torch.zeros(T + 1, 3, device=dev, dtype=torch.float32)
+        self.t_dev = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.emb_row = torch.zeros(self.emb_all.shape[-1], device=dev, dtype=self.emb_all.dtype)
+        self.coefs = torch.zeros(3, device=dev, dtype=torch.float32)
+        self.feats = torch.zeros(N, 1 + Lp + L, P.kp_feat, device=dev, dtype=dtype)
+        self.T = T
+
+        def body():
+            ops.sampler_step_select(self.emb_all, self.coef_table, self.t_dev, self.emb_row, self.coefs)
+            ops.denoiser_pack_input(self.x, self.prev_m, self.ind, self.feats)
+            dec = net.trunk(self.feats, self.tok, self.mem, dtype, kv_list=self.kv, row0_add=self.emb_row)
+            res = ops.heads_static_mix(dec, self.stat, Lp + L, dm, nb, net.use_head_alpha)
+            z = torch.randn_like(self.x)  # graph-safe philox stream; sigma_1 = 0 reproduces z = 0 at t = 1
+            ops.cfg_ddpm_step_dev(self.x, res, z, self.scales, self.coefs, n_entries, Lp, mode, target)
+        self.body = body
+        # warm-up on a side stream (allocator + lazy kernel loading), then capture
+        self.t_dev.fill_(1)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            body()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            body()
+
+    def run(self, T, motion_at_T, ops_in, coefficients):
+        self.x.copy_(motion_at_T)
+        for name in ("prev_m", "mem", "stat", "emb_all"):
+            getattr(self, name).copy_(ops_in[name])
+        self.tok.copy_(ops_in["tok_person"])
+        if self.ind is not None:
+            self.ind.copy_(ops_in["ind_in"])
+        if self.scales is not None:
+            self.scales.copy_(ops_in["scales"])
+        for dst, src in zip(self.kv, ops_in["kv_list"]):
+            dst.copy_(src)
+        tab = torch.zeros(T + 1, 3)
+        for t in range(1, T + 1):
+            c0, c1, sg = coefficients(t)
+            tab[t, 0], tab[t, 1], tab[t, 2] = c0, c1, (sg if t > 1 else 0.0)
+        self.coef_table.copy_(tab)
+        self.t_dev.fill_(T)
+        for _ in range(T):
+            self.graph.replay()
+        return self.x.clone()
+
+
+def _graph_loop(model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, motion_at_T, prev_m, ind_in,
+                mem, kv_list, stat, tok_person, emb_all, scales, coefficients):
+    like = dict(prev_m=prev_m, ind_in=ind_in, mem=mem, kv_list=kv_list, stat=stat, tok_person=tok_person,
+                emb_all=emb_all, scales=scales)
+    key = (T, N, n_entries, Lp, L, mode, target, dtype, ind_in is not None, id(net._packed))
+    cache = model.__dict__.setdefault("_step_graphs", {})
+    g = cache.get(key)
+    if g is None:
+        cache.clear()  # one resident graph (its private memory pool holds all step intermediates)
+        g = cache[key] = _StepGraph(model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, like)
+    return g.run(T, motion_at_T.float(), like, coefficients)

@@ -71,6 +71,7 @@ class FLAME(nn.Module):
             cur = int(parents[cur])
         self.register_buffer("neck_kin_chain", torch.tensor(chain, dtype=torch.long))
         self._packed = None
+        self.lbs_precision = getattr(config, "lbs_precision", None)  # None -> utils.lbs.DEFAULT_PRECISION
 
     def _pack(self):
         if self._packed is None or self._packed["dev"] != self.v_template.device:
@@ -116,7 +117,8 @@ class FLAME(nn.Module):
             full_pose = torch.cat([head, self.neck_pose_mat.expand(B, -1), pose_params[:, 9:], eye_pose_params], dim=1)
         full_pose = full_pose.float().contiguous()
         vertices, _ = _lbs.lbs(betas, full_pose, self.v_template, self.shapedirs, self.posedirs, self.J_regressor,
-                               self.parents, self.lbs_weights, pose2rot, self.dtype, constants=p["lbs"])
+                               self.parents, self.lbs_weights, pose2rot, self.dtype, constants=p["lbs"],
+                               precision=self.lbs_precision)
         landmarks2d = landmarks3d = None
         if return_lm2d:
             if not pose2rot:

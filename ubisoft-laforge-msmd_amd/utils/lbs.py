@@ -36,6 +36,11 @@ class LbsConstants:
         pd = posedirs.float().reshape(-1, V, 3)                      # (P, V, 3)
         dirs[:, NB:NB + pd.shape[0], :V] = pd.permute(2, 0, 1)
         self.dirs = dirs.contiguous()
+        # split-bf16 form for the fast kernel: dirs ~= hi + lo, regrouped in 8-element K octets (2, 3, KP/8, Vp, 8)
+        hi = dirs.to(torch.bfloat16)
+        lo = (dirs - hi.float()).to(torch.bfloat16)
+        oct_ = lambda t: t.reshape(3, KP // 8, 8, Vp).permute(0, 1, 3, 2)
+        self.dirs_hl = torch.stack([oct_(hi), oct_(lo)], 0).contiguous()
         tp = torch.zeros(3, Vp, device=dev, dtype=torch.float32)
         tp[:, :V] = vt.t()
         self.template_planes = tp.contiguous()
@@ -59,8 +64,13 @@ def _constants(v_template, shapedirs, posedirs, J_regressor, parents, lbs_weight
     return c
 
 
+# "bf16x3": split-bf16 MFMA products with fp32 accumulation (max-abs-err ~1e-6 on FLAME-scale vertices, 5x fewer
+# matrix cycles); "fp32": exact-fp32 MFMA.  Both far inside the 1e-4 budget of BASELINE.json.
+DEFAULT_PRECISION = "bf16x3"
+
+
 def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_weights, pose2rot=True,
-        dtype=torch.float32, constants: LbsConstants = None):
+        dtype=torch.float32, constants: LbsConstants = None, precision: str = None):
     """reference utils/lbs.py:141-223.  Returns (verts (B, V, 3), posed joints (B, J, 3))."""
     if dtype != torch.float32:
         raise TypeError("lbs runs in fp32")
@@ -68,8 +78,16 @@ def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_
     B = max(betas.shape[0], pose.shape[0])
     betas = betas.float().expand(B, -1).contiguous()
     pose = pose.float().reshape(pose.shape[0], -1).expand(B, -1).contiguous()
-    coef, A, joints = ops.lbs_prepare(betas, pose, c.JS, c.parents, KP, pose_is_matrix=not pose2rot)
-    verts = ops.lbs_skin(coef, A, c.template_planes, c.dirs, c.weight_planes, c.V)
+    precision = precision or DEFAULT_PRECISION
+    if precision not in ("bf16x3", "fp32"):
+        raise ValueError(f"Unknown LBS precision {precision}!")
+    split = precision == "bf16x3"
+    coef, coef_hl, A, joints = ops.lbs_prepare(betas, pose, c.JS, c.parents, KP, pose_is_matrix=not pose2rot,
+                                               want_split=split)
+    if split:
+        verts = ops.lbs_skin_bf16x3(coef_hl, A, c.template_planes, c.dirs_hl, c.weight_planes, c.V)
+    else:
+        verts = ops.lbs_skin(coef, A, c.template_planes, c.dirs, c.weight_planes, c.V)
     return verts, joints
 
 
