@@ -216,6 +216,28 @@ int msmd_rotation_convert(int op, const float* in, const float* in2, float* out,
                           msmd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Losses / training-step pieces (reference utils/common.py:198-620, 443-454, 769-832; training_script.py:548-551).
+ */
+/* out[0] = scale * mean over valid (n, t) of mean_{c in [c_lo, c_hi)} crit(D^order gt, D^order pred)
+ *   gt, pred: (N, T, C) fp32; D^order = order-th temporal difference (0 = value, 1 = velocity, 2 = smoothness);
+ *   frame t of the differenced sequence is valid when mask[t + order] holds, mask[tm] = tm < prefix ||
+ *   tm - prefix < end_idx[n] (end_idx NULL: all valid).  criterion 0 = squared error, 1 = absolute error.
+ *   mode 1: compare D^order pred against 0 (the smoothness term).  acc_ws: 2 doubles of scratch.
+ *   out is NaN when no frame is valid (the reference returns None there). */
+int msmd_masked_seq_loss(const float* gt, const float* pred, const int* end_idx, float* out, double* acc_ws,
+                         int N, int T, int C, int c_lo, int c_hi, int order, int prefix, int criterion, int mode,
+                         float scale, msmd_stream_t stream);
+/* out[0] = -0.5 * sum(1 + logvar - mu^2 - exp(logvar)) over n elements. */
+int msmd_kl_loss(const float* mu, const float* logvar, float* out, double* acc_ws, long n, msmd_stream_t stream);
+/* In place: x (N, L, inner)[n, end_idx[n]*unit :, :] = 0 (or the last kept row when replicate != 0). */
+int msmd_truncate_rows(float* x, const int* end_idx, int N, int L, int inner, int unit, int replicate,
+                       msmd_stream_t stream);
+/* One Adam step (torch.optim.Adam defaults) on flat fp32 arenas of n elements; grad is multiplied by grad_scale
+ * first (1/world_size after a sum all-reduce).  step is the 1-based step count for bias correction. */
+int msmd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                   float beta1, float beta2, float eps, int step, float grad_scale, msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Small utilities.
  */
 int msmd_cast(const void* x, void* y, long n, int in_dtype, int out_dtype, msmd_stream_t stream);

@@ -425,9 +425,83 @@ def g4_rotations(M, SE, mc):
     save("g4_rotations", **out)
 
 
+# --------------------------------------------------------------------------- G5 losses / scheduler
+def g5_losses(M, SE, mc):
+    from utils import common as C
+    from utils.scheduler import GradualWarmupScheduler
+    args = ref_args()
+    N = 3
+    gt = synth.normalish("loss/gt", (N, 100, 67))
+    prev = synth.normalish("loss/prev", (N, 10, 67))
+    target = synth.normalish("loss/target", (N, 110, 67))
+    end_idx = torch.tensor([100, 37, 1])
+    out = {}
+    for start in (True, False):
+        for use_end in (False, True):
+            r = C.compute_loss_no_vert(args, start, None, t(gt), None, t(target), t(prev), None, None,
+                                       end_idx=end_idx if use_end else None)
+            out[f"nv_{int(start)}_{int(use_end)}"] = np.array([np.nan if v is None else float(v) for v in r], np.float64)
+    args1 = ref_args(criterion="l1")
+    r = C.compute_loss_no_vert(args1, False, None, t(gt), None, t(target), t(prev), None, None, end_idx=end_idx)
+    out["nv_l1"] = np.array([np.nan if v is None else float(v) for v in r], np.float64)
+    mu = synth.normalish("loss/mu", (N, 256))
+    logvar = (0.3 * synth.normalish("loss/logvar", (N, 256))).astype(np.float32)
+    out["kl"] = np.float64(C.compute_KL_loss(t(mu), t(logvar)))
+    # vertex-space variant (legacy 54-d motion) through the reference FLAME on the synthetic asset
+    from utils import flame as FL
+    with tempfile.TemporaryDirectory() as td:
+        pkl, npy = write_flame_asset(td)
+        cfg = FL.FLAMEConfig
+        cfg.flame_model_path, cfg.flame_lmk_embedding_path = pkl, npy
+        fl = FL.FLAME(cfg).eval()
+    L = 12
+    argsv = ref_args(n_motions=L, n_prev_motions=4)
+    gt54 = (0.5 * synth.normalish("loss/gt54", (2, L, 54))).astype(np.float32)
+    prev54 = (0.5 * synth.normalish("loss/prev54", (2, 4, 54))).astype(np.float32)
+    tgt54 = (0.5 * synth.normalish("loss/tgt54", (2, L + 4, 54))).astype(np.float32)
+    shape = (0.5 * synth.normalish("loss/shape", (2, 100))).astype(np.float32)
+    stats = {"exp_mean": t(0.1 * synth.normalish("st/em", (50,))), "exp_std": t(1 + 0.1 * np.abs(synth.normalish("st/es", (50,)))),
+             "pose_mean": t(0.05 * synth.normalish("st/pm", (6,))), "pose_std": t(1 + 0.1 * np.abs(synth.normalish("st/ps", (6,)))),
+             "shape_mean": t(np.zeros(100, np.float32)), "shape_std": t(np.ones(100, np.float32))}
+    for start in (True, False):
+        r = C.compute_loss(argsv, start, t(shape), t(gt54), None, t(tgt54), t(prev54), stats, fl,
+                           end_idx=torch.tensor([L, 5]))
+        out[f"vert_{int(start)}"] = np.array([np.nan if v is None else float(v) for v in r], np.float64)
+    # coefficient glue
+    cd = C.get_coef_dict(t(gt54), t(shape), stats, with_global_pose=False)
+    out["coef_exp"], out["coef_pose"], out["coef_shape"] = cd["exp"].numpy(), cd["pose"].numpy(), cd["shape"].numpy()
+    verts = C.coef_dict_to_vertices(cd, fl, flame_batch_size=7)
+    out["coef_verts_sub"] = verts.numpy()[:, :, ::79]
+    out["motion_coef"] = C.get_motion_coef({"exp": cd["exp"], "pose": cd["pose"]}, "aa", with_global_pose=False).numpy()
+    # truncation with a fixed end index (the random draw is host RNG)
+    a = synth.audio_clips(2, 64000, tag="trunc")
+    mc_ = synth.motion_clips(2, tag="trunc_m")
+    e = torch.tensor([3, 77])
+    out["trunc_audio_zero"] = C._truncate_audio(t(a), (e * 640).long(), "zero").numpy()[:, ::97]
+    out["trunc_audio_rep"] = C._truncate_audio(t(a), (e * 640).long(), "replicate").numpy()[:, ::97]
+    cdt = C._truncate_coef_dict({"exp": t(mc_[..., :50]), "pose_any": t(mc_[..., 50:])}, e, "replicate")
+    out["trunc_motion_rep"] = torch.cat([cdt["exp"], cdt["pose_any"]], -1).numpy()
+    # scheduler trace
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([{"params": [p], "lr": 2e-5}])
+    sch = GradualWarmupScheduler(opt, 1, 10)
+    lrs = []
+    for _ in range(15):
+        opt.step(); sch.step(); lrs.append(opt.param_groups[0]["lr"])
+    out["warmup_lrs"] = np.array(lrs, np.float64)
+    # Adam reference trace (torch.optim.Adam, lr 2e-5) on a fixed gradient sequence
+    w = torch.nn.Parameter(t(synth.normalish("adam/w", (1000,))).clone())
+    opt = torch.optim.Adam([w], lr=2e-3)
+    for i in range(3):
+        w.grad = t(synth.normalish(f"adam/g{i}", (1000,)))
+        opt.step()
+    out["adam_w3"] = w.detach().numpy()
+    save("g5_losses", **out)
+
+
 ALL = dict(g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
            g3_forward=g3_forward, g3_style=g3_style, g3_sample=g3_sample, g3_infer=g3_infer,
-           g4_flame=g4_flame, g4_rotations=g4_rotations)
+           g4_flame=g4_flame, g4_rotations=g4_rotations, g5_losses=g5_losses)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

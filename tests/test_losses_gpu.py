@@ -1,0 +1,129 @@
+"""GPU parity of losses / coefficient glue / truncation / Adam against goldens from the reference
+(utils/common.py, utils/scheduler.py, torch.optim.Adam)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from msmd_amd import synth
+from msmd_amd.config import default_args
+
+from conftest import load_golden
+from helpers import maxabs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def vals(r):
+    return np.array([np.nan if v is None else float(v) for v in r], np.float64)
+
+
+def test_compute_loss_no_vert_and_kl():
+    from msmd_amd.utils import common as C
+    g = load_golden("g5_losses")
+    args = default_args()
+    N = 3
+    gt = dev(synth.normalish("loss/gt", (N, 100, 67)))
+    prev = dev(synth.normalish("loss/prev", (N, 10, 67)))
+    target = dev(synth.normalish("loss/target", (N, 110, 67)))
+    end_idx = torch.tensor([100, 37, 1], device=DEV)
+    for start in (True, False):
+        for use_end in (False, True):
+            r = C.compute_loss_no_vert(args, start, None, gt, None, target, prev, None, None,
+                                       end_idx=end_idx if use_end else None)
+            ref = g[f"nv_{int(start)}_{int(use_end)}"]
+            got = vals(r)
+            assert np.array_equal(np.isnan(got), np.isnan(ref)), (start, use_end)
+            # losses are O(1) means of squared differences of O(1) values: fp32 reduction noise
+            assert np.nanmax(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))) < 2e-6, (start, use_end, got, ref)
+    r = C.compute_loss_no_vert(default_args(criterion="l1"), False, None, gt, None, target, prev, None, None,
+                               end_idx=end_idx)
+    assert np.nanmax(np.abs(vals(r) - g["nv_l1"])) < 5e-6
+    d = C.compute_loss_no_vert(args, False, None, gt, None, target, prev, None, None, end_idx=end_idx, return_dict=True)
+    assert set(d) == {"noise", "vel", "smooth", "head_angle", "head_vel", "head_smooth", "head_trans"}
+    mu = dev(synth.normalish("loss/mu", (N, 256)))
+    logvar = dev((0.3 * synth.normalish("loss/logvar", (N, 256))).astype(np.float32))
+    assert abs(float(C.compute_KL_loss(mu, logvar)) - float(g["kl"])) < 1e-3 * abs(float(g["kl"])) * 1e-2 + 1e-3
+    with pytest.raises(NotImplementedError):
+        C.compute_loss_no_vert(default_args(criterion="huber"), True, None, gt, None, target, prev, None, None)
+    with pytest.raises(ValueError):
+        C.compute_loss_no_vert(default_args(target="bogus"), True, None, gt, None, target, prev, None, None)
+
+
+def _flame():
+    from msmd_amd.utils.flame import FLAME, FLAMEConfig
+    cfg = SimpleNamespace(**vars(FLAMEConfig))
+    cfg.asset = synth.flame_asset()
+    return FLAME(cfg).to(DEV)
+
+
+def test_vertex_space_loss_and_coef_glue():
+    from msmd_amd.utils import common as C
+    g = load_golden("g5_losses")
+    fl = _flame()
+    L = 12
+    argsv = default_args(n_motions=L, n_prev_motions=4)
+    gt54 = dev((0.5 * synth.normalish("loss/gt54", (2, L, 54))).astype(np.float32))
+    prev54 = dev((0.5 * synth.normalish("loss/prev54", (2, 4, 54))).astype(np.float32))
+    tgt54 = dev((0.5 * synth.normalish("loss/tgt54", (2, L + 4, 54))).astype(np.float32))
+    shape = dev((0.5 * synth.normalish("loss/shape", (2, 100))).astype(np.float32))
+    stats = {"exp_mean": dev(0.1 * synth.normalish("st/em", (50,))),
+             "exp_std": dev(1 + 0.1 * np.abs(synth.normalish("st/es", (50,)))),
+             "pose_mean": dev(0.05 * synth.normalish("st/pm", (6,))),
+             "pose_std": dev(1 + 0.1 * np.abs(synth.normalish("st/ps", (6,)))),
+             "shape_mean": dev(np.zeros(100, np.float32)), "shape_std": dev(np.ones(100, np.float32))}
+    for start in (True, False):
+        r = C.compute_loss(argsv, start, shape, gt54, None, tgt54, prev54, stats, fl,
+                           end_idx=torch.tensor([L, 5], device=DEV))
+        ref = g[f"vert_{int(start)}"]
+        got = vals(r)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), start
+        # vertex terms are ~1e-4 .. 1e-3 in magnitude (FLAME-scale vertices): relative tolerance
+        assert np.nanmax(np.abs(got - ref) / np.maximum(1e-6, np.abs(ref))) < 2e-3, (start, got, ref)
+    cd = C.get_coef_dict(gt54, shape, stats, with_global_pose=False)
+    assert maxabs(cd["exp"].cpu().numpy(), g["coef_exp"]) < 1e-6 and maxabs(cd["pose"].cpu().numpy(), g["coef_pose"]) < 1e-6
+    assert maxabs(cd["shape"].cpu().numpy(), g["coef_shape"]) < 1e-6
+    verts = C.coef_dict_to_vertices(cd, fl, flame_batch_size=7)
+    assert verts.shape == (2, L, 5023, 3)
+    assert maxabs(verts.cpu().numpy()[:, :, ::79], g["coef_verts_sub"]) < 5e-6
+    mc = C.get_motion_coef({"exp": cd["exp"], "pose": cd["pose"]}, "aa", with_global_pose=False)
+    assert maxabs(mc.cpu().numpy(), g["motion_coef"]) < 1e-6
+
+
+def test_truncation_scheduler_adam():
+    from msmd_amd.utils import common as C
+    from msmd_amd.utils.scheduler import GradualWarmupScheduler
+    from msmd_amd import ops
+    g = load_golden("g5_losses")
+    a = dev(synth.audio_clips(2, 64000, tag="trunc"))
+    m = dev(synth.motion_clips(2, tag="trunc_m"))
+    e = torch.tensor([3, 77], device=DEV)
+    assert np.array_equal(C._truncate_audio(a, (e * 640).long(), "zero").cpu().numpy()[:, ::97], g["trunc_audio_zero"])
+    assert np.array_equal(C._truncate_audio(a, (e * 640).long(), "replicate").cpu().numpy()[:, ::97], g["trunc_audio_rep"])
+    cdt = C._truncate_coef_dict({"exp": m[..., :50], "pose_any": m[..., 50:]}, e, "replicate")
+    assert np.array_equal(torch.cat([cdt["exp"], cdt["pose_any"]], -1).cpu().numpy(), g["trunc_motion_rep"])
+    at, mt, ei = C.truncate_motion_coef_and_audio(a, m, 100)
+    assert at.shape == a.shape and mt.shape == m.shape and ei.shape == (2,) and int(ei.min()) >= 1 and int(ei.max()) < 100
+    k = int(ei[0])
+    assert float(at[0, k * 640:].abs().max()) == 0.0 and float(mt[0, k:].abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        C._truncate_audio(a, e, "bogus")
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([{"params": [p], "lr": 2e-5}])
+    sch = GradualWarmupScheduler(opt, 1, 10)
+    lrs = []
+    for _ in range(15):
+        opt.step(); sch.step(); lrs.append(opt.param_groups[0]["lr"])
+    assert np.allclose(lrs, g["warmup_lrs"], rtol=1e-12, atol=0)
+    # fused Adam kernel vs torch.optim.Adam trace
+    w = dev(synth.normalish("adam/w", (1000,))).clone()
+    m1, v1 = torch.zeros_like(w), torch.zeros_like(w)
+    for i in range(3):
+        ops.adam_step_(w, dev(synth.normalish(f"adam/g{i}", (1000,))), m1, v1, 2e-3, i + 1)
+    assert maxabs(w.cpu().numpy(), g["adam_w3"]) < 2e-6

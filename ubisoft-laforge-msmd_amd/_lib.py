@@ -35,6 +35,8 @@ def parse_header(path: str = HEADER):
                 a = " ".join(a.split())
                 if "*" in a:
                     types.append(ctypes.c_void_p)
+                elif a.startswith("double") or a.startswith("const double"):
+                    types.append(ctypes.c_double)
                 else:
                     base = a.replace("const ", "").split(" ")[0]
                     types.append(_CTYPE[base])

@@ -1,0 +1,146 @@
+// Masked sequence losses (reference utils/common.py:198-620): masked MSE / L1 on a sequence, its first
+// temporal difference (velocity) or second difference (smoothness), averaged over a channel range and over the
+// valid frames.  One generic reduction kernel serves the parameter-space losses (C = 67) and the vertex-space
+// ones (C = 15069); HBM-bound streaming reads, fp64 accumulation across workgroups.
+#include "common.h"
+
+struct LossArgs {
+  const float* gt; const float* pred; const int* end_idx; double* acc;
+  int N, T, C, c_lo, c_hi, order, prefix, criterion, vs_zero, mode;
+};
+
+__device__ __forceinline__ float diff_at(const float* p, long row_stride, int order) {
+  if (order == 0) return p[0];
+  if (order == 1) return p[row_stride] - p[0];
+  return (p[2 * row_stride] - p[row_stride]) - (p[row_stride] - p[0]);
+}
+
+// mode 0: value = crit(D gt, D pred); mode 1 (smooth): crit(D pred, 0) (reference compares against zeros, or,
+// in the vertex-space variant, vel_pred[1:] against vel_pred[:-1], which is the same quantity).
+__global__ __launch_bounds__(256) void masked_seq_loss_kernel(const LossArgs p) {
+  __shared__ float red[16];
+  const int Td = p.T - p.order;
+  const int nc = p.c_hi - p.c_lo;
+  const long rows = (long)p.N * Td;
+  double local_sum = 0.0;
+  double local_cnt = 0.0;
+  for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = (int)(row / Td), t = (int)(row % Td);
+    const int tm = t + p.order;  // mask index: mask[:, order:]
+    bool valid = tm < p.prefix;
+    if (!valid) {
+      const int e = p.end_idx ? p.end_idx[n] : (p.T - p.prefix);
+      valid = (tm - p.prefix) < e;
+    }
+    if (!valid) continue;  // block-uniform
+    const float* g = p.gt + ((long)n * p.T + t) * p.C + p.c_lo;
+    const float* q = p.pred + ((long)n * p.T + t) * p.C + p.c_lo;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < nc; c += blockDim.x) {
+      const float dp = diff_at(q + c, p.C, p.order);
+      const float dg = p.mode == 1 ? 0.f : diff_at(g + c, p.C, p.order);
+      const float d = dg - dp;
+      s += p.criterion == 0 ? d * d : fabsf(d);
+    }
+    const float tot = block_sum(s, red);
+    if (threadIdx.x == 0) {
+      local_sum += (double)tot / (double)nc;
+      local_cnt += 1.0;
+    }
+  }
+  if (threadIdx.x == 0 && local_cnt > 0.0) {
+    atomicAdd(&p.acc[0], local_sum);
+    atomicAdd(&p.acc[1], local_cnt);
+  }
+}
+
+__global__ void loss_finish_kernel(const double* acc, float* out, float scale) {
+  out[0] = acc[1] > 0.0 ? (float)(acc[0] / acc[1] * (double)scale) : nanf("");
+}
+
+extern "C" int msmd_masked_seq_loss(const float* gt, const float* pred, const int* end_idx, float* out, double* acc_ws,
+                                    int N, int T, int C, int c_lo, int c_hi, int order, int prefix, int criterion,
+                                    int mode, float scale, msmd_stream_t stream) {
+  if (N <= 0 || T <= order || C <= 0 || c_lo < 0 || c_hi > C || c_hi <= c_lo || order < 0 || order > 2 || !acc_ws)
+    return 1;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(acc_ws, 0, 2 * sizeof(double), st);
+  if (e != hipSuccess) return (int)e;
+  LossArgs p{gt, pred, end_idx, acc_ws, N, T, C, c_lo, c_hi, order, prefix, criterion, 0, mode};
+  const long rows = (long)N * (T - order);
+  const int threads = (c_hi - c_lo) >= 1024 ? 256 : 64;
+  dim3 grid((unsigned)min(rows, (long)4096)), block(threads);
+  hipLaunchKernelGGL(masked_seq_loss_kernel, grid, block, 0, st, p);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, acc_ws, out, scale);
+  MSMD_RETURN_LAST();
+}
+
+// KL divergence of the style VAE (reference utils/common.py:443-454): -0.5 * sum(1 + logvar - mu^2 - exp(logvar)).
+__global__ void kl_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, double* acc, long n) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    s += 1.0f + logvar[i] - mu[i] * mu[i] - expf(logvar[i]);
+  const float tot = block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(&acc[0], (double)tot);
+}
+__global__ void kl_finish_kernel(const double* acc, float* out) { out[0] = (float)(-0.5 * acc[0]); }
+
+extern "C" int msmd_kl_loss(const float* mu, const float* logvar, float* out, double* acc_ws, long n,
+                            msmd_stream_t stream) {
+  if (n <= 0 || !acc_ws) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(acc_ws, 0, 2 * sizeof(double), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kl_kernel, dim3((unsigned)min((n + 255) / 256, (long)256)), dim3(256), 0, st, mu, logvar, acc_ws, n);
+  hipLaunchKernelGGL(kl_finish_kernel, dim3(1), dim3(1), 0, st, acc_ws, out);
+  MSMD_RETURN_LAST();
+}
+
+// Truncation augmentation (reference utils/common.py:769-798): x[n, end[n]*unit:] = 0 or the last kept value.
+__global__ void truncate_rows_kernel(float* __restrict__ x, const int* __restrict__ end_idx, int L, int inner, int unit,
+                                     int replicate) {
+  const int n = blockIdx.y;
+  const long e = (long)end_idx[n] * unit;  // first overwritten index along L
+  const long total = (long)L * inner;
+  float* row = x + (long)n * total;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long l = i / inner;
+    if (l >= e) row[i] = replicate ? row[(e - 1) * inner + i % inner] : 0.f;
+  }
+}
+
+extern "C" int msmd_truncate_rows(float* x, const int* end_idx, int N, int L, int inner, int unit, int replicate,
+                                  msmd_stream_t stream) {
+  if (N <= 0 || L <= 0 || inner <= 0 || unit <= 0) return 1;
+  const long total = (long)L * inner;
+  dim3 grid((unsigned)min((total + 255) / 256, (long)1024), N), block(256);
+  hipLaunchKernelGGL(truncate_rows_kernel, grid, block, 0, (hipStream_t)stream, x, end_idx, L, inner, unit, replicate);
+  MSMD_RETURN_LAST();
+}
+
+// Fused multi-tensor Adam step on a flat parameter / gradient / moment arena (torch.optim.Adam semantics,
+// reference training_script.py:548-551: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float bc1, float bc2,
+                            float grad_scale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * grad_scale;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
+extern "C" int msmd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                              float beta1, float beta2, float eps, int step, float grad_scale, msmd_stream_t stream) {
+  if (n <= 0 || step <= 0) return 1;
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  dim3 grid((unsigned)min((n + 255) / 256, (long)4096)), block(256);
+  hipLaunchKernelGGL(adam_kernel, grid, block, 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                     beta2, eps, bc1, bc2, grad_scale);
+  MSMD_RETURN_LAST();
+}

@@ -316,3 +316,42 @@ def rotation_convert(op, x, in_width, out_shape_tail, x2=None, conv=0):
         x2 = x2.contiguous().float()
     _lib.check(lib.msmd_rotation_convert(op, _p(x), _p(x2), _p(out), n, conv, _stream()), "msmd_rotation_convert")
     return out
+
+
+# ----------------------------------------------------------------------------- losses / training pieces
+def masked_seq_loss(gt, pred, end_idx, c_lo, c_hi, order, prefix, criterion=0, mode=0, scale=1.0):
+    """0-dim fp32 tensor = scale * masked mean (see msmd_masked_seq_loss in include/msmd_hip.h)."""
+    lib = _lib.load()
+    _need_cuda(gt, pred)
+    N, T, C = pred.shape
+    out = torch.empty(1, device=pred.device, dtype=torch.float32)
+    ws = torch.empty(2, device=pred.device, dtype=torch.float64)
+    _lib.check(lib.msmd_masked_seq_loss(_p(gt), _p(pred), _p(end_idx), _p(out), _p(ws), N, T, C, c_lo, c_hi, order,
+                                        prefix, criterion, mode, float(scale), _stream()), "msmd_masked_seq_loss")
+    return out[0]
+
+
+def kl_loss(mu, logvar):
+    lib = _lib.load()
+    out = torch.empty(1, device=mu.device, dtype=torch.float32)
+    ws = torch.empty(2, device=mu.device, dtype=torch.float64)
+    _lib.check(lib.msmd_kl_loss(_p(mu), _p(logvar), _p(out), _p(ws), mu.numel(), _stream()), "msmd_kl_loss")
+    return out[0]
+
+
+def truncate_rows_(x, end_idx_i32, unit=1, replicate=False):
+    """In place on x (N, L[, inner])."""
+    lib = _lib.load()
+    N, L = x.shape[0], x.shape[1]
+    inner = x.numel() // (N * L)
+    _lib.check(lib.msmd_truncate_rows(_p(x), _p(end_idx_i32), N, L, inner, unit, int(replicate), _stream()),
+               "msmd_truncate_rows")
+    return x
+
+
+def adam_step_(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    lib = _lib.load()
+    _lib.check(lib.msmd_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), float(lr),
+                                  float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream()),
+               "msmd_adam_step")
+    return param
