@@ -210,8 +210,9 @@ def cfg_entries(cfg_cond, cfg_mode):
 
 def sample(sd, sched, audio_feat, shape_feat, style_feat, motion_at_T, z_list, prev_motion_feat=None,
            prev_audio_feat=None, indicator=None, cfg_mode="incremental", cfg_cond=("audio", "style"),
-           cfg_scale=1.15, flexibility=0, dynamic_threshold=None, target="sample", n_motions=100, **net_kw):
-    """reference model.py:283-440 with noise injected: ``z_list[t]`` is the draw used at
+           cfg_scale=1.15, flexibility=0, dynamic_threshold=None, target="sample", n_motions=100, guidance=None,
+           separate=False, **net_kw):
+    """reference model.py:283-440 with noise injected (guidance: model.py:762-767; separate: model.py:442-651): ``z_list[t]`` is the draw used at
     step t (t = T..2; step 1 uses zeros).  audio_feat is (N, L, 512) features."""
     N = audio_feat.shape[0]
     T = sched["betas"].shape[0] - 1
@@ -244,6 +245,7 @@ def sample(sd, sched, audio_feat, shape_feat, style_feat, motion_at_T, z_list, p
     ind_in = np.concatenate([indicator] * n_entries, axis=0) if indicator is not None else None
     style_in = nn.f32(np.concatenate([style_feat] * n_entries, axis=0))  # static branch: real style everywhere
     x = nn.f32(motion_at_T)
+    cum_static = np.zeros_like(x)
     for t in range(T, 0, -1):
         z = nn.f32(z_list[t]) if t > 1 else np.zeros_like(x)
         alpha = sched["alphas"][t]
@@ -251,23 +253,35 @@ def sample(sd, sched, audio_feat, shape_feat, style_feat, motion_at_T, z_list, p
         alpha_bar_prev = sched["alpha_bars"][t - 1]
         sigma = F32(sched["sigmas_flex"][t] * F32(flexibility) + sched["sigmas_inflex"][t] * F32(1 - flexibility))
         motion_in = np.concatenate([x] * n_entries, axis=0)
+        if guidance is not None:
+            motion_in[:, guidance[0], :] = guidance[1]
         step_in = np.full((N * n_entries,), t, dtype=np.int64)
-        res = denoising_net(sd, motion_in, audio_in, person_in, style_in, prev_m, prev_a, step_in, ind_in, **net_kw)
+        if separate:
+            dyn, static4, alpha_t = denoising_net(sd, motion_in, audio_in, person_in, style_in, prev_m, prev_a, step_in,
+                                                  ind_in, keep_separate=True, **net_kw)
+            static = np.concatenate([(static4[..., :-3] * alpha_t[..., None]).sum(axis=2), static4[..., -3:].sum(axis=2)],
+                                    axis=-1).astype(F32)
+            res = (dyn + static).astype(F32)
+        else:
+            res = denoising_net(sd, motion_in, audio_in, person_in, style_in, prev_m, prev_a, step_in, ind_in, **net_kw)
         if dynamic_threshold:
             dt_ratio, dt_min, dt_max = dynamic_threshold
             absr = np.abs(res[:, -n_motions:].reshape(N * n_entries, -1))
             s = np.quantile(absr.astype(np.float64), dt_ratio, axis=1).astype(F32)
             s = np.clip(s, dt_min, dt_max)[:, None, None]
             res = np.clip(res, -s, s)
-        res = [r.copy() for r in np.split(res, n_entries, axis=0)]
-        theta = res[0][:, -n_motions:]  # a VIEW of res[0]: in-place accumulation (model.py:407-415)
+        streams = [res] + ([static, dyn, alpha_t] if separate else [])
+        streams = [[r.copy() for r in np.split(v, n_entries, axis=0)] for v in streams]
+        heads = [st[0][:, -n_motions:] for st in streams]  # VIEWS of entry 0: in-place accumulation (model.py:407-415)
         for i in range(n_entries - 1):
-            if cfg_mode == "independent":
-                theta += F32(cfg_scale[i]) * (res[i + 1][:, -n_motions:] - res[0][:, -n_motions:])
-            elif cfg_mode == "incremental":
-                theta += F32(cfg_scale[i]) * (res[i + 1][:, -n_motions:] - res[i][:, -n_motions:])
-            else:
-                raise NotImplementedError(f"Unknown cfg_mode {cfg_mode}")
+            for st, hd in zip(streams, heads):
+                if cfg_mode == "independent":
+                    hd += F32(cfg_scale[i]) * (st[i + 1][:, -n_motions:] - st[0][:, -n_motions:])
+                elif cfg_mode == "incremental":
+                    hd += F32(cfg_scale[i]) * (st[i + 1][:, -n_motions:] - st[i][:, -n_motions:])
+                else:
+                    raise NotImplementedError(f"Unknown cfg_mode {cfg_mode}")
+        theta = heads[0]
         if target == "noise":
             c0 = F32(1) / np.sqrt(alpha)
             c1 = (F32(1) - alpha) / np.sqrt(F32(1) - alpha_bar)
@@ -278,4 +292,8 @@ def sample(sd, sched, audio_feat, shape_feat, style_feat, motion_at_T, z_list, p
             x = (c0 * x + c1 * theta + sigma * z).astype(F32)
         else:
             raise ValueError(f"Unknown target type: {target}")
+        if separate:
+            cum_static = (cum_static + c1 * heads[1]).astype(F32)
+    if separate:
+        return x, heads[2], cum_static, heads[3]
     return x

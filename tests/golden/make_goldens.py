@@ -292,6 +292,17 @@ def g3_sample(M, SE, mc):
     y, _, _ = model_n.sample(t(x["audio_feat"]), t(x["shape"]), t(x["style"]), motion_at_T=t(xT), cfg_scale=1.15,
                              indicator=t(x["indicator"]))
     out["noise_x0"], out["noise_z"] = y.numpy(), np.stack([z.numpy() for z in zs])
+    # sample_separate (model.py:442-651).  The reference only works at batch size 1 here: its static-feature tiling
+    # (model.py:983-984) multiplies the batch instead of matching it, so B > 1 raises a shape error.
+    torch.manual_seed(555)
+    zs = [torch.randn(1, 100, 67) for _ in range(T - 1)]
+    torch.manual_seed(555)
+    r = model.sample_separate(t(x["audio_feat"][:1]), t(x["shape"][:1]), t(x["style"][:1]), t(x["prev_motion"][:1]),
+                              t(x["prev_audio"][:1]), motion_at_T=t(xT[:1]), indicator=t(x["indicator"][:1]),
+                              cfg_scale=1.3)
+    out["sep_z"] = np.stack([z.numpy() for z in zs])
+    out["sep_x0"], out["sep_dyn"], out["sep_static"], out["sep_alpha"] = (r[0].numpy(), r[3].numpy(), r[4].numpy(),
+                                                                            r[5].numpy())
     save("g3_sample", **out)
 
 

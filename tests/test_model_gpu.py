@@ -150,6 +150,29 @@ def test_sampler_fp32():
                                          dev(x["prev_audio"]), motion_at_T=xT, indicator=dev(x["indicator"]),
                                          noise=noise, **kw)
             assert maxabs(y.cpu().numpy(), g[f"{name}_x0"]) < 1e-4, (name, maxabs(y.cpu().numpy(), g[f"{name}_x0"]))
+        # sample_separate vs the reference's own output
+        z = g["sep_z"]
+        r = model.sample_separate(dev(x["audio_feat"][:1]), dev(x["shape"][:1]), dev(x["style"][:1]),
+                                  dev(x["prev_motion"][:1]), dev(x["prev_audio"][:1]), motion_at_T=xT[:1],
+                                  indicator=dev(x["indicator"][:1]), cfg_scale=1.3,
+                                  noise={T - i: dev(z[i]) for i in range(T - 1)})
+        for got, key in zip((r[0], r[3], r[4], r[5]), ("sep_x0", "sep_dyn", "sep_static", "sep_alpha")):
+            assert maxabs(got.cpu().numpy(), g[key]) < 1e-4, key
+        # sample_with_guide: the reference's call is broken (model.py:770); parity is pinned on the oracle
+        from oracle import diffusion as od
+        from helpers import msmd_state_dict
+        sd, _ = msmd_state_dict("wav2vec2")
+        idx = [0, 5, 99]
+        gv = synth.normalish("sm/guide", (3, 67))
+        zi = g["inc_z"]
+        ref = od.sample(sd, od.diffusion_schedule(T, "cosine"), x["audio_feat"], x["shape"], x["style"],
+                        synth.normalish("sm/xT", (2, 100, 67)), {T - i: zi[i] for i in range(T - 1)}, x["prev_motion"],
+                        x["prev_audio"], x["indicator"], cfg_scale=1.15, guidance=(idx, gv))
+        y, _, _ = model.sample_with_guide(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]), dev(x["prev_motion"]),
+                                          dev(x["prev_audio"]), motion_at_T=xT, indicator=dev(x["indicator"]),
+                                          guidance_indice=idx, guidance_values=dev(gv),
+                                          noise={T - i: dev(zi[i]) for i in range(T - 1)})
+        assert maxabs(y.cpu().numpy(), ref) < 1e-4
         traj, _, _ = model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]), motion_at_T=xT,
                                   indicator=dev(x["indicator"]), ret_traj=True)
         assert sorted(traj) == [0, 1, 2, 3]

@@ -189,6 +189,12 @@ def test_sampler():
         y = od.sample(sd, sched, x["audio_feat"], x["shape"], x["style"], xT, z_list, x["prev_motion"],
                       x["prev_audio"], x["indicator"], **kw)
         assert maxabs(y, g[f"{name}_x0"]) <= 1e-4, (name, maxabs(y, g[f"{name}_x0"]))
+    z = g["sep_z"]
+    y, dyn, cum, al = od.sample(sd, sched, x["audio_feat"][:1], x["shape"][:1], x["style"][:1], xT[:1],
+                                {T - i: z[i] for i in range(T - 1)}, x["prev_motion"][:1], x["prev_audio"][:1],
+                                x["indicator"][:1], cfg_scale=1.3, separate=True)
+    assert maxabs(y, g["sep_x0"]) <= 1e-4 and maxabs(dyn, g["sep_dyn"]) <= 1e-4
+    assert maxabs(cum, g["sep_static"]) <= 1e-4 and maxabs(al, g["sep_alpha"]) <= 1e-4
     z = g["noise_z"]
     y = od.sample(sd, od.diffusion_schedule(T, "linear"), x["audio_feat"], x["shape"], x["style"], xT,
                   {T - i: z[i] for i in range(T - 1)}, indicator=x["indicator"], target="noise")

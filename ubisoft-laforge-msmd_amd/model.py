@@ -487,3 +487,28 @@ class MSMD(nn.Module):
         from .sampler import sample as _sample
         return _sample(self, audio_or_feat, shape_feat, style_feat, prev_motion_feat, prev_audio_feat, motion_at_T,
                        indicator, cfg_mode, cfg_cond, cfg_scale, flexibility, dynamic_threshold, ret_traj, noise)
+
+    @torch.no_grad()
+    def sample_separate(self, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=None, prev_audio_feat=None,
+                        motion_at_T=None, indicator=None, cfg_mode=None, cfg_cond=None, cfg_scale=1.15, flexibility=0,
+                        dynamic_threshold=None, ret_traj=False, alpah_t_modification=None, return_all_alpha=False,
+                        noise=None):
+        """reference model.py:442-651: same loop, additionally returns the CFG-combined dynamic part of the last
+        step, the accumulated static pose and the blend weights (argument spelling kept from the reference)."""
+        from .sampler import sample as _sample
+        return _sample(self, audio_or_feat, shape_feat, style_feat, prev_motion_feat, prev_audio_feat, motion_at_T,
+                       indicator, cfg_mode, cfg_cond, cfg_scale, flexibility, dynamic_threshold, ret_traj, noise,
+                       separate=dict(alpha_mod=alpah_t_modification, return_all_alpha=return_all_alpha))
+
+    @torch.no_grad()
+    def sample_with_guide(self, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=None,
+                          prev_audio_feat=None, motion_at_T=None, indicator=None, cfg_mode=None, cfg_cond=None,
+                          cfg_scale=1.15, flexibility=0, dynamic_threshold=None, ret_traj=False, guidance_indice=None,
+                          guidance_values=None, noise=None):
+        """reference model.py:653-818 (naive in-painting: guided frames overwrite the denoiser INPUT each step).
+        The reference's call at model.py:770 omits `static_style_feat` and raises TypeError; here the static
+        branch receives the real style exactly as in `sample` (documented fix)."""
+        from .sampler import sample as _sample
+        return _sample(self, audio_or_feat, shape_feat, style_feat, prev_motion_feat, prev_audio_feat, motion_at_T,
+                       indicator, cfg_mode, cfg_cond, cfg_scale, flexibility, dynamic_threshold, ret_traj, noise,
+                       guidance=(guidance_indice, guidance_values))

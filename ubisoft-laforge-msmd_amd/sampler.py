@@ -32,7 +32,10 @@ def _entries(cfg_cond, cfg_mode):
 
 def sample(model, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=None, prev_audio_feat=None,
            motion_at_T=None, indicator=None, cfg_mode=None, cfg_cond=None, cfg_scale=1.15, flexibility=0,
-           dynamic_threshold=None, ret_traj=False, noise=None):
+           dynamic_threshold=None, ret_traj=False, noise=None, guidance=None, separate=None):
+    """guidance = (indices, values): naive in-painting of the denoiser INPUT (reference model.py:762-767).
+    separate = dict(alpha_mod=callable|None, return_all_alpha=bool): also track the dynamic / static / alpha
+    streams (reference sample_separate, model.py:442-651)."""
     net = model.denoising_net
     dtype = model.compute_dtype
     dev = model.device
@@ -128,7 +131,7 @@ def sample(model, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=N
         return float(c0), float(c1), float(sigma)
 
     use_graph = (noise is None and not dynamic_threshold and not ret_traj and getattr(model, "use_hip_graph", True)
-                 and T > 1)
+                 and T > 1 and guidance is None and separate is None)
     if use_graph:
         x = _graph_loop(model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, motion_at_T, prev_m,
                         ind_in, mem, kv_list, stat, tok_person, emb_all, scales, coefficients)
@@ -137,26 +140,66 @@ def sample(model, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=N
     x = motion_at_T.float().clone().contiguous()
     traj = {T: motion_at_T} if ret_traj else None
     feats = torch.empty(N, 1 + Lp + L, P.kp_feat, device=dev, dtype=dtype)
+    if separate is not None:
+        cum_static = torch.zeros_like(x)
+        alpha_traj = []
+        stat_full = stat[torch.arange(N, device=dev) % stat.shape[0]]  # (N, nb, dm): real style for every entry
     for t in range(T, 0, -1):
         if t > 1:
             z = noise[t].float().contiguous() if noise is not None else torch.randn_like(x)
         else:
             z = None
         c0, c1, sigma = coefficients(t)
-        ops.denoiser_pack_input(x, prev_m, ind_in, feats)
+        x_in = x
+        if guidance is not None and guidance[0] is not None:
+            x_in = x.clone()
+            x_in[:, guidance[0], :] = guidance[1].to(x_in.dtype)
+        ops.denoiser_pack_input(x_in, prev_m, ind_in, feats)
         dec = net.trunk(feats, tok_person, mem, dtype, kv_list=kv_list, row0_add=emb_all[t])
-        res = ops.heads_static_mix(dec, stat, Lp + L, dm, nb, net.use_head_alpha)
+        if separate is None:
+            res = ops.heads_static_mix(dec, stat, Lp + L, dm, nb, net.use_head_alpha)
+        else:
+            # diagnostic variant: stream bookkeeping in host-library tensor algebra on (N, 110, 4, 67)-sized data
+            dyn, alpha_t = dec[..., :dm], dec[..., dm:]
+            if separate.get("alpha_mod") is not None:
+                alpha_t = separate["alpha_mod"](alpha_t)
+            sf = stat_full[:, None]  # (N, 1, nb, dm)
+            if net.use_head_alpha:
+                static = (sf * alpha_t.unsqueeze(-1)).sum(dim=2)
+            else:
+                static = torch.cat([(sf[..., :-3] * alpha_t.unsqueeze(-1)).sum(dim=2),
+                                    sf[..., -3:].sum(dim=2).expand(-1, Lp + L, -1)], dim=-1)
+            res = dyn + static
         if dynamic_threshold:
             # optional K15 (off in the reference's inference driver, inference.py:272): host-library quantile
             dt_ratio, dt_min, dt_max = dynamic_threshold
             s = torch.quantile(res[:, -L:].reshape(N, -1).abs(), dt_ratio, dim=1)
             s = torch.clamp(s, min=dt_min, max=dt_max)[..., None, None]
             res = torch.clamp(res, min=-s, max=s).contiguous()
-        ops.cfg_ddpm_step(x, res, z, scales, n_entries, Lp, mode, target, c0, c1, sigma)
+        if separate is None:
+            ops.cfg_ddpm_step(x, res, z, scales, n_entries, Lp, mode, target, c0, c1, sigma)
+        else:
+            streams = [list(v.contiguous().clone().chunk(n_entries)) for v in (res, static, dyn, alpha_t)]
+            heads = [st[0][:, -L:] for st in streams]  # views: in-place accumulation as the reference (model.py:590-618)
+            for i in range(n_entries - 1):
+                for st, hd in zip(streams, heads):
+                    base = st[0] if cfg_mode == "independent" else st[i]
+                    hd += cfg_scale[i] * (st[i + 1][:, -L:] - base[:, -L:])
+            theta, theta_static, theta_dyn, theta_alpha = heads
+            zz = z if z is not None else torch.zeros_like(x)
+            if target == 1:
+                x = c0 * (x - c1 * theta) + sigma * zz
+            else:
+                x = c0 * x + c1 * theta + sigma * zz
+            cum_static = cum_static + c1 * theta_static
+            alpha_traj.append(theta_alpha)
         if ret_traj:
             traj[t - 1] = x.clone()
     if ret_traj:
         return traj, motion_at_T, audio_feat
+    if separate is not None:
+        last_alpha = torch.cat(alpha_traj, dim=0) if separate.get("return_all_alpha") else theta_alpha
+        return x, motion_at_T, audio_feat, theta_dyn, cum_static, last_alpha
     return x, motion_at_T, audio_feat
 
 
