@@ -158,3 +158,49 @@ def test_world_size_2_gloo_timing_and_sharding(tmp_path):
     out = json.loads(line)
     assert out["steps"] == 4 and out["total"] == 9.0
     assert out["elapsed"] >= 3 * 0.04 * 0.95  # max over ranks = the slow rank
+
+
+def test_grad_bucket_reducer_world_2_gloo(tmp_path):
+    """DP parity definition (SURVEY.md 8e): all-reduced grad / world == mean of per-shard single-rank grads;
+    parameters without a gradient stay zero; buckets launch from hooks during backward."""
+    script = tmp_path / "gr.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, json
+        sys.path.insert(0, {ROOT!r})
+        import torch, torch.distributed as td
+        from msmd_amd import dp
+        rank, world = dp.init("gloo")
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.GELU(), torch.nn.Linear(32, 8))
+        unused = torch.nn.Parameter(torch.ones(5))            # never receives a gradient (e.g. LayerDrop)
+        frozen = torch.nn.Parameter(torch.ones(3), requires_grad=False)
+        params = list(net.parameters()) + [unused, frozen]
+        red = dp.GradBucketReducer(params, bucket_mb=0.001)
+        assert len(red.buckets) > 1 and red.kl_weight_scale == 2.0
+        x = torch.randn(8, 16)
+        red.zero_grad()
+        shard = x[list(dp.shard_clips(8, rank, world))]
+        net(shard).pow(2).mean().backward()
+        flat, scale = red.finish()
+        g_dp = [(p.grad * scale).clone() for p in net.parameters()]
+        # single-process reference: mean of the two shard gradients
+        ref = []
+        for r in range(world):
+            for p in net.parameters():
+                p.grad = None
+            net(x[list(dp.shard_clips(8, r, world))]).pow(2).mean().backward()
+            ref.append([p.grad.clone() for p in net.parameters()])
+        err = max(float((a - (b0 + b1) / 2).abs().max()) for a, b0, b1 in zip(g_dp, ref[0], ref[1]))
+        if rank == 0:
+            print(json.dumps(dict(err=err, unused=float(flat[red.slot[id(unused)][1]:][:5].abs().max()),
+                                  n=int(flat.numel()))))
+        td.destroy_process_group()
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29618")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29618", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["err"] < 1e-6 and out["unused"] == 0.0 and out["n"] == 16 * 32 + 32 + 32 * 8 + 8 + 5

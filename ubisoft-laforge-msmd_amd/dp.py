@@ -59,3 +59,121 @@ def timed_steps(step_fn, steps: int, warmup: int, sync=None, device=None):
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         elapsed = float(tt.item())
     return elapsed
+
+
+# ----------------------------------------------------------------------------- gradient exchange (training)
+class GradBucketReducer:
+    """Bucketed gradient all-reduce overlapped with backward.
+
+    * every trainable parameter's ``.grad`` is a VIEW into one flat fp32 arena, laid out in REVERSE registration
+      order (heads -> decoder layers 7..0 -> audio_feature_map -> encoder layers 11..0 -> ...), i.e. the order in
+      which backward produces gradients, cut into ~bucket_mb buckets;
+    * a post-accumulate-grad hook per parameter counts arrivals; when a bucket is complete its all-reduce (sum)
+      is launched on a dedicated side stream behind an event recorded on the compute stream, so the collective
+      (RCCL over xGMI with backend "nccl") runs under the rest of backward;
+    * ``finish()`` launches buckets that did not complete (parameters that received no gradient this step stay
+      zero in the arena: LayerDrop-skipped layers, unused null tokens), makes the compute stream wait for the
+      side stream and returns the flat arena; the 1/world_size factor is folded into the optimizer step
+      (``msmd_adam_step(grad_scale=1/world)``).
+    Frozen parameters (requires_grad=False) are excluded.  With world_size 1 nothing is communicated.
+    The KL term of the reference is a batch SUM (utils/common.py:454): scale its weight by world_size to keep
+    parity with a single-process global batch (`kl_weight_scale`).
+    """
+
+    def __init__(self, params, bucket_mb: float = 32.0, process_group=None):
+        import torch.distributed as td
+        self.td = td
+        self.group = process_group
+        self.world = td.get_world_size(process_group) if td.is_initialized() else 1
+        self.params = [p for p in params if p.requires_grad][::-1]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.arena = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.buckets = []  # (start, end, [param indices])
+        cap = int(bucket_mb * (1 << 20) / 4)
+        off = start = 0
+        members = []
+        self.slot = {}
+        for i, p in enumerate(self.params):
+            n = p.numel()
+            p.grad = self.arena[off:off + n].view_as(p)
+            self.slot[id(p)] = (len(self.buckets), off, n)
+            members.append(i)
+            off += n
+            if off - start >= cap:
+                self.buckets.append((start, off, members))
+                start, members = off, []
+        if members:
+            self.buckets.append((start, off, members))
+        self.pending = [len(m) for _, _, m in self.buckets]
+        self.launched = [False] * len(self.buckets)
+        self.cuda = dev.type == "cuda"
+        self.side = torch.cuda.Stream(device=dev) if self.cuda else None
+        self.works = []
+        self.enabled = True  # set False on gradient-accumulation micro-steps (reference training_script.py:199)
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._hook)
+
+    @property
+    def kl_weight_scale(self):
+        return float(self.world)
+
+    def zero_grad(self):
+        """Zero the arena (grads are views) and re-arm the arrival counters."""
+        self.arena.zero_()
+        self.pending = [len(m) for _, _, m in self.buckets]
+        self.launched = [False] * len(self.buckets)
+        self.works = []
+
+    def _hook(self, p):
+        b, off, n = self.slot[id(p)]
+        if p.grad.data_ptr() != self.arena[off:off + n].data_ptr():  # autograd replaced the view: copy back
+            self.arena[off:off + n].copy_(p.grad.reshape(-1))
+            p.grad = self.arena[off:off + n].view_as(p)
+        self.pending[b] -= 1
+        if self.pending[b] == 0 and self.enabled:
+            self._launch(b)
+
+    def _launch(self, b):
+        if self.launched[b] or self.world == 1:
+            self.launched[b] = True
+            return
+        self.launched[b] = True
+        start, end, _ = self.buckets[b]
+        view = self.arena[start:end]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                self.works.append(self.td.all_reduce(view, op=self.td.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.works.append(self.td.all_reduce(view, op=self.td.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Call after backward on a stepping iteration: returns (flat_grad_arena, grad_scale)."""
+        for b in range(len(self.buckets)):
+            if not self.launched[b]:
+                self._launch(b)
+        for w in self.works:
+            if w is not None:
+                w.wait()
+        if self.cuda and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.side)
+        return self.arena, 1.0 / self.world
+
+
+def flatten_parameters(params):
+    """Re-home trainable parameters into one flat fp32 arena (views), in the reducer's order, so the fused Adam
+    kernel (msmd_adam_step) updates the whole model in one launch.  Returns the flat tensor."""
+    ps = [p for p in params if p.requires_grad][::-1]
+    flat = torch.empty(sum(p.numel() for p in ps), device=ps[0].device, dtype=torch.float32)
+    off = 0
+    for p in ps:
+        n = p.numel()
+        flat[off:off + n].copy_(p.data.reshape(-1))
+        p.data = flat[off:off + n].view_as(p)
+        off += n
+    return flat
