@@ -81,12 +81,26 @@ def roofline_leg(model, b, steps=3):
             big_n += 1
     achieved = big_f / (big_ms * 1e-3) / 1e12 if big_ms > 0 else 0.0
     return dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
+                frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=pmc_traffic(),
                 kernel="gemm2_kernel<bf16,128,128,4,2,2> (csrc/gemm.hip)",
                 launches_per_step=big_n // steps, gflop_per_step=round(big_f / steps / 1e9, 1),
                 ms_per_step_in_kernel=round(big_ms / steps, 3),
                 all_gemm_tflops=round(flops / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
                 all_gemm_launches_per_step=n_launch // steps, all_gemm_ms_per_step=round(ms / steps, 3))
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE collected in SEPARATE runs of this same command; KB units; FETCH_SIZE doubled per the gfx950
+    correction of MI355X_MICROARCH.md section HBM).  PMC counters cannot be read from inside this process, so the
+    figure comes from profiles/ (null when the file is absent)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_fetch_write_per_kernel.json")
+    try:
+        d = json.load(open(path))
+        k = [v for name, v in d.items() if "gemm2_kernel" in name and "Li128ELi128ELi4ELi2ELi2E" in name][0]
+        return round((2.0 * k["fetch_kb_avg"] + k["write_kb_avg"]) * 1024.0)
+    except Exception:
+        return None
 
 
 def cpu_baseline_leg(B=4):
