@@ -61,11 +61,22 @@ __global__ __launch_bounds__(64) void lbs_prepare_kernel(const float* __restrict
   __shared__ float sR[LBS_MAXJ * 9];
   const int b = blockIdx.x, t = threadIdx.x;
   const float* be = betas + (long)b * NB;
-  // joints = J_regressor . (template + sum_l beta_l shapedirs_l): linear, so use the precomputed JS table
-  if (t < J * 3) {
-    float acc = JS[t];
-    for (int l = 0; l < NB; ++l) acc = fmaf(be[l], JS[(long)(1 + l) * J * 3 + t], acc);
-    sJ[t] = acc;
+  // joints = J_regressor . (template + sum_l beta_l shapedirs_l): linear, so use the precomputed JS table.
+  // 64 lanes = 4 slices of the beta range x 16 output slots (J*3 <= 16), combined with two shuffles.
+  __shared__ float sB[256];
+  for (int l = t; l < NB; l += 64) sB[l] = be[l];
+  __syncthreads();
+  {
+    const int slot = t & 15, slice = t >> 4;
+    float acc = 0.f;
+    if (slot < J * 3) {
+      const int per = (NB + 3) / 4, l0 = slice * per, l1 = min(NB, l0 + per);
+#pragma unroll 8
+      for (int l = l0; l < l1; ++l) acc = fmaf(sB[l], JS[(long)(1 + l) * J * 3 + slot], acc);
+    }
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    if (t < J * 3) sJ[t] = acc + JS[t];
   }
   if (t < J) {
     float R[9];
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(64) void lbs_prepare_kernel(const float* __restrict
 extern "C" int msmd_lbs_prepare(const float* betas, const float* pose, const float* JS, const int* parents,
                                 float* coef, void* coef_hl, float* A, float* joints, int B, int NB, int J, int Kp,
                                 int pose_is_matrix, msmd_stream_t stream) {
-  if (B <= 0 || NB <= 0 || J <= 0 || J > LBS_MAXJ || Kp < NB + (J - 1) * 9) return 1;
+  if (B <= 0 || NB <= 0 || NB > 256 || J <= 0 || J > 5 || Kp < NB + (J - 1) * 9) return 1;
   hipLaunchKernelGGL(lbs_prepare_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, betas, pose, JS, parents, coef,
                      (bf16_t*)coef_hl, A, joints, NB, J, Kp, pose_is_matrix);
   MSMD_RETURN_LAST();
@@ -256,7 +267,13 @@ __global__ __launch_bounds__(256) void lbs_skin_bf16x3_kernel(const bf16_t* __re
                                                               const float* __restrict__ wts, float* __restrict__ verts,
                                                               int B, int V, int Vp, int frames_per_block) {
   constexpr int Kp = KG * 32;
-  __shared__ __attribute__((aligned(16))) float sA[16 * J * 12];
+  constexpr int NCH = 2 * Kp / 8;               // 16-B chunks per frame row of coef_hl (hi then lo)
+  constexpr int COEF_BYTES = NCH * 16 * 16;     // one 16-frame tile, chunk-major [chunk][frame] -> conflict-free reads
+  constexpr int A_BYTES = 16 * J * 12 * 4;      // 16 frames x J x 3x4 fp32
+  constexpr int A_CHUNKS = A_BYTES / 16;
+  constexpr int STAGE = COEF_BYTES + ((A_BYTES + 1023) / 1024) * 1024;
+  // Two stages, filled by LDS-DMA one tile ahead of the MFMAs (no register staging, one barrier per tile).
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int v = blockIdx.x * 64 + wid * 16 + i;
@@ -278,21 +295,48 @@ __global__ __launch_bounds__(256) void lbs_skin_bf16x3_kernel(const bf16_t* __re
 #pragma unroll
   for (int j = 0; j < J; ++j) w[j] = wts[(long)j * Vp + v];
 
-  for (int f0 = f_begin; f0 < f_end; f0 += 16) {
-    __syncthreads();
-    for (int k = tid; k < 16 * J * 12; k += 256) {
-      const int f = f0 + k / (J * 12);
-      sA[k] = f < f_end ? A[(long)f * J * 12 + k % (J * 12)] : 0.f;
+  typedef __attribute__((address_space(3))) void lds_t;
+  typedef __attribute__((address_space(1))) const void gbl_t;
+  auto issue = [&](int f0, int stage) {
+    unsigned char* base = smem + stage * STAGE;
+    // coefficient tile: LDS slot p = chunk*16 + frame  <-  global (frame f0 + p%16, chunk p/16)
+#pragma unroll
+    for (int k = 0; k < NCH * 16 / 256; ++k) {
+      const int p = (k * 4 + wid) * 64 + lane;
+      const int fr = min(f0 + (p & 15), B - 1), ch = p >> 4;
+      __builtin_amdgcn_global_load_lds((gbl_t*)(coef_hl + (long)fr * 2 * Kp + ch * 8),
+                                       (lds_t*)(base + (k * 4 + wid) * 1024), 16, 0, 0);
     }
-    const int fa = min(f0 + i, B - 1);
-    const bf16_t* ch = coef_hl + ((long)fa * 2) * Kp + 8 * q;
+    // rigid transforms of the 16 frames: contiguous in global memory
+    {
+      const int p = wid * 64 + lane;
+      const long gofs = min((long)f0 * J * 12 + (long)p * 4, (long)B * J * 12 - 4);
+      if (wid * 64 < A_CHUNKS)
+        __builtin_amdgcn_global_load_lds((gbl_t*)(A + gofs), (lds_t*)(base + COEF_BYTES + wid * 1024), 16, 0, 0);
+    }
+  };
+
+  int stage = 0;
+  issue(f_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tile: nothing younger than the loads yet
+  // a wave issues exactly 4 vertex-store instructions per tile unless ALL its vertices are padding
+  const bool wave_stores = __builtin_amdgcn_readfirstlane(blockIdx.x * 64 + wid * 16) < V;
+  for (int f0 = f_begin; f0 < f_end; f0 += 16) {
+    // vmcnt counts stores too: waiting for 0 would serialise on the previous tile's vertex stores (the 4 youngest
+    // VMEM ops of this wave).  Leave them in flight and wait only for this tile's 4 LDS-DMA loads, which are older.
+    if (wave_stores) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (f0 + 16 < f_end) issue(f0 + 16, stage ^ 1);
+    const unsigned char* sc = smem + stage * STAGE;
+    const float* sA = (const float*)(sc + COEF_BYTES);
     f32x4 acc[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
-      const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4*)(ch + 32 * g));
-      const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4*)(ch + Kp + 32 * g));
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4*)(sc + ((4 * g + q) * 16 + i) * 16));
+      const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4*)(sc + ((Kp / 8 + 4 * g + q) * 16 + i) * 16));
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8, dh[c][g]), acc[c], 0, 0, 0);
@@ -300,32 +344,40 @@ __global__ __launch_bounds__(256) void lbs_skin_bf16x3_kernel(const bf16_t* __re
         acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, dh[c][g]), acc[c], 0, 0, 0);
       }
     }
-    __syncthreads();
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int fl = 4 * q + e, f = f0 + fl;
-      float T[12];
+      // packed fp32 maths (v_pk_fma_f32): the epilogue is VALU-issue bound, so halve its instruction count
+      f32x2 T2[6];
 #pragma unroll
-      for (int k = 0; k < 12; ++k) T[k] = 0.f;
+      for (int k = 0; k < 6; ++k) T2[k] = f32x2{0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         const f32x4* ap = (const f32x4*)(sA + (fl * J + j) * 12);
         const f32x4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          T[k] = fmaf(w[j], a0[k], T[k]);
-          T[4 + k] = fmaf(w[j], a1[k], T[4 + k]);
-          T[8 + k] = fmaf(w[j], a2[k], T[8 + k]);
-        }
+        const f32x2 wj = f32x2{w[j], w[j]};
+        T2[0] = __builtin_elementwise_fma(wj, f32x2{a0[0], a0[1]}, T2[0]);
+        T2[1] = __builtin_elementwise_fma(wj, f32x2{a0[2], a0[3]}, T2[1]);
+        T2[2] = __builtin_elementwise_fma(wj, f32x2{a1[0], a1[1]}, T2[2]);
+        T2[3] = __builtin_elementwise_fma(wj, f32x2{a1[2], a1[3]}, T2[3]);
+        T2[4] = __builtin_elementwise_fma(wj, f32x2{a2[0], a2[1]}, T2[4]);
+        T2[5] = __builtin_elementwise_fma(wj, f32x2{a2[2], a2[3]}, T2[5]);
       }
-      const float px = t3[0] + acc[0][e], py = t3[1] + acc[1][e], pz = t3[2] + acc[2][e];
+      const f32x2 pxy = f32x2{t3[0] + acc[0][e], t3[1] + acc[1][e]};
+      const f32x2 pz1 = f32x2{t3[2] + acc[2][e], 1.0f};
       if (f < f_end && v < V) {
-        float* o = verts + ((long)f * V + v) * 3;
-        o[0] = T[0] * px + T[1] * py + T[2] * pz + T[3];
-        o[1] = T[4] * px + T[5] * py + T[6] * pz + T[7];
-        o[2] = T[8] * px + T[9] * py + T[10] * pz + T[11];
+        struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+        F3 o;
+        const f32x2 s0 = __builtin_elementwise_fma(T2[0], pxy, T2[1] * pz1);
+        const f32x2 s1 = __builtin_elementwise_fma(T2[2], pxy, T2[3] * pz1);
+        const f32x2 s2 = __builtin_elementwise_fma(T2[4], pxy, T2[5] * pz1);
+        o.x = s0[0] + s0[1];
+        o.y = s1[0] + s1[1];
+        o.z = s2[0] + s2[1];
+        *(F3*)(verts + ((long)f * V + v) * 3) = o;  // one 12-byte store per lane: 16 lanes = 192 contiguous bytes
       }
     }
+    stage ^= 1;
   }
 }
 
