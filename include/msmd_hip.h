@@ -56,6 +56,13 @@ int msmd_gemm(const void* A, const void* W, const float* bias, const void* resid
               int batch, long strideA, long strideW, long strideC, long strideBias, long strideR,
               msmd_stream_t stream);
 
+/* Two-level batched GEMM C[zo][zi] = A[zo][zi] . W[zo][zi]^T (no bias / residual / activation): operand z =
+ * zo * batch_inner + zi starts at base + zo * stride_o + zi * stride_i.  Used by the explicit (materialised-P)
+ * training attention, where zo = batch and zi = head index into packed (B, T, H*64) tensors. */
+int msmd_gemm_batched2(const void* A, const void* W, void* C, int M, int N, int K, int in_dtype, int out_dtype,
+                       long lda, long ldw, long ldc, int batch_outer, long strideA_o, long strideW_o, long strideC_o,
+                       int batch_inner, long strideA_i, long strideW_i, long strideC_i, msmd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * y = LayerNorm(act(x + residual)) * gamma + beta + post_add      (row-wise over `cols`)
  *   residual, post_add (fp32, cols) may be NULL.  eps as torch (1e-5).  Biased variance.
@@ -236,6 +243,32 @@ int msmd_truncate_rows(float* x, const int* end_idx, int N, int L, int inner, in
  * first (1/world_size after a sum all-reduce).  step is the 1-based step count for bias correction. */
 int msmd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
                    float beta1, float beta2, float eps, int step, float grad_scale, msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Backward-pass building blocks (training; reference training_script.py:195).  dgrad / wgrad are msmd_gemm calls on
+ * transposed operands: dX = dZ . W (W^T as the (K, N) operand), dW = dZ^T . X (both operands transposed).
+ */
+/* y[z][c][r] = x[z][r][c] for batch * batch_inner matrices; matrix z = zo * batch_inner + zi starts at
+ * base + zo * stride + zi * stride_i (elements). */
+int msmd_transpose(const void* x, void* y, int rows, int cols, long ldx, long ldy, int batch, long stride_x,
+                   long stride_y, int batch_inner, long stride_x_i, long stride_y_i, int dtype, msmd_stream_t stream);
+/* out[c] (+)= sum_r x[r][c] in fp32 (bias gradient). */
+int msmd_colsum(const void* x, float* out, long rows, int cols, long ld, int accumulate, int dtype,
+                msmd_stream_t stream);
+/* y = act(z);  dz = dy * act'(z)  (exact erf GELU / ELU derivatives). */
+int msmd_act_fwd(const void* z, void* y, long n, int act, int dtype, msmd_stream_t stream);
+int msmd_act_bwd(const void* dy, const void* z, void* dz, long n, int act, int dtype, msmd_stream_t stream);
+/* LayerNorm backward for y = LN(x)*gamma + beta (x = the LN input, residual already added):
+ * dx (rows, cols); dgamma / dbeta (cols) fp32 are ACCUMULATED into (zero them for a fresh gradient). */
+int msmd_layernorm_bwd(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma, float* dbeta,
+                       int rows, int cols, float eps, int dtype, msmd_stream_t stream);
+/* In place row softmax of scale * s over the first `cols` entries of rows with stride ld (the ld - cols padding
+ * columns are zeroed), optional (Tq, cols) byte mask (row r uses mask row r % Tq);
+ * backward (in place on dP): dS = scale * P o (dP - rowsum(dP o P)). */
+int msmd_softmax_rows(void* s, const uint8_t* mask, long rows, int cols, int ld, int Tq, float scale, int dtype,
+                      msmd_stream_t stream);
+int msmd_softmax_bwd_rows(const void* P, void* dP, long rows, int cols, int ld, float scale, int dtype,
+                          msmd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Small utilities.

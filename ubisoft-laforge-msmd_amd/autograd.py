@@ -1,0 +1,184 @@
+"""Differentiable building blocks for the training path: torch.autograd.Function shims whose forward AND
+backward run on the hand-written HIP kernels (csrc/gemm.hip, backward.hip, norm.hip).
+
+Mixed precision as the inference path: activations in the compute dtype (bf16 or fp32), master weights and all
+gradients of parameters in fp32.  dgrad / wgrad are the same MFMA GEMM on transposed operands:
+    dX = dZ . W        -> gemm(dZ, W^T as the (K, N) operand)
+    dW = dZ^T . X      -> gemm(dZ^T (N, M), X^T (K, M)) with fp32 output
+Training attention materialises P (needed by the backward) with batched GEMMs + a row-softmax kernel.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+ACT_NONE, ACT_GELU, ACT_ELU = ops.ACT_NONE, ops.ACT_GELU, ops.ACT_ELU
+
+
+class WeightCache:
+    """Per-optimizer-step cache of compute-dtype weight copies and their transposes (like AMP's cast cache)."""
+
+    def __init__(self):
+        self.store = {}
+
+    def clear(self):
+        self.store.clear()
+
+    def get(self, w: torch.Tensor, dtype):
+        key = (id(w), dtype)
+        e = self.store.get(key)
+        if e is None or e[0] != w._version:
+            w2 = w.detach().reshape(w.shape[0], -1)
+            K = w2.shape[1]
+            Kp = (K + 7) // 8 * 8
+            wc = ops.pad_cols(w2.float().contiguous(), Kp, dtype)     # (N, Kp)
+            wct = ops.transpose2d(wc[:, :K] if Kp != K else wc, 8)     # (K, Np)
+            e = self.store[key] = (w._version, wc, wct)
+        return e[1], e[2]
+
+
+CACHE = WeightCache()
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x @ w.T + b) + residual   (x: (..., K) compute dtype; w (N, K), b (N) fp32 master parameters)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, residual, act):
+        dtype = x.dtype
+        wc, wct = CACHE.get(w, dtype)
+        K = w.shape[1]
+        xin = x if wc.shape[1] == K else ops.pad_cols(x.contiguous(), wc.shape[1], dtype)
+        xin = xin.contiguous()
+        bf = b.detach().float().contiguous() if b is not None else None
+        if act == ACT_NONE:
+            y = ops.gemm(xin, wc, bf, residual.contiguous() if residual is not None else None)
+            z = None
+        else:
+            z = ops.gemm(xin, wc, bf)
+            y = ops.act_fwd(z, act)
+            if residual is not None:
+                y = y + residual
+        ctx.save_for_backward(xin, z, w)
+        ctx.act, ctx.has_b, ctx.has_r, ctx.K = act, b is not None, residual is not None, K
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xin, z, w = ctx.saved_tensors
+        dtype = xin.dtype
+        dy = dy.contiguous()
+        dz = dy if ctx.act == ACT_NONE else ops.act_bwd(dy, z, ctx.act)
+        N = w.shape[0]
+        Kp = xin.shape[-1]
+        M = xin.numel() // Kp
+        dz2 = dz.reshape(M, N)
+        dx = dw = db = None
+        wc, wct = CACHE.get(w, dtype)
+        if ctx.needs_input_grad[0]:
+            dzp = dz2 if wct.shape[1] == N else ops.pad_cols(dz2, wct.shape[1], dtype)
+            dx = ops.gemm(dzp, wct).reshape(*xin.shape[:-1], wct.shape[0])
+        if ctx.needs_input_grad[1]:
+            dzT = ops.transpose2d(dz2, 8)                      # (N, Mp)
+            xT = ops.transpose2d(xin.reshape(M, Kp), 8)        # (Kp, Mp)
+            dw = ops.gemm(dzT, xT, out_dtype=torch.float32)    # (N, Kp) fp32
+            dw = dw[:, :ctx.K].reshape(w.shape)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = ops.colsum(dz2)
+        dres = dy if ctx.has_r and ctx.needs_input_grad[3] else None
+        return dx, dw, db, dres, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x) * gamma + beta (+ post_add constant row)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, post_add):
+        x = x.contiguous()
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        y = ops.layernorm(x, g, b, post_add=post_add)
+        ctx.save_for_backward(x, g)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(dy.contiguous(), x, g)
+        return dx, dg, db, None
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(scale * Q K^T, masked) V per head (head_dim 64) with P materialised for the backward.
+    q: (B, Tq, H*64), k / v: (B, Tk, H*64); last-dim-contiguous views of packed projections are accepted."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, n_heads, scale, mask):
+        B, Tq, d = q.shape
+        Tk = k.shape[1]
+        H = n_heads
+        dt = q.dtype
+        Tkp = (Tk + 7) // 8 * 8
+        P = torch.empty(B, H, Tq, Tkp, device=q.device, dtype=dt)
+        ops.gemm_batched2(q, k, P, Tq, Tk, 64, q.stride(1), k.stride(1), Tkp, B, q.stride(0), k.stride(0), H * Tq * Tkp,
+                          H, 64, 64, Tq * Tkp)
+        m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
+        ops.softmax_rows_(P, Tk, Tkp, Tq, scale, m8)
+        VT = torch.zeros(B, H, 64, Tkp, device=q.device, dtype=dt)
+        ops.transpose(v, VT, Tk, 64, v.stride(1), Tkp, B, v.stride(0), H * 64 * Tkp, H, 64, 64 * Tkp)
+        O = torch.empty(B, Tq, d, device=q.device, dtype=dt)
+        ops.gemm_batched2(P, VT, O, Tq, 64, Tkp, Tkp, Tkp, d, B, H * Tq * Tkp, H * 64 * Tkp, Tq * d, H, Tq * Tkp,
+                          64 * Tkp, 64)
+        ctx.save_for_backward(q, k, v, P)
+        ctx.dims = (B, H, Tq, Tk, Tkp, d, scale)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, k, v, P = ctx.saved_tensors
+        B, H, Tq, Tk, Tkp, d, scale = ctx.dims
+        dt = q.dtype
+        dev = q.device
+        dO = dO.contiguous()
+        Tqp = (Tq + 7) // 8 * 8
+        # dV_h = P_h^T . dO_h
+        PT = torch.zeros(B, H, Tk, Tqp, device=dev, dtype=dt)
+        ops.transpose(P, PT, Tq, Tk, Tkp, Tqp, B * H, Tq * Tkp, Tk * Tqp)
+        dOT = torch.zeros(B, H, 64, Tqp, device=dev, dtype=dt)
+        ops.transpose(dO, dOT, Tq, 64, d, Tqp, B, Tq * d, H * 64 * Tqp, H, 64, 64 * Tqp)
+        dV = torch.empty(B, Tk, d, device=dev, dtype=dt)
+        ops.gemm_batched2(PT, dOT, dV, Tk, 64, Tqp, Tqp, Tqp, d, B, H * Tk * Tqp, H * 64 * Tqp, Tk * d, H, Tk * Tqp,
+                          64 * Tqp, 64)
+        # dP_h = dO_h . V_h^T ; dS = scale * P o (dP - rowsum(dP o P))
+        dP = torch.empty(B, H, Tq, Tkp, device=dev, dtype=dt)
+        ops.gemm_batched2(dO, v, dP, Tq, Tk, 64, d, v.stride(1), Tkp, B, Tq * d, v.stride(0), H * Tq * Tkp, H, 64, 64,
+                          Tq * Tkp)
+        ops.softmax_bwd_rows_(P, dP, Tk, Tkp, scale)
+        dS = dP
+        # dQ_h = dS_h . K_h
+        KT = torch.zeros(B, H, 64, Tkp, device=dev, dtype=dt)
+        ops.transpose(k, KT, Tk, 64, k.stride(1), Tkp, B, k.stride(0), H * 64 * Tkp, H, 64, 64 * Tkp)
+        dQ = torch.empty(B, Tq, d, device=dev, dtype=dt)
+        ops.gemm_batched2(dS, KT, dQ, Tq, 64, Tkp, Tkp, Tkp, d, B, H * Tq * Tkp, H * 64 * Tkp, Tq * d, H, Tq * Tkp,
+                          64 * Tkp, 64)
+        # dK_h = dS_h^T . Q_h
+        dST = torch.zeros(B, H, Tk, Tqp, device=dev, dtype=dt)
+        ops.transpose(dS, dST, Tq, Tk, Tkp, Tqp, B * H, Tq * Tkp, Tk * Tqp)
+        QT = torch.zeros(B, H, 64, Tqp, device=dev, dtype=dt)
+        ops.transpose(q, QT, Tq, 64, q.stride(1), Tqp, B, q.stride(0), H * 64 * Tqp, H, 64, 64 * Tqp)
+        dK = torch.empty(B, Tk, d, device=dev, dtype=dt)
+        ops.gemm_batched2(dST, QT, dK, Tk, 64, Tqp, Tqp, Tqp, d, B, H * Tk * Tqp, H * 64 * Tqp, Tk * d, H, Tk * Tqp,
+                          64 * Tqp, 64)
+        return dQ, dK, dV, None, None, None
+
+
+def linear(x, w, b=None, act=ACT_NONE, residual=None):
+    return LinearFn.apply(x, w, b, residual, act)
+
+
+def layer_norm(x, gamma, beta, post_add=None):
+    return LayerNormFn.apply(x, gamma, beta, post_add)
+
+
+def attention(q, k, v, n_heads, scale, mask=None):
+    return AttentionFn.apply(q, k, v, n_heads, scale, mask)

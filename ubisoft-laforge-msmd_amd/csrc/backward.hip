@@ -1,0 +1,276 @@
+// Backward-pass building blocks (training path, reference training_script.py:195 `loss.backward()`):
+// transposes feeding the MFMA GEMM for dgrad / wgrad, bias-gradient column sums, activation and LayerNorm
+// backward, row softmax forward / backward for the explicit (materialised-P) training attention.
+// All HBM-bound streaming kernels except the GEMMs they feed.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// Batched 2-D transpose through a padded LDS tile: y[b][c][r] = x[b][r][c].
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, T* __restrict__ y, int rows, int cols,
+                                                        long ldx, long ldy, long sx, long sy, int inner, long sx2,
+                                                        long sy2) {
+  __shared__ T tile[64][65];
+  const int zo = blockIdx.z / inner, zi = blockIdx.z % inner;
+  const T* xb = x + zo * sx + zi * sx2;
+  T* yb = y + zo * sy + zi * sy2;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + i * 4, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + i * 4][tx] = xb[(long)r * ldx + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + i * 4, r = r0 + tx;
+    if (r < rows && c < cols) yb[(long)c * ldy + r] = tile[tx][ty + i * 4];
+  }
+}
+
+extern "C" int msmd_transpose(const void* x, void* y, int rows, int cols, long ldx, long ldy, int batch, long stride_x,
+                              long stride_y, int batch_inner, long stride_x_i, long stride_y_i, int dtype,
+                              msmd_stream_t stream) {
+  if (rows <= 0 || cols <= 0 || batch <= 0 || batch_inner <= 0) return 1;
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64, batch * batch_inner), block(256);
+  if (dtype == MSMD_F32)
+    hipLaunchKernelGGL(transpose_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)x, (float*)y, rows,
+                       cols, ldx, ldy, stride_x, stride_y, batch_inner, stride_x_i, stride_y_i);
+  else
+    hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y,
+                       rows, cols, ldx, ldy, stride_x, stride_y, batch_inner, stride_x_i, stride_y_i);
+  MSMD_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// out[c] (+)= sum_r x[r][c]   (bias gradients; fp32 accumulation, atomics across row blocks)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long rows,
+                                                     int cols, long ld, int rows_per_block) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  for (long r = r0; r < r1; ++r) s += to_f32(x[r * ld + c]);
+  atomicAdd(&out[c], s);
+}
+
+extern "C" int msmd_colsum(const void* x, float* out, long rows, int cols, long ld, int accumulate, int dtype,
+                           msmd_stream_t stream) {
+  if (rows <= 0 || cols <= 0) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int rpb = 128;
+  dim3 grid((cols + 255) / 256, (unsigned)((rows + rpb - 1) / rpb)), block(256);
+  if (dtype == MSMD_F32)
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, (const float*)x, out, rows, cols, ld, rpb);
+  else
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, out, rows, cols, ld, rpb);
+  MSMD_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// y = act(z)  /  dz = dy * act'(z)
+__device__ __forceinline__ float act_grad(float z, int act) {
+  if (act == MSMD_ACT_GELU) {
+    const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+    return cdf + z * 0.3989422804014327f * expf(-0.5f * z * z);
+  }
+  if (act == MSMD_ACT_ELU) return z > 0.f ? 1.0f : expf(z);
+  return 1.0f;
+}
+
+template <typename T>
+__global__ void act_fwd_kernel(const T* __restrict__ z, T* __restrict__ y, long n, int act) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = from_f32<T>(apply_act(to_f32(z[i]), act));
+}
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z, T* __restrict__ dz, long n, int act) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dz[i] = from_f32<T>(to_f32(dy[i]) * act_grad(to_f32(z[i]), act));
+}
+
+extern "C" int msmd_act_fwd(const void* z, void* y, long n, int act, int dtype, msmd_stream_t stream) {
+  if (n <= 0) return 1;
+  dim3 grid((unsigned)min((n + 255) / 256, (long)8192)), block(256);
+  if (dtype == MSMD_F32)
+    hipLaunchKernelGGL(act_fwd_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)z, (float*)y, n, act);
+  else
+    hipLaunchKernelGGL(act_fwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)z, (bf16_t*)y, n, act);
+  MSMD_RETURN_LAST();
+}
+extern "C" int msmd_act_bwd(const void* dy, const void* z, void* dz, long n, int act, int dtype, msmd_stream_t stream) {
+  if (n <= 0) return 1;
+  dim3 grid((unsigned)min((n + 255) / 256, (long)8192)), block(256);
+  if (dtype == MSMD_F32)
+    hipLaunchKernelGGL(act_bwd_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)dy, (const float*)z,
+                       (float*)dz, n, act);
+  else
+    hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy,
+                       (const bf16_t*)z, (bf16_t*)dz, n, act);
+  MSMD_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm backward: one wave per row; x is the LN INPUT (already x + residual), y = xhat*gamma + beta.
+//   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+//   dgamma += dy * xhat, dbeta += dy  (fp32 atomics; dgamma/dbeta must be zeroed or hold the running sum)
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma, T* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int rows, int cols, float eps) {
+  __shared__ float sg[4 * 64 * MAXC], sb[4 * 64 * MAXC];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wid;
+  float xv[MAXC], gv[MAXC], dyv[MAXC];
+  float s = 0.f;
+  const bool live = row < rows;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = i * 64 + lane;
+    xv[i] = (live && c < cols) ? to_f32(x[(long)row * cols + c]) : 0.f;
+    dyv[i] = (live && c < cols) ? to_f32(dy[(long)row * cols + c]) : 0.f;
+    s += xv[i];
+  }
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = i * 64 + lane;
+    const float d = (c < cols) ? xv[i] - mean : 0.f;
+    q += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cols + eps);
+  float sg1 = 0.f, sg2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = i * 64 + lane;
+    xv[i] = (c < cols) ? (xv[i] - mean) * rstd : 0.f;  // xhat
+    gv[i] = (c < cols) ? dyv[i] * gamma[c] : 0.f;
+    sg1 += gv[i];
+    sg2 += gv[i] * xv[i];
+  }
+  const float m1 = wave_sum(sg1) / (float)cols, m2 = wave_sum(sg2) / (float)cols;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = i * 64 + lane;
+    if (live && c < cols) dx[(long)row * cols + c] = from_f32<T>(rstd * (gv[i] - m1 - xv[i] * m2));
+    sg[(wid * MAXC + i) * 64 + lane] = live ? dyv[i] * xv[i] : 0.f;
+    sb[(wid * MAXC + i) * 64 + lane] = live ? dyv[i] : 0.f;
+  }
+  __syncthreads();
+  // combine the block's 4 rows, then one atomic per column per block
+  for (int k = threadIdx.x; k < MAXC * 64; k += 256) {
+    const int c = k;  // k = i*64 + lane
+    if (c < cols) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        a += sg[w * MAXC * 64 + k];
+        b += sb[w * MAXC * 64 + k];
+      }
+      atomicAdd(&dgamma[c], a);
+      atomicAdd(&dbeta[c], b);
+    }
+  }
+}
+
+extern "C" int msmd_layernorm_bwd(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma,
+                                  float* dbeta, int rows, int cols, float eps, int dtype, msmd_stream_t stream) {
+  if (rows <= 0 || cols <= 0 || cols > 1024) return 1;
+  dim3 grid((rows + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MSMD_F32) {
+    if (cols <= 512)
+      hipLaunchKernelGGL((layernorm_bwd_kernel<float, 8>), grid, block, 0, st, (const float*)dy, (const float*)x, gamma,
+                         (float*)dx, dgamma, dbeta, rows, cols, eps);
+    else
+      hipLaunchKernelGGL((layernorm_bwd_kernel<float, 16>), grid, block, 0, st, (const float*)dy, (const float*)x,
+                         gamma, (float*)dx, dgamma, dbeta, rows, cols, eps);
+  } else {
+    if (cols <= 512)
+      hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 8>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x,
+                         gamma, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps);
+    else
+      hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 16>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x,
+                         gamma, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps);
+  }
+  MSMD_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Row softmax over a (rows, cols) score matrix with scale and optional (Tq, Tk) byte mask shared by all
+// batches (row r uses mask row r % Tq), in place;   and its backward  dS = scale * P o (dP - rowsum(dP o P)).
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(T* __restrict__ s, const uint8_t* __restrict__ mask, long rows,
+                                                           int cols, int ld, int Tq, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  T* p = s + row * ld;
+  for (int c = cols + lane; c < ld; c += 64) p[c] = from_f32<T>(0.f);  // padding columns contribute nothing
+  const uint8_t* m = mask ? mask + (long)(row % Tq) * cols : nullptr;
+  float mx = -INFINITY;
+  for (int c = lane; c < cols; c += 64) {
+    const float v = (m && m[c]) ? -INFINITY : to_f32(p[c]) * scale;
+    mx = fmaxf(mx, v);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int c = lane; c < cols; c += 64) {
+    const float v = (m && m[c]) ? -INFINITY : to_f32(p[c]) * scale;
+    sum += expf(v - mx);
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int c = lane; c < cols; c += 64) {
+    const float v = (m && m[c]) ? -INFINITY : to_f32(p[c]) * scale;
+    p[c] = from_f32<T>(expf(v - mx) * inv);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const T* __restrict__ P, T* __restrict__ dP, long rows,
+                                                               int cols, int ld, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* p = P + row * ld;
+  T* d = dP + row * ld;
+  for (int c = cols + lane; c < ld; c += 64) d[c] = from_f32<T>(0.f);
+  float dot = 0.f;
+  for (int c = lane; c < cols; c += 64) dot += to_f32(p[c]) * to_f32(d[c]);
+  dot = wave_sum(dot);
+  for (int c = lane; c < cols; c += 64) d[c] = from_f32<T>(scale * to_f32(p[c]) * (to_f32(d[c]) - dot));
+}
+
+extern "C" int msmd_softmax_rows(void* s, const uint8_t* mask, long rows, int cols, int ld, int Tq, float scale,
+                                 int dtype, msmd_stream_t stream) {
+  if (rows <= 0 || cols <= 0 || Tq <= 0 || ld < cols) return 1;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (dtype == MSMD_F32)
+    hipLaunchKernelGGL(softmax_rows_kernel<float>, grid, block, 0, (hipStream_t)stream, (float*)s, mask, rows, cols, ld,
+                       Tq, scale);
+  else
+    hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (bf16_t*)s, mask, rows, cols,
+                       ld, Tq, scale);
+  MSMD_RETURN_LAST();
+}
+extern "C" int msmd_softmax_bwd_rows(const void* P, void* dP, long rows, int cols, int ld, float scale, int dtype,
+                                     msmd_stream_t stream) {
+  if (rows <= 0 || cols <= 0 || ld < cols) return 1;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (dtype == MSMD_F32)
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)P,
+                       (float*)dP, rows, cols, ld, scale);
+  else
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)P,
+                       (bf16_t*)dP, rows, cols, ld, scale);
+  MSMD_RETURN_LAST();
+}

@@ -22,6 +22,7 @@ struct GemmArgs {
   int act; int vec_ok; float inv_rpb;
   long strideA, strideW, strideC, strideBias, strideR;
   int mt, nt;
+  int batch_inner; long strideA2, strideW2, strideC2;  // z = outer * batch_inner + inner (attention: batch x heads)
 };
 
 template <typename T> struct Mfma;
@@ -69,7 +70,8 @@ template <typename TO> __device__ __forceinline__ float act_out(float x, int act
 template <typename TO, int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int z, int m_base,
                                                        int n_base, int fr, int fq) {
-  TO* __restrict__ C = (TO*)p.C + z * p.strideC + (long)(m_base + fr) * p.ldc + n_base + fq * 4;
+  TO* __restrict__ C = (TO*)p.C + (z / p.batch_inner) * p.strideC + (z % p.batch_inner) * p.strideC2 +
+                       (long)(m_base + fr) * p.ldc + n_base + fq * 4;
   const TO* __restrict__ R = p.R ? (const TO*)p.R + z * p.strideR + (long)(m_base + fr) * p.ldr + n_base + fq * 4 : nullptr;
   const float* __restrict__ bias = p.bias ? p.bias + z * p.strideBias + n_base + fq * 4 : nullptr;
   f32x4 bv[FN];
@@ -108,7 +110,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
     gemm_epilogue_interior<TO, FM, FN>(p, acc, z, m_base, n_base, fr, fq);
     return;
   }
-  TO* __restrict__ C = (TO*)p.C + z * p.strideC;
+  TO* __restrict__ C = (TO*)p.C + (z / p.batch_inner) * p.strideC + (z % p.batch_inner) * p.strideC2;
   const TO* __restrict__ R = p.R ? (const TO*)p.R + z * p.strideR : nullptr;
   const float* __restrict__ bias = p.bias ? p.bias + z * p.strideBias : nullptr;
 #pragma unroll
@@ -175,8 +177,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
   const int m_tile = (slot / p.nt) * 8 + xcd, n_tile = slot % p.nt;
   if (m_tile >= p.mt) return;
   const int z = blockIdx.z;
-  const T* __restrict__ A = (const T*)p.A + z * p.strideA;
-  const T* __restrict__ W = (const T*)p.W + z * p.strideW;
+  const int zo = z / p.batch_inner, zi = z % p.batch_inner;
+  const T* __restrict__ A = (const T*)p.A + zo * p.strideA + zi * p.strideA2;
+  const T* __restrict__ W = (const T*)p.W + zo * p.strideW + zi * p.strideW2;
   const int m0 = m_tile * BM, n0 = n_tile * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
@@ -280,8 +283,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const GemmArgs p) {
   const int m_tile = (slot / p.nt) * 8 + xcd, n_tile = slot % p.nt;
   if (m_tile >= p.mt) return;
   const int z = blockIdx.z;
-  const bf16_t* __restrict__ A = (const bf16_t*)p.A + z * p.strideA;
-  const bf16_t* __restrict__ W = (const bf16_t*)p.W + z * p.strideW;
+  const int zo = z / p.batch_inner, zi = z % p.batch_inner;
+  const bf16_t* __restrict__ A = (const bf16_t*)p.A + zo * p.strideA + zi * p.strideA2;
+  const bf16_t* __restrict__ W = (const bf16_t*)p.W + zo * p.strideW + zi * p.strideW2;
   const int m0 = m_tile * BM, n0 = n_tile * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
@@ -404,13 +408,14 @@ static int launch_gemm(GemmArgs& p, int batch, hipStream_t st) {
   MSMD_RETURN_LAST();
 }
 
-extern "C" int msmd_gemm(const void* A, const void* W, const float* bias, const void* residual, void* C, int M,
-                         int N, int K, int in_dtype, int out_dtype, long lda, int rows_per_batch,
-                         long a_batch_stride, long ldw, long ldc, long ldr, int act, int batch, long strideA,
-                         long strideW, long strideC, long strideBias, long strideR, msmd_stream_t stream) {
-  if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || !A || !W || !C) return 1;
+static int gemm_impl(const void* A, const void* W, const float* bias, const void* residual, void* C, int M, int N, int K,
+                     int in_dtype, int out_dtype, long lda, int rows_per_batch, long a_batch_stride, long ldw, long ldc,
+                     long ldr, int act, int batch, long strideA, long strideW, long strideC, long strideBias,
+                     long strideR, int batch_inner, long strideA2, long strideW2, long strideC2, msmd_stream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch_inner <= 0 || !A || !W || !C) return 1;
   const int E = in_dtype == MSMD_BF16 ? 8 : 4;
-  if (K % E || lda % E || ldw % E || a_batch_stride % E || strideA % E || strideW % E) return 1;
+  if (K % E || lda % E || ldw % E || a_batch_stride % E || strideA % E || strideW % E || strideA2 % E || strideW2 % E)
+    return 1;
   if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return 1;
   if (rows_per_batch <= 0) rows_per_batch = M;
   GemmArgs p;
@@ -420,26 +425,45 @@ extern "C" int msmd_gemm(const void* A, const void* W, const float* bias, const 
   p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.act = act;
   p.inv_rpb = 1.0f / (float)rows_per_batch;
   p.strideA = strideA; p.strideW = strideW; p.strideC = strideC; p.strideBias = strideBias; p.strideR = strideR;
+  p.batch_inner = batch_inner; p.strideA2 = strideA2; p.strideW2 = strideW2; p.strideC2 = strideC2;
   const int osz = out_dtype == MSMD_BF16 ? 2 : 4;
-  p.vec_ok = (ldc % 4 == 0) && (strideC % 4 == 0) && (((uintptr_t)C % (4 * osz)) == 0) &&
+  p.vec_ok = (ldc % 4 == 0) && (strideC % 4 == 0) && (strideC2 % 4 == 0) && (((uintptr_t)C % (4 * osz)) == 0) &&
              (!residual || ((ldr % 4 == 0) && (strideR % 4 == 0) && (((uintptr_t)residual % (4 * osz)) == 0)));
   hipStream_t st = (hipStream_t)stream;
+  const int nz = batch * batch_inner;
   if (in_dtype == MSMD_BF16 && (K % 64) == 0 && g_tuning[0] >= 0) {
     // Measured on MI355X (tools/bench_gemm.py): the 128x128 LDS-DMA kernel wins once the grid fills the
     // chip at 2 workgroups per CU; below that, 64x64 tiles (deep ring for long K) keep more CUs busy.
     int variant = g_tuning[0];
     if (variant == 0) {
-      const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+      const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nz;
       if (N > 64 && tiles128 >= 192) variant = 13;  // 128x128, 8 waves (4x2), 2-stage ring, 2 workgroups/CU
       else variant = (K >= 1024) ? 9 : 12;
     }
-    const int r = out_dtype == MSMD_BF16 ? dispatch_gemm2<bf16_t>(p, batch, st, variant)
-                                         : dispatch_gemm2<float>(p, batch, st, variant);
+    const int r = out_dtype == MSMD_BF16 ? dispatch_gemm2<bf16_t>(p, nz, st, variant)
+                                         : dispatch_gemm2<float>(p, nz, st, variant);
     if (r >= 0) return r;
   }
-  if (in_dtype == MSMD_BF16 && out_dtype == MSMD_BF16) return launch_gemm<bf16_t, bf16_t>(p, batch, st);
-  if (in_dtype == MSMD_BF16 && out_dtype == MSMD_F32) return launch_gemm<bf16_t, float>(p, batch, st);
-  if (in_dtype == MSMD_F32 && out_dtype == MSMD_F32) return launch_gemm<float, float>(p, batch, st);
-  if (in_dtype == MSMD_F32 && out_dtype == MSMD_BF16) return launch_gemm<float, bf16_t>(p, batch, st);
+  if (in_dtype == MSMD_BF16 && out_dtype == MSMD_BF16) return launch_gemm<bf16_t, bf16_t>(p, nz, st);
+  if (in_dtype == MSMD_BF16 && out_dtype == MSMD_F32) return launch_gemm<bf16_t, float>(p, nz, st);
+  if (in_dtype == MSMD_F32 && out_dtype == MSMD_F32) return launch_gemm<float, float>(p, nz, st);
+  if (in_dtype == MSMD_F32 && out_dtype == MSMD_BF16) return launch_gemm<float, bf16_t>(p, nz, st);
   return 1;
+}
+
+extern "C" int msmd_gemm(const void* A, const void* W, const float* bias, const void* residual, void* C, int M,
+                         int N, int K, int in_dtype, int out_dtype, long lda, int rows_per_batch,
+                         long a_batch_stride, long ldw, long ldc, long ldr, int act, int batch, long strideA,
+                         long strideW, long strideC, long strideBias, long strideR, msmd_stream_t stream) {
+  return gemm_impl(A, W, bias, residual, C, M, N, K, in_dtype, out_dtype, lda, rows_per_batch, a_batch_stride, ldw, ldc,
+                   ldr, act, batch, strideA, strideW, strideC, strideBias, strideR, 1, 0, 0, 0, stream);
+}
+
+extern "C" int msmd_gemm_batched2(const void* A, const void* W, void* C, int M, int N, int K, int in_dtype,
+                                  int out_dtype, long lda, long ldw, long ldc, int batch_outer, long strideA_o,
+                                  long strideW_o, long strideC_o, int batch_inner, long strideA_i, long strideW_i,
+                                  long strideC_i, msmd_stream_t stream) {
+  return gemm_impl(A, W, nullptr, nullptr, C, M, N, K, in_dtype, out_dtype, lda, 0, 0, ldw, ldc, 0, MSMD_ACT_NONE,
+                   batch_outer, strideA_o, strideW_o, strideC_o, 0, 0, batch_inner, strideA_i, strideW_i, strideC_i,
+                   stream);
 }

@@ -355,3 +355,79 @@ def adam_step_(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.99
                                   float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream()),
                "msmd_adam_step")
     return param
+
+
+# ----------------------------------------------------------------------------- backward building blocks
+def gemm_batched2(a, w, out, M, N, K, lda, ldw, ldc, batch_outer, sA_o, sW_o, sC_o, batch_inner, sA_i, sW_i, sC_i):
+    lib = _lib.load()
+    _lib.check(lib.msmd_gemm_batched2(_p(a), _p(w), _p(out), M, N, K, _dt(a), _dt(out), lda, ldw, ldc, batch_outer,
+                                      sA_o, sW_o, sC_o, batch_inner, sA_i, sW_i, sC_i, _stream()), "msmd_gemm_batched2")
+    return out
+
+
+def transpose(x, out, rows, cols, ldx, ldy, batch=1, sx=0, sy=0, batch_inner=1, sx_i=0, sy_i=0):
+    lib = _lib.load()
+    _lib.check(lib.msmd_transpose(_p(x), _p(out), rows, cols, ldx, ldy, batch, sx, sy, batch_inner, sx_i, sy_i, _dt(x),
+                                  _stream()), "msmd_transpose")
+    return out
+
+
+def transpose2d(x, pad_to=8):
+    """(rows, cols) -> (cols, rows_padded) with zero padding of the new inner dim to a multiple of `pad_to`."""
+    rows, cols = x.shape
+    rp = (rows + pad_to - 1) // pad_to * pad_to
+    out = torch.zeros(cols, rp, device=x.device, dtype=x.dtype) if rp != rows else \
+        torch.empty(cols, rp, device=x.device, dtype=x.dtype)
+    return transpose(x, out, rows, cols, x.stride(0), rp)
+
+
+def colsum(x2d, out=None, accumulate=False):
+    lib = _lib.load()
+    rows, cols = x2d.shape
+    if out is None:
+        out = torch.empty(cols, device=x2d.device, dtype=torch.float32)
+    _lib.check(lib.msmd_colsum(_p(x2d), _p(out), rows, cols, x2d.stride(0), int(accumulate), _dt(x2d), _stream()),
+               "msmd_colsum")
+    return out
+
+
+def act_fwd(z, act):
+    lib = _lib.load()
+    y = torch.empty_like(z)
+    _lib.check(lib.msmd_act_fwd(_p(z), _p(y), z.numel(), act, _dt(z), _stream()), "msmd_act_fwd")
+    return y
+
+
+def act_bwd(dy, z, act):
+    lib = _lib.load()
+    dz = torch.empty_like(z)
+    _lib.check(lib.msmd_act_bwd(_p(dy), _p(z), _p(dz), z.numel(), act, _dt(z), _stream()), "msmd_act_bwd")
+    return dz
+
+
+def layernorm_bwd(dy, x, gamma, eps=1e-5):
+    lib = _lib.load()
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    dx = torch.empty_like(x)
+    dg = torch.zeros(cols, device=x.device, dtype=torch.float32)
+    db = torch.zeros(cols, device=x.device, dtype=torch.float32)
+    _lib.check(lib.msmd_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(dx), _p(dg), _p(db), rows, cols, eps, _dt(x),
+                                      _stream()), "msmd_layernorm_bwd")
+    return dx, dg, db
+
+
+def softmax_rows_(s, cols, ld, Tq, scale, mask=None):
+    lib = _lib.load()
+    rows = s.numel() // ld
+    _lib.check(lib.msmd_softmax_rows(_p(s), _p(mask), rows, cols, ld, Tq, float(scale), _dt(s), _stream()),
+               "msmd_softmax_rows")
+    return s
+
+
+def softmax_bwd_rows_(P, dP, cols, ld, scale):
+    lib = _lib.load()
+    rows = P.numel() // ld
+    _lib.check(lib.msmd_softmax_bwd_rows(_p(P), _p(dP), rows, cols, ld, float(scale), _dt(P), _stream()),
+               "msmd_softmax_bwd_rows")
+    return dP
