@@ -270,6 +270,11 @@ int msmd_softmax_rows(void* s, const uint8_t* mask, long rows, int cols, int ld,
 int msmd_softmax_bwd_rows(const void* P, void* dP, long rows, int cols, int ld, float scale, int dtype,
                           msmd_stream_t stream);
 
+/* Transposed unfold of the zero-padded group-major signal xp (B, G, Tp, Cg) for the grouped positional-conv
+ * weight gradient: out (G, Kk*Cg, ld_out)[g][kk*Cg + ci][b*T + t] = xp[b][g][t + kk][ci] (columns >= B*T zero). */
+int msmd_unfold_t(const void* xp, void* out, int B, int T, int Tp, int G, int Cg, int Kk, long ld_out, int dtype,
+                  msmd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Small utilities.
  */

@@ -510,9 +510,97 @@ def g5_losses(M, SE, mc):
     save("g5_losses", **out)
 
 
+# --------------------------------------------------------------------------- G6 one fixed-noise training step
+G6_PARAMS = [
+    "denoising_net.PE", "denoising_net.person_proj.weight", "denoising_net.feature_proj.weight",
+    "denoising_net.diff_step_map.0.weight", "denoising_net.transformer.layers.0.self_attn.in_proj_weight",
+    "denoising_net.transformer.layers.0.multihead_attn.in_proj_weight",
+    "denoising_net.transformer.layers.1.linear2.weight", "denoising_net.transformer.layers.1.norm3.weight",
+    "denoising_net.motion_dec.2.bias", "denoising_net.static_feature_mapping.3.2.weight",
+    "audio_feature_map.weight", "start_motion_feat", "start_audio_feat",
+    "audio_encoder.encoder.layers.1.feed_forward.output_dense.weight",
+    "audio_encoder.encoder.layers.0.attention.q_proj.weight", "audio_encoder.encoder.layers.0.layer_norm.bias",
+    "audio_encoder.encoder.layer_norm.weight", "audio_encoder.encoder.pos_conv_embed.conv.bias",
+    "audio_encoder.encoder.pos_conv_embed.conv.weight_g", "audio_encoder.encoder.pos_conv_embed.conv.weight_v",
+    "audio_encoder.feature_projection.projection.weight", "audio_encoder.feature_projection.layer_norm.weight",
+]
+G6_STYLE = ["input_layers.1.weight", "input_layers.5.bias", "encoder.self_attn.in_proj_weight", "encoder.linear1.weight",
+            "output_layers.7.bias"]
+
+
+def g6_train(M, SE, mc):
+    """Window-0 training forward of the reference in eval mode (no dropout) WITH gradients: fixed t / eps, no CFG
+    masking, style from the VAE mean path; loss = weighted parameter-space terms + KL; records losses and the
+    gradients' norms and leading entries for parameters spread over every component."""
+    from transformers import Wav2Vec2Config
+    import utils.wav2vec2 as w2
+    from utils import common as C
+    w2.Wav2Vec2Model.from_pretrained = classmethod(
+        lambda cls, name, **kw: cls(Wav2Vec2Config(attn_implementation="eager", num_hidden_layers=2)))
+    torch.set_grad_enabled(True)
+    try:
+        args = ref_args(n_layers=2)
+        model = M.get_diffusion_model(args, device="cpu").eval()
+        synth.load_synthetic(model)
+        se = SE.get_style_encoder(args, "vae2").eval()
+        synth.load_synthetic(se)
+        B = 2
+        audio = t(synth.audio_clips(B, 64000, tag="g6_audio"))
+        motion = t(synth.motion_clips(B, tag="g6_motion"))
+        eps = synth.normalish("g6/eps", (B, 100, 67))
+        zst = synth.normalish("g6/zstyle", (B, 256))
+        shape = torch.zeros(B, 100)
+        ind = torch.ones(B, 100)
+        ind[1, 70:] = 0
+        end_idx = torch.tensor([100, 70])
+        with mock_randn_like([t(zst), t(eps)]):
+            style, mu, logvar = se(motion)
+            noise, target, _, _ = model(motion, audio, shape, style, time_step=[7, 311], indicator=ind,
+                                        train_with_CFG=False)
+        losses = C.compute_loss_no_vert(args, True, None, motion, noise, target, None, None, None, end_idx=end_idx)
+        kl = C.compute_KL_loss(mu, logvar)
+        wts = [args.l_vert, args.l_vel * 4.5e-8 * 1e8, args.l_smooth * 4e-7 * 1e7, args.l_head_angle, args.l_head_vel,
+               args.l_head_smooth]
+        total = sum(w * l for w, l in zip(wts, losses[:6])) + 1e-3 * kl
+        total.backward()
+        out = dict(losses=np.array([float(l) for l in losses[:6]] + [float(kl), float(total)], np.float64),
+                   target=target.detach().numpy(), mu=mu.detach().numpy())
+        named = dict(model.named_parameters())
+        for k in G6_PARAMS:
+            kk = k.replace("weight_g", "parametrizations.weight.original0").replace("weight_v", "parametrizations.weight.original1")
+            gr = named[kk].grad
+            out["gn/" + k] = np.float64(gr.norm())
+            out["g8/" + k] = gr.reshape(-1)[:8].numpy().astype(np.float64)
+        snamed = dict(se.named_parameters())
+        for k in G6_STYLE:
+            gr = snamed[k].grad
+            out["sn/" + k] = np.float64(gr.norm())
+            out["s8/" + k] = gr.reshape(-1)[:8].numpy().astype(np.float64)
+        save("g6_train", **out)
+    finally:
+        torch.set_grad_enabled(False)
+        w2.Wav2Vec2Model.from_pretrained = classmethod(
+            lambda cls, name, **kw: cls(Wav2Vec2Config(attn_implementation="eager")))
+
+
+class mock_randn_like:
+    """Feed a fixed sequence of tensors to torch.randn_like (style VAE eps, then diffusion eps)."""
+
+    def __init__(self, seq):
+        self.seq = list(seq)
+
+    def __enter__(self):
+        self.orig = torch.randn_like
+        torch.randn_like = lambda x, *a, **k: self.seq.pop(0).to(x.dtype)
+        return self
+
+    def __exit__(self, *a):
+        torch.randn_like = self.orig
+
+
 ALL = dict(g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
            g3_forward=g3_forward, g3_style=g3_style, g3_sample=g3_sample, g3_infer=g3_infer,
-           g4_flame=g4_flame, g4_rotations=g4_rotations, g5_losses=g5_losses)
+           g4_flame=g4_flame, g4_rotations=g4_rotations, g5_losses=g5_losses, g6_train=g6_train)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -274,3 +274,37 @@ extern "C" int msmd_softmax_bwd_rows(const void* P, void* dP, long rows, int col
                        (bf16_t*)dP, rows, cols, ld, scale);
   MSMD_RETURN_LAST();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Transposed unfold for the positional-conv weight gradient: out[g][kk*Cg + ci][b*T + t] = xp[b][g][t + kk][ci]
+// (xp: zero-padded group-major (B, G, Tp, Cg)).  dW_g = dZ_g^T . unfold_g is then one batched MFMA GEMM.
+template <typename T>
+__global__ __launch_bounds__(256) void unfold_t_kernel(const T* __restrict__ xp, T* __restrict__ out, int B, int Tn,
+                                                       int Tp, int G, int Cg, int Kk, long ld_out) {
+  const int g = blockIdx.z;
+  const int row = blockIdx.y;  // kk * Cg + ci
+  const int kk = row / Cg, ci = row % Cg;
+  T* o = out + ((long)g * Kk * Cg + row) * ld_out;
+  const long n = (long)B * Tn;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < ld_out; i += (long)gridDim.x * blockDim.x) {
+    T v = from_f32<T>(0.f);
+    if (i < n) {
+      const int b = (int)(i / Tn), t = (int)(i % Tn);
+      v = xp[(((long)b * G + g) * Tp + t + kk) * Cg + ci];
+    }
+    o[i] = v;
+  }
+}
+
+extern "C" int msmd_unfold_t(const void* xp, void* out, int B, int T, int Tp, int G, int Cg, int Kk, long ld_out,
+                             int dtype, msmd_stream_t stream) {
+  if (B <= 0 || T <= 0 || Tp < T + Kk - 1 || G <= 0 || Cg <= 0 || Kk <= 0 || ld_out < (long)B * T) return 1;
+  dim3 grid((unsigned)min((ld_out + 255) / 256, (long)64), Kk * Cg, G), block(256);
+  if (dtype == MSMD_F32)
+    hipLaunchKernelGGL(unfold_t_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)xp, (float*)out, B, T,
+                       Tp, G, Cg, Kk, ld_out);
+  else
+    hipLaunchKernelGGL(unfold_t_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)xp, (bf16_t*)out, B,
+                       T, Tp, G, Cg, Kk, ld_out);
+  MSMD_RETURN_LAST();
+}

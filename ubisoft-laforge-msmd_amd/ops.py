@@ -431,3 +431,13 @@ def softmax_bwd_rows_(P, dP, cols, ld, scale):
     _lib.check(lib.msmd_softmax_bwd_rows(_p(P), _p(dP), rows, cols, ld, float(scale), _dt(P), _stream()),
                "msmd_softmax_bwd_rows")
     return dP
+
+
+def unfold_t(xp, T, Kk):
+    """xp (B, G, Tp, Cg) -> (G, Kk*Cg, Mp) with Mp = B*T rounded up to 8 (zero padded)."""
+    lib = _lib.load()
+    B, G, Tp, Cg = xp.shape
+    Mp = (B * T + 7) // 8 * 8
+    out = torch.empty(G, Kk * Cg, Mp, device=xp.device, dtype=xp.dtype)
+    _lib.check(lib.msmd_unfold_t(_p(xp), _p(out), B, T, Tp, G, Cg, Kk, Mp, _dt(xp), _stream()), "msmd_unfold_t")
+    return out

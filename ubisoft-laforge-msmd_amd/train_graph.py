@@ -1,0 +1,320 @@
+"""Differentiable (training) forward of the audio -> motion path, assembled from the HIP autograd blocks.
+
+Mirrors the inference graph of model.py / utils/wav2vec2.py / style_encoder.py layer for layer, but every dense
+op is an `autograd.Function` whose forward and backward are HIP kernels (autograd.py).  What is NOT a HIP kernel
+here, on purpose, for round 1 of the training row: tensor concatenation / slicing / dtype casts / residual adds
+and the final static-basis mix on (N, 110, 67)-sized tensors run as PyTorch autograd ops (plumbing-sized data).
+
+Semantics: eval-mode arithmetic (no dropout / LayerDrop / SpecAugment): the reference's stochastic regularisers
+are not reproduced yet; gradient parity is asserted against the reference's autograd in eval mode
+(tests/golden g6_train).  The frozen conv feature extractor runs the no-grad inference kernels
+(reference model.py:97: `_freeze_parameters`).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import autograd as ag
+from . import ops
+from .utils.model_common import pad_audio_plan
+from .utils.wav2vec2 import CONV_KERNEL, CONV_STRIDE  # noqa: F401
+
+
+def _p(tree, name):
+    return tree.get(name) if hasattr(tree, "get") else getattr(tree, name)
+
+
+# ----------------------------------------------------------------------------- positional grouped conv
+class PosConvFn(torch.autograd.Function):
+    """z = grouped Conv1d(k=128, pad=64, groups=16)(h)[:, :T] + bias on a channels-last (B, T, 768) tensor.
+    Forward: G windowed GEMMs over the zero-padded group-major copy.  Backward: data gradient = the same windowed
+    GEMM on the zero-padded upstream gradient with kernel-flipped, (ci <-> co)-swapped weights; weight gradient =
+    dZ_g^T . unfold_g (transposed unfold + batched GEMM); bias gradient = column sum."""
+
+    @staticmethod
+    def forward(ctx, h, w, bias):
+        B, T, d = h.shape
+        G = 16
+        cg = d // G
+        kpos = w.shape[2]
+        dt = h.dtype
+        wp = w.detach().reshape(G, cg, cg, kpos).permute(0, 1, 3, 2).reshape(G, cg, kpos * cg).to(dt).contiguous()
+        xp = ops.group_pad(h.contiguous(), G, kpos // 2)
+        Tp = T + kpos
+        z = torch.empty_like(h)
+        ops.gemm(xp, wp, bias.detach().float().contiguous(), None, ops.ACT_NONE, out=z, M=B * T, N=cg, K=kpos * cg,
+                 lda=cg, rows_per_batch=T, a_batch_stride=G * Tp * cg, ldw=kpos * cg, ldc=d, batch=G, strideA=Tp * cg,
+                 strideW=cg * kpos * cg, strideC=cg, strideBias=cg)
+        ctx.save_for_backward(xp, w)
+        ctx.dims = (B, T, d, G, cg, kpos)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        xp, w = ctx.saved_tensors
+        B, T, d, G, cg, kpos = ctx.dims
+        dt = dz.dtype
+        dz = dz.contiguous()
+        dh = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dx[s] = sum_{kk', co} dzp[s + 65 + kk'][co] * w[co][ci][127 - kk'],  dzp = dz padded by 128 each side
+            w2 = w.detach().reshape(G, cg, cg, kpos).flip(3).permute(0, 2, 3, 1).reshape(G, cg, kpos * cg).to(dt).contiguous()
+            dzp = ops.group_pad(dz, G, kpos)  # (B, G, T + 2*kpos, cg)
+            Tp2 = T + 2 * kpos
+            dh = torch.empty(B, T, d, device=dz.device, dtype=dt)
+            a_view = dzp.reshape(-1)[(kpos // 2 + 1) * cg:]
+            ops.gemm(a_view, w2, None, None, ops.ACT_NONE, out=dh, M=B * T, N=cg, K=kpos * cg, lda=cg, rows_per_batch=T,
+                     a_batch_stride=G * Tp2 * cg, ldw=kpos * cg, ldc=d, batch=G, strideA=Tp2 * cg,
+                     strideW=cg * kpos * cg, strideC=cg)
+        if ctx.needs_input_grad[1]:
+            Tp = T + kpos
+            unf = ops.unfold_t(xp, T, kpos)                     # (G, kpos*cg, Mp)
+            Mp = unf.shape[-1]
+            dzT = torch.zeros(G, cg, Mp, device=dz.device, dtype=dt)
+            # dz (B*T, G*cg) -> per group (cg, B*T)
+            ops.transpose(dz, dzT, B * T, cg, d, Mp, G, cg, cg * Mp)
+            dwp = torch.empty(G, cg, kpos * cg, device=dz.device, dtype=torch.float32)
+            ops.gemm(dzT, unf, None, None, ops.ACT_NONE, out=dwp, M=cg, N=kpos * cg, K=Mp, lda=Mp, ldw=Mp,
+                     ldc=kpos * cg, batch=G, strideA=cg * Mp, strideW=kpos * cg * Mp, strideC=cg * kpos * cg)
+            dw = dwp.reshape(G, cg, kpos, cg).permute(0, 1, 3, 2).reshape(w.shape)  # (co, ci, kk)
+        if ctx.needs_input_grad[2]:
+            db = ops.colsum(dz.reshape(B * T, d))
+        return dh, dw, db
+
+
+def _fold_weight_norm(g, v):
+    """weight_norm(dim=2): w = g * v / ||v||_{dims 0,1} as torch autograd ops on the (768, 48, 128) parameter."""
+    return v * (g / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+
+
+# ----------------------------------------------------------------------------- audio encoder
+def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
+    """Differentiable counterpart of Wav2Vec2Model.encode (utils/wav2vec2.py): (B, L) audio -> (B, frame_num, 768)."""
+    c = enc.config
+    with torch.no_grad():
+        r, rep = pad_audio_plan(audio.shape[1])
+        x = enc.feature_extractor_cl(audio, dtype, r, rep)
+        T50 = x.shape[1]
+        crop = min(round(frame_num * 50 / output_fps), T50)
+        if not (crop == T50 and frame_num == T50):
+            x = ops.interp_linear(x, frame_num, crop)
+    g = lambda n: enc.get_parameter(n)
+    h = ag.layer_norm(x, g("feature_projection.layer_norm.weight"), g("feature_projection.layer_norm.bias"))
+    h = ag.linear(h, g("feature_projection.projection.weight"), g("feature_projection.projection.bias"))
+    w = _fold_weight_norm(g("encoder.pos_conv_embed.conv.weight_g"), g("encoder.pos_conv_embed.conv.weight_v"))
+    z = PosConvFn.apply(h, w, g("encoder.pos_conv_embed.conv.bias"))
+    h = h + ag_act(z, ops.ACT_GELU)
+    h = ag.layer_norm(h, g("encoder.layer_norm.weight"), g("encoder.layer_norm.bias"))
+    d, H = c.hidden_size, c.num_attention_heads
+    for n in range(c.num_hidden_layers):
+        p = f"encoder.layers.{n}."
+        wq, wk, wv = (g(p + f"attention.{k}_proj.weight") for k in "qkv")
+        bq, bk, bv = (g(p + f"attention.{k}_proj.bias") for k in "qkv")
+        qkv = ag.linear(h, torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0))
+        a = ag.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, (d // H) ** -0.5)
+        h = ag.layer_norm(ag.linear(a, g(p + "attention.out_proj.weight"), g(p + "attention.out_proj.bias"),
+                                    residual=h), g(p + "layer_norm.weight"), g(p + "layer_norm.bias"))
+        f = ag.linear(h, g(p + "feed_forward.intermediate_dense.weight"), g(p + "feed_forward.intermediate_dense.bias"),
+                      act=ops.ACT_GELU)
+        h = ag.layer_norm(ag.linear(f, g(p + "feed_forward.output_dense.weight"),
+                                    g(p + "feed_forward.output_dense.bias"), residual=h),
+                          g(p + "final_layer_norm.weight"), g(p + "final_layer_norm.bias"))
+    return h
+
+
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, act):
+        z = z.contiguous()
+        ctx.save_for_backward(z)
+        ctx.act = act
+        return ops.act_fwd(z, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (z,) = ctx.saved_tensors
+        return ops.act_bwd(dy.contiguous(), z, ctx.act), None
+
+
+def ag_act(z, act):
+    return ActFn.apply(z, act)
+
+
+def audio_feat_train(model, audio, frame_num, dtype):
+    """reference model.py:250-264 (differentiable): encoder at 2L -> pairwise mean -> audio_feature_map."""
+    h = audio_encoder_train(model.audio_encoder, audio, model.fps, frame_num * 2, dtype)
+    h = 0.5 * (h[:, 0::2] + h[:, 1::2])  # exact 2:1 linear resample
+    return ag.linear(h.contiguous(), model.audio_feature_map.weight, model.audio_feature_map.bias)
+
+
+# ----------------------------------------------------------------------------- denoiser
+def denoiser_train(net, motion_noisy, audio_feat, person_feat, static_style_feat, prev_motion_feat, prev_audio_feat,
+                   step, indicator, dtype):
+    """reference model.py:914-996 (differentiable).  Returns (N, Lp + L, dm) fp32."""
+    P = net.pack(dtype)  # constants only (TE table, mask)
+    g = lambda n: net.get_parameter(n)
+    d, H, nb, dm = net.feature_dim, net.n_heads, net.num_of_basis, net.motion_feat_dim
+    N = person_feat.shape[0]
+    step = torch.as_tensor(step, device=net.device, dtype=torch.long)
+    te = P.te[step].to(dtype)
+    emb = ag.linear(ag.linear(te, g("diff_step_map.0.weight"), g("diff_step_map.0.bias"), act=ops.ACT_GELU),
+                    g("diff_step_map.2.weight"), g("diff_step_map.2.bias"))
+    person = ag.linear(person_feat.reshape(N, -1).to(dtype), g("person_proj.weight"), g("person_proj.bias")) + emb
+    feats = torch.cat([prev_motion_feat, motion_noisy], dim=1)
+    if net.use_indicator:
+        ind = torch.cat([torch.zeros(N, net.n_prev_motions, device=feats.device), indicator.float()], dim=1)
+        feats = torch.cat([feats, ind.unsqueeze(-1)], dim=-1)
+    x = ag.linear(feats.to(dtype), g("feature_proj.weight"), g("feature_proj.bias"))
+    x = torch.cat([person.unsqueeze(1), x], dim=1) + g("PE").to(dtype)
+    mem = torch.cat([prev_audio_feat.to(dtype), audio_feat.to(dtype)], dim=1)
+    scale = (d // H) ** -0.5
+    mask = net.alignment_mask
+    for n in range(net.n_layers):
+        p = f"transformer.layers.{n}."
+        qkv = ag.linear(x, g(p + "self_attn.in_proj_weight"), g(p + "self_attn.in_proj_bias"))
+        a = ag.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale)
+        x = ag.layer_norm(ag.linear(a, g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias"), residual=x),
+                          g(p + "norm1.weight"), g(p + "norm1.bias"))
+        w, b = g(p + "multihead_attn.in_proj_weight"), g(p + "multihead_attn.in_proj_bias")
+        q = ag.linear(x, w[:d], b[:d])
+        kv = ag.linear(mem, w[d:], b[d:])
+        cattn = ag.attention(q, kv[..., :d], kv[..., d:], H, scale, mask)
+        x = ag.layer_norm(ag.linear(cattn, g(p + "multihead_attn.out_proj.weight"),
+                                    g(p + "multihead_attn.out_proj.bias"), residual=x),
+                          g(p + "norm2.weight"), g(p + "norm2.bias"))
+        f = ag.linear(x, g(p + "linear1.weight"), g(p + "linear1.bias"), act=ops.ACT_GELU)
+        x = ag.layer_norm(ag.linear(f, g(p + "linear2.weight"), g(p + "linear2.bias"), residual=x),
+                          g(p + "norm3.weight"), g(p + "norm3.bias"))
+    dec = ag.linear(ag.linear(x[:, 1:].contiguous(), g("motion_dec.0.weight"), g("motion_dec.0.bias"),
+                              act=ops.ACT_GELU), g("motion_dec.2.weight"), g("motion_dec.2.bias")).float()
+    s = static_style_feat.reshape(N, -1).to(dtype)
+    stat = torch.stack([ag.linear(ag.linear(s, g(f"static_feature_mapping.{b}.0.weight"),
+                                            g(f"static_feature_mapping.{b}.0.bias"), act=ops.ACT_GELU),
+                                  g(f"static_feature_mapping.{b}.2.weight"), g(f"static_feature_mapping.{b}.2.bias"))
+                        for b in range(nb)], dim=1).float()                       # (N, nb, dm)
+    dyn, alpha = dec[..., :dm], dec[..., dm:]
+    if net.use_head_alpha:
+        static = (stat[:, None] * alpha.unsqueeze(-1)).sum(dim=2)
+    else:
+        static = torch.cat([(stat[:, None, :, :-3] * alpha.unsqueeze(-1)).sum(dim=2),
+                            stat[:, None, :, -3:].sum(dim=2).expand(-1, dec.shape[1], -1)], dim=-1)
+    return dyn + static
+
+
+# ----------------------------------------------------------------------------- style encoder
+def _conv3(x, w, b, act):
+    """Conv1d(k=3, padding=1) on channels-last x as a linear over the 3-frame window (torch.cat of shifted views)."""
+    xp = torch.nn.functional.pad(x, (0, 0, 1, 1))
+    win = torch.cat([xp[:, :-2], xp[:, 1:-1], xp[:, 2:]], dim=-1)
+    return ag.linear(win.contiguous(), w.permute(0, 2, 1).reshape(w.shape[0], -1), b, act=act)
+
+
+def style_encoder_train(se, motion_coef, dtype):
+    """reference style_encoder.py:178-199 (differentiable) -> (mu, logvar) fp32."""
+    g = lambda n: se.get_parameter(n)
+    B, T, _ = motion_coef.shape
+    x = motion_coef.to(dtype)
+    x = ag.layer_norm(_conv3(x, g("input_layers.1.weight"), g("input_layers.1.bias"), ops.ACT_ELU),
+                      g("input_layers.5.weight"), g("input_layers.5.bias"))
+    x = ag.layer_norm(_conv3(x, g("input_layers.7.weight"), g("input_layers.7.bias"), ops.ACT_ELU),
+                      g("input_layers.11.weight"), g("input_layers.11.bias"), post_add=se.PE.pe[0, T].float().contiguous())
+    d = se.conv_feature_dim
+    qkv = ag.linear(x, g("encoder.self_attn.in_proj_weight"), g("encoder.self_attn.in_proj_bias"))
+    a = ag.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], 8, 64 ** -0.5)
+    x = ag.layer_norm(ag.linear(a, g("encoder.self_attn.out_proj.weight"), g("encoder.self_attn.out_proj.bias"),
+                                residual=x), g("encoder.norm1.weight"), g("encoder.norm1.bias"))
+    f = ag.linear(x, g("encoder.linear1.weight"), g("encoder.linear1.bias"), act=ops.ACT_GELU)
+    x = ag.layer_norm(ag.linear(f, g("encoder.linear2.weight"), g("encoder.linear2.bias"), residual=x),
+                      g("encoder.norm2.weight"), g("encoder.norm2.bias"))
+    x = ag.layer_norm(_conv3(x, g("output_layers.1.weight"), g("output_layers.1.bias"), ops.ACT_ELU),
+                      g("output_layers.5.weight"), g("output_layers.5.bias"))
+    x = _conv3(x, g("output_layers.7.weight"), g("output_layers.7.bias"), ops.ACT_NONE)
+    out = x.float().mean(dim=1)
+    h = se.output_size // 2
+    return out[:, :h], out[:, h:]
+
+
+# ----------------------------------------------------------------------------- MSMD.forward (training)
+def msmd_forward_train(model, motion_feat, audio_or_feat, shape_feat, style_feat, prev_motion_feat, prev_audio_feat,
+                       time_step, indicator, eps, null_style_mask=None, null_audio_mask=None):
+    """reference model.py:146-248 with gradients; stochastic draws are passed in (time_step, eps, CFG masks)."""
+    dtype = model.compute_dtype
+    B = motion_feat.shape[0]
+    if audio_or_feat.ndim == 2:
+        audio_feat_saved = audio_feat_train(model, audio_or_feat, model.n_motions, dtype).float()
+    else:
+        audio_feat_saved = audio_or_feat
+    audio_feat = audio_feat_saved
+    if shape_feat.ndim == 2:
+        shape_feat = shape_feat.unsqueeze(1)
+    if style_feat.ndim == 2:
+        style_feat = style_feat.unsqueeze(1)
+    if prev_motion_feat is None:
+        prev_motion_feat = model.start_motion_feat.expand(B, -1, -1)
+    if prev_audio_feat is None:
+        prev_audio_feat = model.start_audio_feat.expand(B, -1, -1)
+    if null_style_mask is not None:
+        style_feat = torch.where(null_style_mask.view(-1, 1, 1), model.null_style_feat.expand(B, -1, -1), style_feat)
+    if null_audio_mask is not None:
+        audio_feat = torch.where(null_audio_mask.view(-1, 1, 1),
+                                 model.null_audio_feat.expand(B, model.n_motions, -1), audio_feat)
+    person_feat = torch.cat([shape_feat, style_feat], dim=-1)
+    ts = torch.as_tensor(time_step, device=model.device, dtype=torch.long)
+    ab = model.diffusion_sched.alpha_bars[ts]
+    noisy = torch.sqrt(ab).view(-1, 1, 1) * motion_feat + torch.sqrt(1 - ab).view(-1, 1, 1) * eps
+    target = denoiser_train(model.denoising_net, noisy, audio_feat, person_feat, style_feat, prev_motion_feat,
+                            prev_audio_feat, ts, indicator, dtype)
+    return eps, target, motion_feat.detach(), audio_feat_saved.detach()
+
+
+# ----------------------------------------------------------------------------- differentiable losses
+def _masked_mean(v, mask):
+    """mean over selected (n, t) rows of a (N, T[, C]) tensor (reference: loss[mask].mean())."""
+    sel = v[mask]
+    return sel.mean() if sel.numel() > 0 else None
+
+
+def loss_no_vert_train(args, is_starting_sample, motion_coef_gt, target, prev_motion_coef, end_idx=None):
+    """Differentiable restatement of reference utils/common.py:198-442 (target='sample', l2/l1) on (N, 110, 67)
+    tensors with PyTorch autograd ops (plumbing-sized data; the forward-only HIP versions live in utils/common.py).
+    Returns the reference's 7-tuple."""
+    crit = (lambda a, b: (a - b) ** 2) if args.criterion.lower() == "l2" else (lambda a, b: (a - b).abs())
+    n_prev = args.n_prev_motions
+    if is_starting_sample:
+        target = target[:, n_prev:]
+    else:
+        motion_coef_gt = torch.cat([prev_motion_coef, motion_coef_gt], dim=1)
+    N = target.shape[0]
+    if end_idx is None:
+        mask = torch.ones((N, args.n_motions), dtype=torch.bool, device=target.device)
+    else:
+        mask = torch.arange(args.n_motions, device=target.device).expand(N, -1) < end_idx.unsqueeze(1)
+    if not is_starting_sample:
+        mask = torch.cat([torch.ones_like(mask[:, :n_prev]), mask], dim=1)
+    d1 = lambda x: x[:, 1:] - x[:, :-1]
+    gt, pr = motion_coef_gt, target
+    loss_noise = _masked_mean(crit(gt, pr), mask)
+    vg, vp = d1(gt), d1(pr)
+    loss_vel = _masked_mean(crit(vg[..., :-3], vp[..., :-3]).mean(-1) + crit(vg[..., -3:], vp[..., -3:]).mean(-1),
+                            mask[:, 1:])
+    sp = d1(vp)
+    loss_smooth = _masked_mean(crit(sp[..., :-3], 0 * sp[..., :-3]).mean(-1) + crit(sp[..., -3:], 0 * sp[..., -3:]).mean(-1),
+                               mask[:, 2:])
+    hg, hp = gt[..., -3:], pr[..., -3:]
+    loss_head_angle = _masked_mean(crit(hg, hp), mask)
+    loss_head_vel = _masked_mean(crit(d1(hg), d1(hp)).mean(-1), mask[:, 1:])
+    hs = d1(d1(hp))
+    loss_head_smooth = _masked_mean(crit(hs, 0 * hs).mean(-1), mask[:, 2:])
+    loss_head_trans = None
+    if not is_starting_sample and args.l_head_trans > 0:
+        seq = torch.cat([hg[:, n_prev - 3:n_prev], hp[:, n_prev:n_prev + 3]], dim=1)
+        v = d1(seq)
+        a = d1(v)
+        loss_head_trans = (crit(v[:, 2:4], v[:, 1:3]).mean(-1).mean(-1) + crit(a[:, 1:], a[:, :-1]).mean(-1).mean(-1)).mean()
+    return (loss_noise / 2, loss_vel / 2, loss_smooth / 2, loss_head_angle / 2, loss_head_vel / 2, loss_head_smooth / 2,
+            loss_head_trans)
+
+
+def kl_train(mu, logvar):
+    """reference utils/common.py:443-454."""
+    return -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp())
