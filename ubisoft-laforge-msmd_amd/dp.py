@@ -62,6 +62,20 @@ def timed_steps(step_fn, steps: int, warmup: int, sync=None, device=None):
 
 
 # ----------------------------------------------------------------------------- gradient exchange (training)
+ALIGN = 64  # elements: every tensor starts on a 256-byte boundary of its arena (kernels need 16-byte operands)
+
+
+def flat_layout(params):
+    """Arena layout shared by the parameter arena, the gradient arena and the Adam moments: trainable parameters
+    in REVERSE registration order, each offset rounded up to ALIGN elements.  Returns (ordered params, offsets, total)."""
+    ps = [p for p in params if p.requires_grad][::-1]
+    offs, off = [], 0
+    for p in ps:
+        offs.append(off)
+        off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+    return ps, offs, off
+
+
 class GradBucketReducer:
     """Bucketed gradient all-reduce overlapped with backward.
 
@@ -85,28 +99,27 @@ class GradBucketReducer:
         self.td = td
         self.group = process_group
         self.world = td.get_world_size(process_group) if td.is_initialized() else 1
-        self.params = [p for p in params if p.requires_grad][::-1]
+        self.params, offs, total = flat_layout(params)
         if not self.params:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
-        total = sum(p.numel() for p in self.params)
         self.arena = torch.zeros(total, device=dev, dtype=torch.float32)
         self.buckets = []  # (start, end, [param indices])
         cap = int(bucket_mb * (1 << 20) / 4)
-        off = start = 0
+        start = 0
         members = []
         self.slot = {}
-        for i, p in enumerate(self.params):
+        for i, (p, off) in enumerate(zip(self.params, offs)):
             n = p.numel()
             p.grad = self.arena[off:off + n].view_as(p)
             self.slot[id(p)] = (len(self.buckets), off, n)
             members.append(i)
-            off += n
-            if off - start >= cap:
-                self.buckets.append((start, off, members))
-                start, members = off, []
+            end = offs[i + 1] if i + 1 < len(offs) else total
+            if end - start >= cap:
+                self.buckets.append((start, end, members))
+                start, members = end, []
         if members:
-            self.buckets.append((start, off, members))
+            self.buckets.append((start, total, members))
         self.pending = [len(m) for _, _, m in self.buckets]
         self.launched = [False] * len(self.buckets)
         self.cuda = dev.type == "cuda"
@@ -166,14 +179,12 @@ class GradBucketReducer:
 
 
 def flatten_parameters(params):
-    """Re-home trainable parameters into one flat fp32 arena (views), in the reducer's order, so the fused Adam
-    kernel (msmd_adam_step) updates the whole model in one launch.  Returns the flat tensor."""
-    ps = [p for p in params if p.requires_grad][::-1]
-    flat = torch.empty(sum(p.numel() for p in ps), device=ps[0].device, dtype=torch.float32)
-    off = 0
-    for p in ps:
+    """Re-home trainable parameters into one flat fp32 arena (views, `flat_layout` order / alignment) so the fused
+    Adam kernel (msmd_adam_step) updates the whole model in one launch.  Returns the flat tensor."""
+    ps, offs, total = flat_layout(params)
+    flat = torch.zeros(total, device=ps[0].device, dtype=torch.float32)
+    for p, off in zip(ps, offs):
         n = p.numel()
         flat[off:off + n].copy_(p.data.reshape(-1))
         p.data = flat[off:off + n].view_as(p)
-        off += n
     return flat

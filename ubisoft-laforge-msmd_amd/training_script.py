@@ -1,0 +1,164 @@
+"""Training step on the MI355X (drop-in counterpart of reference training_script.py:49-241, 406-438, 548-579).
+
+`Trainer.step` reproduces one iteration of the reference's `train()` loop -- two consecutive 100-frame windows of
+the same clips, VAE style codes, optional cross-style swap and truncation, window 0 handing its last 10 motion /
+audio-feature frames to window 1, parameter-space losses + KL, one backward, Adam with linear warm-up -- on the
+HIP autograd path (train_graph.py), data-parallel over one process per GPU:
+
+  * gradients live in one flat fp32 arena; bucketed all-reduce (RCCL over xGMI, backend "nccl") is launched from
+    post-accumulate-grad hooks on a side stream while backward continues (dp.GradBucketReducer);
+  * parameters live in one flat fp32 arena updated by ONE fused Adam launch (msmd_adam_step), the 1/world_size
+    gradient scaling folded in;
+  * the KL term is a batch SUM in the reference (utils/common.py:454): its weight is multiplied by world_size so
+    that DP over N ranks equals a single-process run on the global batch;
+  * `it % gradient_accumulation_steps == 0` stepping as the reference (training_script.py:199).
+
+Not reproduced (documented): dropout / LayerDrop / SpecAugment noise, the reference's 3x empty_cache()+gc per
+iteration and its per-step .item() syncs (losses are returned as device tensors; log asynchronously).
+The dataset / loader / tensorboard / CLI plumbing of the reference script is out of scope (SURVEY.md section 2
+rows 17-18); `synthetic_batch` produces the loader's tensor contract.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import autograd as ag
+from . import dp, ops, synth
+from . import train_graph as tg
+
+
+def load_loss_weights(args, device=None):
+    """reference training_script.py:406-438 (python floats; same keys and rescaling)."""
+    w = {"noise": 1.0, "vert": float(args.l_vert), "vel": float(args.l_vel), "smooth": float(args.l_smooth),
+         "head_angle": float(args.l_head_angle), "head_vel": float(args.l_head_vel),
+         "head_smooth": float(args.l_head_smooth), "head_trans": float(args.l_head_trans)}
+    if not args.use_vertex_space:
+        w["vel"] *= 4.5e-8
+        w["smooth"] *= 4e-7
+    legacy = args.dataset_type[:9] == "HDTF_TFHP" or args.dataset_type == "flame_mead_ravdess"
+    if not legacy and args.use_vertex_space:
+        w["vert"] *= 1e-7
+        w["vel"] *= 1e-7
+        w["smooth"] *= 2e-8
+    w["kl_div"] = float(args.l_kl_div)
+    return w
+
+
+def synthetic_batch(B, rank=0, device="cuda", it=0):
+    """([audio_0, audio_1], [motion_0, motion_1], shape) with the loader's shapes / normalisation."""
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
+    tag = f"train_r{rank}_it{it}"
+    return ([t(synth.audio_clips(B, 64000, tag=f"{tag}_a{i}")) for i in range(2)],
+            [t(synth.motion_clips(B, tag=f"{tag}_m{i}")) for i in range(2)],
+            torch.zeros(B, 100, device=device))
+
+
+class Trainer:
+    def __init__(self, args, model, style_enc, process_group=None, bucket_mb=32.0):
+        self.args, self.model, self.style_enc = args, model, style_enc
+        self.device = model.device
+        # optimizer param groups of the reference: style encoder first, then the model (same lr)
+        params = [p for p in style_enc.parameters() if p.requires_grad] + \
+                 [p for p in model.parameters() if p.requires_grad]
+        self.flat_param = dp.flatten_parameters(params)
+        self.reducer = dp.GradBucketReducer(params, bucket_mb=bucket_mb, process_group=process_group)
+        self.exp_avg = torch.zeros_like(self.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat_param)
+        self.opt_step = 0
+        self.loss_weights = load_loss_weights(args)
+        self.rng = np.random.RandomState(1234 + (dp.env_rank()[0]))
+        self.lr = float(args.lr)
+        self.warm_iter = int(getattr(args, "warm_iter", 0) or 0)
+        self.sched_step = 0
+
+    # GradualWarmupScheduler(optimizer, 1, warm_iter): lr = base * min(1, step / warm_iter)
+    def current_lr(self):
+        if self.warm_iter <= 0 or self.sched_step > self.warm_iter:
+            return self.lr
+        return self.lr * float(self.sched_step) / self.warm_iter
+
+    def _invalidate_caches(self):
+        ag.CACHE.clear()
+        self.model.denoising_net._packed = None
+        self.model._afm = None
+        self.style_enc._packed = None
+        self.model.audio_encoder._packed = None  # lazily re-packed (bf16 casts of 94 M weights: ~0.1 ms of HBM traffic)
+
+    def step(self, batch, it=1, draws=None):
+        """One iteration.  batch = ([audio_0, audio_1], [motion_0, motion_1], shape).  `draws` may inject the
+        stochastic choices: dict(cross=[bool, bool], end_idx=[tensor|None]*2, t=[list]*2, eps=[tensor]*2,
+        style_eps=[tensor]*2, cfg_flag=[tensor|None]*2).  Returns dict of detached loss tensors (+ 'loss')."""
+        args, model, se = self.args, self.model, self.style_enc
+        dtype = model.compute_dtype
+        audio_pair, motion_pair, shape = batch
+        B = audio_pair[0].shape[0]
+        draws = draws or {}
+        stepping = (it % max(1, args.gradient_accumulation_steps) == 0)
+        self.reducer.enabled = stepping
+        n_prev = args.n_prev_motions
+        lw = dict(self.loss_weights)
+        lw["kl_div"] *= self.reducer.kl_weight_scale
+        with torch.enable_grad():
+            styles, mus, logvars = [], [], []
+            for i in range(2):
+                mu, logvar = tg.style_encoder_train(se, motion_pair[i], dtype)
+                e = draws["style_eps"][i] if "style_eps" in draws else torch.randn_like(mu)
+                styles.append(mu + e * torch.exp(0.5 * logvar))
+                mus.append(mu)
+                logvars.append(logvar)
+            losses = {k: torch.zeros((), device=self.device) for k in lw}
+            prev_motion = prev_audio = None
+            for i in range(2):
+                audio, motion = audio_pair[i], motion_pair[i]
+                style = styles[i]
+                cross = draws["cross"][i] if "cross" in draws else (args.use_cross_style and self.rng.rand() < args.prob_cross_style)
+                if cross:
+                    style = styles[1 - i]
+                if "end_idx" in draws:
+                    end_idx = draws["end_idx"][i]
+                else:
+                    p = args.trunc_prob1 if i == 0 else args.trunc_prob2
+                    end_idx = torch.randint(1, args.n_motions, (B,), device=self.device) if self.rng.rand() < p else None
+                if end_idx is not None:
+                    e32 = end_idx.to(torch.int32).contiguous()
+                    audio_in = ops.truncate_rows_(audio.float().clone().contiguous(), e32, 640, False)
+                    motion_in = ops.truncate_rows_(motion.float().clone().contiguous(), e32, 1, False)
+                    indicator = (torch.arange(args.n_motions, device=self.device).expand(B, -1) < end_idx.unsqueeze(1)).float()
+                else:
+                    audio_in, motion_in = audio, motion
+                    indicator = torch.ones(B, args.n_motions, device=self.device)
+                ts = draws["t"][i] if "t" in draws else model.diffusion_sched.uniform_sample_t(B)
+                eps = draws["eps"][i] if "eps" in draws else torch.randn_like(motion_in)
+                # CFG masking (incremental mode, model.py:205-218): one uniform draw per sample
+                flag = draws["cfg_flag"][i] if "cfg_flag" in draws else torch.rand(B, device=self.device)
+                ns = (flag > 0.55) if flag is not None else None
+                na = (flag > 0.9) if flag is not None else None
+                _, target, _, audio_feat = tg.msmd_forward_train(model, motion_in, audio_in, shape, style, prev_motion,
+                                                                 prev_audio, ts, indicator, eps, ns, na)
+                if i == 0:
+                    if end_idx is not None:  # truncated: hand over the COMPLETE clip's features (training_script.py:152-155)
+                        prev_motion = motion[:, -n_prev:]
+                        with torch.no_grad():
+                            prev_audio = model.extract_audio_feature(audio)[:, -n_prev:]
+                    else:
+                        prev_motion = motion_in[:, -n_prev:].detach()
+                        prev_audio = audio_feat[:, -n_prev:]
+                tup = tg.loss_no_vert_train(args, i == 0, motion_in, target, prev_motion if i == 1 else None, end_idx)
+                for key, val in zip(("noise", "vel", "smooth", "head_angle", "head_vel", "head_smooth", "head_trans"), tup):
+                    if val is not None and lw.get(key, 0) > 0:
+                        losses[key] = losses[key] + val
+                losses["kl_div"] = losses["kl_div"] + tg.kl_train(mus[i], logvars[i])
+            loss = sum(losses[k] * lw[k] for k in losses if lw[k] > 0)
+            loss.backward()
+        out = {k: v.detach() for k, v in losses.items()}
+        out["loss"] = loss.detach()
+        if stepping:
+            flat_grad, scale = self.reducer.finish()
+            self.opt_step += 1
+            ops.adam_step_(self.flat_param, flat_grad, self.exp_avg, self.exp_avg_sq, self.current_lr(), self.opt_step,
+                           grad_scale=scale)
+            self.reducer.zero_grad()
+            self._invalidate_caches()
+        self.sched_step += 1
+        return out
