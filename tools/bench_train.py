@@ -1,0 +1,26 @@
+"""Dev tool: training-step time (BASELINE.json configs[2] per-GPU shape: local batch 32, 2 windows, fwd+bwd+Adam)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from msmd_amd import dp
+from msmd_amd.config import default_args
+from msmd_amd.model import get_diffusion_model
+from msmd_amd.style_encoder import get_style_encoder
+from msmd_amd.training_script import Trainer, synthetic_batch
+
+rank, local_rank, world = dp.env_rank()
+torch.cuda.set_device(local_rank)
+dev = torch.device("cuda", local_rank)
+dp.init("nccl", dev)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+args = default_args(compute_dtype=dtype, lr=2e-5, warm_iter=5000)
+model = get_diffusion_model(args, dev).eval()
+se = get_style_encoder(args, "vae2").to(dev).eval()
+tr = Trainer(args, model, se)
+batch = synthetic_batch(B, rank, dev)
+steps = int(os.environ.get("STEPS", "5"))
+el = dp.timed_steps(lambda: tr.step(batch, it=1), steps, 2, sync=torch.cuda.synchronize, device=dev)
+if rank == 0:
+    print(f"train step: {el / steps * 1e3:.1f} ms/step at local batch {B} x {world} GPUs ({dtype}) -> "
+          f"{B * 200 * world * steps / el:.0f} frames/s; max mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
