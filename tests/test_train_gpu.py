@@ -130,3 +130,46 @@ def test_trainer_step_adam_and_overfit():
     last = float(o["noise"])
     print(f"noise loss {first:.4f} -> {last:.4f}")
     assert last < 0.7 * first
+
+
+def test_trainer_hipgraph_step_matches_eager():
+    """use_graph=True replays forward+backward as one hipGraph: with injected draws the losses and the applied
+    update equal the eager step's; with device-drawn noise (graph-safe Philox) consecutive replays differ and a
+    second truncation pattern captures its own variant."""
+    from msmd_amd.model import get_diffusion_model
+    from msmd_amd.style_encoder import get_style_encoder
+    from msmd_amd.training_script import Trainer, synthetic_batch
+    args = default_args(compute_dtype="fp32", encoder_layers=1, n_layers=1, lr=1e-3, warm_iter=0,
+                        gradient_accumulation_steps=1)
+    B = 2
+    batch = synthetic_batch(B, 0, DEV)
+    draws = dict(cross=[False, True], end_idx=[torch.tensor([60, 100], device=DEV), None], t=[[5, 400], [250, 20]],
+                 eps=[dev(synth.normalish(f"tr/eps{i}", (B, 100, 67))) for i in range(2)],
+                 style_eps=[dev(synth.normalish(f"tr/se{i}", (B, 256))) for i in range(2)],
+                 cfg_flag=[dev(np.array([0.1, 0.7], np.float32)), dev(np.array([0.95, 0.3], np.float32))])
+    res = []
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        model = get_diffusion_model(args, DEV).eval()
+        se = get_style_encoder(args, "vae2").to(DEV).eval()
+        tr = Trainer(args, model, se, use_graph=use_graph)
+        outs = [tr.step(batch, it=it, draws=draws) for it in (1, 2, 3)]
+        torch.cuda.synchronize()
+        res.append((outs, tr.flat_param.clone(), tr))
+    (oe, pe, _), (og, pg, trg) = res
+    for a, b in zip(oe, og):
+        for k in a:
+            assert abs(float(a[k]) - float(b[k])) <= 1e-4 * max(1.0, abs(float(a[k]))), k
+    d = (pe - pg).abs()
+    assert float(d.max()) < 3e-3 and float((d > 1e-5).float().mean()) < 1e-2   # 3 Adam steps of lr 1e-3 (see above)
+    assert len(trg._graphs) == 1
+    # cross-style flag is data, not structure: flipping it reuses the same graph and changes the result
+    d2 = dict(draws, cross=[True, False])
+    o2 = trg.step(batch, it=4, draws=d2)
+    assert len(trg._graphs) == 1
+    # device-drawn noise: new variants, finite losses, replays differ from each other
+    o3 = trg.step(batch, it=5)
+    o4 = trg.step(batch, it=6)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(v).all() for v in list(o2.values()) + list(o3.values()) + list(o4.values()))
+    assert len(trg._graphs) >= 2

@@ -17,9 +17,29 @@ dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 args = default_args(compute_dtype=dtype, lr=2e-5, warm_iter=5000)
 model = get_diffusion_model(args, dev).eval()
 se = get_style_encoder(args, "vae2").to(dev).eval()
-tr = Trainer(args, model, se)
+tr = Trainer(args, model, se, use_graph=bool(os.environ.get('GRAPH')))
 batch = synthetic_batch(B, rank, dev)
 steps = int(os.environ.get("STEPS", "5"))
+if tr.use_graph:
+    tr.capture_all(batch)
+    torch.cuda.synchronize()
+    print('graphs captured; mem', torch.cuda.max_memory_allocated() / 2**30)
+if os.environ.get("ISSUE"):
+    for _ in range(2):
+        tr.step(batch, it=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        tr.step(batch, it=1)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"host issue {(t1 - t0) / 3 * 1e3:.1f} ms/step, total {(t2 - t0) / 3 * 1e3:.1f} ms/step")
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        tr.step(batch, it=1)
+    torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=25, max_name_column_width=60))
 el = dp.timed_steps(lambda: tr.step(batch, it=1), steps, 2, sync=torch.cuda.synchronize, device=dev)
 if rank == 0:
     print(f"train step: {el / steps * 1e3:.1f} ms/step at local batch {B} x {world} GPUs ({dtype}) -> "

@@ -79,12 +79,20 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dzp = dz2 if wct.shape[1] == N else ops.pad_cols(dz2, wct.shape[1], dtype)
             dx = ops.gemm(dzp, wct).reshape(*xin.shape[:-1], wct.shape[0])
+        want_b = ctx.has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dzT = ops.transpose2d(dz2, 8)                      # (N, Mp)
-            xT = ops.transpose2d(xin.reshape(M, Kp), 8)        # (Kp, Mp)
-            dw = ops.gemm(dzT, xT, out_dtype=torch.float32)    # (N, Kp) fp32
-            dw = dw[:, :ctx.K].reshape(w.shape)
-        if ctx.has_b and ctx.needs_input_grad[2]:
+            # x^T with 8 extra rows: row Kp is all ones, so column Kp of the product is the bias gradient
+            # (dz^T . 1) for free inside the wgrad GEMM instead of a separate column-sum pass.
+            Mp = dzT.shape[1]
+            xT = torch.zeros(Kp + 8, Mp, device=xin.device, dtype=dtype)
+            ops.transpose(xin.reshape(M, Kp), xT, M, Kp, Kp, Mp)
+            xT[Kp, :M] = 1
+            dwe = ops.gemm(dzT, xT, out_dtype=torch.float32)   # (N, Kp + 8) fp32
+            dw = dwe[:, :ctx.K].reshape(w.shape)
+            if want_b:
+                db = dwe[:, Kp].contiguous()
+        elif want_b:
             db = ops.colsum(dz2)
         dres = dy if ctx.has_r and ctx.needs_input_grad[3] else None
         return dx, dw, db, dres, None
@@ -124,7 +132,7 @@ class AttentionFn(torch.autograd.Function):
                           H, 64, 64, Tq * Tkp)
         m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
         ops.softmax_rows_(P, Tk, Tkp, Tq, scale, m8)
-        VT = torch.zeros(B, H, 64, Tkp, device=q.device, dtype=dt)
+        VT = (torch.zeros if Tkp != Tk else torch.empty)(B, H, 64, Tkp, device=q.device, dtype=dt)
         ops.transpose(v, VT, Tk, 64, v.stride(1), Tkp, B, v.stride(0), H * 64 * Tkp, H, 64, 64 * Tkp)
         O = torch.empty(B, Tq, d, device=q.device, dtype=dt)
         ops.gemm_batched2(P, VT, O, Tq, 64, Tkp, Tkp, Tkp, d, B, H * Tq * Tkp, H * 64 * Tkp, Tq * d, H, Tq * Tkp,
@@ -142,9 +150,11 @@ class AttentionFn(torch.autograd.Function):
         dO = dO.contiguous()
         Tqp = (Tq + 7) // 8 * 8
         # dV_h = P_h^T . dO_h
-        PT = torch.zeros(B, H, Tk, Tqp, device=dev, dtype=dt)
+        zq = torch.zeros if Tqp != Tq else torch.empty
+        zk = torch.zeros if Tkp != Tk else torch.empty
+        PT = zq(B, H, Tk, Tqp, device=dev, dtype=dt)
         ops.transpose(P, PT, Tq, Tk, Tkp, Tqp, B * H, Tq * Tkp, Tk * Tqp)
-        dOT = torch.zeros(B, H, 64, Tqp, device=dev, dtype=dt)
+        dOT = zq(B, H, 64, Tqp, device=dev, dtype=dt)
         ops.transpose(dO, dOT, Tq, 64, d, Tqp, B, Tq * d, H * 64 * Tqp, H, 64, 64 * Tqp)
         dV = torch.empty(B, Tk, d, device=dev, dtype=dt)
         ops.gemm_batched2(PT, dOT, dV, Tk, 64, Tqp, Tqp, Tqp, d, B, H * Tk * Tqp, H * 64 * Tqp, Tk * d, H, Tk * Tqp,
@@ -156,15 +166,15 @@ class AttentionFn(torch.autograd.Function):
         ops.softmax_bwd_rows_(P, dP, Tk, Tkp, scale)
         dS = dP
         # dQ_h = dS_h . K_h
-        KT = torch.zeros(B, H, 64, Tkp, device=dev, dtype=dt)
+        KT = zk(B, H, 64, Tkp, device=dev, dtype=dt)
         ops.transpose(k, KT, Tk, 64, k.stride(1), Tkp, B, k.stride(0), H * 64 * Tkp, H, 64, 64 * Tkp)
         dQ = torch.empty(B, Tq, d, device=dev, dtype=dt)
         ops.gemm_batched2(dS, KT, dQ, Tq, 64, Tkp, Tkp, Tkp, d, B, H * Tq * Tkp, H * 64 * Tkp, Tq * d, H, Tq * Tkp,
                           64 * Tkp, 64)
         # dK_h = dS_h^T . Q_h
-        dST = torch.zeros(B, H, Tk, Tqp, device=dev, dtype=dt)
+        dST = zq(B, H, Tk, Tqp, device=dev, dtype=dt)
         ops.transpose(dS, dST, Tq, Tk, Tkp, Tqp, B * H, Tq * Tkp, Tk * Tqp)
-        QT = torch.zeros(B, H, 64, Tqp, device=dev, dtype=dt)
+        QT = zq(B, H, 64, Tqp, device=dev, dtype=dt)
         ops.transpose(q, QT, Tq, 64, q.stride(1), Tqp, B, q.stride(0), H * 64 * Tqp, H, 64, 64 * Tqp)
         dK = torch.empty(B, Tk, d, device=dev, dtype=dt)
         ops.gemm_batched2(dST, QT, dK, Tk, 64, Tqp, Tqp, Tqp, d, B, H * Tk * Tqp, H * 64 * Tqp, Tk * d, H, Tk * Tqp,

@@ -124,59 +124,67 @@ template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma, T* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int rows, int cols, float eps) {
+                                                            int rows, int cols, float eps, int rows_per_block) {
   __shared__ float sg[4 * 64 * MAXC], sb[4 * 64 * MAXC];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + wid;
-  float xv[MAXC], gv[MAXC], dyv[MAXC];
-  float s = 0.f;
-  const bool live = row < rows;
+  float ag[MAXC], abt[MAXC];  // this wave's running dgamma / dbeta partials over its rows
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = i * 64 + lane;
-    xv[i] = (live && c < cols) ? to_f32(x[(long)row * cols + c]) : 0.f;
-    dyv[i] = (live && c < cols) ? to_f32(dy[(long)row * cols + c]) : 0.f;
-    s += xv[i];
+  for (int i = 0; i < MAXC; ++i) ag[i] = abt[i] = 0.f;
+  const int r_begin = blockIdx.x * rows_per_block, r_end = min(rows, r_begin + rows_per_block);
+  for (int row = r_begin + wid; row < r_end; row += 4) {
+    float xv[MAXC], gv[MAXC], dyv[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = i * 64 + lane;
+      xv[i] = (c < cols) ? to_f32(x[(long)row * cols + c]) : 0.f;
+      dyv[i] = (c < cols) ? to_f32(dy[(long)row * cols + c]) : 0.f;
+      s += xv[i];
+    }
+    const float mean = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = i * 64 + lane;
+      const float d = (c < cols) ? xv[i] - mean : 0.f;
+      q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cols + eps);
+    float sg1 = 0.f, sg2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = i * 64 + lane;
+      xv[i] = (c < cols) ? (xv[i] - mean) * rstd : 0.f;  // xhat
+      gv[i] = (c < cols) ? dyv[i] * gamma[c] : 0.f;
+      sg1 += gv[i];
+      sg2 += gv[i] * xv[i];
+    }
+    const float m1 = wave_sum(sg1) / (float)cols, m2 = wave_sum(sg2) / (float)cols;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = i * 64 + lane;
+      if (c < cols) dx[(long)row * cols + c] = from_f32<T>(rstd * (gv[i] - m1 - xv[i] * m2));
+      ag[i] += dyv[i] * xv[i];
+      abt[i] += dyv[i];
+    }
   }
-  const float mean = wave_sum(s) / (float)cols;
-  float q = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
-    const int c = i * 64 + lane;
-    const float d = (c < cols) ? xv[i] - mean : 0.f;
-    q += d * d;
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cols + eps);
-  float sg1 = 0.f, sg2 = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = i * 64 + lane;
-    xv[i] = (c < cols) ? (xv[i] - mean) * rstd : 0.f;  // xhat
-    gv[i] = (c < cols) ? dyv[i] * gamma[c] : 0.f;
-    sg1 += gv[i];
-    sg2 += gv[i] * xv[i];
-  }
-  const float m1 = wave_sum(sg1) / (float)cols, m2 = wave_sum(sg2) / (float)cols;
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = i * 64 + lane;
-    if (live && c < cols) dx[(long)row * cols + c] = from_f32<T>(rstd * (gv[i] - m1 - xv[i] * m2));
-    sg[(wid * MAXC + i) * 64 + lane] = live ? dyv[i] * xv[i] : 0.f;
-    sb[(wid * MAXC + i) * 64 + lane] = live ? dyv[i] : 0.f;
+    sg[(wid * MAXC + i) * 64 + lane] = ag[i];
+    sb[(wid * MAXC + i) * 64 + lane] = abt[i];
   }
   __syncthreads();
-  // combine the block's 4 rows, then one atomic per column per block
+  // combine the 4 waves, then ONE atomic per column per block
   for (int k = threadIdx.x; k < MAXC * 64; k += 256) {
-    const int c = k;  // k = i*64 + lane
-    if (c < cols) {
+    if (k < cols) {
       float a = 0.f, b = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         a += sg[w * MAXC * 64 + k];
         b += sb[w * MAXC * 64 + k];
       }
-      atomicAdd(&dgamma[c], a);
-      atomicAdd(&dbeta[c], b);
+      atomicAdd(&dgamma[k], a);
+      atomicAdd(&dbeta[k], b);
     }
   }
 }
@@ -184,22 +192,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 extern "C" int msmd_layernorm_bwd(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma,
                                   float* dbeta, int rows, int cols, float eps, int dtype, msmd_stream_t stream) {
   if (rows <= 0 || cols <= 0 || cols > 1024) return 1;
-  dim3 grid((rows + 3) / 4), block(256);
+  const int rpb = rows >= 4096 ? 32 : 8;  // rows per workgroup: 1 atomic per column per workgroup
+  dim3 grid((rows + rpb - 1) / rpb), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MSMD_F32) {
     if (cols <= 512)
       hipLaunchKernelGGL((layernorm_bwd_kernel<float, 8>), grid, block, 0, st, (const float*)dy, (const float*)x, gamma,
-                         (float*)dx, dgamma, dbeta, rows, cols, eps);
+                         (float*)dx, dgamma, dbeta, rows, cols, eps, rpb);
     else
       hipLaunchKernelGGL((layernorm_bwd_kernel<float, 16>), grid, block, 0, st, (const float*)dy, (const float*)x,
-                         gamma, (float*)dx, dgamma, dbeta, rows, cols, eps);
+                         gamma, (float*)dx, dgamma, dbeta, rows, cols, eps, rpb);
   } else {
     if (cols <= 512)
       hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 8>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x,
-                         gamma, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps);
+                         gamma, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps, rpb);
     else
       hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 16>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x,
-                         gamma, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps);
+                         gamma, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps, rpb);
   }
   MSMD_RETURN_LAST();
 }

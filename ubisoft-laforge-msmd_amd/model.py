@@ -89,6 +89,10 @@ class DiffusionSchedule(nn.Module):
         ts = torch.randint(1, self.num_steps + 1, (batch_size,))
         return ts.tolist()
 
+    def uniform_sample_t_device(self, batch_size):
+        """Same distribution drawn on the device (no host round trip; usable under hipGraph capture)."""
+        return torch.randint(1, self.num_steps + 1, (batch_size,), device=self.betas.device)
+
     def get_sigmas(self, t, flexibility=0):
         assert 0 <= flexibility <= 1
         return self.sigmas_flex[t] * flexibility + self.sigmas_inflex[t] * (1 - flexibility)

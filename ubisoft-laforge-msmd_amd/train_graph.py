@@ -269,9 +269,14 @@ def msmd_forward_train(model, motion_feat, audio_or_feat, shape_feat, style_feat
 
 # ----------------------------------------------------------------------------- differentiable losses
 def _masked_mean(v, mask):
-    """mean over selected (n, t) rows of a (N, T[, C]) tensor (reference: loss[mask].mean())."""
-    sel = v[mask]
-    return sel.mean() if sel.numel() > 0 else None
+    """mean over selected (n, t) rows of a (N, T[, C]) tensor (reference: loss[mask].mean()), written as a masked
+    sum / count so that nothing synchronises with the host (no boolean gather; hipGraph-capturable).  An empty
+    selection gives 0 with zero gradient (the reference would produce NaN there)."""
+    w = mask.to(v.dtype)
+    per_row = v.shape[-1] if v.ndim == 3 else 1
+    if v.ndim == 3:
+        w = w.unsqueeze(-1)
+    return (v * w).sum() / (mask.sum().to(v.dtype) * per_row).clamp(min=1.0)
 
 
 def loss_no_vert_train(args, is_starting_sample, motion_coef_gt, target, prev_motion_coef, end_idx=None):

@@ -55,7 +55,7 @@ def synthetic_batch(B, rank=0, device="cuda", it=0):
 
 
 class Trainer:
-    def __init__(self, args, model, style_enc, process_group=None, bucket_mb=32.0):
+    def __init__(self, args, model, style_enc, process_group=None, bucket_mb=32.0, use_graph=False):
         self.args, self.model, self.style_enc = args, model, style_enc
         self.device = model.device
         # optimizer param groups of the reference: style encoder first, then the model (same lr)
@@ -71,6 +71,8 @@ class Trainer:
         self.lr = float(args.lr)
         self.warm_iter = int(getattr(args, "warm_iter", 0) or 0)
         self.sched_step = 0
+        self.use_graph = bool(use_graph)
+        self._graphs, self._graph_pool, self._flag_table = {}, None, None
 
     # GradualWarmupScheduler(optimizer, 1, warm_iter): lr = base * min(1, step / warm_iter)
     def current_lr(self):
@@ -85,17 +87,16 @@ class Trainer:
         self.style_enc._packed = None
         self.model.audio_encoder._packed = None  # lazily re-packed (bf16 casts of 94 M weights: ~0.1 ms of HBM traffic)
 
-    def step(self, batch, it=1, draws=None):
-        """One iteration.  batch = ([audio_0, audio_1], [motion_0, motion_1], shape).  `draws` may inject the
-        stochastic choices: dict(cross=[bool, bool], end_idx=[tensor|None]*2, t=[list]*2, eps=[tensor]*2,
-        style_eps=[tensor]*2, cfg_flag=[tensor|None]*2).  Returns dict of detached loss tensors (+ 'loss')."""
+    # ------------------------------------------------------------------ forward + backward of one iteration
+    def _fwd_bwd(self, batch, draws, trunc, cross):
+        """Two windows, losses, one backward into the flat gradient arena.  `trunc` = [bool, bool] (host decision:
+        is window i truncated); `cross` = [bool | 0-d bool device tensor] * 2 (use the other window's style).
+        Everything stochastic that is not in `draws` is drawn ON THE DEVICE, and nothing reads back to the host,
+        so the whole function can be captured in a hipGraph."""
         args, model, se = self.args, self.model, self.style_enc
         dtype = model.compute_dtype
         audio_pair, motion_pair, shape = batch
         B = audio_pair[0].shape[0]
-        draws = draws or {}
-        stepping = (it % max(1, args.gradient_accumulation_steps) == 0)
-        self.reducer.enabled = stepping
         n_prev = args.n_prev_motions
         lw = dict(self.loss_weights)
         lw["kl_div"] *= self.reducer.kl_weight_scale
@@ -111,15 +112,14 @@ class Trainer:
             prev_motion = prev_audio = None
             for i in range(2):
                 audio, motion = audio_pair[i], motion_pair[i]
-                style = styles[i]
-                cross = draws["cross"][i] if "cross" in draws else (args.use_cross_style and self.rng.rand() < args.prob_cross_style)
-                if cross:
-                    style = styles[1 - i]
+                if torch.is_tensor(cross[i]):
+                    style = torch.where(cross[i], styles[1 - i], styles[i])
+                else:
+                    style = styles[1 - i] if cross[i] else styles[i]
                 if "end_idx" in draws:
                     end_idx = draws["end_idx"][i]
                 else:
-                    p = args.trunc_prob1 if i == 0 else args.trunc_prob2
-                    end_idx = torch.randint(1, args.n_motions, (B,), device=self.device) if self.rng.rand() < p else None
+                    end_idx = torch.randint(1, args.n_motions, (B,), device=self.device) if trunc[i] else None
                 if end_idx is not None:
                     e32 = end_idx.to(torch.int32).contiguous()
                     audio_in = ops.truncate_rows_(audio.float().clone().contiguous(), e32, 640, False)
@@ -128,7 +128,7 @@ class Trainer:
                 else:
                     audio_in, motion_in = audio, motion
                     indicator = torch.ones(B, args.n_motions, device=self.device)
-                ts = draws["t"][i] if "t" in draws else model.diffusion_sched.uniform_sample_t(B)
+                ts = draws["t"][i] if "t" in draws else model.diffusion_sched.uniform_sample_t_device(B)
                 eps = draws["eps"][i] if "eps" in draws else torch.randn_like(motion_in)
                 # CFG masking (incremental mode, model.py:205-218): one uniform draw per sample
                 flag = draws["cfg_flag"][i] if "cfg_flag" in draws else torch.rand(B, device=self.device)
@@ -153,12 +153,111 @@ class Trainer:
             loss.backward()
         out = {k: v.detach() for k, v in losses.items()}
         out["loss"] = loss.detach()
+        return out
+
+    def _host_choices(self, draws):
+        """The reference's host-side coin flips (training_script.py:99-141): cross-style per window, truncation."""
+        args = self.args
+        cross, trunc = [], []
+        for i in range(2):
+            cross.append(bool(draws["cross"][i]) if "cross" in draws else
+                         bool(args.use_cross_style and self.rng.rand() < args.prob_cross_style))
+            if "end_idx" in draws:
+                trunc.append(draws["end_idx"][i] is not None)
+            else:
+                trunc.append(bool(self.rng.rand() < (args.trunc_prob1 if i == 0 else args.trunc_prob2)))
+        return cross, trunc
+
+    def _optimizer_step(self):
+        flat_grad, scale = self.reducer.finish()
+        self.opt_step += 1
+        ops.adam_step_(self.flat_param, flat_grad, self.exp_avg, self.exp_avg_sq, self.current_lr(), self.opt_step,
+                       grad_scale=scale)
+        self.reducer.zero_grad()
+        self._invalidate_caches()
+
+    def step(self, batch, it=1, draws=None):
+        """One iteration.  batch = ([audio_0, audio_1], [motion_0, motion_1], shape).  `draws` may inject the
+        stochastic choices: dict(cross=[bool, bool], end_idx=[tensor|None]*2, t=[list]*2, eps=[tensor]*2,
+        style_eps=[tensor]*2, cfg_flag=[tensor|None]*2).  Returns dict of detached loss tensors (+ 'loss').
+        With `use_graph` the forward+backward runs as ONE hipGraph replay (see `_graph_fwd_bwd`)."""
+        draws = draws or {}
+        stepping = (it % max(1, self.args.gradient_accumulation_steps) == 0)
+        cross, trunc = self._host_choices(draws)
+        if self.use_graph:
+            self.reducer.enabled = False      # python hooks do not run on replay: buckets are launched by finish()
+            out = self._graph_fwd_bwd(batch, draws, trunc, cross)
+        else:
+            self.reducer.enabled = stepping
+            out = self._fwd_bwd(batch, draws, trunc, cross)
         if stepping:
-            flat_grad, scale = self.reducer.finish()
-            self.opt_step += 1
-            ops.adam_step_(self.flat_param, flat_grad, self.exp_avg, self.exp_avg_sq, self.current_lr(), self.opt_step,
-                           grad_scale=scale)
-            self.reducer.zero_grad()
-            self._invalidate_caches()
+            self._optimizer_step()
         self.sched_step += 1
         return out
+
+    # ------------------------------------------------------------------ hipGraph mode
+    def _graph_fwd_bwd(self, batch, draws, trunc, cross):
+        """Replay (capturing on first use) the hipGraph of `_fwd_bwd` for this (batch size, truncation pattern,
+        injected-draw signature).  The iteration is ~10^4 kernel launches and host-issue bound in eager mode; the
+        replay is one launch.  Inputs are copied into static buffers; the cross-style choice is a device flag, the
+        truncation pattern selects the graph variant (it changes the set of kernels: window 0 truncated adds the
+        no-grad encoder pass of training_script.py:152-155); t / eps / CFG flags / end_idx are drawn inside the
+        graph by torch's graph-safe Philox generator unless injected."""
+        audio_pair, motion_pair, shape = batch
+        B = audio_pair[0].shape[0]
+        key = (B, bool(trunc[0]), bool(trunc[1]), tuple(sorted(k for k in draws if k != "cross")))
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._capture(key, batch, draws, trunc)
+        sb, sd, flags, g, out = ent
+        for dst, src in zip(sb[0] + sb[1] + [sb[2]], list(audio_pair) + list(motion_pair) + [shape]):
+            dst.copy_(src, non_blocking=True)
+        for k, lst in sd.items():
+            for dst, src in zip(lst, draws[k]):
+                if dst is not None:
+                    dst.copy_(torch.as_tensor(src, device=self.device), non_blocking=True)
+        flags.copy_(self._flag_table[int(cross[0]) * 2 + int(cross[1])], non_blocking=True)
+        g.replay()
+        return {k: v.clone() for k, v in out.items()}
+
+    def capture_all(self, batch):
+        """Capture the four truncation variants for this batch shape up front (otherwise each is captured on its
+        first occurrence, inside whatever is being timed)."""
+        B = batch[0][0].shape[0]
+        for t0 in (False, True):
+            for t1 in (False, True):
+                key = (B, t0, t1, ())
+                if key not in self._graphs:
+                    self._capture(key, batch, {}, [t0, t1])
+
+    def _capture(self, key, batch, draws, trunc):
+        audio_pair, motion_pair, shape = batch
+        dev = self.device
+        sb = ([a.clone() for a in audio_pair], [m.clone() for m in motion_pair], shape.clone())
+        sd = {}
+        for k in key[3]:
+            sd[k] = [None if v is None else torch.as_tensor(v, device=dev).clone() for v in draws[k]]
+        flags = torch.zeros(2, dtype=torch.bool, device=dev)
+        if self._flag_table is None:
+            self._flag_table = torch.tensor([[0, 0], [0, 1], [1, 0], [1, 1]], dtype=torch.bool, device=dev)
+        cross = [flags[0], flags[1]]
+        saved = self.reducer.arena.clone()
+        # warm-up on a side stream (allocator / lazy init), then capture; gradients written by both are discarded
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._invalidate_caches()
+            self._fwd_bwd(sb, sd, trunc, cross)
+        torch.cuda.current_stream().wait_stream(s)
+        self._invalidate_caches()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self._graph_pool):
+            out = self._fwd_bwd(sb, sd, trunc, cross)
+        if self._graph_pool is None:
+            self._graph_pool = g.pool()
+        self._invalidate_caches()             # cached casts now live in the graph's pool: eager code must re-make them
+        self.reducer.arena.copy_(saved)
+        self.reducer.pending = [len(m) for _, _, m in self.reducer.buckets]
+        ent = (sb, sd, flags, g, out)
+        self._graphs[key] = ent
+        return ent
