@@ -283,3 +283,30 @@ def test_cfg_ddpm_step_matches_reference_inplace_semantics():
         o.cfg_ddpm_step(xt, dev(res), dev(z), dev(scales), 3, Lp, mode, 0, c0, c1, sg)
         torch.cuda.synchronize()
         assert maxabs(xt.cpu().numpy(), ref) <= 2e-6, name
+
+
+@pytest.mark.parametrize("M,N,K", [(6400, 768, 768), (3552, 512, 72), (200, 64, 200), (111, 2304, 512), (64, 8, 8),
+                                   (1000, 136, 3072)])
+def test_gemm_tn_weight_gradient_product(M, N, K):
+    """msmd_gemm_tn: C = A^T B over row-major operands (+ fused column sums) against fp64 on the same bf16 inputs;
+    covers contraction tails (M % 64 != 0), ragged N / K tiles and the split-contraction atomics path."""
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = (torch.randn(M, N, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    b = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    ref = a.double().t() @ b.double()
+    cs_ref = a.double().sum(0)
+    for splits in (0, 1, 3):
+        o.set_tuning(2, splits)
+        c, cs = o.gemm_tn(a, b, want_colsum=True)
+        torch.cuda.synchronize()
+        tol = 2e-3 * float(ref.abs().max()) + 1e-3
+        assert float((c.double() - ref).abs().max()) < tol, (splits, float((c.double() - ref).abs().max()))
+        assert float((cs.double() - cs_ref).abs().max()) < 2e-3 * float(cs_ref.abs().max()) + 1e-3
+    o.set_tuning(2, 0)
+    # batched, strided views
+    a3 = (torch.randn(3, 120, 64, generator=g)).to(torch.bfloat16).to(DEV)
+    b3 = (torch.randn(3, 120, 40, generator=g)).to(torch.bfloat16).to(DEV)
+    c3 = o.gemm_tn(a3, b3, batch=3, strideA=120 * 64, strideB=120 * 40)
+    ref3 = a3.double().transpose(1, 2) @ b3.double()
+    assert float((c3.double() - ref3).abs().max()) < 2e-3 * float(ref3.abs().max())

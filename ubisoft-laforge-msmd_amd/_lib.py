@@ -27,8 +27,10 @@ def parse_header(path: str = HEADER):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\bint\s+(msmd_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
-        name, args = m.group(1), m.group(2).strip()
+    RESTYPE.clear()
+    for m in re.finditer(r"\b(int|long)\s+(msmd_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        name, args = m.group(2), m.group(3).strip()
+        RESTYPE[name] = _CTYPE[m.group(1)]
         types = []
         if args and args != "void":
             for a in args.split(","):
@@ -42,6 +44,9 @@ def parse_header(path: str = HEADER):
                     types.append(_CTYPE[base])
         protos[name] = types
     return protos
+
+
+RESTYPE = {}
 
 
 class MsmdLibraryError(RuntimeError):
@@ -74,7 +79,7 @@ def load(path: str = LIB_PATH):
         except AttributeError as e:
             raise MsmdLibraryError(f"{path} does not export {name} declared in {HEADER}") from e
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = RESTYPE[name]
     _lib = lib
     return lib
 

@@ -41,6 +41,9 @@ class WeightCache:
 CACHE = WeightCache()
 
 
+USE_GEMM_TN = True
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x @ w.T + b) + residual   (x: (..., K) compute dtype; w (N, K), b (N) fp32 master parameters)."""
 
@@ -80,7 +83,15 @@ class LinearFn(torch.autograd.Function):
             dzp = dz2 if wct.shape[1] == N else ops.pad_cols(dz2, wct.shape[1], dtype)
             dx = ops.gemm(dzp, wct).reshape(*xin.shape[:-1], wct.shape[0])
         want_b = ctx.has_b and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and dtype == torch.bfloat16 and N % 8 == 0 and USE_GEMM_TN:
+            # dW = dZ^T X straight from the row-major operands (transposing LDS reads), bias gradient fused
+            x2 = xin.reshape(M, Kp)
+            if want_b:
+                dwe, db = ops.gemm_tn(dz2, x2, want_colsum=True)
+            else:
+                dwe = ops.gemm_tn(dz2, x2)
+            dw = dwe[:, :ctx.K].reshape(w.shape)
+        elif ctx.needs_input_grad[1]:
             dzT = ops.transpose2d(dz2, 8)                      # (N, Mp)
             # x^T with 8 extra rows: row Kp is all ones, so column Kp of the product is the bias gradient
             # (dz^T . 1) for free inside the wgrad GEMM instead of a separate column-sum pass.

@@ -18,6 +18,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define MSMD_WAVE 64
 
 // Launch-error plumbing: every extern "C" launcher returns a hipError_t-compatible int.
+extern int g_tuning[8];  // msmd_set_tuning knobs (gemm.hip)
 #define MSMD_RETURN_LAST() return (int)hipGetLastError()
 
 __device__ __forceinline__ float to_f32(float x) { return x; }

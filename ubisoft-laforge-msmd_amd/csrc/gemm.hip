@@ -347,7 +347,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const GemmArgs p) {
   gemm_epilogue<TO, FM, FN>(p, acc, z, m0 + wm, n0 + wn, fr, fq);
 }
 
-static int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // shared with gemm_tn.hip (key 2 = forced contraction splits)
 extern "C" int msmd_set_tuning(int key, int value) {
   if (key < 0 || key >= 8) return 1;
   g_tuning[key] = value;

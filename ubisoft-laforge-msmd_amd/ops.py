@@ -81,6 +81,35 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
     return out
 
 
+def set_tuning(key, value):
+    """msmd_set_tuning: 0 = forced GEMM variant (-1: v1 kernel), 2 = forced contraction splits of gemm_tn (0 = auto)."""
+    _lib.check(_lib.load().msmd_set_tuning(int(key), int(value)), "msmd_set_tuning")
+
+
+g_tn_split = True
+
+
+def gemm_tn(a, b, want_colsum=False, *, M=None, N=None, K=None, lda=None, ldb=None, batch=1, strideA=0, strideB=0):
+    """C (N, K) fp32 = a^T @ b for bf16 a (M, N), b (M, K) (contraction over rows: the weight-gradient product, no
+    transposes).  Returns C, or (C, colsum) with colsum[n] = sum_m a[m, n] (the bias gradient) when asked."""
+    _need_cuda(a, b)
+    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
+        raise TypeError("gemm_tn takes bf16 operands")
+    lib = _lib.load()
+    M = a.shape[-2] if M is None else M
+    N = a.shape[-1] if N is None else N
+    K = b.shape[-1] if K is None else K
+    lda = a.stride(-2) if lda is None else lda
+    ldb = b.stride(-2) if ldb is None else ldb
+    out = torch.empty((batch, N, K) if batch > 1 else (N, K), device=a.device, dtype=torch.float32)
+    cs = torch.empty(N, device=a.device, dtype=torch.float32) if want_colsum else None
+    nws = lib.msmd_gemm_tn_workspace(M, N, K, batch) if g_tn_split else 0
+    ws = torch.empty(nws, device=a.device, dtype=torch.uint8) if nws > 0 else None
+    _lib.check(lib.msmd_gemm_tn(_p(a), _p(b), _p(out), _p(cs), M, N, K, lda, ldb, K, batch, strideA, strideB, N * K,
+                                _p(ws), nws, _stream()), "msmd_gemm_tn")
+    return (out, cs) if want_colsum else out
+
+
 def conv1d_cl(x, w_packed, bias=None, *, kernel, stride, act=ACT_NONE, out_dtype=None):
     """Strided Conv1d over a channels-last (B, T, C) signal as ONE windowed GEMM (no im2col).
     w_packed: (Cout, kernel*C) with K index = kk*C + c."""
