@@ -66,12 +66,14 @@ int msmd_gemm_batched2(const void* A, const void* W, void* C, int M, int N, int 
 /* Weight-gradient GEMM: C (N, K) fp32 = A^T . B with A (M, N) bf16 and B (M, K) bf16, both row-major with the
  * contraction index as the slow axis (A = dZ, B = X of a Linear's backward: no transposed copies).  N, K, lda, ldb
  * multiples of 8; pointers 16-byte aligned.  colsum (N) fp32 or NULL: fused bias gradient sum_m A[m][n]
- * (batch must be 1).  C / colsum are fully overwritten.  ws / ws_bytes: optional device workspace for
+ * (batch must be 1).  B may be a windowed view (row r at (r / b_rows_per_window) * b_window_stride +
+ * (r % b_rows_per_window) * ldb; 0 = plain) so a Conv1d weight gradient needs no unfolded copy.
+ * C / colsum are fully overwritten.  ws / ws_bytes: optional device workspace for
  * split-contraction partial products (msmd_gemm_tn_workspace() bytes fill the chip; NULL = unsplit).  Replaces what autograd computes for nn.Linear in the
  * reference's loss.backward() (training_script.py:196). */
 int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsum, int M, int N, int K, long lda, long ldb,
-                 long ldc, int batch, long strideA, long strideB, long strideC, void* ws, long ws_bytes,
-                 msmd_stream_t stream);
+                 long ldc, int batch, long strideA, long strideB, long strideC, int b_rows_per_window,
+                 long b_window_stride, void* ws, long ws_bytes, msmd_stream_t stream);
 long msmd_gemm_tn_workspace(int M, int N, int K, int batch);
 
 /* ------------------------------------------------------------------------------------------------

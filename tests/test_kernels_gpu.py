@@ -310,3 +310,19 @@ def test_gemm_tn_weight_gradient_product(M, N, K):
     c3 = o.gemm_tn(a3, b3, batch=3, strideA=120 * 64, strideB=120 * 40)
     ref3 = a3.double().transpose(1, 2) @ b3.double()
     assert float((c3.double() - ref3).abs().max()) < 2e-3 * float(ref3.abs().max())
+
+
+def test_gemm_tn_windowed_operand_is_conv_weight_gradient():
+    """B operand as overlapping conv windows of a padded group-major signal (PosConvFn.backward): equals the
+    explicit unfold + matmul in fp64."""
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(7)
+    Bn, T, G, cg, kpos = 3, 50, 4, 16, 8
+    Tp = T + kpos
+    xp = torch.randn(Bn, G, Tp, cg, generator=g).to(torch.bfloat16).to(DEV)
+    dz = torch.randn(Bn, T, G * cg, generator=g).to(torch.bfloat16).to(DEV)
+    got = o.gemm_tn(dz, xp, M=Bn * T, N=cg, K=kpos * cg, lda=G * cg, ldb=cg, batch=G, strideA=cg, strideB=Tp * cg,
+                    b_rows_per_window=T, b_window_stride=G * Tp * cg)
+    win = torch.stack([xp[:, :, t:t + kpos].reshape(Bn, G, kpos * cg) for t in range(T)], dim=1).double()  # (B,T,G,K)
+    ref = torch.einsum("btgn,btgk->gnk", dz.double().reshape(Bn, T, G, cg), win)
+    assert float((got.double() - ref).abs().max()) < 2e-3 * float(ref.abs().max())

@@ -117,7 +117,9 @@ def test_trainer_step_adam_and_overfit():
     # the gradient is recomputed by a second backward (fp32 atomics reorder sums): Adam's first update is
     # lr * g / (|g| + eps), so entries with |g| ~ eps move by a fraction of lr; everything else matches to 1e-6
     diff = (p1 - ref.detach()).abs()
-    assert float(diff.max()) < 1e-4 and float((diff > 2e-6).float().mean()) < 1e-3
+    solid = gflat.abs() > 1e-5            # d(update)/dg = lr * eps / (|g| + eps)^2: negligible there
+    assert float(diff[solid].max()) < 5e-6 and float(diff.max()) <= 2.1e-3
+    assert float((diff > 2e-6).float().mean()) < 1e-2
     # over-fit a fixed batch with fixed draws
     tr.flat_param.copy_(p0)
     tr.exp_avg.zero_(); tr.exp_avg_sq.zero_(); tr.opt_step = 0

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 extern "C" int msmd_layernorm_bwd(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma,
                                   float* dbeta, int rows, int cols, float eps, int dtype, msmd_stream_t stream) {
   if (rows <= 0 || cols <= 0 || cols > 1024) return 1;
-  const int rpb = rows >= 4096 ? 32 : 8;  // rows per workgroup: 1 atomic per column per workgroup
+  const int rpb = rows >= 2048 ? 16 : 8;  // rows per workgroup: 1 atomic per column per workgroup
   dim3 grid((rows + rpb - 1) / rpb), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MSMD_F32) {
@@ -205,6 +205,9 @@ extern "C" int msmd_layernorm_bwd(const void* dy, const void* x, const float* ga
   } else {
     if (cols <= 512)
       hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 8>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x,
+                         gamma, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps, rpb);
+    else if (cols <= 768)
+      hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 12>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x,
                          gamma, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps, rpb);
     else
       hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 16>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x,

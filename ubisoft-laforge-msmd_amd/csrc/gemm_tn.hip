@@ -34,6 +34,9 @@ struct TnArgs {
   long strideA, strideB, strideC;
   float* ws;       // partial-product slabs [split][batch][N][K] when splits > 1
   long slab;       // elements per slab
+  int b_rpw;       // B operand windowed rows: row r -> (r / b_rpw) * b_wstride + (r % b_rpw) * ldb  (0 = plain)
+  long b_wstride;
+  float inv_rpw;
 };
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -119,8 +122,16 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnArgs p) {
   auto issue = [&](int kt, int stage) {
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
-      const long r = min(kt * 64 + rowi[i], p.M - 1);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(base[i] + r * ld[i]),
+      const int r = min(kt * 64 + rowi[i], p.M - 1);
+      long off = (long)r * ld[i];
+      if (p.b_rpw > 0 && i >= 2) {  // slots 2, 3 hold the B operand (id >> 10 == 1); fp32 reciprocal + exact fix-up
+        int q = (int)((float)r * p.inv_rpw);
+        int rem = r - q * p.b_rpw;
+        if (rem < 0) { q -= 1; rem += p.b_rpw; }
+        if (rem >= p.b_rpw) { q += 1; rem -= p.b_rpw; }
+        off = (long)q * p.b_wstride + (long)rem * p.ldb;
+      }
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(base[i] + off),
                                        (lds_void_t*)(smem + stage * STAGE + (i * 8 + wid) * 1024), 16, 0, 0);
     }
   };
@@ -260,7 +271,9 @@ static long tn_auto_splits(long tiles, long nk_elems) {
 
 // C (N, K) fp32 = A^T . B with A (M, N) bf16, B (M, K) bf16 (contraction over rows).  N % 8 == 0, K % 8 == 0,
 // lda / ldb multiples of 8 elements, pointers 16-byte aligned.  colsum (N) fp32 or NULL.  batch >= 1 with element
-// strides.  ws / ws_bytes: optional workspace for split-contraction partial slabs (msmd_gemm_tn_workspace gives the
+// strides.  b_rows_per_window / b_window_stride: B may be a windowed view (row r -> (r / rpw) * stride + (r % rpw) * ldb:
+// overlapping conv windows of a padded signal, so a conv weight gradient needs no unfold); 0 = plain.
+// ws / ws_bytes: optional workspace for split-contraction partial slabs (msmd_gemm_tn_workspace gives the
 // size that lets the launch fill the chip; smaller or NULL just means fewer / no splits).
 extern "C" long msmd_gemm_tn_workspace(int M, int N, int K, int batch) {
   const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128) * batch;
@@ -271,8 +284,9 @@ extern "C" long msmd_gemm_tn_workspace(int M, int N, int K, int batch) {
 }
 
 extern "C" int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsum, int M, int N, int K, long lda,
-                            long ldb, long ldc, int batch, long strideA, long strideB, long strideC, void* ws,
-                            long ws_bytes, msmd_stream_t stream) {
+                            long ldb, long ldc, int batch, long strideA, long strideB, long strideC,
+                            int b_rows_per_window, long b_window_stride, void* ws, long ws_bytes,
+                            msmd_stream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (N & 7) || (K & 7) || (lda & 7) || (ldb & 7) || batch < 1) return 1;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15) || ((uintptr_t)ws & 15)) return 1;
   if (colsum && batch != 1) return 1;
@@ -294,6 +308,9 @@ extern "C" int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsu
   p.steps_per_split = (int)((nk + splits - 1) / splits);
   p.splits = (nk + p.steps_per_split - 1) / p.steps_per_split;
   p.ws = (float*)ws; p.slab = slab;
+  p.b_rpw = (b_rows_per_window > 0 && b_rows_per_window < M) ? b_rows_per_window : 0;
+  p.b_wstride = b_window_stride; p.inv_rpw = p.b_rpw ? 1.0f / (float)p.b_rpw : 0.f;
+  if (p.b_rpw && ((b_window_stride & 7) || M >= (1 << 24))) return 1;
   if (p.splits > 1 && colsum) {
     hipError_t e = hipMemsetAsync(colsum, 0, sizeof(float) * N, st);
     if (e != hipSuccess) return (int)e;

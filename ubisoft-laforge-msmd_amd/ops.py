@@ -89,7 +89,8 @@ def set_tuning(key, value):
 g_tn_split = True
 
 
-def gemm_tn(a, b, want_colsum=False, *, M=None, N=None, K=None, lda=None, ldb=None, batch=1, strideA=0, strideB=0):
+def gemm_tn(a, b, want_colsum=False, *, M=None, N=None, K=None, lda=None, ldb=None, batch=1, strideA=0, strideB=0,
+            b_rows_per_window=0, b_window_stride=0):
     """C (N, K) fp32 = a^T @ b for bf16 a (M, N), b (M, K) (contraction over rows: the weight-gradient product, no
     transposes).  Returns C, or (C, colsum) with colsum[n] = sum_m a[m, n] (the bias gradient) when asked."""
     _need_cuda(a, b)
@@ -106,7 +107,7 @@ def gemm_tn(a, b, want_colsum=False, *, M=None, N=None, K=None, lda=None, ldb=No
     nws = lib.msmd_gemm_tn_workspace(M, N, K, batch) if g_tn_split else 0
     ws = torch.empty(nws, device=a.device, dtype=torch.uint8) if nws > 0 else None
     _lib.check(lib.msmd_gemm_tn(_p(a), _p(b), _p(out), _p(cs), M, N, K, lda, ldb, K, batch, strideA, strideB, N * K,
-                                _p(ws), nws, _stream()), "msmd_gemm_tn")
+                                b_rows_per_window, b_window_stride, _p(ws), nws, _stream()), "msmd_gemm_tn")
     return (out, cs) if want_colsum else out
 
 

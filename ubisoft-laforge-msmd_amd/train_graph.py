@@ -68,14 +68,19 @@ class PosConvFn(torch.autograd.Function):
                      strideW=cg * kpos * cg, strideC=cg)
         if ctx.needs_input_grad[1]:
             Tp = T + kpos
-            unf = ops.unfold_t(xp, T, kpos)                     # (G, kpos*cg, Mp)
-            Mp = unf.shape[-1]
-            dzT = torch.zeros(G, cg, Mp, device=dz.device, dtype=dt)
-            # dz (B*T, G*cg) -> per group (cg, B*T)
-            ops.transpose(dz, dzT, B * T, cg, d, Mp, G, cg, cg * Mp)
-            dwp = torch.empty(G, cg, kpos * cg, device=dz.device, dtype=torch.float32)
-            ops.gemm(dzT, unf, None, None, ops.ACT_NONE, out=dwp, M=cg, N=kpos * cg, K=Mp, lda=Mp, ldw=Mp,
-                     ldc=kpos * cg, batch=G, strideA=cg * Mp, strideW=kpos * cg * Mp, strideC=cg * kpos * cg)
+            if dt == torch.bfloat16:
+                # dW_g = dZ_g^T . windows_g(xp): the overlapping conv windows are read in place by the TN GEMM
+                dwp = ops.gemm_tn(dz, xp, M=B * T, N=cg, K=kpos * cg, lda=d, ldb=cg, batch=G, strideA=cg,
+                                  strideB=Tp * cg, b_rows_per_window=T, b_window_stride=G * Tp * cg)
+            else:
+                unf = ops.unfold_t(xp, T, kpos)                     # (G, kpos*cg, Mp)
+                Mp = unf.shape[-1]
+                dzT = torch.zeros(G, cg, Mp, device=dz.device, dtype=dt)
+                # dz (B*T, G*cg) -> per group (cg, B*T)
+                ops.transpose(dz, dzT, B * T, cg, d, Mp, G, cg, cg * Mp)
+                dwp = torch.empty(G, cg, kpos * cg, device=dz.device, dtype=torch.float32)
+                ops.gemm(dzT, unf, None, None, ops.ACT_NONE, out=dwp, M=cg, N=kpos * cg, K=Mp, lda=Mp, ldw=Mp,
+                         ldc=kpos * cg, batch=G, strideA=cg * Mp, strideW=kpos * cg * Mp, strideC=cg * kpos * cg)
             dw = dwp.reshape(G, cg, kpos, cg).permute(0, 1, 3, 2).reshape(w.shape)  # (co, ci, kk)
         if ctx.needs_input_grad[2]:
             db = ops.colsum(dz.reshape(B * T, d))
