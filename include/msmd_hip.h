@@ -99,6 +99,17 @@ int msmd_attention(const void* Q, const void* K, const void* V, void* O, int B, 
                    long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
                    int dtype, msmd_stream_t stream);
 
+/* Fused attention backward (bf16, head_dim 64, Tk <= 256): recomputes P per 64-row query tile and writes
+ * dQ / dK / dV; P, dP and transposed operands never touch HBM.  Same addressing convention as msmd_attention
+ * (base + b*bstride + t*tstride + h*64; strides multiples of 8 elements, bases 16-byte aligned); dQ / dK / dV may
+ * be slices of one packed gradient buffer.  Replaces autograd of the attention modules listed above under the
+ * reference's loss.backward() (training_script.py:196), eval mode (no attention dropout). */
+int msmd_attention_bwd(const void* Q, const void* K, const void* V, const void* dO, void* dQ, void* dK, void* dV,
+                       int B, int H, int Tq, int Tk, long q_bstride, long q_tstride, long k_bstride,
+                       long k_tstride, long v_bstride, long v_tstride, long do_bstride, long do_tstride,
+                       long dq_bstride, long dq_tstride, long dk_bstride, long dk_tstride, long dv_bstride,
+                       long dv_tstride, float scale, const uint8_t* mask, msmd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Audio front end.  pad plan = (reflect_len applied twice per side, replicate_len 0/1), computed on
  * the host exactly as reference utils/model_common.py:110-123.

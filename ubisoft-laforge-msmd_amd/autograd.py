@@ -193,6 +193,74 @@ class AttentionFn(torch.autograd.Function):
         return dQ, dK, dV, None, None, None
 
 
+class FusedSelfAttnFn(torch.autograd.Function):
+    """Self-attention on a packed (B, T, 3 d) projection: fused forward (msmd_attention) and fused backward
+    (msmd_attention_bwd, P recomputed); the gradient comes back as ONE packed tensor (no slice / cat glue)."""
+
+    @staticmethod
+    def forward(ctx, qkv, n_heads, scale, mask):
+        d = qkv.shape[-1] // 3
+        qkv = qkv.contiguous()
+        m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
+        o = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], n_heads, scale, m8)
+        ctx.save_for_backward(qkv, m8)
+        ctx.cfg = (n_heads, scale, d)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, m8 = ctx.saved_tensors
+        H, scale, d = ctx.cfg
+        dqkv = torch.empty_like(qkv)
+        ops.attention_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], do.contiguous(), dqkv[..., :d],
+                          dqkv[..., d:2 * d], dqkv[..., 2 * d:], H, scale, m8)
+        return dqkv, None, None, None
+
+
+class FusedCrossAttnFn(torch.autograd.Function):
+    """Cross-attention: q (B, Tq, d), packed kv (B, Tk, 2 d)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, n_heads, scale, mask):
+        d = q.shape[-1]
+        q, kv = q.contiguous(), kv.contiguous()
+        m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
+        o = ops.attention(q, kv[..., :d], kv[..., d:], n_heads, scale, m8)
+        ctx.save_for_backward(q, kv, m8)
+        ctx.cfg = (n_heads, scale, d)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, m8 = ctx.saved_tensors
+        H, scale, d = ctx.cfg
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        ops.attention_bwd(q, kv[..., :d], kv[..., d:], do.contiguous(), dq, dkv[..., :d], dkv[..., d:], H, scale, m8)
+        return dq, dkv, None, None, None
+
+
+FUSED_ATTENTION = True
+
+
+def _fusable(x, Tk):
+    return FUSED_ATTENTION and x.dtype == torch.bfloat16 and Tk <= 256
+
+
+def self_attention(qkv, n_heads, scale, mask=None):
+    """softmax(scale Q K^T) V on a packed (B, T, 3 d) projection."""
+    d = qkv.shape[-1] // 3
+    if _fusable(qkv, qkv.shape[1]):
+        return FusedSelfAttnFn.apply(qkv, n_heads, scale, mask)
+    return attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], n_heads, scale, mask)
+
+
+def cross_attention(q, kv, n_heads, scale, mask=None):
+    d = q.shape[-1]
+    if _fusable(q, kv.shape[1]):
+        return FusedCrossAttnFn.apply(q, kv, n_heads, scale, mask)
+    return attention(q, kv[..., :d], kv[..., d:], n_heads, scale, mask)
+
+
 def linear(x, w, b=None, act=ACT_NONE, residual=None):
     return LinearFn.apply(x, w, b, residual, act)
 

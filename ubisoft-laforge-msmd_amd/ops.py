@@ -152,6 +152,26 @@ def attention(q, k, v, n_heads, scale, mask=None, out=None):
     return out
 
 
+def attention_bwd(q, k, v, do, dq, dk, dv, n_heads, scale, mask=None):
+    """Fused backward of `attention` (bf16, Tk <= 256): fills dq / dk / dv (views with last dim contiguous)."""
+    _need_cuda(q, k, v, do, dq, dk, dv)
+    lib = _lib.load()
+    B, Tq, d = q.shape
+    Tk = k.shape[1]
+    for t in (q, k, v, do, dq, dk, dv):
+        if t.dtype != torch.bfloat16 or t.stride(-1) != 1:
+            raise TypeError("attention_bwd takes bf16 tensors with a contiguous last dim")
+    m = None
+    if mask is not None:
+        assert mask.dtype in (torch.bool, torch.uint8) and mask.shape == (Tq, Tk) and mask.is_contiguous()
+        m = mask
+    _lib.check(lib.msmd_attention_bwd(_p(q), _p(k), _p(v), _p(do), _p(dq), _p(dk), _p(dv), B, n_heads, Tq, Tk,
+                                      q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                                      do.stride(0), do.stride(1), dq.stride(0), dq.stride(1), dk.stride(0),
+                                      dk.stride(1), dv.stride(0), dv.stride(1), float(scale), _p(m), _stream()),
+               "msmd_attention_bwd")
+
+
 def pad_audio(audio, reflect_len, replicate_len):
     lib = _lib.load()
     B, L = audio.shape

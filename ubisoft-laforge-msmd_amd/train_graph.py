@@ -116,7 +116,7 @@ def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
         wq, wk, wv = (g(p + f"attention.{k}_proj.weight") for k in "qkv")
         bq, bk, bv = (g(p + f"attention.{k}_proj.bias") for k in "qkv")
         qkv = ag.linear(h, torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0))
-        a = ag.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, (d // H) ** -0.5)
+        a = ag.self_attention(qkv, H, (d // H) ** -0.5)
         h = ag.layer_norm(ag.linear(a, g(p + "attention.out_proj.weight"), g(p + "attention.out_proj.bias"),
                                     residual=h), g(p + "layer_norm.weight"), g(p + "layer_norm.bias"))
         f = ag.linear(h, g(p + "feed_forward.intermediate_dense.weight"), g(p + "feed_forward.intermediate_dense.bias"),
@@ -177,13 +177,13 @@ def denoiser_train(net, motion_noisy, audio_feat, person_feat, static_style_feat
     for n in range(net.n_layers):
         p = f"transformer.layers.{n}."
         qkv = ag.linear(x, g(p + "self_attn.in_proj_weight"), g(p + "self_attn.in_proj_bias"))
-        a = ag.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale)
+        a = ag.self_attention(qkv, H, scale)
         x = ag.layer_norm(ag.linear(a, g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias"), residual=x),
                           g(p + "norm1.weight"), g(p + "norm1.bias"))
         w, b = g(p + "multihead_attn.in_proj_weight"), g(p + "multihead_attn.in_proj_bias")
         q = ag.linear(x, w[:d], b[:d])
         kv = ag.linear(mem, w[d:], b[d:])
-        cattn = ag.attention(q, kv[..., :d], kv[..., d:], H, scale, mask)
+        cattn = ag.cross_attention(q, kv, H, scale, mask)
         x = ag.layer_norm(ag.linear(cattn, g(p + "multihead_attn.out_proj.weight"),
                                     g(p + "multihead_attn.out_proj.bias"), residual=x),
                           g(p + "norm2.weight"), g(p + "norm2.bias"))
@@ -225,7 +225,7 @@ def style_encoder_train(se, motion_coef, dtype):
                       g("input_layers.11.weight"), g("input_layers.11.bias"), post_add=se.PE.pe[0, T].float().contiguous())
     d = se.conv_feature_dim
     qkv = ag.linear(x, g("encoder.self_attn.in_proj_weight"), g("encoder.self_attn.in_proj_bias"))
-    a = ag.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], 8, 64 ** -0.5)
+    a = ag.self_attention(qkv, 8, 64 ** -0.5)
     x = ag.layer_norm(ag.linear(a, g("encoder.self_attn.out_proj.weight"), g("encoder.self_attn.out_proj.bias"),
                                 residual=x), g("encoder.norm1.weight"), g("encoder.norm1.bias"))
     f = ag.linear(x, g("encoder.linear1.weight"), g("encoder.linear1.bias"), act=ops.ACT_GELU)
