@@ -68,12 +68,12 @@ int msmd_gemm_batched2(const void* A, const void* W, void* C, int M, int N, int 
  * multiples of 8; pointers 16-byte aligned.  colsum (N) fp32 or NULL: fused bias gradient sum_m A[m][n]
  * (batch must be 1).  B may be a windowed view (row r at (r / b_rows_per_window) * b_window_stride +
  * (r % b_rows_per_window) * ldb; 0 = plain) so a Conv1d weight gradient needs no unfolded copy.
- * C / colsum are fully overwritten.  ws / ws_bytes: optional device workspace for
+ * C / colsum are fully overwritten, or added to when `accumulate` (gradient accumulation in place).  ws / ws_bytes: optional device workspace for
  * split-contraction partial products (msmd_gemm_tn_workspace() bytes fill the chip; NULL = unsplit).  Replaces what autograd computes for nn.Linear in the
  * reference's loss.backward() (training_script.py:196). */
 int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsum, int M, int N, int K, long lda, long ldb,
                  long ldc, int batch, long strideA, long strideB, long strideC, int b_rows_per_window,
-                 long b_window_stride, void* ws, long ws_bytes, msmd_stream_t stream);
+                 long b_window_stride, int accumulate, void* ws, long ws_bytes, msmd_stream_t stream);
 long msmd_gemm_tn_workspace(int M, int N, int K, int batch);
 
 /* ------------------------------------------------------------------------------------------------
@@ -283,9 +283,11 @@ int msmd_colsum(const void* x, float* out, long rows, int cols, long ld, int acc
 int msmd_act_fwd(const void* z, void* y, long n, int act, int dtype, msmd_stream_t stream);
 int msmd_act_bwd(const void* dy, const void* z, void* dz, long n, int act, int dtype, msmd_stream_t stream);
 /* LayerNorm backward for y = LN(x)*gamma + beta (x = the LN input, residual already added):
- * dx (rows, cols); dgamma / dbeta (cols) fp32 are ACCUMULATED into (zero them for a fresh gradient). */
+ * dx (rows, cols); dgamma / dbeta (cols) fp32 are ACCUMULATED into (zero them for a fresh gradient).
+ * ws: optional msmd_layernorm_bwd_workspace() bytes for per-workgroup partial sums (NULL: fp32 atomics). */
 int msmd_layernorm_bwd(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma, float* dbeta,
-                       int rows, int cols, float eps, int dtype, msmd_stream_t stream);
+                       int rows, int cols, float eps, int dtype, void* ws, long ws_bytes, msmd_stream_t stream);
+long msmd_layernorm_bwd_workspace(int rows, int cols);
 /* In place row softmax of scale * s over the first `cols` entries of rows with stride ld (the ld - cols padding
  * columns are zeroed), optional (Tq, cols) byte mask (row r uses mask row r % Tq);
  * backward (in place on dP): dS = scale * P o (dP - rowsum(dP o P)). */

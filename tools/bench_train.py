@@ -18,6 +18,8 @@ args = default_args(compute_dtype=dtype, lr=2e-5, warm_iter=5000)
 model = get_diffusion_model(args, dev).eval()
 se = get_style_encoder(args, "vae2").to(dev).eval()
 tr = Trainer(args, model, se, use_graph=bool(os.environ.get('GRAPH')))
+if os.environ.get('DIRECT') is not None:
+    tr.direct_grad = bool(int(os.environ['DIRECT']))
 batch = synthetic_batch(B, rank, dev)
 steps = int(os.environ.get("STEPS", "5"))
 if tr.use_graph:

@@ -22,7 +22,7 @@ for M, N, K in shapes:
         ops.set_tuning(2, sp)
         for dbg in (0,):
             ops.set_tuning(3, dbg)
-            us = t(lambda: lib.msmd_gemm_tn(a.data_ptr(), b.data_ptr(), c.data_ptr(), None, M, N, K, N, K, K, 1, 0, 0, 0, 0, 0,
+            us = t(lambda: lib.msmd_gemm_tn(a.data_ptr(), b.data_ptr(), c.data_ptr(), None, M, N, K, N, K, K, 1, 0, 0, 0, 0, 0, 0,
                                             ws.data_ptr(), ws.numel(), st))
             print(f"M={M} N={N} K={K} splits={sp} dbg={dbg}: {us:.1f} us  {fl / us / 1e6:.0f} TF", flush=True)
     ops.set_tuning(3, 0); ops.set_tuning(2, 0)

@@ -42,6 +42,9 @@ CACHE = WeightCache()
 
 
 USE_GEMM_TN = True
+# Set by Trainer when bucket launches do not depend on per-parameter hooks (hipGraph mode / single process):
+# LinearFn.backward then adds weight / bias gradients directly into the pre-allocated .grad arena views.
+DIRECT_GRAD = False
 
 
 class LinearFn(torch.autograd.Function):
@@ -65,6 +68,7 @@ class LinearFn(torch.autograd.Function):
                 y = y + residual
         ctx.save_for_backward(xin, z, w)
         ctx.act, ctx.has_b, ctx.has_r, ctx.K = act, b is not None, residual is not None, K
+        ctx.b_ref = b if (b is not None and b.is_leaf) else None
         return y
 
     @staticmethod
@@ -83,7 +87,20 @@ class LinearFn(torch.autograd.Function):
             dzp = dz2 if wct.shape[1] == N else ops.pad_cols(dz2, wct.shape[1], dtype)
             dx = ops.gemm(dzp, wct).reshape(*xin.shape[:-1], wct.shape[0])
         want_b = ctx.has_b and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1] and dtype == torch.bfloat16 and N % 8 == 0 and USE_GEMM_TN:
+        direct = (DIRECT_GRAD and ctx.needs_input_grad[1] and dtype == torch.bfloat16 and N % 8 == 0 and Kp == ctx.K
+                  and w.is_leaf and w.grad is not None and w.grad.is_contiguous() and USE_GEMM_TN)
+        if direct:
+            # accumulate dW (and db) straight into the parameters' .grad views of the flat gradient arena: no fp32
+            # temporary, no autograd add kernel per parameter and window
+            bgrad = None
+            if want_b:
+                b_leaf = ctx.b_ref
+                if b_leaf is not None and b_leaf.grad is not None and b_leaf.grad.is_contiguous():
+                    bgrad = b_leaf.grad
+            ops.gemm_tn(dz2, xin.reshape(M, Kp), out=w.grad.view(N, Kp), colsum_out=bgrad, accumulate=True)
+            if want_b and bgrad is None:
+                db = ops.colsum(dz2)
+        elif ctx.needs_input_grad[1] and dtype == torch.bfloat16 and N % 8 == 0 and USE_GEMM_TN:
             # dW = dZ^T X straight from the row-major operands (transposing LDS reads), bias gradient fused
             x2 = xin.reshape(M, Kp)
             if want_b:

@@ -124,7 +124,8 @@ template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma, T* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int rows, int cols, float eps, int rows_per_block) {
+                                                            int rows, int cols, float eps, int rows_per_block,
+                                                            float* __restrict__ partial) {
   __shared__ float sg[4 * 64 * MAXC], sb[4 * 64 * MAXC];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float ag[MAXC], abt[MAXC];  // this wave's running dgamma / dbeta partials over its rows
@@ -183,36 +184,198 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         a += sg[w * MAXC * 64 + k];
         b += sb[w * MAXC * 64 + k];
       }
-      atomicAdd(&dgamma[k], a);
-      atomicAdd(&dbeta[k], b);
+      if (partial) {  // [block][2][cols]: summed by ln_partial_reduce_kernel (no same-address atomic contention)
+        partial[((long)blockIdx.x * 2 + 0) * cols + k] = a;
+        partial[((long)blockIdx.x * 2 + 1) * cols + k] = b;
+      } else {
+        atomicAdd(&dgamma[k], a);
+        atomicAdd(&dbeta[k], b);
+      }
     }
   }
 }
 
+__global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int nblocks, int cols) {
+  // 32 columns x 8 row groups per workgroup: coalesced 128-byte rows, 8-way split of the nblocks-long sum
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int which = blockIdx.y;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < cols) {
+    int b = rg;
+    for (; b + 8 < nblocks; b += 16) {
+      s0 += partial[((long)b * 2 + which) * cols + c];
+      s1 += partial[((long)(b + 8) * 2 + which) * cols + c];
+    }
+    if (b < nblocks) s0 += partial[((long)b * 2 + which) * cols + c];
+  }
+  red[rg][cl] = s0 + s1;
+  __syncthreads();
+  if (rg == 0 && c < cols) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += red[g][cl];
+    (which ? dbeta : dgamma)[c] += s;
+  }
+}
+
+// 4-wide variant: lane owns columns (i * 64 + lane) * 4 + {0..3}: 8-byte (bf16) / 16-byte (fp32) accesses, and two
+// rounds of two independent wave reductions (sum x, sum x^2 | sum g, sum g xhat) instead of four dependent ones.
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { typedef f32x4 type; };
+template <> struct Vec4<bf16_t> { typedef __bf16 type __attribute__((ext_vector_type(4))); };
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd4_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                             const float* __restrict__ gamma, T* __restrict__ dx,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             int rows, int cols, float eps, int rows_per_block,
+                                                             float* __restrict__ partial) {
+  typedef typename Vec4<T>::type V4;
+  __shared__ float sg[4][NCH * 256 + 4], sb[4][NCH * 256 + 4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float ag[NCH][4], abt[NCH][4], gam[NCH][4];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (i * 64 + lane) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ag[i][j] = abt[i][j] = 0.f;
+      gam[i][j] = (c + j < cols) ? gamma[c + j] : 0.f;
+    }
+  }
+  const float inv_n = 1.0f / (float)cols;
+  const int r_begin = blockIdx.x * rows_per_block, r_end = min(rows, r_begin + rows_per_block);
+  for (int row = r_begin + wid; row < r_end; row += 4) {
+    float xv[NCH][4], dyv[NCH][4];
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < cols) {
+        const V4 a = *(const V4*)(x + (long)row * cols + c);
+        const V4 d = *(const V4*)(dy + (long)row * cols + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xv[i][j] = (float)a[j];
+          dyv[i][j] = (float)d[j];
+          s += xv[i][j];
+          ss += xv[i][j] * xv[i][j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[i][j] = dyv[i][j] = 0.f;
+      }
+    }
+    // two independent butterfly reductions interleave in the pipeline
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o, 64);
+      ss += __shfl_xor(ss, o, 64);
+    }
+    const float mean = s * inv_n;
+    const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    float g1 = 0.f, g2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = (i * 64 + lane) * 4 + j < cols;
+        xv[i][j] = ok ? (xv[i][j] - mean) * rstd : 0.f;  // xhat
+        const float gv = dyv[i][j] * gam[i][j];
+        g1 += gv;
+        g2 += gv * xv[i][j];
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      g1 += __shfl_xor(g1, o, 64);
+      g2 += __shfl_xor(g2, o, 64);
+    }
+    const float m1 = g1 * inv_n, m2 = g2 * inv_n;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      V4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = from_f32<T>(rstd * (dyv[i][j] * gam[i][j] - m1 - xv[i][j] * m2));
+        ag[i][j] += dyv[i][j] * xv[i][j];
+        abt[i][j] += dyv[i][j];
+      }
+      if (c < cols) *(V4*)(dx + (long)row * cols + c) = o;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sg[wid][(i * 64 + lane) * 4 + j] = ag[i][j];
+      sb[wid][(i * 64 + lane) * 4 + j] = abt[i][j];
+    }
+  __syncthreads();
+  for (int k = threadIdx.x; k < NCH * 256; k += 256) {
+    if (k < cols) {
+      const float a = sg[0][k] + sg[1][k] + sg[2][k] + sg[3][k];
+      const float b = sb[0][k] + sb[1][k] + sb[2][k] + sb[3][k];
+      if (partial) {
+        partial[((long)blockIdx.x * 2 + 0) * cols + k] = a;
+        partial[((long)blockIdx.x * 2 + 1) * cols + k] = b;
+      } else {
+        atomicAdd(&dgamma[k], a);
+        atomicAdd(&dbeta[k], b);
+      }
+    }
+  }
+}
+
+extern "C" long msmd_layernorm_bwd_workspace(int rows, int cols) {
+  const int rpb = rows >= 2048 ? 16 : 8;
+  return (long)((rows + rpb - 1) / rpb) * 2 * cols * (long)sizeof(float);
+}
+
 extern "C" int msmd_layernorm_bwd(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma,
-                                  float* dbeta, int rows, int cols, float eps, int dtype, msmd_stream_t stream) {
+                                  float* dbeta, int rows, int cols, float eps, int dtype, void* ws, long ws_bytes,
+                                  msmd_stream_t stream) {
   if (rows <= 0 || cols <= 0 || cols > 1024) return 1;
+  float* partial = (ws && ws_bytes >= msmd_layernorm_bwd_workspace(rows, cols)) ? (float*)ws : nullptr;
   const int rpb = rows >= 2048 ? 16 : 8;  // rows per workgroup: 1 atomic per column per workgroup
   dim3 grid((rows + rpb - 1) / rpb), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MSMD_F32) {
+  const bool aligned = ((uintptr_t)dy % 16 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dx % 16 == 0);
+  if (cols % 4 == 0 && aligned) {
+#define LN4(T, NCH)                                                                                                  \
+  hipLaunchKernelGGL((layernorm_bwd4_kernel<T, NCH>), grid, block, 0, st, (const T*)dy, (const T*)x, gamma, (T*)dx, \
+                     dgamma, dbeta, rows, cols, eps, rpb, partial)
+    if (dtype == MSMD_F32) {
+      if (cols <= 256) LN4(float, 1); else if (cols <= 512) LN4(float, 2); else if (cols <= 768) LN4(float, 3); else LN4(float, 4);
+    } else {
+      if (cols <= 256) LN4(bf16_t, 1); else if (cols <= 512) LN4(bf16_t, 2); else if (cols <= 768) LN4(bf16_t, 3); else LN4(bf16_t, 4);
+    }
+#undef LN4
+  } else if (dtype == MSMD_F32) {
     if (cols <= 512)
       hipLaunchKernelGGL((layernorm_bwd_kernel<float, 8>), grid, block, 0, st, (const float*)dy, (const float*)x, gamma,
-                         (float*)dx, dgamma, dbeta, rows, cols, eps, rpb);
+                         (float*)dx, dgamma, dbeta, rows, cols, eps, rpb, partial);
     else
       hipLaunchKernelGGL((layernorm_bwd_kernel<float, 16>), grid, block, 0, st, (const float*)dy, (const float*)x,
-                         gamma, (float*)dx, dgamma, dbeta, rows, cols, eps, rpb);
+                         gamma, (float*)dx, dgamma, dbeta, rows, cols, eps, rpb, partial);
   } else {
     if (cols <= 512)
       hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 8>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x,
-                         gamma, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps, rpb);
+                         gamma, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps, rpb, partial);
     else if (cols <= 768)
       hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 12>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x,
-                         gamma, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps, rpb);
+                         gamma, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps, rpb, partial);
     else
       hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, 16>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x,
-                         gamma, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps, rpb);
+                         gamma, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps, rpb, partial);
   }
+  if (partial)
+    hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((cols + 31) / 32, 2), dim3(256), 0, st, partial, dgamma, dbeta,
+                       (int)grid.x, cols);
   MSMD_RETURN_LAST();
 }
 

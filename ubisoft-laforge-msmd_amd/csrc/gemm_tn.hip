@@ -37,6 +37,7 @@ struct TnArgs {
   int b_rpw;       // B operand windowed rows: row r -> (r / b_rpw) * b_wstride + (r % b_rpw) * ldb  (0 = plain)
   long b_wstride;
   float inv_rpw;
+  int accumulate;  // C += product, colsum += sums (gradient accumulation straight into .grad)
 };
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -225,16 +226,17 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnArgs p) {
     for (int i = 0; i < 2; ++i) {
       const int k = k0 + wk + 16 * i + 4 * fq;
       float* dst = C + (long)n * ldc + k;
+      const bool add = p.accumulate && !partial;
       if (vec && k + 3 < p.K) {
-        *(f32x4*)dst = acc[i][j];
+        *(f32x4*)dst = add ? *(const f32x4*)dst + acc[i][j] : acc[i][j];
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (k + e < p.K) dst[e] = acc[i][j][e];
+          if (k + e < p.K) dst[e] = add ? dst[e] + acc[i][j][e] : acc[i][j][e];
       }
     }
     if (do_cs && fq == 0) {
-      if (partial) atomicAdd(p.colsum + n, acs[j][0]);
+      if (partial || p.accumulate) atomicAdd(p.colsum + n, acs[j][0]);
       else p.colsum[n] = acs[j][0];
     }
   }
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnArgs p) {
 
 // C[z][n][k] = sum_s ws[s][z][n][k]
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int splits,
-                                                        long slab, int N, int K, long ldc, long strideC) {
+                                                        long slab, int N, int K, long ldc, long strideC, int accumulate) {
   const long q = (long)blockIdx.x * 256 + threadIdx.x;  // float4 index inside one batch's (N, K)
   const int z = blockIdx.y;
   const int kq = K >> 2;
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     a += b;
   }
   float* dst = C + z * strideC + (long)n * ldc + k;
+  if (accumulate) { a[0] += dst[0]; a[1] += dst[1]; a[2] += dst[2]; a[3] += dst[3]; }
   if (ldc % 4 == 0) *(f32x4*)dst = a;
   else { dst[0] = a[0]; dst[1] = a[1]; dst[2] = a[2]; dst[3] = a[3]; }
 }
@@ -273,6 +276,7 @@ static long tn_auto_splits(long tiles, long nk_elems) {
 // lda / ldb multiples of 8 elements, pointers 16-byte aligned.  colsum (N) fp32 or NULL.  batch >= 1 with element
 // strides.  b_rows_per_window / b_window_stride: B may be a windowed view (row r -> (r / rpw) * stride + (r % rpw) * ldb:
 // overlapping conv windows of a padded signal, so a conv weight gradient needs no unfold); 0 = plain.
+// accumulate: C += product and colsum += sums instead of overwriting (gradient accumulation into .grad).
 // ws / ws_bytes: optional workspace for split-contraction partial slabs (msmd_gemm_tn_workspace gives the
 // size that lets the launch fill the chip; smaller or NULL just means fewer / no splits).
 extern "C" long msmd_gemm_tn_workspace(int M, int N, int K, int batch) {
@@ -285,8 +289,8 @@ extern "C" long msmd_gemm_tn_workspace(int M, int N, int K, int batch) {
 
 extern "C" int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsum, int M, int N, int K, long lda,
                             long ldb, long ldc, int batch, long strideA, long strideB, long strideC,
-                            int b_rows_per_window, long b_window_stride, void* ws, long ws_bytes,
-                            msmd_stream_t stream) {
+                            int b_rows_per_window, long b_window_stride, int accumulate, void* ws,
+                            long ws_bytes, msmd_stream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (N & 7) || (K & 7) || (lda & 7) || (ldb & 7) || batch < 1) return 1;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15) || ((uintptr_t)ws & 15)) return 1;
   if (colsum && batch != 1) return 1;
@@ -311,7 +315,8 @@ extern "C" int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsu
   p.b_rpw = (b_rows_per_window > 0 && b_rows_per_window < M) ? b_rows_per_window : 0;
   p.b_wstride = b_window_stride; p.inv_rpw = p.b_rpw ? 1.0f / (float)p.b_rpw : 0.f;
   if (p.b_rpw && ((b_window_stride & 7) || M >= (1 << 24))) return 1;
-  if (p.splits > 1 && colsum) {
+  p.accumulate = accumulate ? 1 : 0;
+  if (p.splits > 1 && colsum && !accumulate) {
     hipError_t e = hipMemsetAsync(colsum, 0, sizeof(float) * N, st);
     if (e != hipSuccess) return (int)e;
   }
@@ -327,7 +332,7 @@ extern "C" int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsu
   if (p.splits > 1) {
     const long quads = (long)N * (K / 4);
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((quads + 255) / 256), batch), dim3(256), 0, st, p.ws, C,
-                       p.splits, slab, N, K, ldc, strideC);
+                       p.splits, slab, N, K, ldc, strideC, p.accumulate);
   }
   MSMD_RETURN_LAST();
 }

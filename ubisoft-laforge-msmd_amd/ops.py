@@ -90,7 +90,7 @@ g_tn_split = True
 
 
 def gemm_tn(a, b, want_colsum=False, *, M=None, N=None, K=None, lda=None, ldb=None, batch=1, strideA=0, strideB=0,
-            b_rows_per_window=0, b_window_stride=0):
+            b_rows_per_window=0, b_window_stride=0, out=None, colsum_out=None, accumulate=False):
     """C (N, K) fp32 = a^T @ b for bf16 a (M, N), b (M, K) (contraction over rows: the weight-gradient product, no
     transposes).  Returns C, or (C, colsum) with colsum[n] = sum_m a[m, n] (the bias gradient) when asked."""
     _need_cuda(a, b)
@@ -102,13 +102,18 @@ def gemm_tn(a, b, want_colsum=False, *, M=None, N=None, K=None, lda=None, ldb=No
     K = b.shape[-1] if K is None else K
     lda = a.stride(-2) if lda is None else lda
     ldb = b.stride(-2) if ldb is None else ldb
-    out = torch.empty((batch, N, K) if batch > 1 else (N, K), device=a.device, dtype=torch.float32)
-    cs = torch.empty(N, device=a.device, dtype=torch.float32) if want_colsum else None
+    if out is None:
+        out = torch.empty((batch, N, K) if batch > 1 else (N, K), device=a.device, dtype=torch.float32)
+    elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != batch * N * K:
+        raise ValueError("gemm_tn out must be a contiguous fp32 (N, K) tensor")
+    cs = colsum_out if colsum_out is not None else (
+        torch.empty(N, device=a.device, dtype=torch.float32) if want_colsum else None)
     nws = lib.msmd_gemm_tn_workspace(M, N, K, batch) if g_tn_split else 0
     ws = torch.empty(nws, device=a.device, dtype=torch.uint8) if nws > 0 else None
     _lib.check(lib.msmd_gemm_tn(_p(a), _p(b), _p(out), _p(cs), M, N, K, lda, ldb, K, batch, strideA, strideB, N * K,
-                                b_rows_per_window, b_window_stride, _p(ws), nws, _stream()), "msmd_gemm_tn")
-    return (out, cs) if want_colsum else out
+                                b_rows_per_window, b_window_stride, int(bool(accumulate)), _p(ws), nws,
+                                _stream()), "msmd_gemm_tn")
+    return (out, cs) if (want_colsum or colsum_out is not None) else out
 
 
 def conv1d_cl(x, w_packed, bias=None, *, kernel, stride, act=ACT_NONE, out_dtype=None):
@@ -460,10 +465,12 @@ def layernorm_bwd(dy, x, gamma, eps=1e-5):
     cols = x.shape[-1]
     rows = x.numel() // cols
     dx = torch.empty_like(x)
-    dg = torch.zeros(cols, device=x.device, dtype=torch.float32)
-    db = torch.zeros(cols, device=x.device, dtype=torch.float32)
+    dgb = torch.zeros(2, cols, device=x.device, dtype=torch.float32)
+    dg, db = dgb[0], dgb[1]
+    nws = lib.msmd_layernorm_bwd_workspace(rows, cols)
+    ws = torch.empty(nws, device=x.device, dtype=torch.uint8)
     _lib.check(lib.msmd_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(dx), _p(dg), _p(db), rows, cols, eps, _dt(x),
-                                      _stream()), "msmd_layernorm_bwd")
+                                      _p(ws), nws, _stream()), "msmd_layernorm_bwd")
     return dx, dg, db
 
 

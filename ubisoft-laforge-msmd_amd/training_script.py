@@ -73,6 +73,9 @@ class Trainer:
         self.sched_step = 0
         self.use_graph = bool(use_graph)
         self._graphs, self._graph_pool, self._flag_table = {}, None, None
+        # weight gradients are added straight into the arena by the wgrad GEMM when bucket launches do not hang
+        # on per-parameter autograd hooks (graph mode launches them from finish(); world 1 launches nothing)
+        self.direct_grad = self.use_graph or self.reducer.world == 1
 
     # GradualWarmupScheduler(optimizer, 1, warm_iter): lr = base * min(1, step / warm_iter)
     def current_lr(self):
@@ -182,6 +185,7 @@ class Trainer:
         style_eps=[tensor]*2, cfg_flag=[tensor|None]*2).  Returns dict of detached loss tensors (+ 'loss').
         With `use_graph` the forward+backward runs as ONE hipGraph replay (see `_graph_fwd_bwd`)."""
         draws = draws or {}
+        ag.DIRECT_GRAD = self.direct_grad
         stepping = (it % max(1, self.args.gradient_accumulation_steps) == 0)
         cross, trunc = self._host_choices(draws)
         if self.use_graph:
@@ -224,6 +228,7 @@ class Trainer:
         """Capture the four truncation variants for this batch shape up front (otherwise each is captured on its
         first occurrence, inside whatever is being timed)."""
         B = batch[0][0].shape[0]
+        ag.DIRECT_GRAD = self.direct_grad
         for t0 in (False, True):
             for t1 in (False, True):
                 key = (B, t0, t1, ())
