@@ -99,16 +99,35 @@ int msmd_attention(const void* Q, const void* K, const void* V, void* O, int B, 
                    long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
                    int dtype, msmd_stream_t stream);
 
+/* Training-mode attention forward: as msmd_attention with attention-probability dropout p_drop (HF
+ * attention_dropout, nn.MultiheadAttention(dropout=0.1) inside the decoder / encoder layers).  The keep mask is
+ * Philox4x32-10(seed = rng_state[0], step = rng_state[1], site, (b, h, q, key / 4)); rng_state is DEVICE memory so a
+ * captured hipGraph draws fresh masks on every replay once the host side advances the step.  Tk <= 512. */
+int msmd_attention_dropout(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
+                           long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
+                           long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
+                           float p_drop, const unsigned long* rng_state, unsigned int site, int dtype,
+                           msmd_stream_t stream);
+
+/* y = x * keep / (1 - p) (+ residual): nn.Dropout in training mode (HF hidden / activation / feat_proj dropout,
+ * decoder-layer dropout1-3, PositionalEncoding dropout, style-encoder dropouts; utils/model_common.py:101,
+ * style_encoder.py:139-167).  Same Philox stream as above indexed by element / 4; calling it on dy with the same
+ * (rng_state, site) is the backward. */
+int msmd_dropout(const void* x, const void* residual, void* y, long n, float p, const unsigned long* rng_state,
+                 unsigned int site, int dtype, msmd_stream_t stream);
+
 /* Fused attention backward (bf16, head_dim 64, Tk <= 256): recomputes P per 64-row query tile and writes
  * dQ / dK / dV; P, dP and transposed operands never touch HBM.  Same addressing convention as msmd_attention
  * (base + b*bstride + t*tstride + h*64; strides multiples of 8 elements, bases 16-byte aligned); dQ / dK / dV may
  * be slices of one packed gradient buffer.  Replaces autograd of the attention modules listed above under the
- * reference's loss.backward() (training_script.py:196), eval mode (no attention dropout). */
+ * reference's loss.backward() (training_script.py:196).  p_drop / rng_state / site: attention-probability dropout
+ * exactly as the forward msmd_attention_dropout drew it (0 / NULL: none). */
 int msmd_attention_bwd(const void* Q, const void* K, const void* V, const void* dO, void* dQ, void* dK, void* dV,
                        int B, int H, int Tq, int Tk, long q_bstride, long q_tstride, long k_bstride,
                        long k_tstride, long v_bstride, long v_tstride, long do_bstride, long do_tstride,
                        long dq_bstride, long dq_tstride, long dk_bstride, long dk_tstride, long dv_bstride,
-                       long dv_tstride, float scale, const uint8_t* mask, msmd_stream_t stream);
+                       long dv_tstride, float scale, const uint8_t* mask, float p_drop,
+                       const unsigned long* rng_state, unsigned int site, msmd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Audio front end.  pad plan = (reflect_len applied twice per side, replicate_len 0/1), computed on

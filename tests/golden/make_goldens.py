@@ -598,7 +598,25 @@ class mock_randn_like:
         torch.randn_like = self.orig
 
 
-ALL = dict(g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
+def g1_specaug(M, SE, mc):
+    """SpecAugment time-mask indices: the reference wav2vec2 wrapper's own routine (utils/wav2vec2.py:17-53) and the
+    installed transformers' `_compute_mask_indices` (what HubertModel._mask_hidden_states calls, utils/hubert.py:35),
+    both seeded through the global numpy RNG they consume."""
+    import utils.wav2vec2 as w2
+    from transformers.models.wav2vec2.modeling_wav2vec2 import _compute_mask_indices as hf_mask
+    out = {"transformers_version": np.array(transformers.__version__)}
+    cases = [(4, 200, 0.05, 10, 2), (32, 200, 0.05, 10, 2), (2, 500, 0.05, 10, 2), (3, 100, 0.3, 10, 2), (2, 40, 0.65, 10, 0)]
+    out["cases"] = np.array(cases, dtype=np.float64)
+    for i, (b, T, prob, length, mn) in enumerate(cases):
+        for seed in (0, 1234):
+            np.random.seed(seed)
+            out[f"ref_{i}_{seed}"] = w2._compute_mask_indices((b, T), prob, length, min_masks=mn)
+            np.random.seed(seed)
+            out[f"hf_{i}_{seed}"] = hf_mask((b, T), prob, length, min_masks=mn)
+    save("g1_specaug", **out)
+
+
+ALL = dict(g1_specaug=g1_specaug, g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
            g3_forward=g3_forward, g3_style=g3_style, g3_sample=g3_sample, g3_infer=g3_infer,
            g4_flame=g4_flame, g4_rotations=g4_rotations, g5_losses=g5_losses, g6_train=g6_train)
 

@@ -137,3 +137,80 @@ def test_fused_attention_functions_match_unfused_path():
     ag.FUSED_ATTENTION = True
     assert float((res[0][0] - res[1][0]).abs().max()) < 2e-2
     assert float((res[0][1] - res[1][1]).abs().max()) < 3e-2 * float(res[1][1].abs().max())
+
+
+def test_dropout_kernel_statistics_determinism_and_backward():
+    """msmd_dropout: keep rate and 1/(1-p) scaling, pure function of (seed, step, site), residual fusion, and the
+    backward (same call on dy) uses the very same mask."""
+    from msmd_amd import ops
+    n, p = 1 << 20, 0.1
+    state = torch.tensor([1234, 0], dtype=torch.int64, device=DEV)
+    for dt in (torch.bfloat16, torch.float32):
+        x = torch.ones(n + 3, device=DEV, dtype=dt)
+        y = ops.dropout(x, p, state, 7)
+        keep = (y != 0).float().mean().item()
+        assert abs(keep - (1 - p)) < 2e-3, keep
+        nz = y[y != 0].float()
+        assert float((nz - 1 / (1 - p)).abs().max()) < 1e-2
+        assert torch.equal(y, ops.dropout(x, p, state, 7))                  # deterministic
+        assert not torch.equal(y, ops.dropout(x, p, state, 8))              # other site
+        state[1] += 1
+        y2 = ops.dropout(x, p, state, 7)                                    # other step
+        assert not torch.equal(y, y2) and abs((y2 != 0).float().mean().item() - (1 - p)) < 2e-3
+        state[1] -= 1
+        r = torch.full_like(x, 2.0)
+        assert torch.equal(ops.dropout(x, p, state, 7, residual=r), (y.float() + 2.0).to(dt))
+        dy = torch.randn(n + 3, device=DEV).to(dt)
+        dx = ops.dropout(dy, p, state, 7)
+        assert torch.equal(dx != 0, (y != 0) & (dy != 0))
+    # mask bits are uncorrelated between neighbouring elements
+    y = ops.dropout(torch.ones(n, device=DEV), 0.5, state, 3)
+    k = (y != 0).float()
+    assert abs(float((k[1:] * k[:-1]).mean()) - 0.25) < 3e-3
+
+
+@pytest.mark.parametrize("Tq,Tk,masked", [(64, 64, False), (111, 60, True), (200, 48, False)])
+def test_fused_attention_dropout_forward_and_backward(Tq, Tk, masked):
+    """Attention-probability dropout inside the fused kernels.  The keep mask is read back by running the forward
+    with V = identity (O then IS the dropped probability matrix); forward and backward are then checked against
+    torch autograd of softmax(S) o mask / (1 - p) @ V with that mask."""
+    from msmd_amd import ops
+    B, H, pd, scale = 2, 2, 0.25, 0.125
+    d = H * 64
+    g = torch.Generator(device="cpu").manual_seed(Tq * 7 + Tk)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.7).to(torch.bfloat16).to(DEV)
+    q, k, v, do = mk(B, Tq, d), mk(B, Tk, d), mk(B, Tk, d), mk(B, Tq, d)
+    mask = None
+    if masked:
+        mask = torch.rand(Tq, Tk, generator=g) < 0.3
+        mask[:, 0] = False
+        mask = mask.to(DEV)
+    m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
+    state = torch.tensor([99, 5], dtype=torch.int64, device=DEV)
+    site = 11
+    eye = torch.zeros(B, Tk, d, device=DEV, dtype=torch.bfloat16)
+    for h in range(H):
+        eye[:, :, h * 64:h * 64 + Tk] = torch.eye(Tk, device=DEV, dtype=torch.bfloat16)
+    pdrop = ops.attention(q, k, eye, H, scale, m8, p_drop=pd, rng_state=state, site=site).float()
+    pdrop = pdrop.reshape(B, Tq, H, 64)[..., :Tk].permute(0, 2, 1, 3)            # (B, H, Tq, Tk)
+    keep = pdrop != 0
+    heads = lambda t: t.reshape(B, -1, H, 64).transpose(1, 2)
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    s = heads(qf) @ heads(kf).transpose(-1, -2) * scale
+    if mask is not None:
+        s = s.masked_fill(mask, float("-inf"))
+    P = torch.softmax(s, -1)
+    valid = P > 1e-6                                   # tiny probabilities may round to 0 in bf16: not "dropped"
+    rate = keep[valid].float().mean().item()
+    assert abs(rate - (1 - pd)) < 0.03, rate
+    assert float((pdrop - P.detach() * keep / (1 - pd)).abs().max()) < 1e-2
+    o_ref = ((P * keep / (1 - pd)) @ heads(vf)).transpose(1, 2).reshape(B, Tq, d)
+    o_ref.backward(do.float())
+    o = ops.attention(q, k, v, H, scale, m8, p_drop=pd, rng_state=state, site=site)
+    assert float((o.float() - o_ref.detach()).abs().max()) < 3e-2
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ops.attention_bwd(q, k, v, do, dq, dk, dv, H, scale, m8, pd, state, site)
+    torch.cuda.synchronize()
+    for got, ref, name in ((dq, qf.grad, "dq"), (dk, kf.grad, "dk"), (dv, vf.grad, "dv")):
+        err = float((got.float() - ref).abs().max())
+        assert err < 2.5e-2 * float(ref.abs().max()) + 1e-3, (name, err, float(ref.abs().max()))

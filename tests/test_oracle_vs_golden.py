@@ -258,3 +258,16 @@ def test_rotation_conversions():
         assert maxabs(Re, g[f"euler_angles_to_matrix_{conv}"]) <= 2e-6
         assert maxabs(orot.matrix_to_euler_angles(g[f"euler_angles_to_matrix_{conv}"], conv),
                       g[f"matrix_to_euler_angles_{conv}"]) <= 2e-5
+
+
+def test_specaugment_mask_indices_match_reference_and_hf():
+    """Host-side SpecAugment index routines (product code, pure numpy) against masks drawn by the reference's
+    wav2vec2 wrapper and by transformers' routine (HuBERT path) from the same numpy seeds."""
+    from msmd_amd.utils.wav2vec2 import compute_mask_indices, compute_mask_indices_hf
+    g = load_golden("g1_specaug")
+    for i, (b, T, prob, length, mn) in enumerate(g["cases"]):
+        for seed in (0, 1234):
+            a = compute_mask_indices((int(b), int(T)), float(prob), int(length), int(mn), np.random.RandomState(seed))
+            assert np.array_equal(a, g[f"ref_{i}_{seed}"]), ("ref", i, seed)
+            h = compute_mask_indices_hf((int(b), int(T)), float(prob), int(length), int(mn), np.random.RandomState(seed))
+            assert np.array_equal(h, g[f"hf_{i}_{seed}"]), ("hf", i, seed)

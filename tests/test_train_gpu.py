@@ -175,3 +175,43 @@ def test_trainer_hipgraph_step_matches_eager():
     torch.cuda.synchronize()
     assert all(torch.isfinite(v).all() for v in list(o2.values()) + list(o3.values()) + list(o4.values()))
     assert len(trg._graphs) >= 2
+
+
+def test_trainer_train_mode_noise_eager_and_graph():
+    """model.train(): dropout / LayerDrop / SpecAugment are live (losses differ from eval mode and from step to
+    step on a fixed batch with fixed draws), in eager mode and under hipGraph replay; eval mode is unaffected."""
+    from msmd_amd import autograd as ag
+    from msmd_amd.model import get_diffusion_model
+    from msmd_amd.style_encoder import get_style_encoder
+    from msmd_amd.training_script import Trainer, synthetic_batch
+    args = default_args(compute_dtype="bf16", encoder_layers=2, n_layers=2, lr=0.0, warm_iter=0,
+                        gradient_accumulation_steps=1)
+    B = 2
+    batch = synthetic_batch(B, 0, DEV)
+    draws = dict(cross=[False, True], end_idx=[torch.tensor([60, 100], device=DEV), None], t=[[5, 400], [250, 20]],
+                 eps=[dev(synth.normalish(f"tr/eps{i}", (B, 100, 67))) for i in range(2)],
+                 style_eps=[dev(synth.normalish(f"tr/se{i}", (B, 256))) for i in range(2)],
+                 cfg_flag=[dev(np.array([0.1, 0.7], np.float32)), dev(np.array([0.95, 0.3], np.float32))])
+    try:
+        vals = {}
+        for mode, use_graph in (("eval", False), ("train", False), ("train", True)):
+            torch.manual_seed(0)
+            model = get_diffusion_model(args, DEV)
+            se = get_style_encoder(args, "vae2").to(DEV)
+            (model.train() if mode == "train" else model.eval())
+            tr = Trainer(args, model, se, use_graph=use_graph)
+            outs = [float(tr.step(batch, it=i, draws=draws)["noise"]) for i in (1, 2, 3)]
+            torch.cuda.synchronize()
+            assert all(np.isfinite(outs)), (mode, use_graph, outs)
+            vals[(mode, use_graph)] = outs
+            # gradients reached the SpecAugment embedding only in train mode (lr = 0: weights never move)
+        e, t_eager, t_graph = vals[("eval", False)], vals[("train", False)], vals[("train", True)]
+        assert max(abs(a - e[0]) for a in e) < 2e-2 * abs(e[0])               # eval: same loss every step (lr = 0)
+        for t in (t_eager, t_graph):
+            assert len({round(x, 5) for x in t}) == 3                           # fresh masks every step
+            assert all(abs(x - e[0]) > 1e-4 for x in t)                          # and not the eval value
+            assert all(abs(x - e[0]) < 0.5 * abs(e[0]) for x in t)               # yet the same ballpark
+    finally:
+        ag.TrainNoise.active = False
+        ag.TrainNoise.graph_safe = False
+        ag.TrainNoise.spec_masks = None

@@ -149,7 +149,7 @@ class AttentionFn(torch.autograd.Function):
     q: (B, Tq, H*64), k / v: (B, Tk, H*64); last-dim-contiguous views of packed projections are accepted."""
 
     @staticmethod
-    def forward(ctx, q, k, v, n_heads, scale, mask):
+    def forward(ctx, q, k, v, n_heads, scale, mask, p_drop=0.0):
         B, Tq, d = q.shape
         Tk = k.shape[1]
         H = n_heads
@@ -160,13 +160,16 @@ class AttentionFn(torch.autograd.Function):
                           H, 64, 64, Tq * Tkp)
         m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
         ops.softmax_rows_(P, Tk, Tkp, Tq, scale, m8)
+        site = TrainNoise.next_site() if p_drop > 0.0 else 0
+        Pv = ops.dropout(P, p_drop, TrainNoise.state, site) if p_drop > 0.0 else P   # dropped probabilities feed P.V
         VT = (torch.zeros if Tkp != Tk else torch.empty)(B, H, 64, Tkp, device=q.device, dtype=dt)
         ops.transpose(v, VT, Tk, 64, v.stride(1), Tkp, B, v.stride(0), H * 64 * Tkp, H, 64, 64 * Tkp)
         O = torch.empty(B, Tq, d, device=q.device, dtype=dt)
-        ops.gemm_batched2(P, VT, O, Tq, 64, Tkp, Tkp, Tkp, d, B, H * Tq * Tkp, H * 64 * Tkp, Tq * d, H, Tq * Tkp,
+        ops.gemm_batched2(Pv, VT, O, Tq, 64, Tkp, Tkp, Tkp, d, B, H * Tq * Tkp, H * 64 * Tkp, Tq * d, H, Tq * Tkp,
                           64 * Tkp, 64)
         ctx.save_for_backward(q, k, v, P)
         ctx.dims = (B, H, Tq, Tk, Tkp, d, scale)
+        ctx.drop = (p_drop, site)
         return O
 
     @staticmethod
@@ -180,8 +183,10 @@ class AttentionFn(torch.autograd.Function):
         # dV_h = P_h^T . dO_h
         zq = torch.zeros if Tqp != Tq else torch.empty
         zk = torch.zeros if Tkp != Tk else torch.empty
+        p_drop, site = ctx.drop
+        Pv = ops.dropout(P, p_drop, TrainNoise.state, site) if p_drop > 0.0 else P
         PT = zq(B, H, Tk, Tqp, device=dev, dtype=dt)
-        ops.transpose(P, PT, Tq, Tk, Tkp, Tqp, B * H, Tq * Tkp, Tk * Tqp)
+        ops.transpose(Pv, PT, Tq, Tk, Tkp, Tqp, B * H, Tq * Tkp, Tk * Tqp)
         dOT = zq(B, H, 64, Tqp, device=dev, dtype=dt)
         ops.transpose(dO, dOT, Tq, 64, d, Tqp, B, Tq * d, H * 64 * Tqp, H, 64, 64 * Tqp)
         dV = torch.empty(B, Tk, d, device=dev, dtype=dt)
@@ -191,6 +196,8 @@ class AttentionFn(torch.autograd.Function):
         dP = torch.empty(B, H, Tq, Tkp, device=dev, dtype=dt)
         ops.gemm_batched2(dO, v, dP, Tq, Tk, 64, d, v.stride(1), Tkp, B, Tq * d, v.stride(0), H * Tq * Tkp, H, 64, 64,
                           Tq * Tkp)
+        if p_drop > 0.0:
+            dP = ops.dropout(dP, p_drop, TrainNoise.state, site)
         ops.softmax_bwd_rows_(P, dP, Tk, Tkp, scale)
         dS = dP
         # dQ_h = dS_h . K_h
@@ -207,7 +214,70 @@ class AttentionFn(torch.autograd.Function):
         dK = torch.empty(B, Tk, d, device=dev, dtype=dt)
         ops.gemm_batched2(dST, QT, dK, Tk, 64, Tqp, Tqp, Tqp, d, B, H * Tk * Tqp, H * 64 * Tqp, Tk * d, H, Tk * Tqp,
                           64 * Tqp, 64)
-        return dQ, dK, dV, None, None, None
+        return dQ, dK, dV, None, None, None, None
+
+
+class TrainNoise:
+    """Training-mode noise state shared by the autograd functions (reference: model.train() at
+    training_script.py:55 turns on every nn.Dropout, HF LayerDrop and SpecAugment).
+      active      -- regularisers on (Trainer sets it from model.training)
+      state       -- device int64 [seed, step]; kernels read it, so a captured hipGraph draws new masks per replay
+      site        -- per-iteration call-site counter (reset by begin()): with (seed, step) it keys each mask
+      graph_safe  -- no host-side decisions (LayerDrop becomes a device-side select)
+    """
+    active = False
+    state = None
+    site = 0
+    graph_safe = False
+    host_rng = None
+    spec_masks = None   # list of (B, T) bool device tensors consumed in order by audio_encoder_train, or None
+
+    @classmethod
+    def begin(cls):
+        cls.site = 0
+        cls._spec_i = 0
+
+    @classmethod
+    def next_site(cls):
+        cls.site += 1
+        return cls.site
+
+    @classmethod
+    def next_spec_mask(cls):
+        if cls.spec_masks is None:
+            return None
+        m = cls.spec_masks[cls._spec_i]
+        cls._spec_i += 1
+        return m
+
+
+class DropoutFn(torch.autograd.Function):
+    """y = dropout_p(x) (+ residual); the mask is regenerated in the backward from (state, site)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, p, site):
+        ctx.p, ctx.site, ctx.has_r = p, site, residual is not None
+        return ops.dropout(x, p, TrainNoise.state, site, residual)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = ops.dropout(dy, ctx.p, TrainNoise.state, ctx.site)
+        return dx, (dy if ctx.has_r else None), None, None
+
+
+def dropout(x, p, residual=None):
+    """nn.Dropout(p) in the current mode, optionally fused with the residual add that follows it."""
+    if not TrainNoise.active or p <= 0.0:
+        return x if residual is None else x + residual
+    return DropoutFn.apply(x, residual, float(p), TrainNoise.next_site())
+
+
+def linear_dropout(x, w, b, p, residual=None, act=ACT_NONE):
+    """dropout_p(act(x W^T + b)) + residual: eval mode keeps the residual fused in the GEMM epilogue."""
+    if not TrainNoise.active or p <= 0.0:
+        return linear(x, w, b, act=act, residual=residual)
+    return dropout(linear(x, w, b, act=act), p, residual)
 
 
 class FusedSelfAttnFn(torch.autograd.Function):
@@ -215,45 +285,48 @@ class FusedSelfAttnFn(torch.autograd.Function):
     (msmd_attention_bwd, P recomputed); the gradient comes back as ONE packed tensor (no slice / cat glue)."""
 
     @staticmethod
-    def forward(ctx, qkv, n_heads, scale, mask):
+    def forward(ctx, qkv, n_heads, scale, mask, p_drop, site):
         d = qkv.shape[-1] // 3
         qkv = qkv.contiguous()
         m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
-        o = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], n_heads, scale, m8)
+        o = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], n_heads, scale, m8, p_drop=p_drop,
+                          rng_state=TrainNoise.state, site=site)
         ctx.save_for_backward(qkv, m8)
-        ctx.cfg = (n_heads, scale, d)
+        ctx.cfg = (n_heads, scale, d, p_drop, site)
         return o
 
     @staticmethod
     def backward(ctx, do):
         qkv, m8 = ctx.saved_tensors
-        H, scale, d = ctx.cfg
+        H, scale, d, p_drop, site = ctx.cfg
         dqkv = torch.empty_like(qkv)
         ops.attention_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], do.contiguous(), dqkv[..., :d],
-                          dqkv[..., d:2 * d], dqkv[..., 2 * d:], H, scale, m8)
-        return dqkv, None, None, None
+                          dqkv[..., d:2 * d], dqkv[..., 2 * d:], H, scale, m8, p_drop, TrainNoise.state, site)
+        return dqkv, None, None, None, None, None
 
 
 class FusedCrossAttnFn(torch.autograd.Function):
     """Cross-attention: q (B, Tq, d), packed kv (B, Tk, 2 d)."""
 
     @staticmethod
-    def forward(ctx, q, kv, n_heads, scale, mask):
+    def forward(ctx, q, kv, n_heads, scale, mask, p_drop, site):
         d = q.shape[-1]
         q, kv = q.contiguous(), kv.contiguous()
         m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
-        o = ops.attention(q, kv[..., :d], kv[..., d:], n_heads, scale, m8)
+        o = ops.attention(q, kv[..., :d], kv[..., d:], n_heads, scale, m8, p_drop=p_drop, rng_state=TrainNoise.state,
+                          site=site)
         ctx.save_for_backward(q, kv, m8)
-        ctx.cfg = (n_heads, scale, d)
+        ctx.cfg = (n_heads, scale, d, p_drop, site)
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, kv, m8 = ctx.saved_tensors
-        H, scale, d = ctx.cfg
+        H, scale, d, p_drop, site = ctx.cfg
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
-        ops.attention_bwd(q, kv[..., :d], kv[..., d:], do.contiguous(), dq, dkv[..., :d], dkv[..., d:], H, scale, m8)
-        return dq, dkv, None, None, None
+        ops.attention_bwd(q, kv[..., :d], kv[..., d:], do.contiguous(), dq, dkv[..., :d], dkv[..., d:], H, scale, m8,
+                          p_drop, TrainNoise.state, site)
+        return dq, dkv, None, None, None, None, None
 
 
 FUSED_ATTENTION = True
@@ -263,19 +336,26 @@ def _fusable(x, Tk):
     return FUSED_ATTENTION and x.dtype == torch.bfloat16 and Tk <= 256
 
 
-def self_attention(qkv, n_heads, scale, mask=None):
-    """softmax(scale Q K^T) V on a packed (B, T, 3 d) projection."""
+def _pdrop(p):
+    return float(p) if (TrainNoise.active and p > 0.0) else 0.0
+
+
+def self_attention(qkv, n_heads, scale, mask=None, p_drop=0.0):
+    """softmax(scale Q K^T) V on a packed (B, T, 3 d) projection; p_drop = attention-probability dropout, applied
+    in train mode only."""
     d = qkv.shape[-1] // 3
+    p_drop = _pdrop(p_drop)
     if _fusable(qkv, qkv.shape[1]):
-        return FusedSelfAttnFn.apply(qkv, n_heads, scale, mask)
-    return attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], n_heads, scale, mask)
+        return FusedSelfAttnFn.apply(qkv, n_heads, scale, mask, p_drop, TrainNoise.next_site() if p_drop else 0)
+    return attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], n_heads, scale, mask, p_drop)
 
 
-def cross_attention(q, kv, n_heads, scale, mask=None):
+def cross_attention(q, kv, n_heads, scale, mask=None, p_drop=0.0):
     d = q.shape[-1]
+    p_drop = _pdrop(p_drop)
     if _fusable(q, kv.shape[1]):
-        return FusedCrossAttnFn.apply(q, kv, n_heads, scale, mask)
-    return attention(q, kv[..., :d], kv[..., d:], n_heads, scale, mask)
+        return FusedCrossAttnFn.apply(q, kv, n_heads, scale, mask, p_drop, TrainNoise.next_site() if p_drop else 0)
+    return attention(q, kv[..., :d], kv[..., d:], n_heads, scale, mask, p_drop)
 
 
 def linear(x, w, b=None, act=ACT_NONE, residual=None):
@@ -286,5 +366,5 @@ def layer_norm(x, gamma, beta, post_add=None):
     return LayerNormFn.apply(x, gamma, beta, post_add)
 
 
-def attention(q, k, v, n_heads, scale, mask=None):
-    return AttentionFn.apply(q, k, v, n_heads, scale, mask)
+def attention(q, k, v, n_heads, scale, mask=None, p_drop=0.0):
+    return AttentionFn.apply(q, k, v, n_heads, scale, mask, _pdrop(p_drop))

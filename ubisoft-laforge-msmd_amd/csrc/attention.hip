@@ -16,6 +16,9 @@ struct AttnArgs {
   long qb, qt, kb, kt, vb, vt, ob, ot;
   float scale;
   const uint8_t* mask;
+  float p_drop;                     // attention-probability dropout (training); 0 = off
+  const unsigned long* rng_state;   // device [seed, step]
+  unsigned site;
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -128,6 +131,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
     ps += __shfl_xor(ps, 32, 64);
     l_run = l_run * alpha + ps;
     m_run = m_new;
+    if (p.p_drop > 0.f) {  // drop probabilities AFTER the softmax denominator; the 1/(1-p) factor is applied to O
+      const unsigned thr = dropout_threshold(p.p_drop);
+      const unsigned long rowbase = ((unsigned long)(b * p.H + h) * p.Tq + qrow) * 128ul;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const Philox4 r = dropout_bits(p.rng_state, p.site, rowbase + (unsigned long)((kv0 >> 2) + 4 * f + fq));
+        s[f][0] = r.x >= thr ? s[f][0] : 0.f;
+        s[f][1] = r.y >= thr ? s[f][1] : 0.f;
+        s[f][2] = r.z >= thr ? s[f][2] : 0.f;
+        s[f][3] = r.w >= thr ? s[f][3] : 0.f;
+      }
+    }
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   }
 
   if (query < p.Tq) {
-    const float inv = 1.0f / l_run;
+    const float inv = 1.0f / (l_run * (1.0f - p.p_drop));
     T* Op = (T*)p.O + (long)b * p.ob + (long)query * p.ot + h * 64;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -185,18 +200,20 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   }
 }
 
-extern "C" int msmd_attention(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
-                              long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
-                              long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
-                              int dtype, msmd_stream_t stream) {
+static int attention_impl(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
+                          long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
+                          long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
+                          float p_drop, const unsigned long* rng_state, unsigned site, int dtype,
+                          msmd_stream_t stream) {
   if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || !Q || !K || !V || !O) return 1;
+  if (!(p_drop >= 0.f && p_drop < 1.f) || (p_drop > 0.f && (!rng_state || Tk > 512))) return 1;
   const int E = dtype == MSMD_BF16 ? 8 : 4;
   if (q_tstride % E || k_tstride % E || v_tstride % E || o_tstride % 4 || q_bstride % E || k_bstride % E ||
       v_bstride % E || o_bstride % 4)
     return 1;
   if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)V & 15) || ((uintptr_t)O & 15)) return 1;
   AttnArgs p{Q, K, V, O, B, H, Tq, Tk, q_bstride, q_tstride, k_bstride, k_tstride, v_bstride, v_tstride,
-             o_bstride, o_tstride, scale, mask};
+             o_bstride, o_tstride, scale, mask, p_drop, rng_state, site};
   dim3 grid((Tq + 63) / 64, H, B), block(256);
   if (dtype == MSMD_BF16)
     hipLaunchKernelGGL(attn_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);
@@ -205,4 +222,23 @@ extern "C" int msmd_attention(const void* Q, const void* K, const void* V, void*
   else
     return 1;
   MSMD_RETURN_LAST();
+}
+
+extern "C" int msmd_attention(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
+                              long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
+                              long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
+                              int dtype, msmd_stream_t stream) {
+  return attention_impl(Q, K, V, O, B, H, Tq, Tk, q_bstride, q_tstride, k_bstride, k_tstride, v_bstride, v_tstride,
+                        o_bstride, o_tstride, scale, mask, 0.f, nullptr, 0u, dtype, stream);
+}
+
+// Training-mode forward: probabilities are dropped with probability p_drop (mask = Philox(rng_state, site,
+// (b, h, q, key / 4)), regenerated by msmd_attention_bwd with the same arguments).  Tk <= 512.
+extern "C" int msmd_attention_dropout(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq,
+                                      int Tk, long q_bstride, long q_tstride, long k_bstride, long k_tstride,
+                                      long v_bstride, long v_tstride, long o_bstride, long o_tstride, float scale,
+                                      const uint8_t* mask, float p_drop, const unsigned long* rng_state,
+                                      unsigned int site, int dtype, msmd_stream_t stream) {
+  return attention_impl(Q, K, V, O, B, H, Tq, Tk, q_bstride, q_tstride, k_bstride, k_tstride, v_bstride, v_tstride,
+                        o_bstride, o_tstride, scale, mask, p_drop, rng_state, site, dtype, stream);
 }

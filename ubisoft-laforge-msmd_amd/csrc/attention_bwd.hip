@@ -31,6 +31,9 @@ struct AbArgs {
   int B, H, Tq, Tk;
   long q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, do_bs, do_ts, dq_bs, dq_ts, dk_bs, dk_ts, dv_bs, dv_ts;
   float scale;
+  float p_drop;
+  const unsigned long* rng_state;
+  unsigned site;
 };
 
 // byte offset of 16-byte chunk ch (0..7) of row `row` in a [rows][64] bf16 image
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AbArgs p) {
       dof[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(sdO + img_off(qrow, 4 * ks + fq)));
     }
     f32x4 s[NKF], dp[NKF];
+    unsigned long keep = ~0ul;  // 4 keep bits per key fragment
 #pragma unroll
     for (int f = 0; f < NKF; ++f) {
       s[f] = dp[f] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -147,6 +151,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AbArgs p) {
     l += __shfl_xor(l, 32, 64);
     const float inv_l = l > 0.f ? 1.0f / l : 0.f;
     float delta = 0.f;
+    if (p.p_drop > 0.f) {  // same Philox mask as the forward: dP <- dP o keep / (1 - p)
+      const unsigned thr = dropout_threshold(p.p_drop);
+      const float c = 1.0f / (1.0f - p.p_drop);
+      const unsigned long rowbase = ((unsigned long)blockIdx.x * p.Tq + min(qglob, p.Tq - 1)) * 128ul;
+#pragma unroll
+      for (int f = 0; f < NKF; ++f) {
+        const Philox4 r = dropout_bits(p.rng_state, p.site, rowbase + (unsigned long)(4 * f + fq));
+        dp[f][0] = r.x >= thr ? dp[f][0] * c : 0.f;
+        dp[f][1] = r.y >= thr ? dp[f][1] * c : 0.f;
+        dp[f][2] = r.z >= thr ? dp[f][2] * c : 0.f;
+        dp[f][3] = r.w >= thr ? dp[f][3] * c : 0.f;
+        const unsigned long k4 = (r.x >= thr ? 1u : 0u) | (r.y >= thr ? 2u : 0u) | (r.z >= thr ? 4u : 0u) | (r.w >= thr ? 8u : 0u);
+        keep = (keep & ~(15ul << (4 * f))) | (k4 << (4 * f));
+      }
+    }
 #pragma unroll
     for (int f = 0; f < NKF; ++f)
 #pragma unroll
@@ -156,13 +175,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AbArgs p) {
       }
     delta += __shfl_xor(delta, 16, 64);
     delta += __shfl_xor(delta, 32, 64);
+    const float drop_c = 1.0f / (1.0f - p.p_drop);
     // P and dS (bf16) -> registers for dQ and -> the [q][key] LDS images for the dV / dK phase
     bf16x4 pb[NKF], dsb[NKF];
 #pragma unroll
     for (int f = 0; f < NKF; ++f) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        pb[f][e] = (bf16_t)s[f][e];
+        pb[f][e] = (bf16_t)(((keep >> (4 * f + e)) & 1ul) ? s[f][e] * drop_c : 0.f);  // P o keep / (1 - p) feeds dV
         dsb[f][e] = (bf16_t)(s[f][e] * (dp[f][e] - delta) * p.scale);
       }
       *(bf16x4*)(sP + qrow * RS + f * 32 + fq * 8) = pb[f];
@@ -269,9 +289,10 @@ extern "C" int msmd_attention_bwd(const void* Q, const void* K, const void* V, c
                                   void* dV, int B, int H, int Tq, int Tk, long q_bstride, long q_tstride,
                                   long k_bstride, long k_tstride, long v_bstride, long v_tstride, long do_bstride,
                                   long do_tstride, long dq_bstride, long dq_tstride, long dk_bstride, long dk_tstride,
-                                  long dv_bstride, long dv_tstride, float scale, const uint8_t* mask,
-                                  msmd_stream_t stream) {
+                                  long dv_bstride, long dv_tstride, float scale, const uint8_t* mask, float p_drop,
+                                  const unsigned long* rng_state, unsigned int site, msmd_stream_t stream) {
   if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || Tk > 256) return 1;
+  if (!(p_drop >= 0.f && p_drop < 1.f) || (p_drop > 0.f && !rng_state)) return 1;
   const long strides[] = {q_bstride, q_tstride, k_bstride, k_tstride, v_bstride, v_tstride, do_bstride, do_tstride,
                           dq_bstride, dq_tstride, dk_bstride, dk_tstride, dv_bstride, dv_tstride};
   for (long s : strides)
@@ -286,7 +307,7 @@ extern "C" int msmd_attention_bwd(const void* Q, const void* K, const void* V, c
   p.q_bs = q_bstride; p.q_ts = q_tstride; p.k_bs = k_bstride; p.k_ts = k_tstride; p.v_bs = v_bstride; p.v_ts = v_tstride;
   p.do_bs = do_bstride; p.do_ts = do_tstride; p.dq_bs = dq_bstride; p.dq_ts = dq_tstride;
   p.dk_bs = dk_bstride; p.dk_ts = dk_tstride; p.dv_bs = dv_bstride; p.dv_ts = dv_tstride;
-  p.scale = scale;
+  p.scale = scale; p.p_drop = p_drop; p.rng_state = rng_state; p.site = site;
   hipStream_t st = (hipStream_t)stream;
   const int nkf = (Tk + 15) / 16;
   if (nkf <= 7) return launch_attn_bwd<7>(p, st);

@@ -483,3 +483,41 @@ extern "C" int msmd_unfold_t(const void* xp, void* out, int B, int T, int Tp, in
                        T, Tp, G, Cg, Kk, ld_out);
   MSMD_RETURN_LAST();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// y = x * keep / (1 - p) (+ residual), keep ~ Bernoulli(1 - p) from Philox(seed, step, site, index / 4).
+// The same call with x = dy (no residual) is the backward.  n % 4 need not hold.
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, const T* __restrict__ residual,
+                                                      T* __restrict__ y, long n, float p,
+                                                      const unsigned long* __restrict__ rng_state, unsigned site) {
+  const unsigned thr = dropout_threshold(p);
+  const float c = 1.0f / (1.0f - p);
+  const long nq = (n + 3) >> 2;
+  for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+    const Philox4 r = dropout_bits(rng_state, site, (unsigned long)q);
+    const unsigned bits[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long i = q * 4 + j;
+      if (i < n) {
+        float v = bits[j] >= thr ? to_f32(x[i]) * c : 0.f;
+        if (residual) v += to_f32(residual[i]);
+        y[i] = from_f32<T>(v);
+      }
+    }
+  }
+}
+
+extern "C" int msmd_dropout(const void* x, const void* residual, void* y, long n, float p,
+                            const unsigned long* rng_state, unsigned int site, int dtype, msmd_stream_t stream) {
+  if (n <= 0 || !(p >= 0.f && p < 1.f) || !rng_state) return 1;
+  dim3 grid((unsigned)min(((n + 3) / 4 + 255) / 256, (long)8192)), block(256);
+  if (dtype == MSMD_F32)
+    hipLaunchKernelGGL(dropout_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)x,
+                       (const float*)residual, (float*)y, n, p, rng_state, site);
+  else
+    hipLaunchKernelGGL(dropout_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (const bf16_t*)residual, (bf16_t*)y, n, p, rng_state, site);
+  MSMD_RETURN_LAST();
+}

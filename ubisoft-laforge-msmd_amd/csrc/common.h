@@ -18,6 +18,29 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define MSMD_WAVE 64
 
 // Launch-error plumbing: every extern "C" launcher returns a hipError_t-compatible int.
+// Philox4x32-10 (Salmon et al. 2011): counter-based, so a dropout mask is a pure function of
+// (seed, step, call site, element index) and the backward pass regenerates it instead of storing it.
+struct Philox4 { unsigned x, y, z, w; };
+__device__ __forceinline__ Philox4 philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned lo0 = 0xD2511F53u * c0, hi0 = __umulhi(0xD2511F53u, c0);
+    const unsigned lo1 = 0xCD9E8D57u * c2, hi1 = __umulhi(0xCD9E8D57u, c2);
+    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox4{c0, c1, c2, c3};
+}
+// rng_state (device): [0] = seed, [1] = step counter (advanced by the host side once per iteration / graph replay)
+__device__ __forceinline__ Philox4 dropout_bits(const unsigned long* __restrict__ rng_state, unsigned site, unsigned long idx) {
+  const unsigned long seed = rng_state[0], step = rng_state[1];
+  return philox4x32((unsigned)idx, (unsigned)(idx >> 32), site, (unsigned)step, (unsigned)seed,
+                    (unsigned)(seed >> 32) ^ (unsigned)(step >> 32));
+}
+// keep iff uniform [0,1) >= p  <=>  bits >= p * 2^32
+__device__ __forceinline__ unsigned dropout_threshold(float p) { return (unsigned)fminf(p * 4294967296.0f, 4294967295.0f); }
+
 extern int g_tuning[8];  // msmd_set_tuning knobs (gemm.hip)
 #define MSMD_RETURN_LAST() return (int)hipGetLastError()
 

@@ -138,7 +138,20 @@ def layernorm(x, gamma, beta, residual=None, post_add=None, act=ACT_NONE, eps=1e
     return y
 
 
-def attention(q, k, v, n_heads, scale, mask=None, out=None):
+def dropout(x, p, rng_state, site, residual=None, out=None):
+    """y = x * keep / (1 - p) (+ residual); keep = Philox(rng_state[seed, step], site, element / 4).  Calling it on
+    the upstream gradient with the same (rng_state, site) is the backward."""
+    _need_cuda(x, rng_state)
+    x = x.contiguous()
+    if residual is not None:
+        residual = residual.contiguous()
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.load().msmd_dropout(_p(x), _p(residual), _p(out), x.numel(), float(p), _p(rng_state), int(site),
+                                        _dt(x), _stream()), "msmd_dropout")
+    return out
+
+
+def attention(q, k, v, n_heads, scale, mask=None, out=None, p_drop=0.0, rng_state=None, site=0):
     """q: (B, Tq, H*64) view, k/v: (B, Tk, H*64) views (last dim contiguous; may be slices of a packed QKV)."""
     _need_cuda(q, k, v)
     lib = _lib.load()
@@ -151,13 +164,19 @@ def attention(q, k, v, n_heads, scale, mask=None, out=None):
     if mask is not None:
         assert mask.dtype in (torch.bool, torch.uint8) and mask.shape == (Tq, Tk) and mask.is_contiguous()
         m = mask
+    if p_drop > 0.0:
+        _lib.check(lib.msmd_attention_dropout(_p(q), _p(k), _p(v), _p(out), B, n_heads, Tq, Tk, q.stride(0),
+                                              q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                                              out.stride(0), out.stride(1), float(scale), _p(m), float(p_drop),
+                                              _p(rng_state), int(site), _dt(q), _stream()), "msmd_attention_dropout")
+        return out
     _lib.check(lib.msmd_attention(_p(q), _p(k), _p(v), _p(out), B, n_heads, Tq, Tk, q.stride(0), q.stride(1),
                                   k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),
                                   float(scale), _p(m), _dt(q), _stream()), "msmd_attention")
     return out
 
 
-def attention_bwd(q, k, v, do, dq, dk, dv, n_heads, scale, mask=None):
+def attention_bwd(q, k, v, do, dq, dk, dv, n_heads, scale, mask=None, p_drop=0.0, rng_state=None, site=0):
     """Fused backward of `attention` (bf16, Tk <= 256): fills dq / dk / dv (views with last dim contiguous)."""
     _need_cuda(q, k, v, do, dq, dk, dv)
     lib = _lib.load()
@@ -173,7 +192,8 @@ def attention_bwd(q, k, v, do, dq, dk, dv, n_heads, scale, mask=None):
     _lib.check(lib.msmd_attention_bwd(_p(q), _p(k), _p(v), _p(do), _p(dq), _p(dk), _p(dv), B, n_heads, Tq, Tk,
                                       q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
                                       do.stride(0), do.stride(1), dq.stride(0), dq.stride(1), dk.stride(0),
-                                      dk.stride(1), dv.stride(0), dv.stride(1), float(scale), _p(m), _stream()),
+                                      dk.stride(1), dv.stride(0), dv.stride(1), float(scale), _p(m), float(p_drop),
+                                      _p(rng_state), int(site), _stream()),
                "msmd_attention_bwd")
 
 

@@ -5,18 +5,23 @@ op is an `autograd.Function` whose forward and backward are HIP kernels (autogra
 here, on purpose, for round 1 of the training row: tensor concatenation / slicing / dtype casts / residual adds
 and the final static-basis mix on (N, 110, 67)-sized tensors run as PyTorch autograd ops (plumbing-sized data).
 
-Semantics: eval-mode arithmetic (no dropout / LayerDrop / SpecAugment): the reference's stochastic regularisers
-are not reproduced yet; gradient parity is asserted against the reference's autograd in eval mode
-(tests/golden g6_train).  The frozen conv feature extractor runs the no-grad inference kernels
-(reference model.py:97: `_freeze_parameters`).
+Semantics: with `autograd.TrainNoise.active` False this is eval-mode arithmetic, and gradient parity is asserted
+against the reference's autograd in eval mode (tests/golden g6_train).  With it True (Trainer: model.training, the
+reference trains under model.train(), training_script.py:55) the stochastic regularisers are applied where the
+reference's modules apply them: nn.Dropout after every projection / activation / residual branch and on the
+attention probabilities (Philox masks regenerated in the backward, never stored), HF LayerDrop, and SpecAugment
+time masks drawn by the reference's own index routine (bit-identical for a given numpy seed).  The frozen conv
+feature extractor runs the no-grad inference kernels (reference model.py:97: `_freeze_parameters`).
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import autograd as ag
 from . import ops
 from .utils.model_common import pad_audio_plan
+from .utils.wav2vec2 import compute_mask_indices, compute_mask_indices_hf
 from .utils.wav2vec2 import CONV_KERNEL, CONV_STRIDE  # noqa: F401
 
 
@@ -104,26 +109,49 @@ def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
         if not (crop == T50 and frame_num == T50):
             x = ops.interp_linear(x, frame_num, crop)
     g = lambda n: enc.get_parameter(n)
+    noise = ag.TrainNoise
     h = ag.layer_norm(x, g("feature_projection.layer_norm.weight"), g("feature_projection.layer_norm.bias"))
-    h = ag.linear(h, g("feature_projection.projection.weight"), g("feature_projection.projection.bias"))
+    h = ag.linear_dropout(h, g("feature_projection.projection.weight"), g("feature_projection.projection.bias"),
+                          c.feat_proj_dropout)
+    if noise.active and c.apply_spec_augment and c.mask_time_prob > 0:
+        # SpecAugment (utils/wav2vec2.py:99-105 / HF _mask_hidden_states): masked frames <- masked_spec_embed
+        m = noise.next_spec_mask()
+        if m is None:
+            fn = compute_mask_indices_hf if enc.model_type == "hubert" else compute_mask_indices
+            m = torch.from_numpy(fn((h.shape[0], h.shape[1]), c.mask_time_prob, c.mask_time_length,
+                                    c.mask_time_min_masks, noise.host_rng)).to(h.device)
+        h = torch.where(m.unsqueeze(-1), g("masked_spec_embed").to(h.dtype), h)
     w = _fold_weight_norm(g("encoder.pos_conv_embed.conv.weight_g"), g("encoder.pos_conv_embed.conv.weight_v"))
     z = PosConvFn.apply(h, w, g("encoder.pos_conv_embed.conv.bias"))
     h = h + ag_act(z, ops.ACT_GELU)
     h = ag.layer_norm(h, g("encoder.layer_norm.weight"), g("encoder.layer_norm.bias"))
+    h = ag.dropout(h, c.hidden_dropout)
     d, H = c.hidden_size, c.num_attention_heads
     for n in range(c.num_hidden_layers):
+        # LayerDrop (HF Wav2Vec2Encoder): skip the layer with probability layerdrop.  Eager mode skips for real (host
+        # draw, as HF's torch.rand([])); graph-safe mode computes the layer and selects on a device-side draw.
+        skip_flag = None
+        if noise.active and c.layerdrop > 0:
+            if noise.graph_safe:
+                skip_flag = torch.rand((), device=h.device) < c.layerdrop
+            elif (noise.host_rng if noise.host_rng is not None else np.random).rand() < c.layerdrop:
+                continue
+        h_in = h
         p = f"encoder.layers.{n}."
         wq, wk, wv = (g(p + f"attention.{k}_proj.weight") for k in "qkv")
         bq, bk, bv = (g(p + f"attention.{k}_proj.bias") for k in "qkv")
         qkv = ag.linear(h, torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0))
-        a = ag.self_attention(qkv, H, (d // H) ** -0.5)
-        h = ag.layer_norm(ag.linear(a, g(p + "attention.out_proj.weight"), g(p + "attention.out_proj.bias"),
-                                    residual=h), g(p + "layer_norm.weight"), g(p + "layer_norm.bias"))
-        f = ag.linear(h, g(p + "feed_forward.intermediate_dense.weight"), g(p + "feed_forward.intermediate_dense.bias"),
-                      act=ops.ACT_GELU)
-        h = ag.layer_norm(ag.linear(f, g(p + "feed_forward.output_dense.weight"),
-                                    g(p + "feed_forward.output_dense.bias"), residual=h),
+        a = ag.self_attention(qkv, H, (d // H) ** -0.5, p_drop=c.attention_dropout)
+        h = ag.layer_norm(ag.linear_dropout(a, g(p + "attention.out_proj.weight"), g(p + "attention.out_proj.bias"),
+                                            c.hidden_dropout, residual=h),
+                          g(p + "layer_norm.weight"), g(p + "layer_norm.bias"))
+        f = ag.linear_dropout(h, g(p + "feed_forward.intermediate_dense.weight"),
+                              g(p + "feed_forward.intermediate_dense.bias"), c.activation_dropout, act=ops.ACT_GELU)
+        h = ag.layer_norm(ag.linear_dropout(f, g(p + "feed_forward.output_dense.weight"),
+                                            g(p + "feed_forward.output_dense.bias"), c.hidden_dropout, residual=h),
                           g(p + "final_layer_norm.weight"), g(p + "final_layer_norm.bias"))
+        if skip_flag is not None:
+            h = torch.where(skip_flag, h_in, h)
     return h
 
 
@@ -174,21 +202,22 @@ def denoiser_train(net, motion_noisy, audio_feat, person_feat, static_style_feat
     mem = torch.cat([prev_audio_feat.to(dtype), audio_feat.to(dtype)], dim=1)
     scale = (d // H) ** -0.5
     mask = net.alignment_mask
+    pd = 0.1  # nn.TransformerDecoderLayer default dropout (model.py:874-877 passes none): dropout1-3, FFN, attention
     for n in range(net.n_layers):
         p = f"transformer.layers.{n}."
         qkv = ag.linear(x, g(p + "self_attn.in_proj_weight"), g(p + "self_attn.in_proj_bias"))
-        a = ag.self_attention(qkv, H, scale)
-        x = ag.layer_norm(ag.linear(a, g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias"), residual=x),
-                          g(p + "norm1.weight"), g(p + "norm1.bias"))
+        a = ag.self_attention(qkv, H, scale, p_drop=pd)
+        x = ag.layer_norm(ag.linear_dropout(a, g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias"), pd,
+                                            residual=x), g(p + "norm1.weight"), g(p + "norm1.bias"))
         w, b = g(p + "multihead_attn.in_proj_weight"), g(p + "multihead_attn.in_proj_bias")
         q = ag.linear(x, w[:d], b[:d])
         kv = ag.linear(mem, w[d:], b[d:])
-        cattn = ag.cross_attention(q, kv, H, scale, mask)
-        x = ag.layer_norm(ag.linear(cattn, g(p + "multihead_attn.out_proj.weight"),
-                                    g(p + "multihead_attn.out_proj.bias"), residual=x),
+        cattn = ag.cross_attention(q, kv, H, scale, mask, p_drop=pd)
+        x = ag.layer_norm(ag.linear_dropout(cattn, g(p + "multihead_attn.out_proj.weight"),
+                                            g(p + "multihead_attn.out_proj.bias"), pd, residual=x),
                           g(p + "norm2.weight"), g(p + "norm2.bias"))
-        f = ag.linear(x, g(p + "linear1.weight"), g(p + "linear1.bias"), act=ops.ACT_GELU)
-        x = ag.layer_norm(ag.linear(f, g(p + "linear2.weight"), g(p + "linear2.bias"), residual=x),
+        f = ag.linear_dropout(x, g(p + "linear1.weight"), g(p + "linear1.bias"), pd, act=ops.ACT_GELU)
+        x = ag.layer_norm(ag.linear_dropout(f, g(p + "linear2.weight"), g(p + "linear2.bias"), pd, residual=x),
                           g(p + "norm3.weight"), g(p + "norm3.bias"))
     dec = ag.linear(ag.linear(x[:, 1:].contiguous(), g("motion_dec.0.weight"), g("motion_dec.0.bias"),
                               act=ops.ACT_GELU), g("motion_dec.2.weight"), g("motion_dec.2.bias")).float()
@@ -219,20 +248,28 @@ def style_encoder_train(se, motion_coef, dtype):
     g = lambda n: se.get_parameter(n)
     B, T, _ = motion_coef.shape
     x = motion_coef.to(dtype)
-    x = ag.layer_norm(_conv3(x, g("input_layers.1.weight"), g("input_layers.1.bias"), ops.ACT_ELU),
-                      g("input_layers.5.weight"), g("input_layers.5.bias"))
-    x = ag.layer_norm(_conv3(x, g("input_layers.7.weight"), g("input_layers.7.bias"), ops.ACT_ELU),
-                      g("input_layers.11.weight"), g("input_layers.11.bias"), post_add=se.PE.pe[0, T].float().contiguous())
+    on = ag.TrainNoise.active
+
+    def conv_drop_elu(x, name, p):
+        """Conv1d -> Dropout(p) -> ELU (style_encoder.py:137-140): the activation stays fused in eval mode."""
+        if not on:
+            return _conv3(x, g(name + ".weight"), g(name + ".bias"), ops.ACT_ELU)
+        return ag_act(ag.dropout(_conv3(x, g(name + ".weight"), g(name + ".bias"), ops.ACT_NONE), p), ops.ACT_ELU)
+
+    x = ag.layer_norm(conv_drop_elu(x, "input_layers.1", 0.2), g("input_layers.5.weight"), g("input_layers.5.bias"))
+    x = ag.layer_norm(conv_drop_elu(x, "input_layers.7", 0.2), g("input_layers.11.weight"), g("input_layers.11.bias"),
+                      post_add=se.PE.pe[0, T].float().contiguous())
+    x = ag.dropout(x, 0.1)                                   # PositionalEncoding dropout (utils/model_common.py:101)
     d = se.conv_feature_dim
+    pd = 0.1                                                 # nn.TransformerEncoderLayer default dropout
     qkv = ag.linear(x, g("encoder.self_attn.in_proj_weight"), g("encoder.self_attn.in_proj_bias"))
-    a = ag.self_attention(qkv, 8, 64 ** -0.5)
-    x = ag.layer_norm(ag.linear(a, g("encoder.self_attn.out_proj.weight"), g("encoder.self_attn.out_proj.bias"),
-                                residual=x), g("encoder.norm1.weight"), g("encoder.norm1.bias"))
-    f = ag.linear(x, g("encoder.linear1.weight"), g("encoder.linear1.bias"), act=ops.ACT_GELU)
-    x = ag.layer_norm(ag.linear(f, g("encoder.linear2.weight"), g("encoder.linear2.bias"), residual=x),
+    a = ag.self_attention(qkv, 8, 64 ** -0.5, p_drop=pd)
+    x = ag.layer_norm(ag.linear_dropout(a, g("encoder.self_attn.out_proj.weight"), g("encoder.self_attn.out_proj.bias"),
+                                        pd, residual=x), g("encoder.norm1.weight"), g("encoder.norm1.bias"))
+    f = ag.linear_dropout(x, g("encoder.linear1.weight"), g("encoder.linear1.bias"), pd, act=ops.ACT_GELU)
+    x = ag.layer_norm(ag.linear_dropout(f, g("encoder.linear2.weight"), g("encoder.linear2.bias"), pd, residual=x),
                       g("encoder.norm2.weight"), g("encoder.norm2.bias"))
-    x = ag.layer_norm(_conv3(x, g("output_layers.1.weight"), g("output_layers.1.bias"), ops.ACT_ELU),
-                      g("output_layers.5.weight"), g("output_layers.5.bias"))
+    x = ag.layer_norm(conv_drop_elu(x, "output_layers.1", 0.1), g("output_layers.5.weight"), g("output_layers.5.bias"))
     x = _conv3(x, g("output_layers.7.weight"), g("output_layers.7.bias"), ops.ACT_NONE)
     out = x.float().mean(dim=1)
     h = se.output_size // 2

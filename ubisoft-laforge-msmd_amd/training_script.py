@@ -13,8 +13,13 @@ HIP autograd path (train_graph.py), data-parallel over one process per GPU:
     that DP over N ranks equals a single-process run on the global batch;
   * `it % gradient_accumulation_steps == 0` stepping as the reference (training_script.py:199).
 
-Not reproduced (documented): dropout / LayerDrop / SpecAugment noise, the reference's 3x empty_cache()+gc per
-iteration and its per-step .item() syncs (losses are returned as device tensors; log asynchronously).
+  * model.train() / model.eval() select the reference's training-time noise (dropout everywhere the reference's
+    modules have it, HF LayerDrop, SpecAugment; see train_graph.py) exactly as `model.train()` does at
+    training_script.py:55; masks come from a Philox stream keyed by a device-side (seed, step) pair, so the
+    hipGraph replay of iteration k draws iteration k's masks.
+
+Not reproduced (documented): the reference's 3x empty_cache()+gc per iteration and its per-step .item() syncs
+(losses are returned as device tensors; log asynchronously).
 The dataset / loader / tensorboard / CLI plumbing of the reference script is out of scope (SURVEY.md section 2
 rows 17-18); `synthetic_batch` produces the loader's tensor contract.
 """
@@ -76,6 +81,8 @@ class Trainer:
         # weight gradients are added straight into the arena by the wgrad GEMM when bucket launches do not hang
         # on per-parameter autograd hooks (graph mode launches them from finish(); world 1 launches nothing)
         self.direct_grad = self.use_graph or self.reducer.world == 1
+        # Philox (seed, step) for dropout masks: device memory, advanced once per iteration
+        self.noise_state = torch.tensor([0x5EED0000 + 7919 * dp.env_rank()[0], 0], dtype=torch.int64, device=self.device)
 
     # GradualWarmupScheduler(optimizer, 1, warm_iter): lr = base * min(1, step / warm_iter)
     def current_lr(self):
@@ -103,6 +110,10 @@ class Trainer:
         n_prev = args.n_prev_motions
         lw = dict(self.loss_weights)
         lw["kl_div"] *= self.reducer.kl_weight_scale
+        noise = ag.TrainNoise
+        noise.active = bool(model.training)
+        noise.state, noise.host_rng = self.noise_state, self.rng
+        noise.begin()
         with torch.enable_grad():
             styles, mus, logvars = [], [], []
             for i in range(2):
@@ -143,7 +154,10 @@ class Trainer:
                     if end_idx is not None:  # truncated: hand over the COMPLETE clip's features (training_script.py:152-155)
                         prev_motion = motion[:, -n_prev:]
                         with torch.no_grad():
-                            prev_audio = model.extract_audio_feature(audio)[:, -n_prev:]
+                            if noise.active:   # the reference's extra pass also runs under model.train()
+                                prev_audio = tg.audio_feat_train(model, audio, model.n_motions, dtype).float()[:, -n_prev:]
+                            else:
+                                prev_audio = model.extract_audio_feature(audio)[:, -n_prev:]
                     else:
                         prev_motion = motion_in[:, -n_prev:].detach()
                         prev_audio = audio_feat[:, -n_prev:]
@@ -188,6 +202,9 @@ class Trainer:
         ag.DIRECT_GRAD = self.direct_grad
         stepping = (it % max(1, self.args.gradient_accumulation_steps) == 0)
         cross, trunc = self._host_choices(draws)
+        self.noise_state[1] += 1
+        ag.TrainNoise.graph_safe = self.use_graph
+        ag.TrainNoise.spec_masks = None
         if self.use_graph:
             self.reducer.enabled = False      # python hooks do not run on replay: buckets are launched by finish()
             out = self._graph_fwd_bwd(batch, draws, trunc, cross)
@@ -213,9 +230,11 @@ class Trainer:
         ent = self._graphs.get(key)
         if ent is None:
             ent = self._capture(key, batch, draws, trunc)
-        sb, sd, flags, g, out = ent
+        sb, sd, flags, g, out, spec = ent
         for dst, src in zip(sb[0] + sb[1] + [sb[2]], list(audio_pair) + list(motion_pair) + [shape]):
             dst.copy_(src, non_blocking=True)
+        for dst in spec:   # fresh SpecAugment masks, drawn on the host exactly as the reference does
+            dst.copy_(self._draw_spec_mask(dst.shape), non_blocking=True)
         for k, lst in sd.items():
             for dst, src in zip(lst, draws[k]):
                 if dst is not None:
@@ -223,6 +242,13 @@ class Trainer:
         flags.copy_(self._flag_table[int(cross[0]) * 2 + int(cross[1])], non_blocking=True)
         g.replay()
         return {k: v.clone() for k, v in out.items()}
+
+    def _draw_spec_mask(self, shape):
+        from .utils.wav2vec2 import compute_mask_indices, compute_mask_indices_hf
+        c = self.model.audio_encoder.config
+        fn = compute_mask_indices_hf if self.model.audio_encoder.model_type == "hubert" else compute_mask_indices
+        m = fn(tuple(shape), c.mask_time_prob, c.mask_time_length, c.mask_time_min_masks, self.rng)
+        return torch.from_numpy(m).pin_memory() if self.device.type == "cuda" else torch.from_numpy(m)
 
     def capture_all(self, batch):
         """Capture the four truncation variants for this batch shape up front (otherwise each is captured on its
@@ -246,23 +272,34 @@ class Trainer:
         if self._flag_table is None:
             self._flag_table = torch.tensor([[0, 0], [0, 1], [1, 0], [1, 1]], dtype=torch.bool, device=dev)
         cross = [flags[0], flags[1]]
+        # SpecAugment masks are inputs of the graph: one static (B, 2 L) buffer per encoder pass of this variant
+        spec = []
+        enc_cfg = self.model.audio_encoder.config
+        if self.model.training and enc_cfg.apply_spec_augment and enc_cfg.mask_time_prob > 0:
+            B = audio_pair[0].shape[0]
+            n_pass = 2 + (1 if trunc[0] else 0)
+            spec = [self._draw_spec_mask((B, 2 * self.model.n_motions)).to(dev) for _ in range(n_pass)]
+        ag.TrainNoise.graph_safe = True
         saved = self.reducer.arena.clone()
         # warm-up on a side stream (allocator / lazy init), then capture; gradients written by both are discarded
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self._invalidate_caches()
+            ag.TrainNoise.spec_masks = spec or None
             self._fwd_bwd(sb, sd, trunc, cross)
         torch.cuda.current_stream().wait_stream(s)
         self._invalidate_caches()
         g = torch.cuda.CUDAGraph()
+        ag.TrainNoise.spec_masks = spec or None
         with torch.cuda.graph(g, pool=self._graph_pool):
             out = self._fwd_bwd(sb, sd, trunc, cross)
+        ag.TrainNoise.spec_masks = None
         if self._graph_pool is None:
             self._graph_pool = g.pool()
         self._invalidate_caches()             # cached casts now live in the graph's pool: eager code must re-make them
         self.reducer.arena.copy_(saved)
         self.reducer.pending = [len(m) for _, _, m in self.reducer.buckets]
-        ent = (sb, sd, flags, g, out)
+        ent = (sb, sd, flags, g, out, spec)
         self._graphs[key] = ent
         return ent

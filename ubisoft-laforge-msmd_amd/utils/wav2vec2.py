@@ -10,7 +10,8 @@ GEMM over that layout, so nothing is transposed or im2col'ed.
 Differences from the reference that are deliberate:
   * attention maps are never materialised (the reference forces output_attentions=True and keeps
     737 MB of them alive per batch-32 forward for nothing);
-  * SpecAugment / LayerDrop / dropout are training-time noise; the inference path here is eval-mode.
+  * SpecAugment / LayerDrop / dropout are training-time noise: the inference path here is eval-mode, the
+    training graph (train_graph.audio_encoder_train) applies them when the model is in train() mode.
 """
 from __future__ import annotations
 
@@ -24,6 +25,67 @@ from .model_common import ParamTree, pad_audio_plan
 
 CONV_KERNEL = shapes.CONV_KERNEL
 CONV_STRIDE = shapes.CONV_STRIDE
+
+
+def compute_mask_indices(shape, mask_prob, mask_length, min_masks=0, rng=None):
+    """SpecAugment time-mask positions of the reference's wav2vec2 wrapper (utils/wav2vec2.py:17-53, no
+    attention_mask): same draws in the same order from `rng` (a numpy RandomState; default the global np.random,
+    which is what the reference consumes), so a seeded run reproduces the reference's masks bit for bit."""
+    import numpy as np
+    rng = np.random if rng is None else rng
+    bsz, T = shape
+    n_mask = max(min_masks, int(mask_prob * T / float(mask_length) + rng.rand()))
+    spans = []
+    for _ in range(bsz):
+        lengths = np.full(n_mask, mask_length)
+        if lengths.sum() == 0:
+            lengths[0] = min(mask_length, T - 1)
+        min_len = lengths.min()
+        if T - min_len <= n_mask:
+            min_len = T - n_mask - 1
+        starts = rng.choice(T - min_len, n_mask, replace=False)
+        idx = (starts[:, None] + np.arange(mask_length)[None, :]).reshape(-1) if n_mask else np.zeros(0, np.int64)
+        spans.append(np.unique(idx[idx < T]))
+    keep = min(len(m) for m in spans)
+    mask = np.zeros((bsz, T), dtype=bool)
+    for i, idx in enumerate(spans):
+        if len(idx) > keep:
+            idx = rng.choice(idx, keep, replace=False)
+        mask[i, idx] = True
+    return mask
+
+
+def compute_mask_indices_hf(shape, mask_prob, mask_length, min_masks=0, rng=None):
+    """transformers' `_compute_mask_indices` (modeling_wav2vec2.py, used by HubertModel._mask_hidden_states, which the
+    reference's HuBERT wrapper calls at utils/hubert.py:35), no attention_mask: one epsilon draw, then one
+    `choice` of span starts per row."""
+    import numpy as np
+    rng = np.random if rng is None else rng
+    bsz, T = shape
+    if mask_length < 1 or mask_length > T:
+        raise ValueError("mask_length must be in [1, sequence_length]")
+    eps = rng.rand(1).item()
+
+    def n_spans(length):
+        n = max(int(mask_prob * length / mask_length + eps), min_masks)
+        if n * mask_length > T:
+            n = T // mask_length
+        if length - (mask_length - 1) < n:
+            n = max(length - (mask_length - 1), 0)
+        return n
+
+    n_max = n_spans(T)
+    mask = np.zeros((bsz, T), dtype=bool)
+    if n_max == 0:
+        return mask
+    for i in range(bsz):
+        starts = rng.choice(np.arange(T - (mask_length - 1)), n_spans(T), replace=False)
+        dummy = T - 1 if len(starts) == 0 else starts[0]
+        starts = np.concatenate([starts, np.full(n_max - len(starts), dummy, dtype=np.int32)])
+        idx = (starts[:, None] + np.arange(mask_length)[None, :]).reshape(-1)
+        idx[idx > T - 1] = T - 1
+        mask[i, idx] = True
+    return mask
 
 
 def linear_interpolation(features, input_fps, output_fps, output_len=None):
@@ -43,7 +105,11 @@ class Wav2Vec2Model(nn.Module):
         super().__init__()
         cfg = dict(num_hidden_layers=12, hidden_size=768, intermediate_size=3072, num_attention_heads=12,
                    conv_dim=512, num_conv_pos_embeddings=128, num_conv_pos_embedding_groups=16,
-                   layer_norm_eps=1e-5, output_attentions=False)
+                   layer_norm_eps=1e-5, output_attentions=False,
+                   # training-time noise (facebook/wav2vec2-base-960h / hubert-base-ls960 config.json values)
+                   hidden_dropout=0.1, attention_dropout=0.1, activation_dropout=0.1, feat_proj_dropout=0.1,
+                   layerdrop=0.1, apply_spec_augment=True, mask_time_prob=0.05, mask_time_length=10,
+                   mask_time_min_masks=2)
         if config is not None:
             cfg.update(config if isinstance(config, dict) else vars(config))
         self.config = SimpleNamespace(**cfg)
