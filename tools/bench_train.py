@@ -15,8 +15,12 @@ dp.init("nccl", dev)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 args = default_args(compute_dtype=dtype, lr=2e-5, warm_iter=5000)
-model = get_diffusion_model(args, dev).eval()
-se = get_style_encoder(args, "vae2").to(dev).eval()
+model = get_diffusion_model(args, dev)
+se = get_style_encoder(args, "vae2").to(dev)
+if os.environ.get('TRAIN_MODE'):
+    model.train(); se.train()
+else:
+    model.eval(); se.eval()
 tr = Trainer(args, model, se, use_graph=bool(os.environ.get('GRAPH')))
 if os.environ.get('DIRECT') is not None:
     tr.direct_grad = bool(int(os.environ['DIRECT']))
@@ -44,5 +48,5 @@ if os.environ.get("ISSUE"):
     print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=25, max_name_column_width=60))
 el = dp.timed_steps(lambda: tr.step(batch, it=1), steps, 2, sync=torch.cuda.synchronize, device=dev)
 if rank == 0:
-    print(f"train step: {el / steps * 1e3:.1f} ms/step at local batch {B} x {world} GPUs ({dtype}) -> "
+    print(f"train step: {el / steps * 1e3:.1f} ms/step at local batch {B} x {world} GPUs ({dtype}, {'train' if model.training else 'eval'} mode{', hipGraph' if tr.use_graph else ''}) -> "
           f"{B * 200 * world * steps / el:.0f} frames/s; max mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
