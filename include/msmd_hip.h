@@ -77,8 +77,10 @@ int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsum, int M, i
 long msmd_gemm_tn_workspace(int M, int N, int K, int batch);
 
 /* ------------------------------------------------------------------------------------------------
- * y = LayerNorm(act(x + residual)) * gamma + beta + post_add      (row-wise over `cols`)
- *   residual, post_add (fp32, cols) may be NULL.  eps as torch (1e-5).  Biased variance.
+ * y = post_act(LayerNorm(act(x + residual)) * gamma + beta) + post_add      (row-wise over `cols`)
+ *   `act` carries the pre-activation in its low byte and post_act in bits 8-15 (MSMD_ACT_* codes; the LayerNorm ->
+ *   GELU of HF's layer-norm conv stack).  residual, post_add (fp32, cols) may be NULL.  eps as torch (1e-5).
+ *   Biased variance.
  * Replaces: nn.LayerNorm at reference style_encoder.py:142,150,170; HF feature_projection.layer_norm,
  *   encoder.layer_norm, layers.N.{layer_norm,final_layer_norm}; decoder norm1-3 (model.py:874-878).
  */
@@ -150,6 +152,13 @@ int msmd_conv0_stats(const float* audio, const float* w0, float* stats, float* w
 int msmd_conv0_gn_gelu(const float* audio, const float* w0, const float* stats, const float* gamma,
                        const float* beta, void* out, int B, int L, int reflect_len, int replicate_len,
                        int C, int out_dtype, msmd_stream_t stream);
+
+/* conv0 of the feat_extract_norm="layer" stack (hubert-large-style configs; HF HubertLayerNormConvLayer, reached from
+ * utils/hubert.py:22 `self.feature_extractor(input_values)`): out[b][t][:] = GELU(LayerNorm_c(bias + conv1d(k=10,
+ * s=5)(pad_audio(x)))) channels-last, C = 512, pad_audio fused into the loads as above. */
+int msmd_conv0_ln_gelu(const float* audio, const float* w0, const float* bias, const float* gamma, const float* beta,
+                       void* out, int B, int L, int reflect_len, int replicate_len, int C, float eps, int out_dtype,
+                       msmd_stream_t stream);
 
 /* Linear resample along time of a channels-last tensor with F.interpolate(mode='linear',
  * align_corners=False) semantics: y (B, T_out, C) from the first T_crop frames of x (B, T_in, C).

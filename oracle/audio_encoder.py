@@ -71,16 +71,22 @@ def crop_len(frame_num: int, output_fps) -> int:
 
 # --------------------------------------------------------------------------- modules
 def feature_extractor(sd, prefix, audio_padded):
-    """HF Wav2Vec2FeatureEncoder, feat_extract_norm='group' (called at reference
-    utils/wav2vec2.py:79 / utils/hubert.py:22).  (B, S) -> (B, T, 512)."""
+    """HF Wav2Vec2FeatureEncoder / HubertFeatureEncoder (called at reference utils/wav2vec2.py:79 /
+    utils/hubert.py:22).  (B, S) -> (B, T, 512).  feat_extract_norm='group' (base checkpoints: GroupNorm on layer 0
+    only, no conv bias) or 'layer' (large checkpoints: conv bias + LayerNorm over channels after EVERY conv) is
+    read off the state dict."""
+    fe = f"{prefix}feature_extractor.conv_layers."
+    layer_mode = (fe + "1.layer_norm.weight") in sd
     x = nn.f32(audio_padded)[:, :, None]  # (B, S, 1)
     for i, (k, s) in enumerate(zip(CONV_KERNEL, CONV_STRIDE)):
-        w = sd[f"{prefix}feature_extractor.conv_layers.{i}.conv.weight"]
-        x = nn.conv1d_cl(x, w, None, stride=s)
-        if i == 0:
+        w = sd[f"{fe}{i}.conv.weight"]
+        x = nn.conv1d_cl(x, w, sd.get(f"{fe}{i}.conv.bias"), stride=s)
+        if layer_mode:
+            x = nn.layer_norm(x, sd[f"{fe}{i}.layer_norm.weight"], sd[f"{fe}{i}.layer_norm.bias"])
+        elif i == 0:
             # GroupNorm(num_groups=512, num_channels=512): per (sample, channel) over time
-            gw = sd[f"{prefix}feature_extractor.conv_layers.0.layer_norm.weight"]
-            gb = sd[f"{prefix}feature_extractor.conv_layers.0.layer_norm.bias"]
+            gw = sd[f"{fe}0.layer_norm.weight"]
+            gb = sd[f"{fe}0.layer_norm.bias"]
             mean = x.mean(axis=1, keepdims=True, dtype=np.float64)
             var = x.var(axis=1, keepdims=True, dtype=np.float64)
             x = ((x - mean) / np.sqrt(var + 1e-5)).astype(np.float32) * nn.f32(gw) + nn.f32(gb)
@@ -109,7 +115,7 @@ def pos_conv_embed(sd, prefix, h):
     b = nn.f32(sd[f"{prefix}encoder.pos_conv_embed.conv.bias"])
     B, T, C = h.shape
     G = 16
-    cg = C // G
+    cg = C // G   # 48 (base) / 64 (large)
     out = np.empty((B, T, C), dtype=np.float32)
     for g in range(G):
         y = nn.conv1d_cl(h[:, :, g * cg:(g + 1) * cg], w[g * cg:(g + 1) * cg], b[g * cg:(g + 1) * cg],
@@ -118,8 +124,7 @@ def pos_conv_embed(sd, prefix, h):
     return nn.gelu(out)
 
 
-def encoder_layer(sd, p, h, n_heads=12):
-    """HF Wav2Vec2EncoderLayer (post-LN)."""
+def _self_attention(sd, p, h, n_heads):
     d = h.shape[-1]
     hd = d // n_heads
     B, T, _ = h.shape
@@ -131,12 +136,25 @@ def encoder_layer(sd, p, h, n_heads=12):
     v = v.reshape(B, T, n_heads, hd).transpose(0, 2, 1, 3)
     pr = nn.softmax(np.matmul(q, k.transpose(0, 1, 3, 2)), axis=-1)
     a = np.matmul(pr, v).transpose(0, 2, 1, 3).reshape(B, T, d)
-    a = nn.linear(a, sd[p + "attention.out_proj.weight"], sd[p + "attention.out_proj.bias"])
-    h = nn.layer_norm(h + a, sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"])
+    return nn.linear(a, sd[p + "attention.out_proj.weight"], sd[p + "attention.out_proj.bias"])
+
+
+def _feed_forward(sd, p, h):
     f = nn.gelu(nn.linear(h, sd[p + "feed_forward.intermediate_dense.weight"],
                           sd[p + "feed_forward.intermediate_dense.bias"]))
-    f = nn.linear(f, sd[p + "feed_forward.output_dense.weight"], sd[p + "feed_forward.output_dense.bias"])
-    return nn.layer_norm(h + f, sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"])
+    return nn.linear(f, sd[p + "feed_forward.output_dense.weight"], sd[p + "feed_forward.output_dense.bias"])
+
+
+def encoder_layer(sd, p, h, n_heads=12):
+    """HF Wav2Vec2EncoderLayer / HubertEncoderLayer (post-LN)."""
+    h = nn.layer_norm(h + _self_attention(sd, p, h, n_heads), sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"])
+    return nn.layer_norm(h + _feed_forward(sd, p, h), sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"])
+
+
+def encoder_layer_stable(sd, p, h, n_heads=16):
+    """HF HubertEncoderLayerStableLayerNorm (pre-LN; do_stable_layer_norm=True, large checkpoints)."""
+    h = h + _self_attention(sd, p, nn.layer_norm(h, sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"]), n_heads)
+    return h + _feed_forward(sd, p, nn.layer_norm(h, sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"]))
 
 
 def num_encoder_layers(sd, prefix):
@@ -146,7 +164,8 @@ def num_encoder_layers(sd, prefix):
     return n
 
 
-def audio_encoder(sd, prefix, audio_padded, output_fps=25, frame_num=None, n_heads=12, return_stages=False):
+def audio_encoder(sd, prefix, audio_padded, output_fps=25, frame_num=None, n_heads=12, return_stages=False,
+                  stable_layer_norm=False):
     """Eval-mode forward of the wrapper (reference utils/wav2vec2.py:71-119,
     utils/hubert.py:13-51) -> last_hidden_state (B, frame_num, 768)."""
     stages = {}
@@ -165,6 +184,13 @@ def audio_encoder(sd, prefix, audio_padded, output_fps=25, frame_num=None, n_hea
                   sd[f"{prefix}feature_projection.projection.bias"])
     stages["proj"] = x
     x = x + pos_conv_embed(sd, prefix, x)
+    if stable_layer_norm:   # HubertEncoderStableLayerNorm: pre-LN layers, one LayerNorm at the very end
+        stages["posconv"] = x
+        for i in range(num_encoder_layers(sd, prefix)):
+            x = encoder_layer_stable(sd, f"{prefix}encoder.layers.{i}.", x, n_heads)
+            stages[f"layer{i}"] = x
+        x = nn.layer_norm(x, sd[f"{prefix}encoder.layer_norm.weight"], sd[f"{prefix}encoder.layer_norm.bias"])
+        return (x, stages) if return_stages else x
     x = nn.layer_norm(x, sd[f"{prefix}encoder.layer_norm.weight"], sd[f"{prefix}encoder.layer_norm.bias"])
     stages["posconv_ln"] = x
     for i in range(num_encoder_layers(sd, prefix)):

@@ -184,6 +184,54 @@ def g3_audio(M, SE, mc):
                  style_keys=np.array(list(SE.get_style_encoder(args, "vae2").state_dict().keys())))
 
 
+def g3_audio_large(M, SE, mc):
+    """HuBERT-large ARCHITECTURE (feat_extract_norm='layer' + conv biases, stable-layer-norm encoder, 1024 wide, 16
+    heads) through the reference's own wrapper class utils/hubert.py:9-51, 2 transformer layers, synthetic weights;
+    BASELINE.json configs[3] (10 s clip -> 500 frames at 50 fps, 250 at 25 fps x 2)."""
+    import utils.hubert as hb
+    from transformers import HubertConfig
+    cfg = HubertConfig(hidden_size=1024, num_hidden_layers=2, num_attention_heads=16, intermediate_size=4096,
+                       feat_extract_norm="layer", do_stable_layer_norm=True, conv_bias=True,
+                       attn_implementation="eager")
+    enc = hb.HubertModel(cfg).eval()
+    synth.load_synthetic(enc, prefix="audio_encoder.")
+    keys = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    mine = shapes.audio_encoder_shapes(2, 1024, 4096, feat_extract_norm="layer", conv_bias=True)
+    for k, v in mine.items():
+        kk = k.replace("weight_g", "parametrizations.weight.original0").replace("weight_v", "parametrizations.weight.original1")
+        assert keys[kk] == tuple(v), (k, keys[kk], v)
+    assert len([k for k in keys if not synth.is_computed_buffer("audio_encoder." + k)]) == len(mine)
+    grabs = {}
+
+    def hook(name):
+        def fn(mod, inp, outp):
+            o = outp[0] if isinstance(outp, tuple) else outp
+            grabs[name] = o.detach().numpy().copy()
+        return fn
+    hs = [enc.feature_extractor.conv_layers[0].register_forward_hook(hook("conv0")),
+          enc.feature_extractor.register_forward_hook(hook("conv")),
+          enc.feature_projection.register_forward_hook(hook("proj")),
+          enc.encoder.layers[0].register_forward_hook(hook("layer0")),
+          enc.encoder.layers[1].register_forward_hook(hook("layer1"))]
+    out = {}
+    with torch.no_grad():
+        a10 = synth.audio_clips(1, 160000, tag="audio10s")
+        y = enc(mc.pad_audio(t(a10)), 25, frame_num=500).last_hidden_state.numpy()      # (1, 500, 1024)
+        out["hidden_10s"] = y[:, ::2, ::3]
+        out["conv0_10s"] = grabs["conv0"].transpose(0, 2, 1)[:, ::127, ::7]
+        out["conv_10s"] = grabs["conv"].transpose(0, 2, 1)[:, ::5, ::5]
+        out["proj_10s"] = grabs["proj"][:, ::5, ::5]
+        out["layer0_10s"] = grabs["layer0"][:, ::5, ::5]
+        out["layer1_10s"] = grabs["layer1"][:, ::5, ::5]
+        a4 = synth.audio_clips(2, 64000)
+        out["hidden_4s"] = enc(mc.pad_audio(t(a4)), 25, frame_num=200).last_hidden_state.numpy()[:, ::2, ::3]
+        a2 = synth.audio_clips(1, 32000, tag="audio30")
+        out["hidden_fps30_60"] = enc(mc.pad_audio(t(a2)), 30, frame_num=60).last_hidden_state.numpy()
+    for h in hs:
+        h.remove()
+    save("g3_audio_hubert_large", **out)
+
+
 def denoiser_inputs(B, args, tag="dn"):
     d = args.feature_dim
     return dict(
@@ -616,7 +664,7 @@ def g1_specaug(M, SE, mc):
     save("g1_specaug", **out)
 
 
-ALL = dict(g1_specaug=g1_specaug, g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
+ALL = dict(g1_specaug=g1_specaug, g3_audio_large=g3_audio_large, g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
            g3_forward=g3_forward, g3_style=g3_style, g3_sample=g3_sample, g3_infer=g3_infer,
            g4_flame=g4_flame, g4_rotations=g4_rotations, g5_losses=g5_losses, g6_train=g6_train)
 

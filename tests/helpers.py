@@ -40,3 +40,10 @@ def flame_inputs(B, tag="flame"):
 
 def maxabs(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+@functools.lru_cache(maxsize=1)
+def hubert_large_state_dict(n_layers=2):
+    """Encoder-only synthetic state dict of the HuBERT-large ARCHITECTURE (keys prefixed audio_encoder.)."""
+    shp = shapes.audio_encoder_shapes(n_layers, 1024, 4096, feat_extract_norm="layer", conv_bias=True)
+    return synth.fill_state_dict({"audio_encoder." + k: v for k, v in shp.items()})

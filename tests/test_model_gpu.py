@@ -276,3 +276,39 @@ def test_sampler_hip_graph_matches_eager():
     finally:
         model.diffusion_sched = old
         model.__dict__.pop("_step_graphs", None)
+
+
+def test_hubert_large_architecture_fp32_and_bf16():
+    """BASELINE.json configs[3]: HuBERT-large ARCHITECTURE (LayerNorm conv stack with biases, stable-layer-norm
+    encoder, 1024 wide, 16 heads; 2 layers here) on a 10 s clip: fp32 HIP path against the reference wrapper's golden
+    (< 1e-4 on the hidden states) and the bf16 mode's tolerance; then MSMD with audio_model='hubert_large'."""
+    from msmd_amd.utils.hubert import HubertModel
+    from msmd_amd.utils.model_common import pad_audio
+    g = load_golden("g3_audio_hubert_large")
+    enc = HubertModel.large(num_hidden_layers=2)
+    synth.load_synthetic(enc, prefix="audio_encoder.")
+    enc = enc.to(DEV).eval()
+    a10 = dev(synth.audio_clips(1, 160000, tag="audio10s"))
+    x = enc.feature_extractor_cl(a10, torch.float32, 20, 0)
+    assert x.shape == (1, 500, 512)
+    assert maxabs(x.cpu().numpy()[:, ::5, ::5], g["conv_10s"]) < 5e-5
+    h = enc(pad_audio(a10), 25, frame_num=500).last_hidden_state
+    torch.cuda.synchronize()
+    assert h.shape == (1, 500, 1024)
+    assert maxabs(h.cpu().numpy()[:, ::2, ::3], g["hidden_10s"]) < 1e-4
+    a4 = dev(synth.audio_clips(2, 64000))
+    assert maxabs(enc(pad_audio(a4), 25, frame_num=200).last_hidden_state.cpu().numpy()[:, ::2, ::3], g["hidden_4s"]) < 1e-4
+    a2 = dev(synth.audio_clips(1, 32000, tag="audio30"))
+    assert maxabs(enc(pad_audio(a2), 30, frame_num=60).last_hidden_state.cpu().numpy(), g["hidden_fps30_60"]) < 1e-4
+    hb = enc(pad_audio(a10), 25, frame_num=500, dtype=torch.bfloat16).last_hidden_state.float()
+    err = maxabs(hb.cpu().numpy()[:, ::2, ::3], g["hidden_10s"])
+    print(f"hubert-large bf16 max-abs-err on LayerNorm-ed hidden states: {err:.4f}")
+    assert err < 0.15
+    # model-level swap: 10 s clips, 250 motion frames
+    model, args = get_model("hubert_large", "bf16", encoder_layers=2, n_motions=250)
+    assert model.audio_feature_map.weight.shape == (512, 1024)
+    feat = model.extract_audio_feature(dev(synth.audio_clips(2, 160000, tag="audio10s_b")))
+    torch.cuda.synchronize()
+    assert feat.shape == (2, 250, 512) and bool(torch.isfinite(feat).all())
+    frozen = [n for n, p in model.audio_encoder.named_parameters() if not p.requires_grad]
+    assert any(n.startswith("feature_extractor.conv_layers.6.layer_norm") for n in frozen)

@@ -271,3 +271,23 @@ def test_specaugment_mask_indices_match_reference_and_hf():
             assert np.array_equal(a, g[f"ref_{i}_{seed}"]), ("ref", i, seed)
             h = compute_mask_indices_hf((int(b), int(T)), float(prob), int(length), int(mn), np.random.RandomState(seed))
             assert np.array_equal(h, g[f"hf_{i}_{seed}"]), ("hf", i, seed)
+
+
+def test_audio_encoder_hubert_large_architecture():
+    """feat_extract_norm='layer' conv stack + stable-layer-norm encoder (HuBERT-large architecture, 2 layers) against
+    the reference's HubertModel wrapper; 10 s clip (BASELINE.json configs[3]) and the 30 fps crop path."""
+    from helpers import hubert_large_state_dict
+    g = load_golden("g3_audio_hubert_large")
+    sd = hubert_large_state_dict()
+    a10 = synth.audio_clips(1, 160000, tag="audio10s")
+    h, st = oa.audio_encoder(sd, "audio_encoder.", oa.pad_audio(a10), 25, frame_num=500, n_heads=16,
+                             return_stages=True, stable_layer_norm=True)
+    assert h.shape == (1, 500, 1024)
+    assert maxabs(st["conv"][:, ::5, ::5], g["conv_10s"]) <= 2e-5
+    assert maxabs(st["proj"][:, ::5, ::5], g["proj_10s"]) <= 5e-5
+    assert maxabs(st["layer0"][:, ::5, ::5], g["layer0_10s"]) <= 2e-4
+    assert maxabs(st["layer1"][:, ::5, ::5], g["layer1_10s"]) <= 2e-4
+    assert maxabs(h[:, ::2, ::3], g["hidden_10s"]) <= 1e-4
+    a2 = synth.audio_clips(1, 32000, tag="audio30")
+    y = oa.audio_encoder(sd, "audio_encoder.", oa.pad_audio(a2), 30, frame_num=60, n_heads=16, stable_layer_norm=True)
+    assert maxabs(y, g["hidden_fps30_60"]) <= 1e-4

@@ -215,3 +215,25 @@ def test_trainer_train_mode_noise_eager_and_graph():
         ag.TrainNoise.active = False
         ag.TrainNoise.graph_safe = False
         ag.TrainNoise.spec_masks = None
+
+
+def test_hubert_large_training_graph_matches_inference_path():
+    """The differentiable stable-layer-norm encoder (train_graph) reproduces the no-grad inference kernels on the
+    HuBERT-large architecture, and its backward reaches the trainable layers only (layers 0-1 / conv stack /
+    projection frozen as for hubert-base, model.py:103-110)."""
+    from msmd_amd import train_graph as tg
+    from msmd_amd.model import get_diffusion_model
+    args = default_args(audio_model="hubert_large", compute_dtype="fp32", encoder_layers=3, n_motions=50)
+    model = get_diffusion_model(args, DEV).eval()
+    audio = dev(synth.audio_clips(2, 32000, tag="hl_train"))
+    ref = model.extract_audio_feature(audio)
+    with torch.enable_grad():
+        got = tg.audio_feat_train(model, audio, 50, torch.float32).float()
+        got.square().mean().backward()
+    torch.cuda.synchronize()
+    assert maxabs(got.detach().cpu().numpy(), ref.cpu().numpy()) < 1e-4
+    enc = model.audio_encoder
+    assert enc.get_parameter("encoder.layers.2.attention.q_proj.weight").grad is not None
+    assert enc.get_parameter("encoder.layer_norm.weight").grad is not None
+    assert enc.get_parameter("encoder.layers.0.attention.q_proj.weight").grad is None
+    assert enc.get_parameter("feature_extractor.conv_layers.3.layer_norm.weight").grad is None

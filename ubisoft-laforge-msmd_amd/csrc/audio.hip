@@ -201,6 +201,84 @@ extern "C" int msmd_conv0_gn_gelu(const float* audio, const float* w0, const flo
 }
 
 // ---------------------------------------------------------------------------------------------------
+// conv0 of the feat_extract_norm="layer" stack (hubert-large / wav2vec2-large: HF HubertLayerNormConvLayer):
+//   y[t][c] = GELU(LayerNorm_c(bias[c] + sum_k w[c][k] x[5 t + k]))      LayerNorm over the C = 512 channels of a frame
+// One wave per frame: a lane owns 8 consecutive channels (weights in registers, loaded once per wave), the LN
+// statistics are two wave reductions, the frame leaves as one 16-byte (bf16) or two 16-byte (fp32) stores per lane.
+// pad_audio is fused into the signal loads exactly as in the GroupNorm variant.
+template <typename TO>
+__global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restrict__ audio, const float* __restrict__ w0,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, TO* __restrict__ out, int L,
+                                                            int r, int rep, int T0, float eps) {
+  constexpr int FR = 64, C = 512;
+  __shared__ float xs[FR * C0_S + C0_K];
+  const int b = blockIdx.y, t0 = blockIdx.x * FR;
+  const int nt = min(FR, T0 - t0);
+  const int ns = nt * C0_S + (C0_K - C0_S);
+  for (int i = threadIdx.x; i < ns; i += 256) xs[i] = audio[(long)b * L + pad_src(t0 * C0_S + i, L, r, rep)];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c0 = lane * 8;
+  float w[8][C0_K], bs[8], g[8], be[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+#pragma unroll
+    for (int k = 0; k < C0_K; ++k) w[e][k] = w0[(c0 + e) * C0_K + k];
+    bs[e] = bias ? bias[c0 + e] : 0.f;
+    g[e] = gamma[c0 + e];
+    be[e] = beta[c0 + e];
+  }
+  for (int t = wid; t < nt; t += 4) {
+    float y[8], s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = bs[e];
+#pragma unroll
+      for (int k = 0; k < C0_K; ++k) a = fmaf(w[e][k], xs[t * C0_S + k], a);
+      y[e] = a;
+      s += a;
+    }
+    const float mean = wave_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q += (y[e] - mean) * (y[e] - mean);
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = (y[e] - mean) * rstd * g[e] + be[e];
+      o[e] = sizeof(TO) == 2 ? gelu_fast(v) : gelu_erf(v);
+    }
+    TO* op = out + ((long)b * T0 + t0 + t) * C + c0;
+    if constexpr (sizeof(TO) == 4) {
+      *(f32x4*)op = f32x4{o[0], o[1], o[2], o[3]};
+      *(f32x4*)(op + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    } else {
+      *(bf16x8*)op = bf16x8{(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3],
+                            (bf16_t)o[4], (bf16_t)o[5], (bf16_t)o[6], (bf16_t)o[7]};
+    }
+  }
+}
+
+extern "C" int msmd_conv0_ln_gelu(const float* audio, const float* w0, const float* bias, const float* gamma,
+                                  const float* beta, void* out, int B, int L, int reflect_len, int replicate_len,
+                                  int C, float eps, int out_dtype, msmd_stream_t stream) {
+  if (B <= 0 || L <= 0 || C != 512) return 1;
+  const int Lp = L + 4 * reflect_len + 2 * replicate_len;
+  const int T0 = (Lp - C0_K) / C0_S + 1;
+  dim3 grid((T0 + 63) / 64, B), block(256);
+  if (out_dtype == MSMD_F32)
+    hipLaunchKernelGGL(conv0_ln_gelu_kernel<float>, grid, block, 0, (hipStream_t)stream, audio, w0, bias, gamma, beta,
+                       (float*)out, L, reflect_len, replicate_len, T0, eps);
+  else
+    hipLaunchKernelGGL(conv0_ln_gelu_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, audio, w0, bias, gamma, beta,
+                       (bf16_t*)out, L, reflect_len, replicate_len, T0, eps);
+  MSMD_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // F.interpolate(mode='linear', align_corners=False) along time, channels-last.
 // src = fmaf(scale, dst + 0.5, -0.5) clamped at 0 (ATen's fused form; see oracle/nn.py), i0 = floor, w1 = src - i0.
 template <typename T>

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[i][e] = apply_act(v[i][e], act);
+        v[i][e] = apply_act(v[i][e], act & 0xff);
         s += v[i][e];
       }
     } else {
@@ -75,6 +75,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
       load4<float>(beta + c * 4, b);
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+      if (act >> 8) {  // activation AFTER the affine (LayerNorm -> GELU of the layer-norm conv stack)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = sizeof(TO) == 2 ? (((act >> 8) == MSMD_ACT_GELU) ? gelu_fast(o[e]) : apply_act(o[e], act >> 8)) : apply_act(o[e], act >> 8);
+      }
       if (post) {
         float pa[4];
         load4<float>(post + c * 4, pa);

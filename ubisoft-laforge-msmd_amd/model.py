@@ -337,13 +337,24 @@ class MSMD(nn.Module):
             from .utils.hubert import HubertModel
             self.audio_encoder = HubertModel.from_pretrained("facebook/hubert-base-ls960", config=enc_cfg)
             frozen = ("feature_extractor", "feature_projection", "encoder.layers.0.", "encoder.layers.1.")
+        elif self.audio_model == "hubert_large":
+            # BASELINE.json configs[3] "HuBERT-large encoder swap": not reachable in the reference (model.py:100
+            # hard-codes hubert-base and a 768-wide audio_feature_map); same wrapper (utils/hubert.py) and freezing
+            # rule, architecture of facebook/hubert-large-ls960-ft.
+            from .utils.hubert import HubertModel, LARGE_CONFIG
+            cfg = dict(LARGE_CONFIG)
+            if getattr(args, "encoder_layers", None):
+                cfg["num_hidden_layers"] = args.encoder_layers
+            self.audio_encoder = HubertModel.from_pretrained("facebook/hubert-large-ls960-ft", config=cfg)
+            frozen = ("feature_extractor", "feature_projection", "encoder.layers.0.", "encoder.layers.1.")
         else:
             raise ValueError(f"Unknown audio model {self.audio_model}!")
         for name, p in self.audio_encoder.named_parameters():  # model.py:97,101-110
             if name.startswith(frozen):
                 p.requires_grad = False
         if args.architecture == "decoder":
-            self.audio_feature_map = ParamTree({"weight": (args.feature_dim, 768), "bias": (args.feature_dim,)})
+            self.audio_feature_map = ParamTree({"weight": (args.feature_dim, self.audio_encoder.config.hidden_size),
+                                                "bias": (args.feature_dim,)})
             self.start_audio_feat = nn.Parameter(torch.zeros(1, self.n_prev_motions, args.feature_dim))
         else:
             raise ValueError(f"Unknown architecture {args.architecture}!")

@@ -127,13 +127,15 @@ def conv1d_cl(x, w_packed, bias=None, *, kernel, stride, act=ACT_NONE, out_dtype
     return out
 
 
-def layernorm(x, gamma, beta, residual=None, post_add=None, act=ACT_NONE, eps=1e-5, out_dtype=None):
+def layernorm(x, gamma, beta, residual=None, post_add=None, act=ACT_NONE, eps=1e-5, out_dtype=None, post_act=ACT_NONE):
+    """y = post_act(LayerNorm(act(x + residual)) * gamma + beta) + post_add."""
     _need_cuda(x, gamma, beta)
     lib = _lib.load()
     cols = x.shape[-1]
     rows = x.numel() // cols
     y = torch.empty(x.shape, device=x.device, dtype=out_dtype or x.dtype)
-    _lib.check(lib.msmd_layernorm(_p(x), _p(residual), _p(gamma), _p(beta), _p(post_add), _p(y), rows, cols, eps, act,
+    _lib.check(lib.msmd_layernorm(_p(x), _p(residual), _p(gamma), _p(beta), _p(post_add), _p(y), rows, cols, eps,
+                                  act | (post_act << 8),
                                   _dt(x), _dt(y), _stream()), "msmd_layernorm")
     return y
 
@@ -219,6 +221,19 @@ def conv0_gn_gelu(audio, w0, gamma, beta, reflect_len, replicate_len, out_dtype,
     out = torch.empty(B, T0, C, device=audio.device, dtype=out_dtype)
     _lib.check(lib.msmd_conv0_gn_gelu(_p(audio), _p(w0), _p(stats), _p(gamma), _p(beta), _p(out), B, L, reflect_len,
                                       replicate_len, C, _dt(out), _stream()), "msmd_conv0_gn_gelu")
+    return out
+
+
+def conv0_ln_gelu(audio, w0, bias, gamma, beta, reflect_len, replicate_len, out_dtype, eps=1e-5):
+    """GELU(LayerNorm_channels(conv0(pad_audio(audio)) + bias)) -> (B, T0, 512) (feat_extract_norm="layer" stacks)."""
+    lib = _lib.load()
+    B, L = audio.shape
+    C = w0.shape[0]
+    Lp = L + 4 * reflect_len + 2 * replicate_len
+    T0 = (Lp - 10) // 5 + 1
+    out = torch.empty(B, T0, C, device=audio.device, dtype=out_dtype)
+    _lib.check(lib.msmd_conv0_ln_gelu(_p(audio), _p(w0), _p(bias), _p(gamma), _p(beta), _p(out), B, L, reflect_len,
+                                      replicate_len, C, eps, _dt(out), _stream()), "msmd_conv0_ln_gelu")
     return out
 
 

@@ -13,16 +13,21 @@ CONV_STRIDE = (5, 2, 2, 2, 2, 2, 2)
 
 
 def audio_encoder_shapes(n_layers: int = 12, hidden: int = 768, ffn: int = 3072, conv_dim: int = 512,
-                         pos_k: int = 128, pos_groups: int = 16) -> "OrderedDict[str, tuple]":
-    """HF Wav2Vec2Model / HubertModel (base, feat_extract_norm='group', post-LN encoder)."""
+                         pos_k: int = 128, pos_groups: int = 16, feat_extract_norm: str = "group",
+                         conv_bias: bool = False) -> "OrderedDict[str, tuple]":
+    """HF Wav2Vec2Model / HubertModel.  Base checkpoints: feat_extract_norm='group' (GroupNorm on conv layer 0 only,
+    no conv bias), post-LN encoder.  Large checkpoints (hubert-large-ls960-ft, wav2vec2-large): 'layer' (LayerNorm
+    after EVERY conv layer, conv biases) and the stable-layer-norm (pre-LN) encoder, which uses the same key names."""
     s = OrderedDict()
     s["masked_spec_embed"] = (hidden,)
     for i, k in enumerate(CONV_KERNEL):
         cin = 1 if i == 0 else conv_dim
         s[f"feature_extractor.conv_layers.{i}.conv.weight"] = (conv_dim, cin, k)
-        if i == 0:
-            s["feature_extractor.conv_layers.0.layer_norm.weight"] = (conv_dim,)
-            s["feature_extractor.conv_layers.0.layer_norm.bias"] = (conv_dim,)
+        if conv_bias:
+            s[f"feature_extractor.conv_layers.{i}.conv.bias"] = (conv_dim,)
+        if i == 0 or feat_extract_norm == "layer":
+            s[f"feature_extractor.conv_layers.{i}.layer_norm.weight"] = (conv_dim,)
+            s[f"feature_extractor.conv_layers.{i}.layer_norm.bias"] = (conv_dim,)
     s["feature_projection.layer_norm.weight"] = (conv_dim,)
     s["feature_projection.layer_norm.bias"] = (conv_dim,)
     s["feature_projection.projection.weight"] = (hidden, conv_dim)

@@ -124,7 +124,9 @@ def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
     w = _fold_weight_norm(g("encoder.pos_conv_embed.conv.weight_g"), g("encoder.pos_conv_embed.conv.weight_v"))
     z = PosConvFn.apply(h, w, g("encoder.pos_conv_embed.conv.bias"))
     h = h + ag_act(z, ops.ACT_GELU)
-    h = ag.layer_norm(h, g("encoder.layer_norm.weight"), g("encoder.layer_norm.bias"))
+    stable = bool(getattr(c, "do_stable_layer_norm", False))   # pre-LN blocks + one final LayerNorm (large checkpoints)
+    if not stable:
+        h = ag.layer_norm(h, g("encoder.layer_norm.weight"), g("encoder.layer_norm.bias"))
     h = ag.dropout(h, c.hidden_dropout)
     d, H = c.hidden_size, c.num_attention_heads
     for n in range(c.num_hidden_layers):
@@ -140,18 +142,33 @@ def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
         p = f"encoder.layers.{n}."
         wq, wk, wv = (g(p + f"attention.{k}_proj.weight") for k in "qkv")
         bq, bk, bv = (g(p + f"attention.{k}_proj.bias") for k in "qkv")
-        qkv = ag.linear(h, torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0))
-        a = ag.self_attention(qkv, H, (d // H) ** -0.5, p_drop=c.attention_dropout)
-        h = ag.layer_norm(ag.linear_dropout(a, g(p + "attention.out_proj.weight"), g(p + "attention.out_proj.bias"),
-                                            c.hidden_dropout, residual=h),
-                          g(p + "layer_norm.weight"), g(p + "layer_norm.bias"))
-        f = ag.linear_dropout(h, g(p + "feed_forward.intermediate_dense.weight"),
-                              g(p + "feed_forward.intermediate_dense.bias"), c.activation_dropout, act=ops.ACT_GELU)
-        h = ag.layer_norm(ag.linear_dropout(f, g(p + "feed_forward.output_dense.weight"),
-                                            g(p + "feed_forward.output_dense.bias"), c.hidden_dropout, residual=h),
-                          g(p + "final_layer_norm.weight"), g(p + "final_layer_norm.bias"))
+        ln1 = (g(p + "layer_norm.weight"), g(p + "layer_norm.bias"))
+        ln2 = (g(p + "final_layer_norm.weight"), g(p + "final_layer_norm.bias"))
+        wqkv, bqkv = torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0)
+        if stable:   # HubertEncoderLayerStableLayerNorm
+            a = ag.self_attention(ag.linear(ag.layer_norm(h, *ln1), wqkv, bqkv), H, (d // H) ** -0.5,
+                                  p_drop=c.attention_dropout)
+            h = ag.linear_dropout(a, g(p + "attention.out_proj.weight"), g(p + "attention.out_proj.bias"),
+                                  c.hidden_dropout, residual=h)
+            f = ag.linear_dropout(ag.layer_norm(h, *ln2), g(p + "feed_forward.intermediate_dense.weight"),
+                                  g(p + "feed_forward.intermediate_dense.bias"), c.activation_dropout,
+                                  act=ops.ACT_GELU)
+            h = ag.linear_dropout(f, g(p + "feed_forward.output_dense.weight"),
+                                  g(p + "feed_forward.output_dense.bias"), c.hidden_dropout, residual=h)
+        else:
+            a = ag.self_attention(ag.linear(h, wqkv, bqkv), H, (d // H) ** -0.5, p_drop=c.attention_dropout)
+            h = ag.layer_norm(ag.linear_dropout(a, g(p + "attention.out_proj.weight"),
+                                                g(p + "attention.out_proj.bias"), c.hidden_dropout, residual=h), *ln1)
+            f = ag.linear_dropout(h, g(p + "feed_forward.intermediate_dense.weight"),
+                                  g(p + "feed_forward.intermediate_dense.bias"), c.activation_dropout,
+                                  act=ops.ACT_GELU)
+            h = ag.layer_norm(ag.linear_dropout(f, g(p + "feed_forward.output_dense.weight"),
+                                                g(p + "feed_forward.output_dense.bias"), c.hidden_dropout,
+                                                residual=h), *ln2)
         if skip_flag is not None:
             h = torch.where(skip_flag, h_in, h)
+    if stable:
+        h = ag.layer_norm(h, g("encoder.layer_norm.weight"), g("encoder.layer_norm.bias"))
     return h
 
 

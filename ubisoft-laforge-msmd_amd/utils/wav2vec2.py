@@ -106,6 +106,7 @@ class Wav2Vec2Model(nn.Module):
         cfg = dict(num_hidden_layers=12, hidden_size=768, intermediate_size=3072, num_attention_heads=12,
                    conv_dim=512, num_conv_pos_embeddings=128, num_conv_pos_embedding_groups=16,
                    layer_norm_eps=1e-5, output_attentions=False,
+                   feat_extract_norm="group", conv_bias=False, do_stable_layer_norm=False,
                    # training-time noise (facebook/wav2vec2-base-960h / hubert-base-ls960 config.json values)
                    hidden_dropout=0.1, attention_dropout=0.1, activation_dropout=0.1, feat_proj_dropout=0.1,
                    layerdrop=0.1, apply_spec_augment=True, mask_time_prob=0.05, mask_time_length=10,
@@ -114,9 +115,14 @@ class Wav2Vec2Model(nn.Module):
             cfg.update(config if isinstance(config, dict) else vars(config))
         self.config = SimpleNamespace(**cfg)
         c = self.config
+        if isinstance(c.conv_dim, (tuple, list)):   # HF configs carry one entry per conv layer (all 512)
+            c.conv_dim = int(c.conv_dim[0])
+        if c.feat_extract_norm not in ("group", "layer"):
+            raise ValueError(f"Unknown feat_extract_norm {c.feat_extract_norm!r}")
         tree = ParamTree(shapes.audio_encoder_shapes(c.num_hidden_layers, c.hidden_size, c.intermediate_size,
                                                      c.conv_dim, c.num_conv_pos_embeddings,
-                                                     c.num_conv_pos_embedding_groups))
+                                                     c.num_conv_pos_embedding_groups, c.feat_extract_norm,
+                                                     c.conv_bias))
         # adopt the tree's children so state_dict keys carry no extra prefix
         for name, p in tree._parameters.items():
             self.register_parameter(name, p)
@@ -153,6 +159,10 @@ class Wav2Vec2Model(nn.Module):
         fe = "feature_extractor.conv_layers."
         P.w0 = f32(sd[fe + "0.conv.weight"].reshape(c.conv_dim, CONV_KERNEL[0]))
         P.gn_g, P.gn_b = f32(sd[fe + "0.layer_norm.weight"]), f32(sd[fe + "0.layer_norm.bias"])
+        nconv = len(CONV_KERNEL)
+        P.conv_b = [f32(sd[fe + f"{i}.conv.bias"]) if c.conv_bias else None for i in range(nconv)]
+        P.conv_ln = [(f32(sd[fe + f"{i}.layer_norm.weight"]), f32(sd[fe + f"{i}.layer_norm.bias"]))
+                     if c.feat_extract_norm == "layer" else None for i in range(nconv)]
         # conv i>=1: (Cout, Cin, k) -> (Cout, k*Cin), K index = kk*Cin + cin (channels-last window)
         P.conv_w = [cd(sd[fe + f"{i}.conv.weight"].permute(0, 2, 1).reshape(c.conv_dim, -1))
                     for i in range(1, len(CONV_KERNEL))]
@@ -189,10 +199,19 @@ class Wav2Vec2Model(nn.Module):
         P = self.pack(dtype)
         if reflect_len is None:
             reflect_len, replicate_len = 0, 0
-        x = ops.conv0_gn_gelu(audio.float().contiguous(), P.w0, P.gn_g, P.gn_b, reflect_len, replicate_len, dtype,
-                              self.config.layer_norm_eps)
+        eps = self.config.layer_norm_eps
+        if self.config.feat_extract_norm == "layer":
+            # HubertLayerNormConvLayer x 7: conv(+bias) -> LayerNorm over channels -> GELU
+            x = ops.conv0_ln_gelu(audio.float().contiguous(), P.w0, P.conv_b[0], *P.conv_ln[0], reflect_len,
+                                  replicate_len, dtype, eps)
+            for i, w in enumerate(P.conv_w):
+                z = ops.conv1d_cl(x, w, P.conv_b[i + 1], kernel=CONV_KERNEL[i + 1], stride=CONV_STRIDE[i + 1])
+                x = ops.layernorm(z, *P.conv_ln[i + 1], post_act=ops.ACT_GELU, eps=eps)
+            return x
+        x = ops.conv0_gn_gelu(audio.float().contiguous(), P.w0, P.gn_g, P.gn_b, reflect_len, replicate_len, dtype, eps)
         for i, w in enumerate(P.conv_w):
-            x = ops.conv1d_cl(x, w, None, kernel=CONV_KERNEL[i + 1], stride=CONV_STRIDE[i + 1], act=ops.ACT_GELU)
+            x = ops.conv1d_cl(x, w, P.conv_b[i + 1], kernel=CONV_KERNEL[i + 1], stride=CONV_STRIDE[i + 1],
+                              act=ops.ACT_GELU)
         return x
 
     def encode_features(self, x, dtype):
@@ -212,6 +231,16 @@ class Wav2Vec2Model(nn.Module):
         ops.gemm(xp, P.pos_w, P.pos_b, h, ops.ACT_GELU, out=y, M=B * T, N=cg, K=kpos * cg, lda=cg, rows_per_batch=T,
                  a_batch_stride=G * Tp * cg, ldw=kpos * cg, ldc=d, batch=G, strideA=Tp * cg, strideW=cg * kpos * cg,
                  strideC=cg, strideBias=cg, strideR=cg)
+        if c.do_stable_layer_norm:
+            # HubertEncoderStableLayerNorm: pre-LN blocks, ONE LayerNorm after the last layer
+            h = y
+            for L in P.layers:
+                qkv = ops.gemm(ops.layernorm(h, *L.ln1, eps=c.layer_norm_eps), L.wqkv, L.bqkv)
+                a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, (d // H) ** -0.5)
+                h = ops.gemm(a, L.wo, L.bo, residual=h)
+                f = ops.gemm(ops.layernorm(h, *L.ln2, eps=c.layer_norm_eps), L.w1, L.b1, act=ops.ACT_GELU)
+                h = ops.gemm(f, L.w2, L.b2, residual=h)
+            return ops.layernorm(h, *P.enc_ln, eps=c.layer_norm_eps)
         h = ops.layernorm(y, *P.enc_ln, eps=c.layer_norm_eps)
         for L in P.layers:
             qkv = ops.gemm(h, L.wqkv, L.bqkv)
