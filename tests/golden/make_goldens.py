@@ -184,6 +184,31 @@ def g3_audio(M, SE, mc):
                  style_keys=np.array(list(SE.get_style_encoder(args, "vae2").state_dict().keys())))
 
 
+def g2_lr_schedule(M, SE, mc):
+    """Learning-rate sequences of the reference's scheduler set-up (training_script.py:571-581) stepped as its training
+    loop does (l.222-224), using the reference's own utils/scheduler.py class."""
+    from utils.scheduler import GradualWarmupScheduler
+    out = {}
+    cases = [("Warmup", 1e-3, 4, 12, 0.1, 10), ("WarmupThenDecay", 1e-3, 4, 12, 0.1, 20),
+             ("WarmupThenDecay", 2e-5, 50, 400, 0.1, 450), ("Warmup", 2e-5, 5000, 0, 0.1, 5005)]
+    out["cases"] = np.array([(c[0], *map(str, c[1:])) for c in cases])
+    for i, (kind, lr, warm, cos_max, ratio, n) in enumerate(cases):
+        opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=lr)
+        if kind == "Warmup":
+            sch = GradualWarmupScheduler(opt, 1, warm)
+        else:
+            after = torch.optim.lr_scheduler.CosineAnnealingLR(opt, cos_max - warm, lr * ratio)
+            sch = GradualWarmupScheduler(opt, 1, warm, after)
+        seq = []
+        for it in range(n):
+            seq.append(opt.param_groups[0]["lr"])
+            opt.step()
+            if kind != "WarmupThenDecay" or it < cos_max:
+                sch.step()
+        out[f"lr_{i}"] = np.array(seq, dtype=np.float64)
+    save("g2_lr_schedule", **out)
+
+
 def g3_audio_large(M, SE, mc):
     """HuBERT-large ARCHITECTURE (feat_extract_norm='layer' + conv biases, stable-layer-norm encoder, 1024 wide, 16
     heads) through the reference's own wrapper class utils/hubert.py:9-51, 2 transformer layers, synthetic weights;
@@ -664,7 +689,7 @@ def g1_specaug(M, SE, mc):
     save("g1_specaug", **out)
 
 
-ALL = dict(g1_specaug=g1_specaug, g3_audio_large=g3_audio_large, g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
+ALL = dict(g1_specaug=g1_specaug, g2_lr_schedule=g2_lr_schedule, g3_audio_large=g3_audio_large, g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
            g3_forward=g3_forward, g3_style=g3_style, g3_sample=g3_sample, g3_infer=g3_infer,
            g4_flame=g4_flame, g4_rotations=g4_rotations, g5_losses=g5_losses, g6_train=g6_train)
 

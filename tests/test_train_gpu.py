@@ -237,3 +237,51 @@ def test_hubert_large_training_graph_matches_inference_path():
     assert enc.get_parameter("encoder.layer_norm.weight").grad is not None
     assert enc.get_parameter("encoder.layers.0.attention.q_proj.weight").grad is None
     assert enc.get_parameter("feature_extractor.conv_layers.3.layer_norm.weight").grad is None
+
+
+def test_trainer_checkpoint_roundtrip_and_reference_schedule(tmp_path):
+    """save_checkpoint writes the reference's dict (+ optimizer / scheduler / rng extensions); a fresh Trainer that
+    loads it continues bit-identically (same losses and weights as the uninterrupted run); the learning rate follows
+    the reference's GradualWarmupScheduler -> CosineAnnealingLR chain."""
+    import math
+    from msmd_amd.model import get_diffusion_model
+    from msmd_amd.style_encoder import get_style_encoder
+    from msmd_amd.training_script import Trainer, synthetic_batch
+    args = default_args(compute_dtype="fp32", encoder_layers=1, n_layers=1, lr=1e-3, warm_iter=4, scheduler="WarmupThenDecay",
+                        cos_max_iter=12, min_lr_ratio=0.1, gradient_accumulation_steps=1)
+    B = 2
+    batch = synthetic_batch(B, 0, DEV)
+
+    def make():
+        torch.manual_seed(0)
+        model = get_diffusion_model(args, DEV).eval()
+        se = get_style_encoder(args, "vae2").to(DEV).eval()
+        return Trainer(args, model, se)
+
+    def draws(i):
+        return dict(cross=[False, i % 2 == 1], end_idx=[None, None], t=[[5 + i, 400], [250, 20 + i]],
+                    eps=[dev(synth.normalish(f"ck/eps{i}{j}", (B, 100, 67))) for j in range(2)],
+                    style_eps=[dev(synth.normalish(f"ck/se{i}{j}", (B, 256))) for j in range(2)],
+                    cfg_flag=[dev(np.array([0.1, 0.7], np.float32)), dev(np.array([0.95, 0.3], np.float32))])
+    a = make()
+    lrs = []
+    for it in range(6):
+        lrs.append(a.current_lr())
+        a.step(batch, it=it, draws=draws(it))
+    # reference schedule (pinned against the reference's own scheduler classes in tests/test_host_cpu.py): warm-up
+    # 0, 1/4, 2/4, 3/4, 1 x lr, one hand-over iteration at lr, then the cosine towards 0.1 lr
+    assert np.allclose(lrs, [0.0, 2.5e-4, 5e-4, 7.5e-4, 1e-3, 1e-3])
+    path = tmp_path / "iter_0000005.pt"
+    a.save_checkpoint(path, 5)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert {"args", "model", "style_enc", "iter"} <= set(ck) and ck["iter"] == 5
+    out_a = [a.step(batch, it=it, draws=draws(it)) for it in range(6, 9)]
+    b = make()
+    assert b.load_checkpoint(path) == 5
+    out_b = [b.step(batch, it=it, draws=draws(it)) for it in range(6, 9)]
+    torch.cuda.synchronize()
+    for x, y in zip(out_a, out_b):
+        assert abs(float(x["loss"]) - float(y["loss"])) <= 1e-5 * abs(float(x["loss"]))
+    d = (a.flat_param - b.flat_param).abs()
+    assert float(d.max()) < 1e-4 and float((d > 2e-6).float().mean()) < 1e-2
+    assert abs(a.current_lr() - b.current_lr()) < 1e-12

@@ -9,6 +9,8 @@ Training attention materialises P (needed by the backward) with batched GEMMs + 
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import ops
@@ -28,14 +30,16 @@ class WeightCache:
     def get(self, w: torch.Tensor, dtype):
         key = (id(w), dtype)
         e = self.store.get(key)
-        if e is None or e[0] != w._version:
+        # id() values are recycled once a tensor dies: an entry is valid only for the SAME live tensor object (weak
+        # reference), at the same version and storage address
+        if e is None or e[0]() is not w or e[1] != (w._version, w.data_ptr(), tuple(w.shape)):
             w2 = w.detach().reshape(w.shape[0], -1)
             K = w2.shape[1]
             Kp = (K + 7) // 8 * 8
             wc = ops.pad_cols(w2.float().contiguous(), Kp, dtype)     # (N, Kp)
             wct = ops.transpose2d(wc[:, :K] if Kp != K else wc, 8)     # (K, Np)
-            e = self.store[key] = (w._version, wc, wct)
-        return e[1], e[2]
+            e = self.store[key] = (weakref.ref(w), (w._version, w.data_ptr(), tuple(w.shape)), wc, wct)
+        return e[2], e[3]
 
 
 CACHE = WeightCache()

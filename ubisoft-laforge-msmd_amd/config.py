@@ -25,7 +25,7 @@ DEFAULTS = dict(
     l_head_angle=1.0, l_head_vel=0.5, l_head_smooth=0.5, l_head_trans=0.5,
     l_kl_div=1e-7, use_vertex_space=False,
     # training (reference training_script.py:488-513, training_specs.sh)
-    lr=2e-5, warm_iter=5000, batch_size=16, max_iter=2_000_000,
+    lr=2e-5, warm_iter=5000, scheduler="Warmup", cos_max_iter=1_000_000, min_lr_ratio=0.1, batch_size=16, max_iter=2_000_000,
     gradient_accumulation_steps=1, trunc_prob1=0.5, trunc_prob2=0.4,
     prob_cross_style=0.3, use_cross_style=True,
     # engine (new in this build)

@@ -76,6 +76,7 @@ class Trainer:
         self.lr = float(args.lr)
         self.warm_iter = int(getattr(args, "warm_iter", 0) or 0)
         self.sched_step = 0
+        self._build_lr_schedule()
         self.use_graph = bool(use_graph)
         self._graphs, self._graph_pool, self._flag_table = {}, None, None
         # weight gradients are added straight into the arena by the wgrad GEMM when bucket launches do not hang
@@ -84,11 +85,64 @@ class Trainer:
         # Philox (seed, step) for dropout masks: device memory, advanced once per iteration
         self.noise_state = torch.tensor([0x5EED0000 + 7919 * dp.env_rank()[0], 0], dtype=torch.int64, device=self.device)
 
-    # GradualWarmupScheduler(optimizer, 1, warm_iter): lr = base * min(1, step / warm_iter)
+    # ------------------------------------------------------------------ learning-rate schedule
+    def _build_lr_schedule(self):
+        from .utils.scheduler import LrSchedule
+        self._lr = LrSchedule(self.args)
+
     def current_lr(self):
-        if self.warm_iter <= 0 or self.sched_step > self.warm_iter:
-            return self.lr
-        return self.lr * float(self.sched_step) / self.warm_iter
+        # tests poke `self.lr` when no scheduler is configured
+        return self._lr.lr if self._lr.sched is not None else self.lr
+
+    def _scheduler_step(self, it):
+        self._lr.step(it)
+
+    # ------------------------------------------------------------------ checkpoints
+    def save_checkpoint(self, path, it):
+        """The reference's checkpoint dict (training_script.py:227-233: 'args', 'model', 'style_enc', 'iter'; loadable
+        by the reference's load_pretrained_model) plus resumable-training extensions the reference lacks (it restarts
+        Adam and the warm-up from scratch): 'optimizer' (flat Adam moments + step), 'scheduler', 'rng'."""
+        torch.save({
+            "args": self.args,
+            "model": self.model.state_dict(),
+            "style_enc": self.style_enc.state_dict(),
+            "iter": int(it),
+            "optimizer": {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "step": self.opt_step,
+                          "layout": [(n, int(p.numel())) for n, p in self._named_trainable()]},
+            "scheduler": {"sched_step": self.sched_step, "n_calls": self._lr.calls, "lr": self.current_lr()},
+            "rng": {"numpy": self.rng.get_state(), "noise_state": self.noise_state.cpu()},
+        }, path)
+
+    def load_checkpoint(self, path_or_dict):
+        """Restores weights (reference key names; reference-written checkpoints load as they are) and, when present,
+        the optimizer / scheduler / RNG extensions.  Returns the stored iteration."""
+        ck = torch.load(path_or_dict, map_location="cpu", weights_only=False) if not isinstance(path_or_dict, dict) \
+            else path_or_dict
+        self.model.load_state_dict(ck["model"])
+        self.style_enc.load_state_dict(ck["style_enc"])
+        self._invalidate_caches()
+        opt = ck.get("optimizer")
+        if opt is not None:
+            if [(n, k) for n, k in opt["layout"]] != [(n, int(p.numel())) for n, p in self._named_trainable()]:
+                raise ValueError("optimizer state layout does not match this model's trainable parameters")
+            self.exp_avg.copy_(opt["exp_avg"])
+            self.exp_avg_sq.copy_(opt["exp_avg_sq"])
+            self.opt_step = int(opt["step"])
+        sch = ck.get("scheduler")
+        if sch is not None:   # the schedulers are pure functions of their call count: rebuild and replay
+            self.sched_step = int(sch["sched_step"])
+            self._build_lr_schedule()
+            if self._lr.sched is not None:
+                self._lr.replay(sch["n_calls"])
+        rng = ck.get("rng")
+        if rng is not None:
+            self.rng.set_state(rng["numpy"])
+            self.noise_state.copy_(rng["noise_state"])
+        return int(ck.get("iter", 0))
+
+    def _named_trainable(self):
+        out = [("style_enc." + n, p) for n, p in self.style_enc.named_parameters() if p.requires_grad]
+        return out + [("model." + n, p) for n, p in self.model.named_parameters() if p.requires_grad]
 
     def _invalidate_caches(self):
         ag.CACHE.clear()
@@ -214,6 +268,7 @@ class Trainer:
         if stepping:
             self._optimizer_step()
         self.sched_step += 1
+        self._scheduler_step(it)
         return out
 
     # ------------------------------------------------------------------ hipGraph mode

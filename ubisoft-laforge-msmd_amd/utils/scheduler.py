@@ -49,3 +49,43 @@ class GradualWarmupScheduler(_LRScheduler):
             self._last_lr = self.after_scheduler.get_last_lr()
             return None
         return super().step(epoch)
+
+
+class LrSchedule:
+    """The reference's learning-rate schedules (training_script.py:571-581, stepping rule l.222-224) on a 1-element
+    host-side optimizer: `lr` is the value the reference's optimizer would use at the current iteration.
+    'Warmup' = GradualWarmupScheduler(opt, 1, warm_iter); 'WarmupThenDecay' puts CosineAnnealingLR(opt, cos_max_iter -
+    warm_iter, lr * min_lr_ratio) behind it and stops stepping at cos_max_iter; anything else = constant lr."""
+
+    def __init__(self, args):
+        import torch
+        self.kind = getattr(args, "scheduler", "Warmup")
+        self.base = float(args.lr)
+        self.warm = int(getattr(args, "warm_iter", 0) or 0)
+        self.cos_max = int(getattr(args, "cos_max_iter", 0) or 0)
+        self.opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=self.base)
+        self.sched = None
+        self.calls = 0
+        if self.warm > 0 and self.kind in ("Warmup", "WarmupThenDecay"):
+            after = None
+            if self.kind == "WarmupThenDecay":
+                after = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, self.cos_max - self.warm,
+                                                                   self.base * float(args.min_lr_ratio))
+            self.sched = GradualWarmupScheduler(self.opt, 1, self.warm, after)
+
+    @property
+    def lr(self):
+        return float(self.opt.param_groups[0]["lr"]) if self.sched is not None else self.base
+
+    def step(self, it):
+        """Call once per iteration AFTER the optimizer step, with the iteration index (reference l.222-224)."""
+        if self.sched is not None and (self.kind != "WarmupThenDecay" or it < self.cos_max):
+            self.opt.step()   # no-op on the gradient-less dummy parameter; keeps torch's call-order check quiet
+            self.sched.step()
+            self.calls += 1
+
+    def replay(self, n_calls):
+        for _ in range(int(n_calls)):
+            self.opt.step()
+            self.sched.step()
+        self.calls = int(n_calls)
