@@ -225,3 +225,30 @@ def test_lr_schedule_matches_reference_scheduler_sequences():
         s2 = LrSchedule(args)
         s2.replay(s.calls)
         assert s2.lr == s.lr
+
+
+def test_style_clip_ingestion_and_denormalisation():
+    """normalize_motion_coeff (reference inference.py:139-181): statistics, the 30 -> 25 fps resampling rule (checked
+    against scipy.interpolate.interp1d, the routine the reference calls) and denormalize_coeffs as its inverse."""
+    import torch
+    from scipy.interpolate import interp1d
+    from msmd_amd.inference import normalize_motion_coeff, denormalize_coeffs, resample_linear
+    rs = np.random.RandomState(3)
+    for n, fps in ((90, 30), (131, 30), (77, 24), (50, 25)):
+        e, h = rs.randn(n, 50).astype(np.float32), rs.randn(n, 3).astype(np.float32)
+        stats = {"exp_mean": torch.from_numpy(rs.randn(50).astype(np.float32)), "exp_std": torch.from_numpy(rs.rand(50).astype(np.float32) + 0.5),
+                 "pose_mean": torch.from_numpy(rs.randn(3).astype(np.float32)), "pose_std": torch.from_numpy(rs.rand(3).astype(np.float32) + 0.5)}
+        m, shape = normalize_motion_coeff(torch.from_numpy(e), h, stats, device="cpu", original_fps=fps, target_fps=25)
+        en = (e - stats["exp_mean"].numpy()) / (stats["exp_std"].numpy() + 1e-9)
+        hn = (h - stats["pose_mean"].numpy()) / (stats["pose_std"].numpy() + 1e-9)
+        if fps != 25:
+            n_new = int(round(n / fps * 25))
+            x, xn = np.linspace(0, 1, num=n), np.linspace(0, 1, num=n_new)
+            en, hn = interp1d(x, en, axis=0)(xn), interp1d(x, hn, axis=0)(xn)
+            assert np.array_equal(resample_linear(en, en.shape[0]), en)
+        ref = np.concatenate([en, hn], axis=1).astype(np.float32)
+        assert m.shape == (1,) + ref.shape and shape.shape == (1, 100) and float(shape.abs().sum()) == 0
+        assert np.abs(m[0].numpy() - ref).max() < 1e-6
+        ex, hr = denormalize_coeffs(m, stats)
+        if fps == 25:
+            assert np.abs(ex.numpy() - e).max() < 1e-5 and np.abs(hr.numpy() - h).max() < 1e-5

@@ -312,3 +312,45 @@ def test_hubert_large_architecture_fp32_and_bf16():
     assert feat.shape == (2, 250, 512) and bool(torch.isfinite(feat).all())
     frozen = [n for n, p in model.audio_encoder.named_parameters() if not p.requires_grad]
     assert any(n.startswith("feature_extractor.conv_layers.6.layer_norm") for n in frozen)
+
+
+def test_infer_coeffs_batch_equals_per_clip_and_reference_goldens():
+    """infer_coeffs_batch (window i of all clips in one sample() call, one encoder pass per padded length): every
+    clip's result equals the per-clip driver with the same injected noise, and the two golden clips still match the
+    reference's infer_coeffs outputs when batched together with a third clip."""
+    from msmd_amd.inference import infer_coeffs, infer_coeffs_batch, window_plan
+    from msmd_amd.model import DiffusionSchedule
+    g = load_golden("g3_infer")
+    model, args = get_model("wav2vec2", "fp32")
+    T = 2
+    old = model.diffusion_sched
+    model.diffusion_sched = DiffusionSchedule(T, "cosine").to(DEV)
+    try:
+        audios, noises, subs = [], [], []
+        for S in (100000, 32000):
+            n_sub = window_plan(S, args.fps, args.n_motions, 640.0)[2]
+            draws = g[f"draws_{S}"]
+            audios.append(dev(synth.audio_clips(1, S, tag="infer")[0]))
+            noises.append(dict(xT=dev(draws[0]), z=[{2: dev(draws[1 + i])} for i in range(n_sub)]))
+            subs.append(n_sub)
+        S3 = 150001                                     # third clip: 3 windows, ragged length
+        n3 = window_plan(S3, args.fps, args.n_motions, 640.0)[2]
+        audios.append(dev(synth.audio_clips(1, S3, tag="infer3")[0]))
+        noises.append(dict(xT=dev(synth.normalish("ib/xT", (1, 100, 67))),
+                           z=[{2: dev(synth.normalish(f"ib/z{i}", (1, 100, 67)))} for i in range(n3)]))
+        style1 = dev(synth.normalish("infer/style", (1, args.d_style)))
+        styles = torch.cat([style1, style1, dev(synth.normalish("ib/style", (1, args.d_style)))], dim=0)
+        shapes3 = torch.zeros(3, 100, device=DEV)
+        ys = infer_coeffs_batch(model, args, audios, shapes3, 640.0, styles, cfg_scale=1.4, dynamic_threshold=None,
+                                noise=noises)
+        torch.cuda.synchronize()
+        for c, S in enumerate((100000, 32000)):
+            assert ys[c].shape == g[f"coef_{S}"].shape
+            assert maxabs(ys[c].cpu().numpy(), g[f"coef_{S}"]) < 1e-4, S
+        for c in range(3):
+            y1 = infer_coeffs(model, args, audios[c], shapes3[c:c + 1].unsqueeze(0), 640.0, styles[c:c + 1], cfg_scale=1.4,
+                              dynamic_threshold=None, noise=noises[c])
+            assert ys[c].shape == y1.shape
+            assert maxabs(ys[c].cpu().numpy(), y1.cpu().numpy()) < 2e-5, c
+    finally:
+        model.diffusion_sched = old
