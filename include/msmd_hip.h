@@ -339,6 +339,19 @@ int msmd_pad_cols(const void* x, void* y, long rows, int cols_in, int cols_out, 
 /* y[r, :] = mean over T of x[b, t, :]  (B, T, C) -> (B, C) fp32 (style_encoder.py:189). */
 int msmd_mean_time(const void* x, float* y, int B, int T, int C, int dtype, msmd_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Training-batch assembly from an HBM-resident corpus: both consecutive L-frame windows of B samples in one launch
+ * (reference DatasetPickle.__getitem__ + collate_fn, datasets.py:251-368, 424-503).
+ *   audio_flat / coef_flat: all clips back to back (coef rows of C floats); desc (B, 8) int64 per sample:
+ *   [audio offset, audio length, coef row offset, coef rows, start frame of window 0, zero frames padded in front,
+ *    zero audio samples padded in front, clip index]; clip_stats (n_clips, 2) = each clip's audio mean / std.
+ *   out_audio (2, B, n_audio): (x - mean) / (std + 1e-5) inside the clip, 0 in padding, window w covering samples
+ *   [int(start_w * unit), int(end_w * unit)) then padded / trimmed to n_audio; out_motion (2, B, L, C):
+ *   (row - coef_mean) / (coef_std + 1e-9) with zero rows where the reference zero-pads (statistics may be NULL). */
+int msmd_batch_windows(const float* audio_flat, const float* coef_flat, const long* desc, const float* clip_stats,
+                       const float* coef_mean, const float* coef_std, float* out_audio, float* out_motion, int B, int L,
+                       int C, int n_audio, double audio_unit, msmd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -209,6 +209,73 @@ def g2_lr_schedule(M, SE, mc):
     save("g2_lr_schedule", **out)
 
 
+def dataset_raw_clips():
+    """Synthetic decoded corpus (30 fps tracks, 64-d expression codes + 3-d head orientation, 16 kHz audio): clips
+    longer than / equal to / shorter than the 210-frame item length after the 30 -> 25 fps resampling."""
+    raw = {}
+    for name, n30 in (("long_a", 400), ("long_b", 301), ("exact", 252), ("short_a", 200), ("short_b", 131), ("tiny", 40)):
+        n25 = int(round(n30 / 30 * 25))
+        S = int(n25 * 640) + {"long_a": 37, "long_b": -211, "exact": 0, "short_a": 5, "short_b": -400, "tiny": 123}[name]
+        raw[name] = {"audio": (0.3 * synth.normalish(f"ds/{name}/audio", (S,)) + 0.05).astype(np.float32),
+                     "expression_code": synth.normalish(f"ds/{name}/exp", (n30, 64)).astype(np.float64) * 1.5 + 0.2,
+                     "head_orientation": synth.normalish(f"ds/{name}/head", (n30, 3)).astype(np.float64) * 0.3}
+    return raw
+
+
+def _load_dataset_class():
+    """Build the reference's DatasetPickle / incremental_mean_and_std from its file's AST (datasets.py imports
+    torchaudio / librosa / cv2, absent here): this container only."""
+    import pickle as _pickle
+    from scipy.interpolate import interp1d
+    from torch.utils import data
+    src = open(os.path.join(REF, "datasets.py")).read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if (isinstance(n, ast.ClassDef) and n.name == "DatasetPickle")
+            or (isinstance(n, ast.FunctionDef) and n.name == "incremental_mean_and_std")]
+    ns = {"np": np, "torch": torch, "data": data, "interp1d": interp1d, "pickle": _pickle, "tqdm": (lambda x: x)}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "<reference datasets.py>", "exec"), ns)
+    return ns["DatasetPickle"], ns["incremental_mean_and_std"]
+
+
+def g7_dataset(M, SE, mc):
+    """Items and collated batches of the reference's DatasetPickle on a synthetic corpus, numpy seeded."""
+    DatasetPickle, _ = _load_dataset_class()
+    raw = dataset_raw_clips()
+    names = list(raw)
+    tmp = tempfile.mkdtemp()
+    split = os.path.join(tmp, "split.txt")
+    open(split, "w").write("\n".join(names) + "\n")
+    stats_file = os.path.join(tmp, "stats.npz")
+    st = {"exp_mean": synth.normalish("ds/exp_mean", (64,)) * 0.1, "exp_std": np.abs(synth.normalish("ds/exp_std", (64,))) + 0.5,
+          "pose_mean": synth.normalish("ds/pose_mean", (3,)) * 0.1, "pose_std": np.abs(synth.normalish("ds/pose_std", (3,))) + 0.5}
+    np.savez(stats_file, **{k: v.astype(np.float32) for k, v in st.items()})
+    out = {"names": np.array(names)}
+    for mode, rc in (("crop", True), ("nocrop", False)):
+        ds = DatasetPickle("unused", split, coef_stats_file=stats_file, original_fps=30, coef_fps=25, n_motions=100,
+                           clip_len=100, pre_loaded_raw_dataset={k: dict(v) for k, v in raw.items()}, celebv_text=False,
+                           random_crop=rc)
+        order = [0, 3, 1, 4, 2, 5, 0, 4] if rc else [2, 3, 4, 5]   # the reference crashes on clips > 210 frames without random_crop
+        np.random.seed(7)
+        items = [ds[i] for i in order]
+        batch = DatasetPickle.get_collate_fn(SE=False)(items)
+        out[f"{mode}_order"] = np.array(order)
+        out[f"{mode}_audio0"] = batch[0][0].numpy()[:, ::13]
+        out[f"{mode}_audio1"] = batch[0][1].numpy()[:, ::13]
+        out[f"{mode}_audio0_head"] = batch[0][0].numpy()[:, :64]
+        out[f"{mode}_audio1_tail"] = batch[0][1].numpy()[:, -4000:]
+        out[f"{mode}_motion0"] = batch[1][0]["motion"].numpy()
+        out[f"{mode}_motion1"] = batch[1][1]["motion"].numpy()
+        out[f"{mode}_stats"] = np.array([float(batch[2][0]), float(batch[2][1])])
+        out[f"{mode}_item_audio_len"] = np.array([[it[0][0].shape[0], it[0][1].shape[0]] for it in items])
+    # corpus statistics as the reference computes them when no stats file is given (seeded crops, no normalisation)
+    np.random.seed(11)
+    ds = DatasetPickle("unused", split, coef_stats_file=None, original_fps=30, coef_fps=25, n_motions=100, clip_len=100,
+                       pre_loaded_raw_dataset={k: dict(v) for k, v in raw.items()}, celebv_text=False, random_crop=True)
+    for k, v in ds.coef_stats.items():
+        out["stats_" + k] = v.numpy()
+    save("g7_dataset", **out)
+
+
 def g3_audio_large(M, SE, mc):
     """HuBERT-large ARCHITECTURE (feat_extract_norm='layer' + conv biases, stable-layer-norm encoder, 1024 wide, 16
     heads) through the reference's own wrapper class utils/hubert.py:9-51, 2 transformer layers, synthetic weights;
@@ -689,7 +756,7 @@ def g1_specaug(M, SE, mc):
     save("g1_specaug", **out)
 
 
-ALL = dict(g1_specaug=g1_specaug, g2_lr_schedule=g2_lr_schedule, g3_audio_large=g3_audio_large, g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
+ALL = dict(g1_specaug=g1_specaug, g7_dataset=g7_dataset, g2_lr_schedule=g2_lr_schedule, g3_audio_large=g3_audio_large, g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
            g3_forward=g3_forward, g3_style=g3_style, g3_sample=g3_sample, g3_infer=g3_infer,
            g4_flame=g4_flame, g4_rotations=g4_rotations, g5_losses=g5_losses, g6_train=g6_train)
 

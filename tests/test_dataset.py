@@ -1,0 +1,105 @@
+"""Training-data tensor contract: oracle restatement against items / batches recorded from
+the reference's own DatasetPickle (CPU), and the HBM-resident HIP loader against both (GPU)."""
+import numpy as np
+import pytest
+
+from msmd_amd import synth
+from oracle import dataset as ods
+
+from conftest import load_golden
+
+
+def raw_clips():
+    """Same synthetic corpus as tests/golden/make_goldens.py::dataset_raw_clips."""
+    raw = {}
+    for name, n30 in (("long_a", 400), ("long_b", 301), ("exact", 252), ("short_a", 200), ("short_b", 131), ("tiny", 40)):
+        n25 = int(round(n30 / 30 * 25))
+        S = int(n25 * 640) + {"long_a": 37, "long_b": -211, "exact": 0, "short_a": 5, "short_b": -400, "tiny": 123}[name]
+        raw[name] = {"audio": (0.3 * synth.normalish(f"ds/{name}/audio", (S,)) + 0.05).astype(np.float32),
+                     "expression_code": synth.normalish(f"ds/{name}/exp", (n30, 64)).astype(np.float64) * 1.5 + 0.2,
+                     "head_orientation": synth.normalish(f"ds/{name}/head", (n30, 3)).astype(np.float64) * 0.3}
+    return raw
+
+
+def coef_stats():
+    st = {"exp_mean": synth.normalish("ds/exp_mean", (64,)) * 0.1, "exp_std": np.abs(synth.normalish("ds/exp_std", (64,))) + 0.5,
+          "pose_mean": synth.normalish("ds/pose_mean", (3,)) * 0.1, "pose_std": np.abs(synth.normalish("ds/pose_std", (3,))) + 0.5}
+    return {k: v.astype(np.float32) for k, v in st.items()}
+
+
+def check_batch(g, mode, audio, motion, stats, tol):
+    assert np.abs(audio[0][:, ::13] - g[f"{mode}_audio0"]).max() <= tol
+    assert np.abs(audio[1][:, ::13] - g[f"{mode}_audio1"]).max() <= tol
+    assert np.abs(audio[0][:, :64] - g[f"{mode}_audio0_head"]).max() <= tol
+    assert np.abs(audio[1][:, -4000:] - g[f"{mode}_audio1_tail"]).max() <= tol
+    assert np.abs(motion[0] - g[f"{mode}_motion0"]).max() <= tol
+    assert np.abs(motion[1] - g[f"{mode}_motion1"]).max() <= tol
+    assert np.abs(np.asarray(stats, np.float64) - g[f"{mode}_stats"]).max() < 1e-6
+
+
+def test_oracle_items_and_collate_match_reference_dataset():
+    g = load_golden("g7_dataset")
+    raw = raw_clips()
+    names = [str(n) for n in g["names"]]
+    res = {n: {"audio": raw[n]["audio"], "expression_code": ods.resample(raw[n]["expression_code"], 30, 25),
+               "head_orientation": ods.resample(raw[n]["head_orientation"], 30, 25)} for n in names}
+    st = coef_stats()
+    for mode, rc in (("crop", True), ("nocrop", False)):
+        rng = np.random.RandomState(7)
+        items = [ods.get_item(res[names[i]], st, rng, random_crop=rc) for i in g[f"{mode}_order"]]
+        assert [[it[0][0].shape[0], it[0][1].shape[0]] for it in items] == g[f"{mode}_item_audio_len"].tolist()
+        audio, motion, stats = ods.collate(items)
+        check_batch(g, mode, audio, motion, stats, 0.0)       # same fp32 arithmetic: bit-exact
+
+
+@pytest.mark.gpu
+def test_resident_dataset_batches_match_reference_and_oracle():
+    """One msmd_batch_windows launch per batch reproduces the reference's items + collate bit for bit (copies and one
+    fp32 subtract / divide per element), including the short-clip padding branches and the seeded crop draws."""
+    import torch
+    from msmd_amd.datasets import ResidentDataset
+    g = load_golden("g7_dataset")
+    raw = raw_clips()
+    names = [str(n) for n in g["names"]]
+    for mode, rc in (("crop", True), ("nocrop", False)):
+        ds = ResidentDataset(raw, names, coef_stats=coef_stats(), original_fps=30, coef_fps=25, random_crop=rc, seed=7)
+        audio, coefs, stats = ds.batch(g[f"{mode}_order"])
+        torch.cuda.synchronize()
+        assert audio[0].shape == (len(g[f"{mode}_order"]), 64000) and coefs[0]["motion"].shape[1:] == (100, 67)
+        assert coefs[0]["shape"].shape[1:] == (100, 100) and float(coefs[0]["shape"].abs().sum()) == 0
+        check_batch(g, mode, [a.cpu().numpy() for a in audio], [c["motion"].cpu().numpy() for c in coefs],
+                    [float(stats[0]), float(stats[1])], 0.0)
+    # single item surface + whole-clip query
+    ds = ResidentDataset(raw, names, coef_stats=coef_stats(), random_crop=True, seed=7)
+    (a0, a1), (c0, c1), (m, s) = ds[0]
+    assert [a0.shape[0], a1.shape[0]] == g["crop_item_audio_len"][0].tolist() and c0["motion"].shape == (100, 67)
+    audio, cd, _ = ds.query_for_video(3)
+    assert audio.shape[0] == raw["short_a"]["audio"].shape[0] and abs(float(audio.mean())) < 1e-4
+    # corpus statistics (sum / sum-of-squares over seeded crops) against the reference's incremental_mean_and_std
+    ds2 = ResidentDataset(raw, names, coef_stats=None, random_crop=True, seed=11)
+    for k in ("exp_mean", "exp_std", "pose_mean", "pose_std"):
+        assert np.abs(ds2.coef_stats[k].numpy() - g["stats_" + k]).max() < 2e-5, k
+
+
+@pytest.mark.gpu
+def test_trainer_consumes_resident_dataset_batches():
+    """Loader -> Trainer.step hand-off: device-resident batches (no host copy) drive the training iteration."""
+    import torch
+    from msmd_amd.config import default_args
+    from msmd_amd.datasets import ResidentDataset
+    from msmd_amd.model import get_diffusion_model
+    from msmd_amd.style_encoder import get_style_encoder
+    from msmd_amd.training_script import Trainer, batch_from_loader
+    raw = raw_clips()
+    ds = ResidentDataset(raw, list(raw), coef_stats=None, random_crop=True, seed=3)
+    args = default_args(compute_dtype="bf16", encoder_layers=1, n_layers=1, lr=1e-4, warm_iter=0)
+    model = get_diffusion_model(args, "cuda").eval()
+    se = get_style_encoder(args, "vae2").to("cuda").eval()
+    tr = Trainer(args, model, se)
+    sampler = np.random.RandomState(0)
+    for it in range(1, 4):
+        batch = batch_from_loader(ds.batch(sampler.randint(0, len(ds), size=4)))
+        assert batch[0][0].shape == (4, 64000) and batch[1][0].shape == (4, 100, 67) and batch[2].shape == (4, 100)
+        out = tr.step(batch, it=it)
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(v).all()) for v in out.values())

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmsmd_hip.so")
 
 _CTYPE = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
-    "msmd_stream_t": ctypes.c_void_p, "unsigned": ctypes.c_uint,
+    "msmd_stream_t": ctypes.c_void_p, "unsigned": ctypes.c_uint, "double": ctypes.c_double,
 }
 
 

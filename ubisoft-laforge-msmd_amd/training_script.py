@@ -59,6 +59,16 @@ def synthetic_batch(B, rank=0, device="cuda", it=0):
             torch.zeros(B, 100, device=device))
 
 
+def batch_from_loader(item):
+    """(audio_pair, coef_pair, audio_stats) as the reference's loader / datasets.ResidentDataset.batch yields it ->
+    the step's (audio_pair, motion_pair, shape) (training_script.py:77-93: motion = coef['motion'], shape = the first
+    frame's shape row)."""
+    audio_pair, coef_pair, _ = item
+    shape = coef_pair[0]["shape"]
+    shape = shape.clone() if shape.ndim == 2 else shape[:, 0].clone()
+    return list(audio_pair), [coef_pair[0]["motion"], coef_pair[1]["motion"]], shape
+
+
 class Trainer:
     def __init__(self, args, model, style_enc, process_group=None, bucket_mb=32.0, use_graph=False):
         self.args, self.model, self.style_enc = args, model, style_enc
