@@ -103,3 +103,34 @@ def test_trainer_consumes_resident_dataset_batches():
         out = tr.step(batch, it=it)
     torch.cuda.synchronize()
     assert all(bool(torch.isfinite(v).all()) for v in out.values())
+
+
+@pytest.mark.gpu
+def test_validation_pass_over_resident_batches(tmp_path):
+    """training_script.test (reference l.243-403): loss_log keys / aggregation, cross-style rule, model mode restored;
+    the per-batch total equals the weighted sum of its parts."""
+    import json
+    import torch
+    from msmd_amd.config import default_args
+    from msmd_amd.datasets import ResidentDataset
+    from msmd_amd.model import get_diffusion_model
+    from msmd_amd.style_encoder import get_style_encoder
+    from msmd_amd.training_script import load_loss_weights, test
+    raw = raw_clips()
+    ds = ResidentDataset(raw, list(raw), coef_stats=None, random_crop=False, seed=3)
+    args = default_args(compute_dtype="fp32", encoder_layers=1, n_layers=1)
+    model = get_diffusion_model(args, "cuda").train()
+    se = get_style_encoder(args, "vae2").to("cuda").eval()
+    lw = load_loss_weights(args)
+    loader = [ds.batch([2, 3]), ds.batch([4, 5, 3])]
+    torch.manual_seed(1)
+    log = test(args, lw, model, se, loader, n_rounds=2, coef_stats=ds.coef_stats)
+    assert model.training
+    assert len(log["loss"]) == 4 and all(np.isfinite(log["loss"]))
+    keys = [k for k in lw if lw[k] > 0]
+    assert set(log) == set(keys) | {"loss"}
+    for j in range(4):
+        assert abs(sum(log[k][j] * lw[k] for k in keys) - log["loss"][j]) <= 1e-5 * abs(log["loss"][j])
+    path = tmp_path / "metrics.json"
+    saved = test(args, lw, model, se, loader, n_rounds=1, do_save=True, do_save_path=path, coef_stats=ds.coef_stats)
+    assert json.load(open(path))["loss"]["n_samples"] == 2 and saved["loss"]["n_samples"] == 2

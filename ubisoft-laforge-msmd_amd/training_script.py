@@ -59,6 +59,80 @@ def synthetic_batch(B, rank=0, device="cuda", it=0):
             torch.zeros(B, 100, device=device))
 
 
+@torch.no_grad()
+def test(args, loss_weights, model, style_enc, test_loader, current_iter=0, n_rounds=10, mode="val", writer=None,
+         flame=None, out_abc_dir=None, do_save=False, do_save_path=None, do_ignore_style=False, coef_stats=None):
+    """Validation / test pass (reference training_script.py:243-403, same signature): eval-mode forward of both
+    windows with the inference kernels, the other window's style when use_cross_style (l.311-312), no truncation,
+    the HIP loss kernels, KL, per-batch weighted sums; returns the reference's loss_log (lists, or
+    {mean, std, n_samples} per key when do_save, also written to do_save_path as JSON).  `test_loader` is any iterable
+    of the loader tuple (audio_pair, coef_pair, audio_stats), e.g. datasets.ResidentDataset.batch outputs."""
+    import json
+    from collections import defaultdict
+    from .utils.common import compute_KL_loss, compute_loss, compute_loss_no_vert
+    was_training = model.training
+    model.eval()
+    device = model.device
+    if coef_stats is None:
+        ds = getattr(test_loader, "dataset", None)
+        coef_stats = getattr(ds, "coef_stats", None)
+    if coef_stats is not None:
+        coef_stats = {k: v.to(device) for k, v in coef_stats.items()}
+    legacy = args.dataset_type[:9] == "HDTF_TFHP" or args.dataset_type == "flame_mead_ravdess"
+    loss_log = defaultdict(list)
+    for _ in range(n_rounds):
+        for audio_pair, coef_pair, _stats in test_loader:
+            audio_pair = [a.to(device) for a in audio_pair]
+            motion_pair = [coef_pair[i]["motion"].to(device) for i in range(2)]
+            shape = coef_pair[0]["shape"].to(device)
+            shape_coef = shape.clone() if shape.ndim == 2 else shape[:, 0].clone()
+            src = [torch.zeros_like(m) for m in motion_pair] if do_ignore_style else motion_pair
+            enc = [style_enc(src[i]) for i in range(2)]
+            style_pair, mu_pair, logvar_pair = ([e[j] for e in enc] for j in range(3))
+            losses = {k: torch.zeros((), device=device) for k in loss_weights}
+            prev_motion = prev_audio = None
+            for i in range(2):
+                style = style_pair[1 - i] if args.use_cross_style else style_pair[i]
+                B = audio_pair[i].shape[0]
+                indicator = torch.ones(B, args.n_motions, device=device) if args.use_indicator else None
+                shape_in = shape_coef if not getattr(args, "do_ignore_shape", False) else torch.zeros_like(shape_coef)
+                cfg = not getattr(args, "do_ignore_cfg", False)
+                if i == 0:
+                    noise, target, pm, pa = model(motion_pair[i], audio_pair[i], shape_in, style, indicator=indicator,
+                                                  train_with_CFG=cfg)
+                    prev_motion, prev_audio = pm[:, -args.n_prev_motions:], pa[:, -args.n_prev_motions:]
+                else:
+                    noise, target, _, _ = model(motion_pair[i], audio_pair[i], shape_in, style, prev_motion, prev_audio,
+                                                indicator=indicator, train_with_CFG=cfg)
+                fn = compute_loss if (args.use_vertex_space and legacy) else compute_loss_no_vert
+                ld = fn(args, i == 0, shape_coef, motion_pair[i], noise, target, prev_motion, coef_stats, flame, None,
+                        return_dict=True)
+                ld["kl_div"] = compute_KL_loss(mu_pair[i], logvar_pair[i])
+                for k, v in ld.items():
+                    if loss_weights.get(k, 0) > 0 and v is not None:
+                        losses[k] = losses[k] + v
+            total = 0.0
+            for k in losses:
+                if loss_weights[k] > 0:
+                    loss_log[k].append(float(losses[k]))
+                    total = total + losses[k] * loss_weights[k]
+            loss_log["loss"].append(float(total))
+    if writer is not None:
+        writer.add_scalar(f"{mode}/loss", float(np.mean(loss_log["loss"])), current_iter)
+        for k in loss_log:
+            if k != "loss" and loss_weights[k] > 0:
+                writer.add_scalar(f"{mode}/{k}", float(np.mean(loss_log[k])), current_iter)
+    if do_save:
+        for k in list(loss_log):
+            vals = loss_log[k]
+            loss_log[k] = {"mean": float(np.mean(vals)), "std": float(np.std(vals)), "n_samples": len(vals)}
+        with open(do_save_path, "w") as f:
+            json.dump(loss_log, f)
+    if was_training:
+        model.train()
+    return loss_log
+
+
 def batch_from_loader(item):
     """(audio_pair, coef_pair, audio_stats) as the reference's loader / datasets.ResidentDataset.batch yields it ->
     the step's (audio_pair, motion_pair, shape) (training_script.py:77-93: motion = coef['motion'], shape = the first
