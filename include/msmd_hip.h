@@ -339,6 +339,13 @@ int msmd_pad_cols(const void* x, void* y, long rows, int cols_in, int cols_out, 
 /* y[r, :] = mean over T of x[b, t, :]  (B, T, C) -> (B, C) fp32 (style_encoder.py:189). */
 int msmd_mean_time(const void* x, float* y, int B, int T, int C, int dtype, msmd_stream_t stream);
 
+/* Dynamic thresholding of the denoiser output, in place (reference model.py:396-402 / 578-584):
+ * s_n = clamp(torch.quantile(|res[n, -L:, :]|, ratio), dt_min, dt_max) ('linear' interpolation between order
+ * statistics, ATen's lerp), res[n] <- clamp(res[n], -s_n, s_n) over all T_all frames.  res: (N, T_all, C) fp32,
+ * L * C <= 20480.  No sort: bisection on the float bit pattern with block-wide counts. */
+int msmd_dynamic_threshold(float* res, int N, int T_all, int L, int C, float ratio, float dt_min, float dt_max,
+                           msmd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Training-batch assembly from an HBM-resident corpus: both consecutive L-frame windows of B samples in one launch
  * (reference DatasetPickle.__getitem__ + collate_fn, datasets.py:251-368, 424-503).

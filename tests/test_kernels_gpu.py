@@ -326,3 +326,20 @@ def test_gemm_tn_windowed_operand_is_conv_weight_gradient():
     win = torch.stack([xp[:, :, t:t + kpos].reshape(Bn, G, kpos * cg) for t in range(T)], dim=1).double()  # (B,T,G,K)
     ref = torch.einsum("btgn,btgk->gnk", dz.double().reshape(Bn, T, G, cg), win)
     assert float((got.double() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("N,T_all,L,C,q", [(6, 110, 100, 67, 0.9), (3, 110, 100, 67, 0.0), (2, 260, 250, 67, 0.995),
+                                            (4, 10, 10, 7, 0.5), (2, 110, 100, 67, 1.0)])
+def test_dynamic_threshold_matches_torch_quantile(N, T_all, L, C, q):
+    """msmd_dynamic_threshold against the reference's expression (model.py:396-402) evaluated with torch: the
+    threshold is an order statistic / ATen lerp of two of them, so the result is bit-exact."""
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(N * 100 + L)
+    res = (torch.randn(N, T_all, C, generator=g) * 1.3).to(DEV)
+    res[0, -L:, :3] = 0.25                              # ties around the order statistic
+    s = torch.quantile(res[:, -L:].reshape(N, -1).abs(), q, dim=1)
+    s = torch.clamp(s, min=0.5, max=2.0)[..., None, None]
+    want = torch.clamp(res, min=-s, max=s)
+    got = o.dynamic_threshold_(res.clone(), L, q, 0.5, 2.0)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)

@@ -252,7 +252,8 @@ def test_sampler_hip_graph_matches_eager():
     xT = dev(synth.normalish("sm/xT", (2, 100, 67)))
     try:
         zeros = {t: torch.zeros(2, 100, 67, device=DEV) for t in range(2, T + 1)}
-        for kw in (dict(cfg_scale=1.15), dict(cfg_mode="independent", cfg_scale=[1.3, 0.9], flexibility=0.3)):
+        for kw in (dict(cfg_scale=1.15), dict(cfg_scale=1.4, dynamic_threshold=(0.9, 0.5, 2.0)),
+                   dict(cfg_mode="independent", cfg_scale=[1.3, 0.9], flexibility=0.3)):
             eager, _, _ = model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]), dev(x["prev_motion"]),
                                        dev(x["prev_audio"]), motion_at_T=xT, indicator=dev(x["indicator"]), noise=zeros,
                                        **kw)

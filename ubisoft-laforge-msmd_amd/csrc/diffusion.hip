@@ -245,3 +245,80 @@ extern "C" int msmd_cast(const void* x, void* y, long n, int in_dtype, int out_d
 }
 
 extern "C" int msmd_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------------------------------
+// Dynamic thresholding of the denoiser output (reference model.py:396-402, 578-584):
+//   s_n = clamp(quantile_q(|res[n, -L:, :]|), dt_min, dt_max);   res[n] <- clamp(res[n], -s_n, s_n)
+// torch.quantile's default 'linear' rule: rank = q (m - 1), lerp between the floor / ceil order statistics.
+// One 1024-thread workgroup per sequence keeps the m = L C magnitudes in registers and finds the order statistic by
+// bisection on the (non-negative) float bit pattern: 31 rounds of count(x <= mid) instead of a sort.
+template <int MAXE>
+__global__ __launch_bounds__(1024) void dynamic_threshold_kernel(float* __restrict__ res, int T_all, int L, int C,
+                                                                  float q, float dt_min, float dt_max) {
+  __shared__ int red[16];
+  __shared__ unsigned redu[16];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float* base = res + (long)n * T_all * C;
+  const float* tail = base + (long)(T_all - L) * C;
+  const int m = L * C;
+  unsigned v[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    const int i = e * 1024 + tid;
+    v[e] = i < m ? (__float_as_uint(tail[i]) & 0x7FFFFFFFu) : 0xFFFFFFFFu;  // padding sorts last
+  }
+  auto count_le = [&](unsigned x) {
+    int c = 0;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) c += (v[e] <= x) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    __syncthreads();
+    if (lane == 0) red[wid] = c;
+    __syncthreads();
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    return t;
+  };
+  const float rank = q * (float)(m - 1);
+  const int k = (int)floorf(rank);
+  const float w = rank - (float)k;
+  unsigned lo = 0u, hi = 0x7F800000u;  // smallest x with count(<= x) >= k + 1
+  while (lo < hi) {
+    const unsigned mid = lo + ((hi - lo) >> 1);
+    if (count_le(mid) >= k + 1) hi = mid; else lo = mid + 1;
+  }
+  const unsigned b_lo = lo;
+  unsigned b_hi = b_lo;
+  if (w > 0.f && count_le(b_lo) < k + 2) {  // next order statistic = smallest value above b_lo
+    unsigned mn = 0xFFFFFFFFu;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) mn = (v[e] > b_lo && v[e] < mn) ? v[e] : mn;
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o, 64));
+    __syncthreads();
+    if (lane == 0) redu[wid] = mn;
+    __syncthreads();
+#pragma unroll
+    for (int ww = 0; ww < 16; ++ww) mn = min(mn, redu[ww]);
+    b_hi = mn;
+  }
+  const float a = __uint_as_float(b_lo), b = __uint_as_float(b_hi);
+  // ATen lerp: a + w (b - a) for w < 0.5, else b - (b - a)(1 - w)
+  float sq = (w < 0.5f) ? a + w * (b - a) : b - (b - a) * (1.0f - w);
+  sq = fminf(fmaxf(sq, dt_min), dt_max);
+  for (int i = tid; i < T_all * C; i += 1024) base[i] = fminf(fmaxf(base[i], -sq), sq);
+}
+
+extern "C" int msmd_dynamic_threshold(float* res, int N, int T_all, int L, int C, float ratio, float dt_min,
+                                      float dt_max, msmd_stream_t stream) {
+  if (N <= 0 || L <= 0 || T_all < L || C <= 0 || !(ratio >= 0.f && ratio <= 1.f)) return 1;
+  const long m = (long)L * C;
+  hipStream_t st = (hipStream_t)stream;
+  if (m <= 8 * 1024)
+    hipLaunchKernelGGL(dynamic_threshold_kernel<8>, dim3(N), dim3(1024), 0, st, res, T_all, L, C, ratio, dt_min, dt_max);
+  else if (m <= 20 * 1024)
+    hipLaunchKernelGGL(dynamic_threshold_kernel<20>, dim3(N), dim3(1024), 0, st, res, T_all, L, C, ratio, dt_min, dt_max);
+  else
+    return 1;
+  MSMD_RETURN_LAST();
+}

@@ -199,6 +199,17 @@ def attention_bwd(q, k, v, do, dq, dk, dv, n_heads, scale, mask=None, p_drop=0.0
                "msmd_attention_bwd")
 
 
+def dynamic_threshold_(res, L, ratio, dt_min, dt_max):
+    """In-place dynamic thresholding of a (N, T_all, C) fp32 denoiser output on its last L frames' quantile."""
+    _need_cuda(res)
+    if res.dtype != torch.float32 or not res.is_contiguous():
+        raise TypeError("dynamic_threshold_ takes a contiguous fp32 tensor")
+    N, T_all, C = res.shape
+    _lib.check(_lib.load().msmd_dynamic_threshold(_p(res), N, T_all, L, C, float(ratio), float(dt_min), float(dt_max),
+                                                  _stream()), "msmd_dynamic_threshold")
+    return res
+
+
 def pad_audio(audio, reflect_len, replicate_len):
     lib = _lib.load()
     B, L = audio.shape

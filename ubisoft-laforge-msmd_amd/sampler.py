@@ -130,11 +130,12 @@ def sample(model, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=N
             c1 = (1 - alpha) * torch.sqrt(alpha_bar_prev) / (1 - alpha_bar)
         return float(c0), float(c1), float(sigma)
 
-    use_graph = (noise is None and not dynamic_threshold and not ret_traj and getattr(model, "use_hip_graph", True)
+    use_graph = (noise is None and not ret_traj and getattr(model, "use_hip_graph", True)
                  and T > 1 and guidance is None and separate is None)
     if use_graph:
         x = _graph_loop(model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, motion_at_T, prev_m,
-                        ind_in, mem, kv_list, stat, tok_person, emb_all, scales, coefficients)
+                        ind_in, mem, kv_list, stat, tok_person, emb_all, scales, coefficients,
+                        tuple(dynamic_threshold) if dynamic_threshold else None)
         return x, motion_at_T, audio_feat
 
     x = motion_at_T.float().clone().contiguous()
@@ -171,11 +172,9 @@ def sample(model, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=N
                                     sf[..., -3:].sum(dim=2).expand(-1, Lp + L, -1)], dim=-1)
             res = dyn + static
         if dynamic_threshold:
-            # optional K15 (off in the reference's inference driver, inference.py:272): host-library quantile
+            # K15 (off in the reference's inference driver, inference.py:272): quantile + clamp in one launch
             dt_ratio, dt_min, dt_max = dynamic_threshold
-            s = torch.quantile(res[:, -L:].reshape(N, -1).abs(), dt_ratio, dim=1)
-            s = torch.clamp(s, min=dt_min, max=dt_max)[..., None, None]
-            res = torch.clamp(res, min=-s, max=s).contiguous()
+            res = ops.dynamic_threshold_(res.float().contiguous(), L, dt_ratio, dt_min, dt_max)
         if separate is None:
             ops.cfg_ddpm_step(x, res, z, scales, n_entries, Lp, mode, target, c0, c1, sigma)
         else:
@@ -206,7 +205,7 @@ def sample(model, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=N
 class _StepGraph:
     """One captured denoise step (hipGraph): device-side step counter, static operand buffers."""
 
-    def __init__(self, model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, like):
+    def __init__(self, model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, like, dyn=None):
         B = N // n_entries
         self.x = torch.zeros(B, L, dm, device=dev, dtype=torch.float32)
         self.prev_m = torch.zeros_like(like["prev_m"])
@@ -229,6 +228,8 @@ class _StepGraph:
             ops.denoiser_pack_input(self.x, self.prev_m, self.ind, self.feats)
             dec = net.trunk(self.feats, self.tok, self.mem, dtype, kv_list=self.kv, row0_add=self.emb_row)
             res = ops.heads_static_mix(dec, self.stat, Lp + L, dm, nb, net.use_head_alpha)
+            if dyn:
+                res = ops.dynamic_threshold_(res.float().contiguous(), L, *dyn)
             z = torch.randn_like(self.x)  # graph-safe philox stream; sigma_1 = 0 reproduces z = 0 at t = 1
             ops.cfg_ddpm_step_dev(self.x, res, z, self.scales, self.coefs, n_entries, Lp, mode, target)
         self.body = body
@@ -266,13 +267,13 @@ class _StepGraph:
 
 
 def _graph_loop(model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, motion_at_T, prev_m, ind_in,
-                mem, kv_list, stat, tok_person, emb_all, scales, coefficients):
+                mem, kv_list, stat, tok_person, emb_all, scales, coefficients, dyn=None):
     like = dict(prev_m=prev_m, ind_in=ind_in, mem=mem, kv_list=kv_list, stat=stat, tok_person=tok_person,
                 emb_all=emb_all, scales=scales)
-    key = (T, N, n_entries, Lp, L, mode, target, dtype, ind_in is not None, id(net._packed))
+    key = (T, N, n_entries, Lp, L, mode, target, dtype, ind_in is not None, id(net._packed), dyn)
     cache = model.__dict__.setdefault("_step_graphs", {})
     g = cache.get(key)
     if g is None:
         cache.clear()  # one resident graph (its private memory pool holds all step intermediates)
-        g = cache[key] = _StepGraph(model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, like)
+        g = cache[key] = _StepGraph(model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, like, dyn)
     return g.run(T, motion_at_T.float(), like, coefficients)
