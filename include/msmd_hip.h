@@ -244,9 +244,10 @@ int msmd_lbs_skin_bf16x3(const void* coef_hl, const float* A, const float* v_tem
 int msmd_landmarks(const float* verts, const int* faces, const int* lmk_faces_idx, long idx_bstride,
                    const float* bary, long bary_bstride, float* out, int B, int V, int L, msmd_stream_t stream);
 
-/* Dynamic-contour LUT row (utils/flame.py:126-172): row (B) int32 from the neck-chain yaw. */
+/* Dynamic-contour LUT row (utils/flame.py:126-172): row (B) int32 from the neck-chain yaw; full_pose is (B, J*3)
+ * axis-angle (pose2rot=True) or (B, J*9) rotation matrices (pose_is_matrix, pose2rot=False). */
 int msmd_dynamic_lmk_row(const float* full_pose, const int* neck_chain, int n_chain, int* row, int B, int J,
-                         msmd_stream_t stream);
+                         int pose_is_matrix, msmd_stream_t stream);
 
 /* batch_rodrigues (utils/lbs.py:270-301): R (N, 3, 3) from rot_vecs (N, 3). */
 int msmd_batch_rodrigues(const float* rot_vecs, float* R, int N, msmd_stream_t stream);

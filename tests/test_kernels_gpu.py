@@ -343,3 +343,23 @@ def test_dynamic_threshold_matches_torch_quantile(N, T_all, L, C, q):
     got = o.dynamic_threshold_(res.clone(), L, q, 0.5, 2.0)
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+
+
+def test_flame_rotation_matrix_pose_equals_axis_angle_pose():
+    """pose2rot=False (reference utils/flame.py:199-205, 144-149): feeding the rotation matrices of the same
+    axis-angle pose reproduces the golden vertices, dynamic (2-D) and static landmarks, and the LUT rows exactly."""
+    from msmd_amd.utils.flame import FLAME, FLAMEConfig
+    from types import SimpleNamespace
+    g = load_golden("g4_flame")
+    cfg = SimpleNamespace(**vars(FLAMEConfig))
+    cfg.asset = synth.flame_asset()
+    fl = FLAME(cfg).to(DEV)
+    x = flame_inputs(8)
+    pose = dev(g["pose"])                                             # (8, 6): global head + jaw axis-angle
+    R = ops().batch_rodrigues(pose.reshape(-1, 3).contiguous()).reshape(8, 18)
+    v, lm2d, lm3d = fl(dev(x["shape"]), dev(x["exp"]), R, pose2rot=False)
+    torch.cuda.synchronize()
+    assert maxabs(v.cpu().numpy()[:, ::79], g["verts_sub"]) <= 5e-6
+    assert maxabs(lm2d.cpu().numpy(), g["lm2d"]) <= 5e-6 and maxabs(lm3d.cpu().numpy(), g["lm3d"]) <= 5e-6
+    va, la, _ = fl(dev(x["shape"]), dev(x["exp"]), pose)
+    assert maxabs(v.cpu().numpy(), va.cpu().numpy()) <= 2e-6 and maxabs(lm2d.cpu().numpy(), la.cpu().numpy()) <= 2e-6

@@ -425,18 +425,28 @@ extern "C" int msmd_landmarks(const float* verts, const int* faces, const int* l
   MSMD_RETURN_LAST();
 }
 
-// LUT row of utils/flame.py:126-172 (pose2rot=True): relative neck rotation -> yaw degrees -> row in [0, 78]
+// LUT row of utils/flame.py:126-172: relative neck rotation -> yaw degrees -> row in [0, 78].  The pose is axis-angle
+// (pose2rot=True, J x 3) or row-major rotation matrices (pose2rot=False, J x 9).
 __global__ void dyn_lmk_row_kernel(const float* __restrict__ full_pose, const int* __restrict__ chain, int n_chain,
-                                   int* __restrict__ row, int B, int J) {
+                                   int* __restrict__ row, int B, int J, int pose_is_matrix) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   float rel[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
   for (int n = 0; n < n_chain; ++n) {
     const int j = chain[n];
-    const float r[3] = {full_pose[((long)b * J + j) * 3], full_pose[((long)b * J + j) * 3 + 1],
-                        full_pose[((long)b * J + j) * 3 + 2]};
+    float r[3] = {0.f, 0.f, 0.f};
+    if (!pose_is_matrix) {
+      r[0] = full_pose[((long)b * J + j) * 3];
+      r[1] = full_pose[((long)b * J + j) * 3 + 1];
+      r[2] = full_pose[((long)b * J + j) * 3 + 2];
+    }
     float R[9], o[9];
-    rodrigues(r, R);
+    if (pose_is_matrix) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R[k] = full_pose[((long)b * J + j) * 9 + k];
+    } else {
+      rodrigues(r, R);
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -453,9 +463,9 @@ __global__ void dyn_lmk_row_kernel(const float* __restrict__ full_pose, const in
 }
 
 extern "C" int msmd_dynamic_lmk_row(const float* full_pose, const int* neck_chain, int n_chain, int* row, int B, int J,
-                                    msmd_stream_t stream) {
+                                    int pose_is_matrix, msmd_stream_t stream) {
   if (B <= 0 || n_chain <= 0) return 1;
   hipLaunchKernelGGL(dyn_lmk_row_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, full_pose,
-                     neck_chain, n_chain, row, B, J);
+                     neck_chain, n_chain, row, B, J, pose_is_matrix);
   MSMD_RETURN_LAST();
 }

@@ -388,13 +388,13 @@ def landmarks(verts, faces_i32, lmk_faces_idx_i32, bary):
     return out
 
 
-def dynamic_lmk_row(full_pose, neck_chain_i32):
+def dynamic_lmk_row(full_pose, neck_chain_i32, pose_is_matrix=False):
     lib = _lib.load()
     B = full_pose.shape[0]
-    J = full_pose.shape[1] // 3
+    J = full_pose.shape[1] // (9 if pose_is_matrix else 3)
     row = torch.empty(B, device=full_pose.device, dtype=torch.int32)
     _lib.check(lib.msmd_dynamic_lmk_row(_p(full_pose), _p(neck_chain_i32), neck_chain_i32.shape[0], _p(row), B, J,
-                                        _stream()), "msmd_dynamic_lmk_row")
+                                        int(pose_is_matrix), _stream()), "msmd_dynamic_lmk_row")
     return row
 
 

@@ -121,9 +121,7 @@ class FLAME(nn.Module):
                                precision=self.lbs_precision)
         landmarks2d = landmarks3d = None
         if return_lm2d:
-            if not pose2rot:
-                raise NotImplementedError("dynamic landmarks from rotation-matrix poses are not built yet")
-            row = ops.dynamic_lmk_row(full_pose, p["chain"]).long()
+            row = ops.dynamic_lmk_row(full_pose, p["chain"], pose_is_matrix=not pose2rot).long()
             idx = torch.cat([p["dyn_idx"][row], p["static_idx"].unsqueeze(0).expand(B, -1)], 1).contiguous()
             bary = torch.cat([self.dynamic_lmk_bary_coords[row], self.lmk_bary_coords.unsqueeze(0).expand(B, -1, -1)],
                              1).contiguous()
