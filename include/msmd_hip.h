@@ -46,6 +46,8 @@ int msmd_set_tuning(int key, int value);
  *   bias: fp32 (N) or NULL.  residual: (M, N) ld ldr or NULL.  C: (M, N) ld ldc.
  *   in_dtype: dtype of A and W.  out_dtype: dtype of C and residual.
  *   batch > 1 launches independent problems with the given element strides (grouped conv).
+ *   act: MSMD_ACT_* in bits 0-7; bits 8-15 may carry a kernel-variant hint chosen by a host-side autotuner (0 = the
+ *   library's own shape heuristic; every variant computes bit-identical results).
  *   Requirements: K % (16 / sizeof(in)) == 0, lda/ldw/a_batch_stride/strideA/strideW multiples of the same.
  * Replaces: nn.Linear / nn.Conv1d / nn.MultiheadAttention projections at reference model.py:115,856-906,
  *   style_encoder.py:135-175, utils/wav2vec2.py:79,95,111 (HF conv stack, projection, pos-conv, encoder FFN).

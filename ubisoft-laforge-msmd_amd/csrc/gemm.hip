@@ -413,6 +413,8 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
                      long ldr, int act, int batch, long strideA, long strideW, long strideC, long strideBias,
                      long strideR, int batch_inner, long strideA2, long strideW2, long strideC2, msmd_stream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch_inner <= 0 || !A || !W || !C) return 1;
+  const int hint = (act >> 8) & 0xff;  // caller-chosen kernel variant (host-side autotune), 0 = heuristic below
+  act &= 0xff;
   const int E = in_dtype == MSMD_BF16 ? 8 : 4;
   if (K % E || lda % E || ldw % E || a_batch_stride % E || strideA % E || strideW % E || strideA2 % E || strideW2 % E)
     return 1;
@@ -434,7 +436,7 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
   if (in_dtype == MSMD_BF16 && (K % 64) == 0 && g_tuning[0] >= 0) {
     // Measured on MI355X (tools/bench_gemm.py): the 128x128 LDS-DMA kernel wins once the grid fills the
     // chip at 2 workgroups per CU; below that, 64x64 tiles (deep ring for long K) keep more CUs busy.
-    int variant = g_tuning[0];
+    int variant = g_tuning[0] ? g_tuning[0] : hint;
     if (variant == 0) {
       const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nz;
       if (N > 64 && tiles128 >= 192) variant = 13;  // 128x128, 8 waves (4x2), 2-stage ring, 2 workgroups/CU
