@@ -97,7 +97,7 @@ def pmc_traffic():
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_fetch_write_per_kernel.json")
     try:
         d = json.load(open(path))
-        k = [v for name, v in d.items() if "gemm2_kernel" in name and "Li128ELi128ELi4ELi2ELi2E" in name][0]
+        k = [v for name, v in d.items() if "gemm2_kernel" in name and "Li128ELi128ELi4ELi2ELi2E" in name][0]  # same tile / traffic as the pipelined variant
         return round((2.0 * k["fetch_kb_avg"] + k["write_kb_avg"]) * 1024.0)
     except Exception:
         return None

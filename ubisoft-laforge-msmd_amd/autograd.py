@@ -139,11 +139,18 @@ class LayerNormFn(torch.autograd.Function):
         g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         y = ops.layernorm(x, g, b, post_add=post_add)
         ctx.save_for_backward(x, g)
+        ctx.refs = (gamma, beta) if (gamma.is_leaf and beta.is_leaf) else None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, g = ctx.saved_tensors
+        refs = ctx.refs
+        if (DIRECT_GRAD and refs is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+                and all(r.grad is not None and r.grad.is_contiguous() and r.grad.dtype == torch.float32 for r in refs)):
+            # the kernel accumulates dgamma / dbeta: aim it at the parameters' .grad views of the gradient arena
+            dx, _, _ = ops.layernorm_bwd(dy.contiguous(), x, g, dg_out=refs[0].grad.view(-1), db_out=refs[1].grad.view(-1))
+            return dx, None, None, None
         dx, dg, db = ops.layernorm_bwd(dy.contiguous(), x, g)
         return dx, dg, db, None
 

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE>
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const GemmArgs p) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int STAGE = (BM + BN) * 128;
@@ -330,17 +330,40 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const GemmArgs p) {
     if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, (stage + NSTAGE - 1) % NSTAGE);
     const unsigned char* sa = smem + stage * STAGE;
     const unsigned char* sw = sa + BM * 128;
+    if constexpr (PIPE) {
+      // Explicit software pipeline: issue the fragment reads of BOTH 32-deep k-steps, then the MFMAs.  Left to
+      // itself hipcc re-uses 16 fragment registers and emits read / lgkmcnt(0) / 4 MFMA groups, exposing the LDS
+      // latency four times per K tile; pinned like this the second k-step's reads land behind the first's MFMAs.
+      u32x4 fx[2][FM], fw[2][FN];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      u32x4 fx[FM], fw[FN];
+      for (int g = 0; g < 2; ++g) {
 #pragma unroll
-      for (int j = 0; j < FM; ++j) fx[j] = *(const u32x4*)(sa + lds_off(wm + j * 16 + fr, g * 4 + fq));
+        for (int j = 0; j < FM; ++j) fx[g][j] = *(const u32x4*)(sa + lds_off(wm + j * 16 + fr, g * 4 + fq));
 #pragma unroll
-      for (int i = 0; i < FN; ++i) fw[i] = *(const u32x4*)(sw + lds_off(wn + i * 16 + fr, g * 4 + fq));
+        for (int i = 0; i < FN; ++i) fw[g][i] = *(const u32x4*)(sw + lds_off(wn + i * 16 + fr, g * 4 + fq));
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < FN; ++i)
+      for (int g = 0; g < 2; ++g) {
 #pragma unroll
-        for (int j = 0; j < FM; ++j) Mfma<bf16_t>::run(fw[i], fx[j], acc[i][j]);
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+          for (int j = 0; j < FM; ++j) Mfma<bf16_t>::run(fw[g][i], fx[g][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        u32x4 fx[FM], fw[FN];
+#pragma unroll
+        for (int j = 0; j < FM; ++j) fx[j] = *(const u32x4*)(sa + lds_off(wm + j * 16 + fr, g * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < FN; ++i) fw[i] = *(const u32x4*)(sw + lds_off(wn + i * 16 + fr, g * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+          for (int j = 0; j < FM; ++j) Mfma<bf16_t>::run(fw[i], fx[j], acc[i][j]);
+      }
     }
     stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
   }
@@ -354,11 +377,11 @@ extern "C" int msmd_set_tuning(int key, int value) {
   return 0;
 }
 
-template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE>
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false>
 static int launch_gemm2(GemmArgs& p, int batch, hipStream_t st) {
   constexpr int lds = NSTAGE * (BM + BN) * 128;
   static bool attr_done = false;
-  auto kfn = gemm2_kernel<TO, BM, BN, WM, WN, NSTAGE>;
+  auto kfn = gemm2_kernel<TO, BM, BN, WM, WN, NSTAGE, PIPE>;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
@@ -388,6 +411,17 @@ static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
     case 14: return launch_gemm2<TO, 128, 64, 2, 2, 2>(p, batch, st);
     case 15: return launch_gemm2<TO, 64, 128, 2, 2, 2>(p, batch, st);
     case 16: return launch_gemm2<TO, 128, 128, 2, 4, 2>(p, batch, st);
+    case 17: return launch_gemm2<TO, 128, 128, 4, 2, 2, true>(p, batch, st);
+    case 18: return launch_gemm2<TO, 128, 128, 2, 4, 2, true>(p, batch, st);
+    case 19: return launch_gemm2<TO, 64, 64, 2, 2, 2, true>(p, batch, st);
+    case 20: return launch_gemm2<TO, 64, 64, 2, 2, 4, true>(p, batch, st);
+    case 21: return launch_gemm2<TO, 128, 128, 2, 2, 2, true>(p, batch, st);
+    case 22: return launch_gemm2<TO, 256, 128, 4, 2, 3, true>(p, batch, st);
+    case 23: return launch_gemm2<TO, 128, 128, 4, 2, 3, true>(p, batch, st);
+    case 24: return launch_gemm2<TO, 256, 256, 2, 4, 2, true>(p, batch, st);
+    case 25: return launch_gemm2<TO, 256, 256, 4, 2, 2, true>(p, batch, st);
+    case 26: return launch_gemm2<TO, 128, 256, 2, 4, 3, true>(p, batch, st);
+    case 27: return launch_gemm2<TO, 256, 128, 4, 2, 2, true>(p, batch, st);
     default: return -1;
   }
 }
@@ -439,7 +473,7 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
     int variant = g_tuning[0] ? g_tuning[0] : hint;
     if (variant == 0) {
       const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nz;
-      if (N > 64 && tiles128 >= 192) variant = 13;  // 128x128, 8 waves (4x2), 2-stage ring, 2 workgroups/CU
+      if (N > 64 && tiles128 >= 192) variant = g_tuning[4] ? 13 : 17;  // 128x128, 8 waves (4x2), 2-stage ring, 2 workgroups/CU, fragment reads pipelined
       else variant = (K >= 1024) ? 9 : 12;
     }
     const int r = out_dtype == MSMD_BF16 ? dispatch_gemm2<bf16_t>(p, nz, st, variant)

@@ -547,13 +547,18 @@ def act_bwd(dy, z, act):
     return dz
 
 
-def layernorm_bwd(dy, x, gamma, eps=1e-5):
+def layernorm_bwd(dy, x, gamma, eps=1e-5, dg_out=None, db_out=None):
+    """dx, dgamma, dbeta.  With dg_out / db_out (fp32, cols) the parameter gradients are ACCUMULATED into those
+    buffers (e.g. the parameters' .grad views) instead of fresh tensors."""
     lib = _lib.load()
     cols = x.shape[-1]
     rows = x.numel() // cols
     dx = torch.empty_like(x)
-    dgb = torch.zeros(2, cols, device=x.device, dtype=torch.float32)
-    dg, db = dgb[0], dgb[1]
+    if dg_out is None:
+        dgb = torch.zeros(2, cols, device=x.device, dtype=torch.float32)
+        dg, db = dgb[0], dgb[1]
+    else:
+        dg, db = dg_out, db_out
     nws = lib.msmd_layernorm_bwd_workspace(rows, cols)
     ws = torch.empty(nws, device=x.device, dtype=torch.uint8)
     _lib.check(lib.msmd_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(dx), _p(dg), _p(db), rows, cols, eps, _dt(x),
