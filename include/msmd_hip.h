@@ -24,6 +24,7 @@ extern "C" {
 
 #define MSMD_F32 0
 #define MSMD_BF16 1
+#define MSMD_F16 2 /* IEEE half storage, fp32 accumulate: inference kernels (GEMM, attention, norm, audio, diffusion) */
 
 #define MSMD_ACT_NONE 0
 #define MSMD_ACT_GELU 1 /* exact erf GELU */

@@ -363,3 +363,32 @@ def test_flame_rotation_matrix_pose_equals_axis_angle_pose():
     assert maxabs(lm2d.cpu().numpy(), g["lm2d"]) <= 5e-6 and maxabs(lm3d.cpu().numpy(), g["lm3d"]) <= 5e-6
     va, la, _ = fl(dev(x["shape"]), dev(x["exp"]), pose)
     assert maxabs(v.cpu().numpy(), va.cpu().numpy()) <= 2e-6 and maxabs(lm2d.cpu().numpy(), la.cpu().numpy()) <= 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(6400, 768, 768), (300, 136, 512), (64, 72, 40)])
+def test_gemm_and_attention_fp16_storage(M, N, K):
+    """fp16 operands through the LDS-DMA MFMA kernels and the register-staged fallback (odd K) against fp64 on the
+    same fp16-rounded inputs; attention in fp16 against torch in fp32."""
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    a = (torch.randn(M, K, generator=g) * 0.5).half().to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).half().to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    r = torch.randn(M, N, generator=g).half().to(DEV)
+    y = o.gemm(a, w, b, r, o.ACT_GELU)
+    ref = torch.nn.functional.gelu(a.double() @ w.double().t() + b.double()) + r.double()
+    assert y.dtype == torch.float16 and float((y.double() - ref).abs().max()) < 4e-3
+    y32 = o.gemm(a, w, b, None, o.ACT_NONE, out_dtype=torch.float32)
+    assert float((y32.double() - (a.double() @ w.double().t() + b.double())).abs().max()) < 2e-4
+    if K == 768:
+        B, T, H = 2, 200, 12
+        qkv = (torch.randn(B, T, 3 * H * 64, generator=g) * 0.7).half().to(DEV)
+        d = H * 64
+        out = o.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, 0.125)
+        hd = lambda t: t.float().reshape(B, T, H, 64).transpose(1, 2)
+        want = (torch.softmax(hd(qkv[..., :d]) @ hd(qkv[..., d:2 * d]).transpose(-1, -2) * 0.125, -1)
+                @ hd(qkv[..., 2 * d:])).transpose(1, 2).reshape(B, T, d)
+        assert float((out.float() - want).abs().max()) < 3e-3
+        ln = o.layernorm(qkv[..., :d].contiguous(), torch.ones(d, device=DEV), torch.zeros(d, device=DEV))
+        assert ln.dtype == torch.float16
+        assert float((ln.float() - torch.nn.functional.layer_norm(qkv[..., :d].float(), (d,))).abs().max()) < 4e-3

@@ -355,3 +355,27 @@ def test_infer_coeffs_batch_equals_per_clip_and_reference_goldens():
             assert maxabs(ys[c].cpu().numpy(), y1.cpu().numpy()) < 2e-5, c
     finally:
         model.diffusion_sched = old
+
+
+def test_fp16_mode_tolerance_and_sampler():
+    """fp16 storage mode (BASELINE.json configs[4] names fp16): IEEE half operands on v_mfma_f32_16x16x32_f16, fp32
+    accumulation / LayerNorm / softmax.  11 significand bits instead of bf16's 8: stated tolerance 0.012 max-abs on
+    the same goldens the bf16 test holds to 0.08; the hipGraph sampler runs in the same mode."""
+    g = load_golden("g3_forward")
+    ga = load_golden("g3_audio_wav2vec2")
+    model, args = get_model("wav2vec2", "fp16")
+    assert model.compute_dtype == torch.float16
+    x = denoiser_inputs(2, args, tag="fw")
+    audio = dev(synth.audio_clips(2, 64000, tag="fw_audio"))
+    eps, target, _, afeat = model(dev(x["motion"]), audio, dev(x["shape"]), dev(x["style"]), time_step=[3, 499],
+                                  indicator=dev(x["indicator"]), train_with_CFG=False, eps=dev(g["a_eps"]))
+    e_t = maxabs(target.cpu().numpy(), g["a_target"])
+    e_a = maxabs(afeat.cpu().numpy()[:, ::2, ::3], g["a_audio_feat"])
+    print(f"fp16 mode: target err {e_t:.5f}, audio feat err {e_a:.5f}, |target| max {np.abs(g['a_target']).max():.2f}")
+    assert np.isfinite(e_t) and e_t <= 0.012 and e_a <= 0.012
+    feat = model.extract_audio_feature(dev(synth.audio_clips(2, 64000)))
+    assert maxabs(feat.cpu().numpy(), ga["feat"]) <= 0.012
+    xs = denoiser_inputs(2, args, tag="sm")
+    out, _, _ = model.sample(dev(xs["audio_feat"]), dev(xs["shape"]), dev(xs["style"]), indicator=dev(xs["indicator"]))
+    torch.cuda.synchronize()
+    assert out.shape == (2, 100, 67) and bool(torch.isfinite(out).all())

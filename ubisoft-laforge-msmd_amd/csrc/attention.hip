@@ -85,8 +85,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
           const u32x4 a = *(const u32x4*)(sK + row * 128 + (((4 * g + fq) ^ ((row >> 1) & 7)) << 4));
-          s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                         __builtin_bit_cast(bf16x8, qf[g]), s[f], 0, 0, 0);
+          s[f] = mfma16<T>(a, qf[g], s[f]);
         }
       } else {
 #pragma unroll
@@ -153,8 +152,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
         const int f0 = 2 * pr, f1 = 2 * pr + 1;
-        const bf16x8 pb = bf16x8{(bf16_t)s[f0][0], (bf16_t)s[f0][1], (bf16_t)s[f0][2], (bf16_t)s[f0][3],
-                                 (bf16_t)s[f1][0], (bf16_t)s[f1][1], (bf16_t)s[f1][2], (bf16_t)s[f1][3]};
+        typedef typename Vec8T<T>::type V8;
+        const V8 pbv = V8{(T)s[f0][0], (T)s[f0][1], (T)s[f0][2], (T)s[f0][3],
+                          (T)s[f1][0], (T)s[f1][1], (T)s[f1][2], (T)s[f1][3]};
+        const u32x4 pb = __builtin_bit_cast(u32x4, pbv);
         // transposed read: lane i = 4 q' + p' of each 16-lane group addresses row key0 + q', cols d0 + 4 p'
         const int qp = fr >> 2, pp = fr & 3;
 #pragma unroll
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
               (s16x4 __attribute__((address_space(3)))*)(sV + r1 * 128 + ((d ^ ((r1 >> 1) & 3)) << 5) + pp * 8));
           typedef short s16x8 __attribute__((ext_vector_type(8)));
           const s16x8 va = s16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          acc_o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va), pb, acc_o[d], 0, 0, 0);
+          acc_o[d] = mfma16<T>(__builtin_bit_cast(u32x4, va), pb, acc_o[d]);
         }
       }
     } else {
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = acc_o[d][e] * inv;
       if constexpr (BF)
-        *(bf16x4*)(Op + 16 * d + 4 * fq) = bf16x4{(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+        *(typename Vec4T<T>::type*)(Op + 16 * d + 4 * fq) = pack4<T>(o[0], o[1], o[2], o[3]);
       else
         *(f32x4*)(Op + 16 * d + 4 * fq) = f32x4{o[0], o[1], o[2], o[3]};
     }
@@ -207,7 +208,7 @@ static int attention_impl(const void* Q, const void* K, const void* V, void* O, 
                           msmd_stream_t stream) {
   if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || !Q || !K || !V || !O) return 1;
   if (!(p_drop >= 0.f && p_drop < 1.f) || (p_drop > 0.f && (!rng_state || Tk > 512))) return 1;
-  const int E = dtype == MSMD_BF16 ? 8 : 4;
+  const int E = dtype == MSMD_F32 ? 4 : 8;
   if (q_tstride % E || k_tstride % E || v_tstride % E || o_tstride % 4 || q_bstride % E || k_bstride % E ||
       v_bstride % E || o_bstride % 4)
     return 1;
@@ -217,6 +218,8 @@ static int attention_impl(const void* Q, const void* K, const void* V, void* O, 
   dim3 grid((Tq + 63) / 64, H, B), block(256);
   if (dtype == MSMD_BF16)
     hipLaunchKernelGGL(attn_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);
+  else if (dtype == MSMD_F16)
+    hipLaunchKernelGGL(attn_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, p);
   else if (dtype == MSMD_F32)
     hipLaunchKernelGGL(attn_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
   else

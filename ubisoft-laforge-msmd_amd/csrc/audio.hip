@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
       }
       TO* op = out + ((long)b * T0 + t0 + t) * C + c0;
       if constexpr (sizeof(TO) == 4) *(f32x4*)op = f32x4{o[0], o[1], o[2], o[3]};
-      else *(bf16x4*)op = bf16x4{(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+      else *(typename Vec4T<TO>::type*)op = pack4<TO>(o[0], o[1], o[2], o[3]);
     }
   }
 }
@@ -194,6 +194,9 @@ extern "C" int msmd_conv0_gn_gelu(const float* audio, const float* w0, const flo
   if (out_dtype == MSMD_F32)
     hipLaunchKernelGGL(conv0_gn_gelu_kernel<float>, grid, block, 0, (hipStream_t)stream, audio, w0, stats, gamma, beta,
                        (float*)out, L, reflect_len, replicate_len, C, T0);
+  else if (out_dtype == MSMD_F16)
+    hipLaunchKernelGGL(conv0_gn_gelu_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, audio, w0, stats, gamma,
+                       beta, (f16_t*)out, L, reflect_len, replicate_len, C, T0);
   else
     hipLaunchKernelGGL(conv0_gn_gelu_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, audio, w0, stats, gamma,
                        beta, (bf16_t*)out, L, reflect_len, replicate_len, C, T0);
@@ -256,8 +259,8 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
       *(f32x4*)op = f32x4{o[0], o[1], o[2], o[3]};
       *(f32x4*)(op + 4) = f32x4{o[4], o[5], o[6], o[7]};
     } else {
-      *(bf16x8*)op = bf16x8{(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3],
-                            (bf16_t)o[4], (bf16_t)o[5], (bf16_t)o[6], (bf16_t)o[7]};
+      *(typename Vec8T<TO>::type*)op = typename Vec8T<TO>::type{(TO)o[0], (TO)o[1], (TO)o[2], (TO)o[3],
+                                                               (TO)o[4], (TO)o[5], (TO)o[6], (TO)o[7]};
     }
   }
 }
@@ -272,6 +275,9 @@ extern "C" int msmd_conv0_ln_gelu(const float* audio, const float* w0, const flo
   if (out_dtype == MSMD_F32)
     hipLaunchKernelGGL(conv0_ln_gelu_kernel<float>, grid, block, 0, (hipStream_t)stream, audio, w0, bias, gamma, beta,
                        (float*)out, L, reflect_len, replicate_len, T0, eps);
+  else if (out_dtype == MSMD_F16)
+    hipLaunchKernelGGL(conv0_ln_gelu_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, audio, w0, bias, gamma, beta,
+                       (f16_t*)out, L, reflect_len, replicate_len, T0, eps);
   else
     hipLaunchKernelGGL(conv0_ln_gelu_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, audio, w0, bias, gamma, beta,
                        (bf16_t*)out, L, reflect_len, replicate_len, T0, eps);
@@ -306,6 +312,9 @@ extern "C" int msmd_interp_linear(const void* x, void* y, int B, int T_in, int T
   if (dtype == MSMD_F32)
     hipLaunchKernelGGL(interp_linear_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)x, (float*)y,
                        T_in, T_crop, T_out, C);
+  else if (dtype == MSMD_F16)
+    hipLaunchKernelGGL(interp_linear_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)x,
+                       (f16_t*)y, T_in, T_crop, T_out, C);
   else
     hipLaunchKernelGGL(interp_linear_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x,
                        (bf16_t*)y, T_in, T_crop, T_out, C);
@@ -334,6 +343,9 @@ extern "C" int msmd_group_pad(const void* x, void* y, int B, int T, int G, int C
   if (dtype == MSMD_F32)
     hipLaunchKernelGGL(group_pad_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)x, (float*)y, T, G,
                        Cg, pad);
+  else if (dtype == MSMD_F16)
+    hipLaunchKernelGGL(group_pad_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)x, (f16_t*)y, T,
+                       G, Cg, pad);
   else
     hipLaunchKernelGGL(group_pad_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, T,
                        G, Cg, pad);

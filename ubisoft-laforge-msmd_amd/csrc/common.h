@@ -9,6 +9,9 @@ typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -46,10 +49,31 @@ extern int g_tuning[8];  // msmd_set_tuning knobs (gemm.hip)
 
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+__device__ __forceinline__ float to_f32(f16_t x) { return (float)x; }
 
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }  // RNE, v_cvt_pk_bf16_f32
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float x) { return (f16_t)x; }     // RNE, v_cvt_f16_f32
+
+// 4- and 8-wide vectors of a storage type (8 / 16 bytes for the 16-bit types)
+template <typename T> struct Vec4T;
+template <> struct Vec4T<float> { typedef f32x4 type; };
+template <> struct Vec4T<bf16_t> { typedef bf16x4 type; };
+template <> struct Vec4T<f16_t> { typedef f16x4 type; };
+template <typename T> struct Vec8T;
+template <> struct Vec8T<bf16_t> { typedef bf16x8 type; };
+template <> struct Vec8T<f16_t> { typedef f16x8 type; };
+template <typename T> __device__ __forceinline__ typename Vec4T<T>::type pack4(float a, float b, float c, float d) {
+  return typename Vec4T<T>::type{(T)a, (T)b, (T)c, (T)d};
+}
+// 16x16x32 MFMA on 8 x 16-bit operands held as 4 dwords
+template <typename T> __device__ __forceinline__ f32x4 mfma16(const u32x4 a, const u32x4 b, const f32x4 c) {
+  if constexpr (sizeof(T) == 2 && __is_same(T, f16_t))
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 // Exact erf GELU (HF ACT2FN['gelu'] / torch F.gelu(approximate='none')).
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -100,3 +124,4 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 template <typename T> struct Elems16;                     // elements per 16-byte chunk
 template <> struct Elems16<float> { static constexpr int n = 4; };
 template <> struct Elems16<bf16_t> { static constexpr int n = 8; };
+template <> struct Elems16<f16_t> { static constexpr int n = 8; };

@@ -38,6 +38,9 @@ extern "C" int msmd_denoiser_pack_input(const float* motion, const float* eps, c
   if (out_dtype == MSMD_F32)
     hipLaunchKernelGGL(pack_input_kernel<float>, grid, block, 0, (hipStream_t)stream, motion, eps, c0, c1, prev_motion,
                        indicator, (float*)feats, L, Lp, dm, Kpad, motion_batch);
+  else if (out_dtype == MSMD_F16)
+    hipLaunchKernelGGL(pack_input_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, motion, eps, c0, c1,
+                       prev_motion, indicator, (f16_t*)feats, L, Lp, dm, Kpad, motion_batch);
   else
     hipLaunchKernelGGL(pack_input_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, motion, eps, c0, c1,
                        prev_motion, indicator, (bf16_t*)feats, L, Lp, dm, Kpad, motion_batch);
@@ -69,6 +72,9 @@ extern "C" int msmd_add_pe_token(void* x, const float* pe, const void* tok0, con
   if (dtype == MSMD_F32)
     hipLaunchKernelGGL(add_pe_token_kernel<float>, grid, block, 0, (hipStream_t)stream, (float*)x, pe,
                        (const float*)tok0, (const float*)row0_add, T, d);
+  else if (dtype == MSMD_F16)
+    hipLaunchKernelGGL(add_pe_token_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (f16_t*)x, pe,
+                       (const f16_t*)tok0, (const f16_t*)row0_add, T, d);
   else
     hipLaunchKernelGGL(add_pe_token_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (bf16_t*)x, pe,
                        (const bf16_t*)tok0, (const bf16_t*)row0_add, T, d);
@@ -101,6 +107,9 @@ extern "C" int msmd_heads_static_mix(const void* dec, long ld_dec, const void* s
   if (dtype == MSMD_F32)
     hipLaunchKernelGGL(heads_mix_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)dec, ld_dec,
                        (const float*)stat, out, L, dm, nb, stat_batch, use_head_alpha);
+  else if (dtype == MSMD_F16)
+    hipLaunchKernelGGL(heads_mix_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)dec, ld_dec,
+                       (const f16_t*)stat, out, L, dm, nb, stat_batch, use_head_alpha);
   else
     hipLaunchKernelGGL(heads_mix_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dec, ld_dec,
                        (const bf16_t*)stat, out, L, dm, nb, stat_batch, use_head_alpha);
@@ -165,6 +174,9 @@ extern "C" int msmd_sampler_step_select(const void* emb_all, const float* coef_t
   if (dtype == MSMD_F32)
     hipLaunchKernelGGL(step_select_kernel<float>, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)emb_all,
                        coef_table, t_dev, (float*)emb_row, coefs, d);
+  else if (dtype == MSMD_F16)
+    hipLaunchKernelGGL(step_select_kernel<f16_t>, dim3(1), dim3(256), 0, (hipStream_t)stream, (const f16_t*)emb_all,
+                       coef_table, t_dev, (f16_t*)emb_row, coefs, d);
   else
     hipLaunchKernelGGL(step_select_kernel<bf16_t>, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)emb_all,
                        coef_table, t_dev, (bf16_t*)emb_row, coefs, d);
@@ -230,6 +242,15 @@ extern "C" int msmd_pad_cols(const void* x, void* y, long rows, int cols_in, int
                        cols_in, cols_out);
   else if (in_dtype == MSMD_BF16 && out_dtype == MSMD_F32)
     hipLaunchKernelGGL((pad_cols_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)x, (float*)y, rows,
+                       cols_in, cols_out);
+  else if (in_dtype == MSMD_F32 && out_dtype == MSMD_F16)
+    hipLaunchKernelGGL((pad_cols_kernel<float, f16_t>), grid, block, 0, st, (const float*)x, (f16_t*)y, rows,
+                       cols_in, cols_out);
+  else if (in_dtype == MSMD_F16 && out_dtype == MSMD_F32)
+    hipLaunchKernelGGL((pad_cols_kernel<f16_t, float>), grid, block, 0, st, (const f16_t*)x, (float*)y, rows,
+                       cols_in, cols_out);
+  else if (in_dtype == MSMD_F16 && out_dtype == MSMD_F16)
+    hipLaunchKernelGGL((pad_cols_kernel<f16_t, f16_t>), grid, block, 0, st, (const f16_t*)x, (f16_t*)y, rows,
                        cols_in, cols_out);
   else if (in_dtype == MSMD_BF16 && out_dtype == MSMD_BF16)
     hipLaunchKernelGGL((pad_cols_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, rows,

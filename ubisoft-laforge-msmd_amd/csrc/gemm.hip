@@ -33,6 +33,11 @@ template <> struct Mfma<bf16_t> {
                                                   acc, 0, 0, 0);
   }
 };
+template <> struct Mfma<f16_t> {
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+  }
+};
 template <> struct Mfma<float> {
   // one 16-B chunk = 4 fp32; lane (l>>4) owns k = 4*(l>>4)+e in MFMA step e (K is permuted
   // identically for both operands, which leaves the contraction unchanged).
@@ -92,13 +97,13 @@ __device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const 
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += r[e];
         } else {
-          const bf16x4 r = *(const bf16x4*)(rrow + i * 16);
+          const typename Vec4T<TO>::type r = *(const typename Vec4T<TO>::type*)(rrow + i * 16);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
         }
       }
       if constexpr (sizeof(TO) == 4) *(f32x4*)(crow + i * 16) = f32x4{v[0], v[1], v[2], v[3]};
-      else *(bf16x4*)(crow + i * 16) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      else *(typename Vec4T<TO>::type*)(crow + i * 16) = pack4<TO>(v[0], v[1], v[2], v[3]);
     }
   }
 }
@@ -138,7 +143,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += r[e];
           } else {
-            const bf16x4 r = *(const bf16x4*)rp;
+            const typename Vec4T<TO>::type r = *(const typename Vec4T<TO>::type*)rp;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
           }
@@ -146,7 +151,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
         if constexpr (sizeof(TO) == 4) {
           *(f32x4*)cp = f32x4{v[0], v[1], v[2], v[3]};
         } else {
-          *(bf16x4*)cp = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+          *(typename Vec4T<TO>::type*)cp = pack4<TO>(v[0], v[1], v[2], v[3]);
         }
       } else {
 #pragma unroll
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false>
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t>
 __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const GemmArgs p) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int STAGE = (BM + BN) * 128;
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < FN; ++i)
 #pragma unroll
-          for (int j = 0; j < FM; ++j) Mfma<bf16_t>::run(fw[g][i], fx[g][j], acc[i][j]);
+          for (int j = 0; j < FM; ++j) Mfma<TI>::run(fw[g][i], fx[g][j], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < FN; ++i)
 #pragma unroll
-          for (int j = 0; j < FM; ++j) Mfma<bf16_t>::run(fw[i], fx[j], acc[i][j]);
+          for (int j = 0; j < FM; ++j) Mfma<TI>::run(fw[i], fx[j], acc[i][j]);
       }
     }
     stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
@@ -377,11 +382,11 @@ extern "C" int msmd_set_tuning(int key, int value) {
   return 0;
 }
 
-template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false>
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t>
 static int launch_gemm2(GemmArgs& p, int batch, hipStream_t st) {
   constexpr int lds = NSTAGE * (BM + BN) * 128;
   static bool attr_done = false;
-  auto kfn = gemm2_kernel<TO, BM, BN, WM, WN, NSTAGE, PIPE>;
+  auto kfn = gemm2_kernel<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI>;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
@@ -442,6 +447,16 @@ static int launch_gemm(GemmArgs& p, int batch, hipStream_t st) {
   MSMD_RETURN_LAST();
 }
 
+template <typename TO>
+static int dispatch_gemm2_f16(GemmArgs& p, int batch, hipStream_t st, int variant) {
+  switch (variant) {
+    case 9: return launch_gemm2<TO, 64, 64, 2, 2, 4, false, f16_t>(p, batch, st);
+    case 12: return launch_gemm2<TO, 64, 64, 2, 2, 2, false, f16_t>(p, batch, st);
+    case 17: return launch_gemm2<TO, 128, 128, 4, 2, 2, true, f16_t>(p, batch, st);
+    default: return -1;
+  }
+}
+
 static int gemm_impl(const void* A, const void* W, const float* bias, const void* residual, void* C, int M, int N, int K,
                      int in_dtype, int out_dtype, long lda, int rows_per_batch, long a_batch_stride, long ldw, long ldc,
                      long ldr, int act, int batch, long strideA, long strideW, long strideC, long strideBias,
@@ -449,7 +464,7 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch_inner <= 0 || !A || !W || !C) return 1;
   const int hint = (act >> 8) & 0xff;  // caller-chosen kernel variant (host-side autotune), 0 = heuristic below
   act &= 0xff;
-  const int E = in_dtype == MSMD_BF16 ? 8 : 4;
+  const int E = in_dtype == MSMD_F32 ? 4 : 8;
   if (K % E || lda % E || ldw % E || a_batch_stride % E || strideA % E || strideW % E || strideA2 % E || strideW2 % E)
     return 1;
   if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return 1;
@@ -462,7 +477,7 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
   p.inv_rpb = 1.0f / (float)rows_per_batch;
   p.strideA = strideA; p.strideW = strideW; p.strideC = strideC; p.strideBias = strideBias; p.strideR = strideR;
   p.batch_inner = batch_inner; p.strideA2 = strideA2; p.strideW2 = strideW2; p.strideC2 = strideC2;
-  const int osz = out_dtype == MSMD_BF16 ? 2 : 4;
+  const int osz = out_dtype == MSMD_F32 ? 4 : 2;
   p.vec_ok = (ldc % 4 == 0) && (strideC % 4 == 0) && (strideC2 % 4 == 0) && (((uintptr_t)C % (4 * osz)) == 0) &&
              (!residual || ((ldr % 4 == 0) && (strideR % 4 == 0) && (((uintptr_t)residual % (4 * osz)) == 0)));
   hipStream_t st = (hipStream_t)stream;
@@ -480,6 +495,17 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
                                          : dispatch_gemm2<float>(p, nz, st, variant);
     if (r >= 0) return r;
   }
+  if (in_dtype == MSMD_F16 && (out_dtype == MSMD_F16 || out_dtype == MSMD_F32) && (K % 64) == 0 && g_tuning[0] >= 0) {
+    // fp16 storage: same LDS-DMA kernels with v_mfma_f32_16x16x32_f16 (the heuristic's variants only)
+    const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nz;
+    const int variant = (N > 64 && tiles128 >= 192) ? 17 : ((K >= 1024) ? 9 : 12);
+    const int r = out_dtype == MSMD_F16 ? dispatch_gemm2_f16<f16_t>(p, nz, st, variant)
+                                        : dispatch_gemm2_f16<float>(p, nz, st, variant);
+    if (r >= 0) return r;
+  }
+  if (in_dtype == MSMD_F16 && out_dtype == MSMD_F16) return launch_gemm<f16_t, f16_t>(p, nz, st);
+  if (in_dtype == MSMD_F16 && out_dtype == MSMD_F32) return launch_gemm<f16_t, float>(p, nz, st);
+  if (in_dtype == MSMD_F32 && out_dtype == MSMD_F16) return launch_gemm<float, f16_t>(p, nz, st);
   if (in_dtype == MSMD_BF16 && out_dtype == MSMD_BF16) return launch_gemm<bf16_t, bf16_t>(p, nz, st);
   if (in_dtype == MSMD_BF16 && out_dtype == MSMD_F32) return launch_gemm<bf16_t, float>(p, nz, st);
   if (in_dtype == MSMD_F32 && out_dtype == MSMD_F32) return launch_gemm<float, float>(p, nz, st);

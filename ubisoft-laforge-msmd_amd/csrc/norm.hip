@@ -10,12 +10,20 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
   const bf16x4 t = *(const bf16x4*)p;
   v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
 }
+template <> __device__ __forceinline__ void load4<f16_t>(const f16_t* p, float* v) {
+  const f16x4 t = *(const f16x4*)p;
+  v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
 template <typename T> __device__ __forceinline__ void store4(T* p, const float* v);
 template <> __device__ __forceinline__ void store4<float>(float* p, const float* v) {
   *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
 }
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float* v) {
   *(bf16x4*)p = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+}
+
+template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, const float* v) {
+  *(f16x4*)p = f16x4{(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};
 }
 
 // cols % 4 == 0, cols <= 4 * 64 * MAXC
@@ -121,6 +129,12 @@ extern "C" int msmd_layernorm(const void* x, const void* residual, const float* 
     return launch_ln<bf16_t, float>(x, residual, gamma, beta, post_add, y, rows, cols, eps, act, st);
   if (in_dtype == MSMD_F32 && out_dtype == MSMD_BF16)
     return launch_ln<float, bf16_t>(x, residual, gamma, beta, post_add, y, rows, cols, eps, act, st);
+  if (in_dtype == MSMD_F16 && out_dtype == MSMD_F16)
+    return launch_ln<f16_t, f16_t>(x, residual, gamma, beta, post_add, y, rows, cols, eps, act, st);
+  if (in_dtype == MSMD_F16 && out_dtype == MSMD_F32)
+    return launch_ln<f16_t, float>(x, residual, gamma, beta, post_add, y, rows, cols, eps, act, st);
+  if (in_dtype == MSMD_F32 && out_dtype == MSMD_F16)
+    return launch_ln<float, f16_t>(x, residual, gamma, beta, post_add, y, rows, cols, eps, act, st);
   return 1;
 }
 
@@ -141,6 +155,8 @@ extern "C" int msmd_mean_time(const void* x, float* y, int B, int T, int C, int 
   dim3 grid((C + 255) / 256, B), block(256);
   if (dtype == MSMD_F32)
     hipLaunchKernelGGL(mean_time_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)x, y, T, C);
+  else if (dtype == MSMD_F16)
+    hipLaunchKernelGGL(mean_time_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)x, y, T, C);
   else
     hipLaunchKernelGGL(mean_time_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, y, T, C);
   MSMD_RETURN_LAST();

@@ -25,6 +25,8 @@ def _cd(args) -> torch.dtype:
         return torch.bfloat16
     if name in ("fp32", "float32", torch.float32):
         return torch.float32
+    if name in ("fp16", "float16", "half", torch.float16):   # inference only: the training kernels are bf16 / fp32
+        return torch.float16
     raise ValueError(f"Unknown compute dtype {name}!")
 
 

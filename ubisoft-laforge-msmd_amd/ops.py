@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_ELU = 0, 1, 2
 CONV0_SPLITS = 16
 
@@ -28,6 +28,8 @@ def _dt(t: torch.Tensor) -> int:
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
+    if t.dtype == torch.float16:
+        return F16
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
