@@ -379,3 +379,39 @@ def test_fp16_mode_tolerance_and_sampler():
     out, _, _ = model.sample(dev(xs["audio_feat"]), dev(xs["shape"]), dev(xs["style"]), indicator=dev(xs["indicator"]))
     torch.cuda.synchronize()
     assert out.shape == (2, 100, 67) and bool(torch.isfinite(out).all())
+
+
+def test_diagonal_cross_attention_fast_path_equals_general_path():
+    """align_mask_width = 1: a motion token's cross-attention softmax has one admissible key, so the branch returns
+    V[t - 1] W_o^T + b_o for t >= 1 irrespective of the query (exactly, in any precision); only the person token needs
+    scores.  The fast path (and its step-invariant hoisting in the sampler) must reproduce the general masked kernels;
+    width 2 keeps the general path."""
+    from msmd_amd.model import DiffusionSchedule
+    model, args = get_model("wav2vec2", "fp32")
+    net = model.denoising_net
+    assert net.pack(torch.float32).diag
+    x = denoiser_inputs(3, args, tag="dg")
+    person = torch.cat([dev(x["shape"])[:, None], dev(x["style"])[:, None]], dim=-1)
+    call = lambda: net(dev(x["motion"]), dev(x["audio_feat"]), person, dev(x["style"])[:, None], dev(x["prev_motion"]),
+                       dev(x["prev_audio"]), [7, 250, 499], dev(x["indicator"]))
+    net.diag_single_pass = True
+    fast = call()
+    net.diag_single_pass = False
+    net.diag_fast_path = False
+    try:
+        slow = call()
+        assert maxabs(fast.cpu().numpy(), slow.cpu().numpy()) < 2e-6
+        old = model.diffusion_sched
+        model.diffusion_sched = DiffusionSchedule(4, "cosine").to(DEV)
+        xT = dev(synth.normalish("dg/xT", (3, 100, 67)))
+        zs = {t: dev(synth.normalish(f"dg/z{t}", (3, 100, 67))) for t in range(2, 5)}
+        kw = dict(motion_at_T=xT, indicator=dev(x["indicator"]), cfg_scale=1.3)
+        s_slow, _, _ = model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]), noise=zs, **kw)
+        net.diag_fast_path = True
+        s_fast, _, _ = model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]), noise=zs, **kw)
+        assert maxabs(s_fast.cpu().numpy(), s_slow.cpu().numpy()) < 1e-5
+        model.diffusion_sched = old
+    finally:
+        net.diag_fast_path = True
+    m2, _ = get_model("wav2vec2", "fp32", align_mask_width=2)
+    assert not m2.denoising_net.pack(torch.float32).diag

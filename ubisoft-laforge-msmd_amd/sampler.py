@@ -108,6 +108,8 @@ def sample(model, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=N
     tab = model.diffusion_sched.host_tables()
     mem = torch.cat([ops.cast(prev_a.contiguous(), dtype), ops.cast(audio_in.contiguous(), dtype)], dim=1)
     kv_list = net.memory_kv(mem, dtype)
+    cross_list = (net.memory_cross(kv_list, dtype)
+                  if (net.pack(dtype).diag and getattr(net, "diag_fast_path", True)) else None)
     stat = net.static_bases(style_feat, dtype).float().contiguous()  # real style for every entry (model.py:374)
     pf = ops.pad_cols(person_in.reshape(N, -1).float().contiguous(), P.kp_person, dtype)
     tok_person = ops.gemm(pf, *P.pp)                                   # (N, d) without the step embedding
@@ -135,7 +137,7 @@ def sample(model, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=N
     if use_graph:
         x = _graph_loop(model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, motion_at_T, prev_m,
                         ind_in, mem, kv_list, stat, tok_person, emb_all, scales, coefficients,
-                        tuple(dynamic_threshold) if dynamic_threshold else None)
+                        tuple(dynamic_threshold) if dynamic_threshold else None, cross_list)
         return x, motion_at_T, audio_feat
 
     x = motion_at_T.float().clone().contiguous()
@@ -156,7 +158,7 @@ def sample(model, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=N
             x_in = x.clone()
             x_in[:, guidance[0], :] = guidance[1].to(x_in.dtype)
         ops.denoiser_pack_input(x_in, prev_m, ind_in, feats)
-        dec = net.trunk(feats, tok_person, mem, dtype, kv_list=kv_list, row0_add=emb_all[t])
+        dec = net.trunk(feats, tok_person, mem, dtype, kv_list=kv_list, row0_add=emb_all[t], cross_list=cross_list)
         if separate is None:
             res = ops.heads_static_mix(dec, stat, Lp + L, dm, nb, net.use_head_alpha)
         else:
@@ -212,6 +214,7 @@ class _StepGraph:
         self.ind = torch.zeros_like(like["ind_in"]) if like["ind_in"] is not None else None
         self.mem = torch.zeros_like(like["mem"])
         self.kv = [torch.zeros_like(k) for k in like["kv_list"]]
+        self.cross = [torch.zeros_like(r) for r in like["cross_list"]] if like.get("cross_list") is not None else None
         self.stat = torch.zeros_like(like["stat"])
         self.tok = torch.zeros_like(like["tok_person"])
         self.emb_all = torch.zeros_like(like["emb_all"])
@@ -226,7 +229,8 @@ class _StepGraph:
         def body():
             ops.sampler_step_select(self.emb_all, self.coef_table, self.t_dev, self.emb_row, self.coefs)
             ops.denoiser_pack_input(self.x, self.prev_m, self.ind, self.feats)
-            dec = net.trunk(self.feats, self.tok, self.mem, dtype, kv_list=self.kv, row0_add=self.emb_row)
+            dec = net.trunk(self.feats, self.tok, self.mem, dtype, kv_list=self.kv, row0_add=self.emb_row,
+                            cross_list=self.cross)
             res = ops.heads_static_mix(dec, self.stat, Lp + L, dm, nb, net.use_head_alpha)
             if dyn:
                 res = ops.dynamic_threshold_(res.float().contiguous(), L, *dyn)
@@ -255,6 +259,9 @@ class _StepGraph:
             self.scales.copy_(ops_in["scales"])
         for dst, src in zip(self.kv, ops_in["kv_list"]):
             dst.copy_(src)
+        if self.cross is not None:
+            for dst, src in zip(self.cross, ops_in["cross_list"]):
+                dst.copy_(src)
         tab = torch.zeros(T + 1, 3)
         for t in range(1, T + 1):
             c0, c1, sg = coefficients(t)
@@ -267,10 +274,10 @@ class _StepGraph:
 
 
 def _graph_loop(model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, motion_at_T, prev_m, ind_in,
-                mem, kv_list, stat, tok_person, emb_all, scales, coefficients, dyn=None):
-    like = dict(prev_m=prev_m, ind_in=ind_in, mem=mem, kv_list=kv_list, stat=stat, tok_person=tok_person,
+                mem, kv_list, stat, tok_person, emb_all, scales, coefficients, dyn=None, cross_list=None):
+    like = dict(prev_m=prev_m, ind_in=ind_in, mem=mem, kv_list=kv_list, cross_list=cross_list, stat=stat, tok_person=tok_person,
                 emb_all=emb_all, scales=scales)
-    key = (T, N, n_entries, Lp, L, mode, target, dtype, ind_in is not None, id(net._packed), dyn)
+    key = (T, N, n_entries, Lp, L, mode, target, dtype, ind_in is not None, id(net._packed), dyn, cross_list is not None)
     cache = model.__dict__.setdefault("_step_graphs", {})
     g = cache.get(key)
     if g is None:
