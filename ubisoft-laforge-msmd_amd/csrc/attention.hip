@@ -23,8 +23,11 @@ struct AttnArgs {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <typename T>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
+// NW waves per workgroup = 16 NW query rows sharing every staged K / V tile (short sequences fit one workgroup per
+// (batch, head): T = 111 -> 7 waves, T = 200 -> 13 waves, so K / V are read from HBM / L2 once instead of once per
+// 64 queries).
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_kernel(const AttnArgs p) {
   constexpr bool BF = sizeof(T) == 2;
   constexpr int KROW = BF ? 128 : 256;  // bytes per K row in LDS (64 elements)
   constexpr int VROW = BF ? 128 : 272;  // fp32 V rows padded to 68 floats
@@ -36,7 +39,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int query = blockIdx.x * 64 + wid * 16 + fr;
+  constexpr int NT = 64 * NW;
+  const int query = blockIdx.x * (16 * NW) + wid * 16 + fr;
   const int qrow = query < p.Tq ? query : p.Tq - 1;
   const T* Qp = (const T*)p.Q + (long)b * p.qb + (long)qrow * p.qt + h * 64;
   const T* Kb = (const T*)p.K + (long)b * p.kb + h * 64;
@@ -55,9 +59,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   for (int kv0 = 0; kv0 < p.Tk; kv0 += 64) {
     __syncthreads();
     // ---- stage K and V tiles (rows beyond Tk are zero-filled)
-#pragma unroll
-    for (int i = 0; i < NCH / 4; ++i) {
-      const int c = tid + i * 256;
+    for (int c = tid; c < 64 * NCH; c += NT) {
       const int row = c / NCH, ch = c % NCH;
       const int key = kv0 + row;
       u32x4 kk = u32x4{0, 0, 0, 0}, vv = u32x4{0, 0, 0, 0};
@@ -215,15 +217,22 @@ static int attention_impl(const void* Q, const void* K, const void* V, void* O, 
   if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)V & 15) || ((uintptr_t)O & 15)) return 1;
   AttnArgs p{Q, K, V, O, B, H, Tq, Tk, q_bstride, q_tstride, k_bstride, k_tstride, v_bstride, v_tstride,
              o_bstride, o_tstride, scale, mask, p_drop, rng_state, site};
-  dim3 grid((Tq + 63) / 64, H, B), block(256);
-  if (dtype == MSMD_BF16)
-    hipLaunchKernelGGL(attn_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);
-  else if (dtype == MSMD_F16)
-    hipLaunchKernelGGL(attn_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, p);
-  else if (dtype == MSMD_F32)
-    hipLaunchKernelGGL(attn_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
-  else
-    return 1;
+  const int need = (Tq + 15) / 16;   // waves that cover all queries of one (batch, head)
+  const int nw = need <= 4 ? 4 : (need <= 7 ? 7 : (need <= 13 ? 13 : 16));
+  dim3 grid((Tq + 16 * nw - 1) / (16 * nw), H, B), block(64 * nw);
+  hipStream_t st = (hipStream_t)stream;
+#define MSMD_ATTN(T)                                                                                   \
+  do {                                                                                                 \
+    if (nw == 4) hipLaunchKernelGGL((attn_kernel<T, 4>), grid, block, 0, st, p);                       \
+    else if (nw == 7) hipLaunchKernelGGL((attn_kernel<T, 7>), grid, block, 0, st, p);                  \
+    else if (nw == 13) hipLaunchKernelGGL((attn_kernel<T, 13>), grid, block, 0, st, p);                \
+    else hipLaunchKernelGGL((attn_kernel<T, 16>), grid, block, 0, st, p);                              \
+  } while (0)
+  if (dtype == MSMD_BF16) MSMD_ATTN(bf16_t);
+  else if (dtype == MSMD_F16) MSMD_ATTN(f16_t);
+  else if (dtype == MSMD_F32) MSMD_ATTN(float);
+  else return 1;
+#undef MSMD_ATTN
   MSMD_RETURN_LAST();
 }
 
