@@ -156,11 +156,12 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
   const int ns = nt * C0_S + (C0_K - C0_S);
   for (int i = threadIdx.x; i < ns; i += 256) xs[i] = audio[(long)b * L + pad_src(t0 * C0_S + i, L, r, rep)];
   __syncthreads();
-  const int half = threadIdx.x >> 7, q = threadIdx.x & 127;
-  for (int c0 = q * 4; c0 < C; c0 += 512) {
-    float w[4][C0_K], sc[4], sh[4];
+  // 16-byte stores: a lane owns 8 consecutive channels, a wave one full 512-channel frame row (1 KB contiguous)
+  const int grp = threadIdx.x >> 6, q = threadIdx.x & 63;
+  for (int c0 = q * 8; c0 < C; c0 += 512) {
+    float w[8][C0_K], sc[8], sh[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 8; ++e) {
       const int c = c0 + e;
 #pragma unroll
       for (int k = 0; k < C0_K; ++k) w[e][k] = w0[c * C0_K + k];
@@ -168,18 +169,23 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
       sc[e] = rstd * gamma[c];
       sh[e] = beta[c] - mean * sc[e];
     }
-    for (int t = half; t < nt; t += 2) {
-      float o[4];
+    for (int t = grp; t < nt; t += 4) {
+      float o[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < 8; ++e) {
         float y = 0.f;
 #pragma unroll
         for (int k = 0; k < C0_K; ++k) y = fmaf(w[e][k], xs[t * C0_S + k], y);
         o[e] = sizeof(TO) == 2 ? gelu_fast(fmaf(y, sc[e], sh[e])) : gelu_erf(fmaf(y, sc[e], sh[e]));
       }
       TO* op = out + ((long)b * T0 + t0 + t) * C + c0;
-      if constexpr (sizeof(TO) == 4) *(f32x4*)op = f32x4{o[0], o[1], o[2], o[3]};
-      else *(typename Vec4T<TO>::type*)op = pack4<TO>(o[0], o[1], o[2], o[3]);
+      if constexpr (sizeof(TO) == 4) {
+        *(f32x4*)op = f32x4{o[0], o[1], o[2], o[3]};
+        *(f32x4*)(op + 4) = f32x4{o[4], o[5], o[6], o[7]};
+      } else {
+        *(typename Vec8T<TO>::type*)op = typename Vec8T<TO>::type{(TO)o[0], (TO)o[1], (TO)o[2], (TO)o[3],
+                                                                 (TO)o[4], (TO)o[5], (TO)o[6], (TO)o[7]};
+      }
     }
   }
 }
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
 extern "C" int msmd_conv0_gn_gelu(const float* audio, const float* w0, const float* stats, const float* gamma,
                                   const float* beta, void* out, int B, int L, int reflect_len, int replicate_len,
                                   int C, int out_dtype, msmd_stream_t stream) {
-  if (B <= 0 || L <= 0 || C <= 0 || (C & 3)) return 1;
+  if (B <= 0 || L <= 0 || C <= 0 || (C & 7)) return 1;
   const int Lp = L + 4 * reflect_len + 2 * replicate_len;
   const int T0 = (Lp - C0_K) / C0_S + 1;
   dim3 grid((T0 + 63) / 64, B), block(256);
