@@ -488,7 +488,12 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
     int variant = g_tuning[0] ? g_tuning[0] : hint;
     if (variant == 0) {
       const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nz;
-      if (N > 64 && tiles128 >= 192) variant = g_tuning[4] ? 13 : 17;  // 128x128, 8 waves (4x2), 2-stage ring, 2 workgroups/CU, fragment reads pipelined
+      if (N > 64 && tiles128 >= 192) {
+        variant = g_tuning[4] ? 13 : 17;  // 128x128, 8 waves (4x2), 2-stage ring, 2 workgroups/CU, fragment reads pipelined
+        // experiment knobs (tools/ab_graph.py): 5 = variant for M >= 20000 (conv stack), 6 = variant for the rest
+        if (M >= 20000 && g_tuning[5] > 0) variant = g_tuning[5];
+        if (M < 20000 && g_tuning[6] > 0) variant = g_tuning[6];
+      }
       else variant = (K >= 1024) ? 9 : 12;
     }
     const int r = out_dtype == MSMD_BF16 ? dispatch_gemm2<bf16_t>(p, nz, st, variant)
