@@ -161,8 +161,16 @@ class DenoisingNetwork_MSMD(nn.Module):
             mask = enc_dec_mask(motion_len, motion_len, 1, self.align_mask_width - 1, device="cpu")
             mask = torch.nn.functional.pad(mask, (0, 0, 1, 0), value=False)
             self.register_buffer("alignment_mask", mask)
+            # purely diagonal mask (width 1)?  decided here on the host, once: pack() may run under hipGraph capture
+            Tq, Tk = mask.shape
+            want = torch.ones(Tq, Tk, dtype=torch.bool)
+            want[0] = False
+            if Tq == Tk + 1:
+                want[torch.arange(1, Tq), torch.arange(0, Tk)] = False
+            self._diag_mask = bool(Tq == Tk + 1 and torch.equal(mask.bool(), want))
         else:
             self.alignment_mask = None
+            self._diag_mask = False
         self._packed = None
         self._packed_dtype = None
         self.to(device)
@@ -205,15 +213,7 @@ class DenoisingNetwork_MSMD(nn.Module):
         # align_mask_width == 1 (the default): motion token t >= 1 sees exactly audio frame t - 1 and the person token
         # sees everything.  A softmax over ONE key is exactly 1, so cross-attention returns V[t - 1] for those rows
         # whatever Q is: only row 0 needs a query, scores and a softmax (see trunk / memory_cross).
-        P.diag = False
-        if self.alignment_mask is not None:
-            m = self.alignment_mask
-            Tq, Tk = m.shape
-            want = torch.ones(Tq, Tk, dtype=torch.bool, device=m.device)
-            want[0] = False
-            if Tq == Tk + 1:
-                want[torch.arange(1, Tq), torch.arange(0, Tk)] = False
-                P.diag = bool(torch.equal(m.bool(), want))
+        P.diag = self._diag_mask
         P.layers = []
         for n in range(self.n_layers):
             p = f"transformer.layers.{n}."
