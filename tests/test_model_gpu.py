@@ -415,3 +415,21 @@ def test_diagonal_cross_attention_fast_path_equals_general_path():
         net.diag_fast_path = True
     m2, _ = get_model("wav2vec2", "fp32", align_mask_width=2)
     assert not m2.denoising_net.pack(torch.float32).diag
+
+
+def test_capture_forward_replays_equal_eager_on_new_inputs():
+    """MSMD.capture_forward: one hipGraph per static shape; replays on NEW inputs equal the eager forward bit for bit."""
+    model, args = get_model("wav2vec2", "bf16")
+    x = denoiser_inputs(2, args, tag="cf")
+    mk = lambda tag: dev(synth.audio_clips(2, 64000, tag=tag))
+    ts = torch.tensor([3, 499], device=DEV)
+    eps = dev(synth.normalish("cf/eps", (2, 100, 67)))
+    run = model.capture_forward(dev(x["motion"]), mk("cf_a0"), dev(x["shape"]), dev(x["style"]), ts, dev(x["indicator"]), eps)
+    for tag, t2 in (("cf_a1", [10, 20]), ("cf_a2", [400, 1])):
+        a = mk(tag)
+        t2 = torch.tensor(t2, device=DEV)
+        got = [o.clone() for o in run(audio=a, time_step=t2)]
+        ref = model(dev(x["motion"]), a, dev(x["shape"]), dev(x["style"]), time_step=t2, indicator=dev(x["indicator"]),
+                    train_with_CFG=False, eps=eps)
+        torch.cuda.synchronize()
+        assert all(torch.equal(g, r) for g, r in zip(got, ref))
