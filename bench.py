@@ -109,7 +109,9 @@ def pmc_traffic():
     WRITE_SIZE collected in SEPARATE runs of this same command; KB units; FETCH_SIZE doubled per the gfx950
     correction of MI355X_MICROARCH.md section HBM).  PMC counters cannot be read from inside this process, so the
     figure comes from profiles/ (null when the file is absent)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_fetch_write_per_kernel.json")
+    path = os.path.join(ROOT, "profiles", "r01d_pmc_hbm_fetch_write_per_kernel.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_fetch_write_per_kernel.json")
     try:
         d = json.load(open(path))
         k = [v for name, v in d.items() if "gemm2_kernel" in name and "Li128ELi128ELi4ELi2ELi2E" in name][0]  # same tile / traffic as the pipelined variant
