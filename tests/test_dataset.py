@@ -134,3 +134,65 @@ def test_validation_pass_over_resident_batches(tmp_path):
     path = tmp_path / "metrics.json"
     saved = test(args, lw, model, se, loader, n_rounds=1, do_save=True, do_save_path=path, coef_stats=ds.coef_stats)
     assert json.load(open(path))["loss"]["n_samples"] == 2 and saved["loss"]["n_samples"] == 2
+
+
+@pytest.mark.gpu
+def test_training_cli_end_to_end_on_a_decoded_corpus(tmp_path):
+    """training_script.main with the reference's flag names: chunked-pickle corpus -> resident loader -> 4 iterations
+    (train-mode noise on) -> checkpoint in the reference's format -> resume -> test mode."""
+    import pickle
+    import torch
+    from msmd_amd.training_script import build_parser, main
+    raw = raw_clips()
+    # a corpus longer than 2.1 windows after the 30 -> 25 fps resampling, written as two pickle chunks
+    names = list(raw)
+    path = tmp_path / "corpus.pkl"
+    with open(path, "wb") as f:
+        pickle.dump({k: raw[k] for k in names[:3]}, f)
+        pickle.dump({k: raw[k] for k in names[3:]}, f)
+    assert build_parser().parse_args(["--exp_name", "x", "--data_root", "y"]).n_motions == 750   # reference default
+    common = ["--exp_name", "cli", "--data_root", str(path), "--exp_root", str(tmp_path), "--n_motions", "100",
+              "--n_prev_motions", "10", "--fps", "25", "--audio_model", "wav2vec2", "--rot_repr", "aa", "--use_indicator",
+              "--use_cross_style", "--batch_size", "2", "--log_iter", "1", "--warm_iter", "2"]
+    tr = main(common + ["--max_iter", "3", "--save_iter", "2", "--val_iter", "3"])
+    torch.cuda.synchronize()
+    ck = sorted((tmp_path / "cli" / "checkpoints").glob("iter_*.pt"))
+    assert [c.name for c in ck] == ["iter_0000002.pt", "iter_0000003.pt"] and (tmp_path / "cli" / "args.json").exists()
+    assert tr.opt_step == 4
+    tr2 = main(common + ["--max_iter", "5", "--save_iter", "100", "--val_iter", "100", "--continue_from", str(tmp_path / "cli")])
+    assert tr2.opt_step == 4 + 3                      # resumed at iteration 3 (inclusive range, as the reference's loop)
+    res = main(common + ["--mode", "test", "--max_iter", "5"])
+    assert np.isfinite(np.mean(res["loss"]))
+    # inference CLI (reference flag names) on the checkpoint just written: style clip pickles + decoded audio -> pickles
+    import os
+    from msmd_amd import inference
+    from msmd_amd.model import DiffusionSchedule
+    root = tmp_path / "models"
+    os.makedirs(root / "DPT", exist_ok=True)
+    os.symlink(tmp_path / "cli", root / "DPT" / "cli")
+    stats = {k: torch.from_numpy(v) for k, v in coef_stats().items()}
+    files = {}
+    for name, obj in (("stats", stats), ("style_exp", torch.from_numpy(raw["long_a"]["expression_code"]).float()),
+                      ("style_head", raw["long_a"]["head_orientation"].astype(np.float32))):
+        files[name] = tmp_path / f"{name}.pkl"
+        with open(files[name], "wb") as f:
+            pickle.dump(obj, f)
+    np.save(tmp_path / "speech.npy", raw["short_a"]["audio"][:52000])
+    real = inference.load_model
+
+    def short_schedule(*a):                              # keep the test fast: 3 denoising steps
+        m, se, margs = real(*a)
+        m.diffusion_sched = DiffusionSchedule(3, "cosine").to(m.device)
+        return m, se, margs
+    inference.load_model = short_schedule
+    try:
+        out = inference.main(["--model_root", str(root), "--model_name", "cli", "--model_iter", "0000003",
+                              "--style_clip_exp_code_path", str(files["style_exp"]), "--style_clip_head_rot_path",
+                              str(files["style_head"]), "--audio_clip", str(tmp_path / "speech.npy"), "--coef_dict_path",
+                              str(files["stats"]), "--output_dir", str(tmp_path / "out"), "--versions_of_render", "2"])
+    finally:
+        inference.load_model = real
+    assert len(out) == 4
+    exp = pickle.load(open(out[0], "rb"))
+    rot = pickle.load(open(out[1], "rb"))
+    assert exp.shape == (int(52000 / 16000 * 25), 64) and rot.shape == (exp.shape[0], 3) and np.isfinite(exp).all()

@@ -86,7 +86,7 @@ def load_model(model_root: str, model_name: str, iter_num: str, device: torch.de
     model_args = load_args(Path(os.path.join(model_root, "DPT", model_name)))
     model = get_diffusion_model(model_args, device)
     ckpt = Path(model_root) / "DPT" / model_name / "checkpoints" / f"iter_{iter_num}.pt"
-    data = torch.load(ckpt, map_location=device)
+    data = torch.load(ckpt, map_location=device, weights_only=False)  # reference checkpoints pickle their args Namespace
     style_enc = get_style_encoder(model_args, model_args.style_enc_model_style)
     style_enc.load_state_dict(data["style_enc"])
     style_enc.to(device).eval()
@@ -205,3 +205,71 @@ def infer_coeffs_batch(model, args, audios, shape_coefs, audio_unit, style_feats
                 m = m[:, :-plans[c][4]]
             outs[c].append(m)
     return [torch.cat(o, dim=1) for o in outs]
+
+
+# ----------------------------------------------------------------------------- command line (reference flag names)
+def build_parser():
+    """The reference's inference flags (inference.py:190-201), same names and defaults."""
+    import argparse
+    ap = argparse.ArgumentParser(description="Single style + audio inference for MSMD on MI355X.")
+    for name in ("model_root", "model_name", "model_iter", "style_clip_exp_code_path", "style_clip_head_rot_path",
+                 "audio_clip"):
+        ap.add_argument("--" + name, type=str, required=True)
+    ap.add_argument("--coef_dict_path", type=str, default="PATH-TO-COEF-STATS")
+    ap.add_argument("--cfg_level", type=float, default=1.4)
+    ap.add_argument("--output_dir", type=str, default="/experiments/refactor")
+    ap.add_argument("--versions_of_render", type=int, default=1)
+    return ap
+
+
+def load_audio_16k(path):
+    """16 kHz mono samples from a decoded file (.npy / pickle of a float array).  Decoding compressed media (the
+    reference calls librosa.load, inference.py:226) is outside the hot path; hand this function the decoded samples."""
+    path = str(path)
+    if path.endswith(".npy"):
+        return np.load(path).astype(np.float32)
+    with open(path, "rb") as f:
+        return np.asarray(pkl.load(f), dtype=np.float32)
+
+
+def main(argv=None):
+    """The non-media part of reference inference.py:189-279: load model + style encoder, ingest the style clip, z-norm
+    the audio, sample the style code, run infer_coeffs per repetition seed, de-normalise and write the two pickles
+    (`overall_exp_code_*`, `overall_head_rot_*`) under <output_dir>/<model>_iter_<iter>/temp/.  Mesh decoding and
+    video rendering of the reference script are not part of this path."""
+    import os
+    args = build_parser().parse_args(argv)
+    device = torch.device("cuda")
+    model, style_enc, model_args = load_model(args.model_root, args.model_name, args.model_iter, device)
+    motion_coeff, shape_coef = query_for_motion_coeff(args, args.style_clip_exp_code_path, args.style_clip_head_rot_path,
+                                                      device=device)
+    shape_coef = shape_coef.unsqueeze(1)
+    audio = load_audio_16k(args.audio_clip)
+    audio = (audio - audio.mean()) / (audio.std() + 1e-5)
+    audio_tensor = torch.from_numpy(audio).float().to(device)
+    style_clip = motion_coeff[:, :100, :]
+    style_coeff = style_enc.sample(style_clip) if model_args.style_enc_model_style.startswith("vae") else style_enc(style_clip)
+    with open(args.coef_dict_path, "rb") as f:
+        coef_stats = {k: v.to(device) for k, v in pkl.load(f).items()}
+    style_name = os.path.splitext(os.path.basename(args.style_clip_exp_code_path))[0]
+    audio_name = os.path.splitext(os.path.basename(args.audio_clip))[0]
+    clip = f"style=_{style_name}_audio={audio_name}"
+    temp = os.path.join(args.output_dir, f"{args.model_name}_iter_{args.model_iter}", "temp")
+    os.makedirs(temp, exist_ok=True)
+    written = []
+    for seed in range(args.versions_of_render):
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        coef = infer_coeffs(model, model_args, audio_tensor, shape_coef, 640.0, style_coeff, cfg_scale=args.cfg_level,
+                            dynamic_threshold=None)
+        exp_code, head_rot = denormalize_coeffs(coef, coef_stats)
+        for tag, val in (("exp_code", exp_code), ("head_rot", head_rot)):
+            out = os.path.join(temp, f"overall_{tag}_{clip}_seed_{seed}.pkl")
+            with open(out, "wb") as f:
+                pkl.dump(val.cpu().numpy(), f)
+            written.append(out)
+    return written
+
+
+if __name__ == "__main__":
+    main()

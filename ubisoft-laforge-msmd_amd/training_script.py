@@ -442,3 +442,115 @@ class Trainer:
         ent = (sb, sd, flags, g, out, spec)
         self._graphs[key] = ent
         return ent
+
+
+# ----------------------------------------------------------------------------- command line (reference flag names)
+# (flag, type | "flag", default): the reference's argparse surface (training_script.py:449-513) as data; args.json files
+# written by either implementation load into either (utils.model_common.load_args_with_defaults takes this parser).
+_FLAGS = [
+    ("mode", str, "train"), ("exp_name", str, None), ("data_root", str, None), ("max_iter", int, 2000000),
+    ("batch_size", int, 16), ("num_workers", int, 2), ("generator_model_style", str, "MSMD"),
+    ("style_enc_model_style", str, "vae2"), ("training_loss_style", str, "MSMD"),
+    ("dataset_type", str, "ravdess+celebv-text-medium"), ("audio_model", str, "hubert"), ("d_style", int, 256),
+    ("use_indicator", "flag", False), ("use_cross_style", "flag", False), ("use_vertex_space", "flag", False),
+    ("num_of_basis", int, 4), ("prob_cross_style", float, 0.5), ("l_vert", float, 1.0), ("l_vel", float, 0.5),
+    ("l_smooth", float, 10.0), ("l_kl_div", float, 1e-7), ("l_head_angle", float, 1.0), ("l_head_vel", float, 0.5),
+    ("l_head_smooth", float, 0.5), ("l_head_trans", float, 0.5), ("scheduler", str, "Warmup"), ("lr", float, 2e-5),
+    ("warm_iter", int, 5000), ("cos_max_iter", int, 1000000), ("min_lr_ratio", float, 0.1),
+    ("gradient_accumulation_steps", int, 1), ("n_motions", int, 750), ("n_prev_motions", int, 100), ("fps", int, 30),
+    ("trunc_prob1", float, 0.5), ("trunc_prob2", float, 0.5), ("pad_mode", str, "zero"), ("rot_repr", str, "euler"),
+    ("no_head_pose", "flag", False), ("do_ignore_shape", "flag", False), ("do_ignore_cfg", "flag", False),
+    ("log_iter", int, 100), ("save_iter", int, 10000), ("val_iter", int, 10000), ("log_smooth_win", int, 50),
+    ("continue_from", str, None),
+]
+
+
+def build_parser():
+    """argparse parser with the reference's flag names, types and defaults, plus this build's knobs."""
+    import argparse
+    ap = argparse.ArgumentParser(description="MSMD training on MI355X (reference-compatible flags)")
+    for name, kind, default in _FLAGS:
+        if kind == "flag":
+            ap.add_argument("--" + name, action="store_true")
+        elif name == "mode":
+            ap.add_argument("--mode", type=str, default="train", choices=["train", "test"])
+        elif name == "scheduler":
+            ap.add_argument("--scheduler", type=str, default=default, choices=["Warmup", "WarmupThenDecay"])
+        else:
+            ap.add_argument("--" + name, type=kind, default=default, required=name in ("exp_name", "data_root"))
+    ap.add_argument("--compute_dtype", type=str, default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--hip_graph", action="store_true", help="replay forward+backward as one hipGraph per truncation pattern")
+    ap.add_argument("--exp_root", type=str, default="experiments")
+    return ap
+
+
+def main(argv=None):
+    """Training / test driver over a DECODED corpus: --data_root is a (chunked) pickle of
+    {clip: {audio, expression_code, head_orientation}} (datasets.load_dict_in_chunks); the reference's per-dataset
+    directory layouts, torchaudio decoding, tensorboard and renderer hooks are outside this path."""
+    import time
+    from pathlib import Path
+    from .config import default_args
+    from .datasets import ResidentDataset, load_dict_in_chunks
+    from .model import get_diffusion_model
+    from .style_encoder import get_style_encoder
+    from .utils.model_common import save_args
+    cli = build_parser().parse_args(argv)
+    args = default_args(**{k: v for k, v in vars(cli).items() if v is not None})
+    rank, local_rank, world = dp.env_rank()
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dp.init("nccl", device)
+    raw = {}
+    for chunk in load_dict_in_chunks(cli.data_root):
+        raw.update(chunk)
+    names = sorted(raw)
+    n_val = max(1, len(names) // 20)
+    train_set = ResidentDataset(raw, names[n_val:], coef_fps=args.fps, original_fps=getattr(args, "original_fps", 30),
+                                n_motions=args.n_motions, clip_len=args.n_motions, device=device, seed=1234 + rank)
+    val_set = ResidentDataset(raw, names[:n_val], coef_stats=train_set.coef_stats, coef_fps=args.fps,
+                              original_fps=getattr(args, "original_fps", 30), n_motions=args.n_motions,
+                              clip_len=args.n_motions, device=device, random_crop=False)
+    model = get_diffusion_model(args, device)
+    style_enc = get_style_encoder(args, args.style_enc_model_style).to(device)
+    trainer = Trainer(args, model, style_enc, use_graph=cli.hip_graph)
+    exp_dir = Path(cli.exp_root) / cli.exp_name
+    ckpt_dir = exp_dir / "checkpoints"
+    start_iter = 0
+    if cli.continue_from:
+        found = sorted((Path(cli.continue_from) / "checkpoints").glob("iter_*.pt"))
+        if not found:
+            raise ValueError(f"No checkpoints found in {cli.continue_from}/checkpoints")
+        start_iter = trainer.load_checkpoint(found[-1])
+    lw = load_loss_weights(args)
+    val_loader = [val_set.batch(list(range(i, min(i + 2, len(val_set))))) for i in range(0, len(val_set), 2)]
+    if cli.mode == "test":
+        res = test(args, lw, model, style_enc, val_loader, args.max_iter, n_rounds=5, mode="test", coef_stats=train_set.coef_stats)
+        if rank == 0:
+            for k, v in res.items():
+                print(f"{k}: {np.mean(v):.4f}")
+        return res
+    if rank == 0:
+        ckpt_dir.mkdir(parents=True, exist_ok=True)
+        save_args(args, exp_dir)
+    model.train()
+    sampler = np.random.RandomState(99 + rank)
+    t0, log = time.time(), []
+    for it in range(start_iter, args.max_iter + 1):
+        batch = batch_from_loader(train_set.batch(sampler.randint(0, len(train_set), size=args.batch_size)))
+        log.append(trainer.step(batch, it=it)["loss"])
+        if rank == 0 and it % args.log_iter == 0 and it != start_iter:
+            vals = torch.stack(log[-args.log_smooth_win:]).mean().item()   # the only host sync, once per log interval
+            print(f"iter {it}: loss {vals:.5f}  lr {trainer.current_lr():.3e}  {(time.time() - t0) / max(1, it - start_iter) * 1e3:.1f} ms/it")
+            log = log[-args.log_smooth_win:]
+        if rank == 0 and ((it % args.save_iter == 0 and it not in (0, start_iter)) or it == args.max_iter):
+            trainer.save_checkpoint(ckpt_dir / f"iter_{it:07}.pt", it)
+        if (it % args.val_iter == 0 and it not in (0, start_iter)) or it == args.max_iter:
+            res = test(args, lw, model, style_enc, val_loader, it, 1, "val", coef_stats=train_set.coef_stats)
+            if rank == 0:
+                print(f"iter {it}: val loss {np.mean(res['loss']):.5f}")
+    return trainer
+
+
+if __name__ == "__main__":
+    main()

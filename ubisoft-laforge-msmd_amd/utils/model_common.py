@@ -106,7 +106,7 @@ def load_pretrained_model(args, model, style_encoder, device="cuda", parser=None
     files = sorted((exp_dir / "checkpoints").glob("iter_*.pt"))
     if len(files) == 0:
         raise ValueError(f"No checkpoints found in {exp_dir / 'checkpoints'}")
-    ckpt = torch.load(files[-1], map_location=device)
+    ckpt = torch.load(files[-1], map_location=device, weights_only=False)  # holds the args Namespace
     style_encoder.load_state_dict(ckpt["style_enc"])
     model.load_state_dict(ckpt["model"])
     return args, model, style_encoder, ckpt.get("iter", 0)
