@@ -59,6 +59,17 @@ int msmd_gemm(const void* A, const void* W, const float* bias, const void* resid
               int batch, long strideA, long strideW, long strideC, long strideBias, long strideR,
               msmd_stream_t stream);
 
+/* msmd_gemm with the training epilogue:  C = dropout_p(act(A . W^T + bias)) + residual, and optionally
+ * z_out = A . W^T + bias (the pre-activation the backward needs; layout and dtype of C).  The keep mask is
+ * Philox4x32-10(rng_state[seed, step], site, (m * N + n) / 4) -- exactly msmd_dropout's mask on a contiguous (M, N)
+ * tensor, so msmd_dropout / msmd_act_bwd_dropout regenerate it in the backward.  p_drop > 0 requires N % 4 == 0,
+ * ldc == N, batch == 1.  Replaces nn.Linear -> activation -> nn.Dropout (-> residual add) chains of the HF encoder
+ * layers, nn.TransformerDecoderLayer / EncoderLayer and the style encoder in train() mode. */
+int msmd_gemm_ex(const void* A, const void* W, const float* bias, const void* residual, void* C, int M, int N, int K,
+                 int in_dtype, int out_dtype, long lda, int rows_per_batch, long a_batch_stride, long ldw, long ldc,
+                 long ldr, int act, int batch, long strideA, long strideW, long strideC, long strideBias, long strideR,
+                 void* z_out, float p_drop, const unsigned long* rng_state, unsigned int site, msmd_stream_t stream);
+
 /* Two-level batched GEMM C[zo][zi] = A[zo][zi] . W[zo][zi]^T (no bias / residual / activation): operand z =
  * zo * batch_inner + zi starts at base + zo * stride_o + zi * stride_i.  Used by the explicit (materialised-P)
  * training attention, where zo = batch and zi = head index into packed (B, T, H*64) tensors. */
@@ -314,6 +325,9 @@ int msmd_colsum(const void* x, float* out, long rows, int cols, long ld, int acc
 /* y = act(z);  dz = dy * act'(z)  (exact erf GELU / ELU derivatives). */
 int msmd_act_fwd(const void* z, void* y, long n, int act, int dtype, msmd_stream_t stream);
 int msmd_act_bwd(const void* dy, const void* z, void* dz, long n, int act, int dtype, msmd_stream_t stream);
+/* dz = dropout_mask(dy) * act'(z): backward of y = dropout_p(act(z)) in one pass (mask as msmd_dropout / msmd_gemm_ex). */
+int msmd_act_bwd_dropout(const void* dy, const void* z, void* dz, long n, int act, float p,
+                         const unsigned long* rng_state, unsigned int site, int dtype, msmd_stream_t stream);
 /* LayerNorm backward for y = LN(x)*gamma + beta (x = the LN input, residual already added):
  * dx (rows, cols); dgamma / dbeta (cols) fp32 are ACCUMULATED into (zero them for a fresh gradient).
  * ws: optional msmd_layernorm_bwd_workspace() bytes for per-workgroup partial sums (NULL: fp32 atomics). */

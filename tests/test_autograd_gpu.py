@@ -214,3 +214,43 @@ def test_fused_attention_dropout_forward_and_backward(Tq, Tk, masked):
     for got, ref, name in ((dq, qf.grad, "dq"), (dk, kf.grad, "dk"), (dv, vf.grad, "dv")):
         err = float((got.float() - ref).abs().max())
         assert err < 2.5e-2 * float(ref.abs().max()) + 1e-3, (name, err, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("act_name,with_res", [("gelu", True), ("none", True), ("gelu", False)])
+def test_fused_linear_activation_dropout_epilogue(act_name, with_res):
+    """msmd_gemm_ex: y = dropout(act(x W^T + b)) + residual in one launch (z written for the backward), and the
+    one-pass backward msmd_act_bwd_dropout: same Philox mask as msmd_dropout on the (M, N) output, forward and all four
+    gradients against torch autograd in fp32 with that mask."""
+    from msmd_amd import autograd as ag, ops
+    M, K, N, p, site = 333, 256, 512, 0.2, 41
+    g = torch.Generator(device="cpu").manual_seed(11)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    x, res, gy = mk(M, K), mk(M, N), mk(M, N)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).requires_grad_(True)
+    b = (torch.randn(N, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    act = ops.ACT_GELU if act_name == "gelu" else ops.ACT_NONE
+    state = torch.tensor([77, 3], dtype=torch.int64, device=DEV)
+    old = (ag.TrainNoise.active, ag.TrainNoise.state)
+    ag.TrainNoise.active, ag.TrainNoise.state = True, state
+    try:
+        xq = x.clone().requires_grad_(True)
+        rq = res.clone().requires_grad_(True)
+        y = ag.LinearFn.apply(xq, w, b, rq if with_res else None, act, p, site)
+        y.backward(gy)
+        keep = ops.dropout(torch.ones(M, N, device=DEV), p, state, site) != 0
+        xf = x.float().requires_grad_(True)
+        wf = w.detach().to(torch.bfloat16).float().requires_grad_(True)
+        bf = b.detach().clone().requires_grad_(True)
+        rf = res.float().requires_grad_(True)
+        z = xf @ wf.t() + bf
+        a = torch.nn.functional.gelu(z) if act_name == "gelu" else z
+        yr = a * keep / (1 - p) + (rf if with_res else 0)
+        yr.backward(gy.float())
+        torch.cuda.synchronize()
+        assert float((y.float() - yr.detach()).abs().max()) < 3e-2
+        rel = lambda got, ref: float((got.float() - ref).abs().max() / (ref.abs().max() + 1e-9))
+        assert rel(xq.grad, xf.grad) < 2e-2 and rel(w.grad, wf.grad) < 2e-2 and rel(b.grad, bf.grad) < 2e-2
+        if with_res:
+            assert rel(rq.grad, rf.grad) < 1e-2
+    finally:
+        ag.TrainNoise.active, ag.TrainNoise.state = old

@@ -55,24 +55,25 @@ class LinearFn(torch.autograd.Function):
     """y = act(x @ w.T + b) + residual   (x: (..., K) compute dtype; w (N, K), b (N) fp32 master parameters)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, act):
+    def forward(ctx, x, w, b, residual, act, p_drop=0.0, site=0):
+        """y = dropout_p(act(x W^T + b)) + residual in ONE GEMM launch: the epilogue also writes the pre-activation z
+        (needed by the backward) when there is an activation, and applies the Philox keep mask."""
         dtype = x.dtype
         wc, wct = CACHE.get(w, dtype)
         K = w.shape[1]
         xin = x if wc.shape[1] == K else ops.pad_cols(x.contiguous(), wc.shape[1], dtype)
         xin = xin.contiguous()
         bf = b.detach().float().contiguous() if b is not None else None
-        if act == ACT_NONE:
-            y = ops.gemm(xin, wc, bf, residual.contiguous() if residual is not None else None)
-            z = None
-        else:
-            z = ops.gemm(xin, wc, bf)
-            y = ops.act_fwd(z, act)
-            if residual is not None:
-                y = y + residual
+        res = residual.contiguous() if residual is not None else None
+        z = None
+        if act != ACT_NONE:
+            z = torch.empty(*xin.shape[:-1], w.shape[0], device=x.device, dtype=dtype)
+        y = ops.gemm(xin, wc, bf, res, act, z_out=z, p_drop=p_drop, rng_state=TrainNoise.state if p_drop > 0 else None,
+                     site=site)
         ctx.save_for_backward(xin, z, w)
         ctx.act, ctx.has_b, ctx.has_r, ctx.K = act, b is not None, residual is not None, K
         ctx.b_ref = b if (b is not None and b.is_leaf) else None
+        ctx.drop = (p_drop, site)
         return y
 
     @staticmethod
@@ -80,7 +81,12 @@ class LinearFn(torch.autograd.Function):
         xin, z, w = ctx.saved_tensors
         dtype = xin.dtype
         dy = dy.contiguous()
-        dz = dy if ctx.act == ACT_NONE else ops.act_bwd(dy, z, ctx.act)
+        p_drop, site = ctx.drop
+        if p_drop > 0.0:
+            dz = (ops.dropout(dy, p_drop, TrainNoise.state, site) if ctx.act == ACT_NONE
+                  else ops.act_bwd_dropout(dy, z, ctx.act, p_drop, TrainNoise.state, site))
+        else:
+            dz = dy if ctx.act == ACT_NONE else ops.act_bwd(dy, z, ctx.act)
         N = w.shape[0]
         Kp = xin.shape[-1]
         M = xin.numel() // Kp
@@ -127,7 +133,7 @@ class LinearFn(torch.autograd.Function):
         elif want_b:
             db = ops.colsum(dz2)
         dres = dy if ctx.has_r and ctx.needs_input_grad[3] else None
-        return dx, dw, db, dres, None
+        return dx, dw, db, dres, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -288,6 +294,8 @@ def linear_dropout(x, w, b, p, residual=None, act=ACT_NONE):
     """dropout_p(act(x W^T + b)) + residual: eval mode keeps the residual fused in the GEMM epilogue."""
     if not TrainNoise.active or p <= 0.0:
         return linear(x, w, b, act=act, residual=residual)
+    if w.shape[0] % 4 == 0:   # mask index needs N % 4 == 0 (every Linear on the path); else compose
+        return LinearFn.apply(x, w, b, residual, act, float(p), TrainNoise.next_site())
     return dropout(linear(x, w, b, act=act), p, residual)
 
 

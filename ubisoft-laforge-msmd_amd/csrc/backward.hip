@@ -521,3 +521,36 @@ extern "C" int msmd_dropout(const void* x, const void* residual, void* y, long n
                        (const bf16_t*)residual, (bf16_t*)y, n, p, rng_state, site);
   MSMD_RETURN_LAST();
 }
+
+// dz = dropout_mask(dy) * act'(z): the backward of y = dropout(act(z)) in ONE pass (mask regenerated from the same
+// Philox stream as the forward GEMM epilogue / msmd_dropout: index = element / 4).
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_dropout_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                              T* __restrict__ dz, long n, int act, float p,
+                                                              const unsigned long* __restrict__ rng, unsigned site) {
+  const unsigned thr = dropout_threshold(p);
+  const float c = 1.0f / (1.0f - p);
+  const long nq = (n + 3) >> 2;
+  for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+    const Philox4 r = dropout_bits(rng, site, (unsigned long)q);
+    const unsigned bits[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long i = q * 4 + j;
+      if (i < n) dz[i] = from_f32<T>(bits[j] >= thr ? to_f32(dy[i]) * c * act_grad(to_f32(z[i]), act) : 0.f);
+    }
+  }
+}
+
+extern "C" int msmd_act_bwd_dropout(const void* dy, const void* z, void* dz, long n, int act, float p,
+                                    const unsigned long* rng_state, unsigned int site, int dtype, msmd_stream_t stream) {
+  if (n <= 0 || !(p > 0.f && p < 1.f) || !rng_state) return 1;
+  dim3 grid((unsigned)min(((n + 3) / 4 + 255) / 256, (long)8192)), block(256);
+  if (dtype == MSMD_F32)
+    hipLaunchKernelGGL(act_bwd_dropout_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)dy,
+                       (const float*)z, (float*)dz, n, act, p, rng_state, site);
+  else
+    hipLaunchKernelGGL(act_bwd_dropout_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy,
+                       (const bf16_t*)z, (bf16_t*)dz, n, act, p, rng_state, site);
+  MSMD_RETURN_LAST();
+}

@@ -23,6 +23,9 @@ struct GemmArgs {
   long strideA, strideW, strideC, strideBias, strideR;
   int mt, nt;
   int batch_inner; long strideA2, strideW2, strideC2;  // z = outer * batch_inner + inner (attention: batch x heads)
+  // training epilogue (msmd_gemm_ex): optional pre-activation copy Z (layout of C) and dropout on act(.) before the
+  // residual add; the keep mask is Philox(rng, site, (m * N + n) / 4), i.e. msmd_dropout's on a contiguous (M, N) C
+  void* Z; float p_drop; const unsigned long* rng; unsigned site;
 };
 
 template <typename T> struct Mfma;
@@ -90,7 +93,24 @@ __device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const 
     for (int i = 0; i < FN; ++i) {
       float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = act_out<TO>(acc[i][j][e] + bv[i][e], p.act);
+      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[i][e];
+      if (p.Z) {
+        TO* zp = (TO*)p.Z + (crow + i * 16 - (TO*)p.C);
+        if constexpr (sizeof(TO) == 4) *(f32x4*)zp = f32x4{v[0], v[1], v[2], v[3]};
+        else *(typename Vec4T<TO>::type*)zp = pack4<TO>(v[0], v[1], v[2], v[3]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = act_out<TO>(v[e], p.act);
+      if (p.p_drop > 0.f) {
+        const long idx = (long)(m_base + j * 16 + fr) * p.N + (n_base + i * 16 + fq * 4);
+        const Philox4 rb = dropout_bits(p.rng, p.site, (unsigned long)(idx >> 2));
+        const unsigned thr = dropout_threshold(p.p_drop);
+        const float c = 1.0f / (1.0f - p.p_drop);
+        v[0] = rb.x >= thr ? v[0] * c : 0.f;
+        v[1] = rb.y >= thr ? v[1] * c : 0.f;
+        v[2] = rb.z >= thr ? v[2] * c : 0.f;
+        v[3] = rb.w >= thr ? v[3] * c : 0.f;
+      }
       if (rrow) {
         if constexpr (sizeof(TO) == 4) {
           const f32x4 r = *(const f32x4*)(rrow + i * 16);
@@ -133,8 +153,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
       if (m >= p.M) continue;
       float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = act_out<TO>(acc[i][j][e] + bv[e], p.act);
+      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[e];
       TO* cp = C + (long)m * p.ldc + n;
+      if (p.Z) {
+        TO* zp = (TO*)p.Z + (cp - (TO*)p.C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.N) zp[e] = (TO)v[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = act_out<TO>(v[e], p.act);
+      if (p.p_drop > 0.f) {   // launcher guarantees N % 4 == 0 and ldc == N here
+        const Philox4 rb = dropout_bits(p.rng, p.site, (unsigned long)(((long)m * p.N + n) >> 2));
+        const unsigned thr = dropout_threshold(p.p_drop);
+        const float c = 1.0f / (1.0f - p.p_drop);
+        v[0] = rb.x >= thr ? v[0] * c : 0.f;
+        v[1] = rb.y >= thr ? v[1] * c : 0.f;
+        v[2] = rb.z >= thr ? v[2] * c : 0.f;
+        v[3] = rb.w >= thr ? v[3] * c : 0.f;
+      }
       if (p.vec_ok && n + 3 < p.N) {
         if (R) {
           const TO* rp = R + (long)m * p.ldr + n;
@@ -460,7 +497,8 @@ static int dispatch_gemm2_f16(GemmArgs& p, int batch, hipStream_t st, int varian
 static int gemm_impl(const void* A, const void* W, const float* bias, const void* residual, void* C, int M, int N, int K,
                      int in_dtype, int out_dtype, long lda, int rows_per_batch, long a_batch_stride, long ldw, long ldc,
                      long ldr, int act, int batch, long strideA, long strideW, long strideC, long strideBias,
-                     long strideR, int batch_inner, long strideA2, long strideW2, long strideC2, msmd_stream_t stream) {
+                     long strideR, int batch_inner, long strideA2, long strideW2, long strideC2, msmd_stream_t stream,
+                     void* z_out = nullptr, float p_drop = 0.f, const unsigned long* rng = nullptr, unsigned site = 0) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch_inner <= 0 || !A || !W || !C) return 1;
   const int hint = (act >> 8) & 0xff;  // caller-chosen kernel variant (host-side autotune), 0 = heuristic below
   act &= 0xff;
@@ -477,6 +515,9 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
   p.inv_rpb = 1.0f / (float)rows_per_batch;
   p.strideA = strideA; p.strideW = strideW; p.strideC = strideC; p.strideBias = strideBias; p.strideR = strideR;
   p.batch_inner = batch_inner; p.strideA2 = strideA2; p.strideW2 = strideW2; p.strideC2 = strideC2;
+  p.Z = z_out; p.p_drop = p_drop; p.rng = rng; p.site = site;
+  if (p_drop != 0.f && (!(p_drop > 0.f && p_drop < 1.f) || !rng || (N & 3) || ldc != N || batch != 1 || batch_inner != 1))
+    return 1;  // the mask index assumes one contiguous (M, N) output
   const int osz = out_dtype == MSMD_F32 ? 4 : 2;
   p.vec_ok = (ldc % 4 == 0) && (strideC % 4 == 0) && (strideC2 % 4 == 0) && (((uintptr_t)C % (4 * osz)) == 0) &&
              (!residual || ((ldr % 4 == 0) && (strideR % 4 == 0) && (((uintptr_t)residual % (4 * osz)) == 0)));
@@ -524,6 +565,16 @@ extern "C" int msmd_gemm(const void* A, const void* W, const float* bias, const 
                          long strideW, long strideC, long strideBias, long strideR, msmd_stream_t stream) {
   return gemm_impl(A, W, bias, residual, C, M, N, K, in_dtype, out_dtype, lda, rows_per_batch, a_batch_stride, ldw, ldc,
                    ldr, act, batch, strideA, strideW, strideC, strideBias, strideR, 1, 0, 0, 0, stream);
+}
+
+extern "C" int msmd_gemm_ex(const void* A, const void* W, const float* bias, const void* residual, void* C, int M,
+                            int N, int K, int in_dtype, int out_dtype, long lda, int rows_per_batch,
+                            long a_batch_stride, long ldw, long ldc, long ldr, int act, int batch, long strideA,
+                            long strideW, long strideC, long strideBias, long strideR, void* z_out, float p_drop,
+                            const unsigned long* rng_state, unsigned int site, msmd_stream_t stream) {
+  return gemm_impl(A, W, bias, residual, C, M, N, K, in_dtype, out_dtype, lda, rows_per_batch, a_batch_stride, ldw, ldc,
+                   ldr, act, batch, strideA, strideW, strideC, strideBias, strideR, 1, 0, 0, 0, stream, z_out, p_drop,
+                   rng_state, site);
 }
 
 extern "C" int msmd_gemm_batched2(const void* A, const void* W, void* C, int M, int N, int K, int in_dtype,

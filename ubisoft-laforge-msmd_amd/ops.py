@@ -82,8 +82,9 @@ def _autotune_gemm(lib, args, key, out, residual):
 
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None, *, M=None, K=None, lda=None,
          rows_per_batch=0, a_batch_stride=0, batch=1, strideA=0, strideW=0, strideC=0, strideBias=0, strideR=0,
-         N=None, ldw=None, ldc=None):
-    """C = act(A @ W^T + bias) + residual.  a: (..., K) contiguous unless M/K/lda describe a windowed view;
+         N=None, ldw=None, ldc=None, z_out=None, p_drop=0.0, rng_state=None, site=0):
+    """C = dropout_p(act(A @ W^T + bias)) + residual (p_drop = 0: no dropout); z_out (like C) receives the
+    pre-activation A @ W^T + bias when given (training epilogue, msmd_gemm_ex).  a: (..., K) contiguous unless M/K/lda describe a windowed view;
     w: (N, K) (or (batch, N, K) with strideW).  Returns C with a's leading dims + (N,)."""
     _need_cuda(a, w, bias, residual)
     lib = _lib.load()
@@ -117,7 +118,11 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
         if v is None:
             v = _autotune_gemm(lib, args, key, out, residual)
         args[16] = act | (v << 8)
-    _lib.check(lib.msmd_gemm(*args), "msmd_gemm")
+    if z_out is not None or p_drop > 0.0:
+        _lib.check(lib.msmd_gemm_ex(*args[:-1], _p(z_out), float(p_drop), _p(rng_state), int(site), args[-1]),
+                   "msmd_gemm_ex")
+    else:
+        _lib.check(lib.msmd_gemm(*args), "msmd_gemm")
     if GEMM_TRACE is not None:
         e1.record()
         GEMM_TRACE.append((M, N, K, batch, _dt(a), e0, e1))
@@ -540,6 +545,14 @@ def act_fwd(z, act):
     y = torch.empty_like(z)
     _lib.check(lib.msmd_act_fwd(_p(z), _p(y), z.numel(), act, _dt(z), _stream()), "msmd_act_fwd")
     return y
+
+
+def act_bwd_dropout(dy, z, act, p, rng_state, site):
+    """dz = dropout_mask(dy) * act'(z) (one pass; mask of the forward msmd_gemm_ex / msmd_dropout)."""
+    dz = torch.empty_like(z)
+    _lib.check(_lib.load().msmd_act_bwd_dropout(_p(dy), _p(z), _p(dz), z.numel(), act, float(p), _p(rng_state),
+                                                int(site), _dt(z), _stream()), "msmd_act_bwd_dropout")
+    return dz
 
 
 def act_bwd(dy, z, act):
