@@ -40,3 +40,17 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _reset_training_noise():
+    """The training-noise switch is module-level state: start every test from eval-mode arithmetic."""
+    yield
+    try:
+        from msmd_amd import autograd as ag
+        ag.TrainNoise.active = False
+        ag.TrainNoise.graph_safe = False
+        ag.TrainNoise.spec_masks = None
+        ag.DIRECT_GRAD = False
+    except Exception:
+        pass

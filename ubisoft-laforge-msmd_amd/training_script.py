@@ -306,6 +306,7 @@ class Trainer:
                 losses["kl_div"] = losses["kl_div"] + tg.kl_train(mus[i], logvars[i])
             loss = sum(losses[k] * lw[k] for k in losses if lw[k] > 0)
             loss.backward()
+        noise.active = False    # module-level switch: never leak train-mode noise into other callers of the graph
         out = {k: v.detach() for k, v in losses.items()}
         out["loss"] = loss.detach()
         return out
