@@ -433,3 +433,23 @@ def test_capture_forward_replays_equal_eager_on_new_inputs():
                     train_with_CFG=False, eps=eps)
         torch.cuda.synchronize()
         assert all(torch.equal(g, r) for g, r in zip(got, ref))
+
+
+@pytest.mark.parametrize("B,S,frames", [(1, 32000, 50), (3, 48000, 75), (33, 16000, 25), (2, 31999, 50), (2, 64001, 100)])
+def test_ragged_batches_and_clip_lengths_against_oracle(B, S, frames):
+    """Odd batch sizes (1, 3, 33) and clip lengths -- incl. lengths that are NOT a multiple of the 320-sample audio unit
+    (31999: no padding branch; 64001: reflect + replicate branch of pad_audio) -- through extract_audio_feature in fp32
+    against the oracle on a 2-layer encoder."""
+    from msmd_amd import shapes
+    from oracle import audio_encoder as oae
+    model, args = get_model("wav2vec2", "fp32", encoder_layers=2, n_layers=2)
+    sd = synth.fill_state_dict(shapes.msmd_shapes(args, 2))
+    audio = synth.audio_clips(B, S, tag=f"rag{B}_{S}")
+    got = model.extract_audio_feature(dev(audio), frames)
+    torch.cuda.synchronize()
+    ref = oae.extract_audio_feature(sd, audio[:3], fps=args.fps, frame_num=frames)
+    assert got.shape == (B, frames, 512)
+    assert maxabs(got[:3].cpu().numpy(), ref) < 1e-4
+    if B > 3:   # rows are independent: the same clip gives the same features wherever it sits in the batch
+        again = model.extract_audio_feature(dev(audio[-2:]), frames)
+        assert torch.equal(again, got[-2:])
