@@ -78,6 +78,17 @@ def roofline_leg(model, b, steps=3):
         step(model, b)
     torch.cuda.synchronize()
     trace, ops.GEMM_TRACE = ops.GEMM_TRACE, None
+    # an event pair around NOTHING still measures the record-to-record latency of the queue; subtract it so that the
+    # per-launch figure is the kernel's duration (what rocprofv3 --kernel-trace reports in profiles/)
+    empt = []
+    for _ in range(200):
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        a1.record()
+        empt.append((a0, a1))
+    torch.cuda.synchronize()
+    gaps = sorted(x.elapsed_time(y) for x, y in empt)
+    overhead = gaps[len(gaps) // 2]
     flops = 0.0
     ms = 0.0
     n_launch = 0
@@ -85,7 +96,7 @@ def roofline_leg(model, b, steps=3):
     big_n = 0
     for (M, N, K, batch, dt, e0, e1) in trace:
         f = 2.0 * M * N * K * batch
-        d = e0.elapsed_time(e1)
+        d = max(e0.elapsed_time(e1) - overhead, 1e-4)
         flops += f
         ms += d
         n_launch += 1
@@ -101,7 +112,8 @@ def roofline_leg(model, b, steps=3):
                 launches_per_step=big_n // steps, gflop_per_step=round(big_f / steps / 1e9, 1),
                 ms_per_step_in_kernel=round(big_ms / steps, 3),
                 all_gemm_tflops=round(flops / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
-                all_gemm_launches_per_step=n_launch // steps, all_gemm_ms_per_step=round(ms / steps, 3))
+                all_gemm_launches_per_step=n_launch // steps, all_gemm_ms_per_step=round(ms / steps, 3),
+                event_overhead_us=round(overhead * 1e3, 2))
 
 
 def pmc_traffic():
