@@ -56,26 +56,43 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const AttnArgs p) {
   for (int d = 0; d < 4; ++d) acc_o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
-  for (int kv0 = 0; kv0 < p.Tk; kv0 += 64) {
-    __syncthreads();
-    // ---- stage K and V tiles (rows beyond Tk are zero-filled)
-    for (int c = tid; c < 64 * NCH; c += NT) {
+  // K / V tiles are prefetched one tile ahead into registers: the global loads of tile t + 1 are in flight while tile
+  // t is being multiplied, so the staging latency (~2 us per 64-key tile) is off the critical path.
+  constexpr int NPF = (64 * NCH + NT - 1) / NT;   // 16-byte chunks of each of K, V a thread carries per tile
+  u32x4 pk[NPF], pv[NPF];
+  auto prefetch = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int c = tid + i * NT;
       const int row = c / NCH, ch = c % NCH;
       const int key = kv0 + row;
-      u32x4 kk = u32x4{0, 0, 0, 0}, vv = u32x4{0, 0, 0, 0};
-      if (key < p.Tk) {
-        kk = *(const u32x4*)(Kb + (long)key * p.kt + ch * (16 / sizeof(T)));
-        vv = *(const u32x4*)(Vb + (long)key * p.vt + ch * (16 / sizeof(T)));
+      pk[i] = pv[i] = u32x4{0, 0, 0, 0};
+      if (c < 64 * NCH && key < p.Tk) {
+        pk[i] = *(const u32x4*)(Kb + (long)key * p.kt + ch * (16 / sizeof(T)));
+        pv[i] = *(const u32x4*)(Vb + (long)key * p.vt + ch * (16 / sizeof(T)));
       }
-      if constexpr (BF) {
-        *(u32x4*)(sK + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kk;
-        *(u32x4*)(sV + row * 128 + ((((ch >> 1) ^ ((row >> 1) & 3)) << 5) + ((ch & 1) << 4))) = vv;
-      } else {
-        *(u32x4*)(sK + row * 256 + ((ch ^ (row & 15)) << 4)) = kk;
-        *(u32x4*)(sV + row * 272 + (ch << 4)) = vv;
+    }
+  };
+  prefetch(0);
+  for (int kv0 = 0; kv0 < p.Tk; kv0 += 64) {
+    __syncthreads();
+    // ---- stage the prefetched K and V tiles (rows beyond Tk are zero-filled)
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int c = tid + i * NT;
+      if (c < 64 * NCH) {
+        const int row = c / NCH, ch = c % NCH;
+        if constexpr (BF) {
+          *(u32x4*)(sK + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = pk[i];
+          *(u32x4*)(sV + row * 128 + ((((ch >> 1) ^ ((row >> 1) & 3)) << 5) + ((ch & 1) << 4))) = pv[i];
+        } else {
+          *(u32x4*)(sK + row * 256 + ((ch ^ (row & 15)) << 4)) = pk[i];
+          *(u32x4*)(sV + row * 272 + (ch << 4)) = pv[i];
+        }
       }
     }
     __syncthreads();
+    if (kv0 + 64 < p.Tk) prefetch(kv0 + 64);
 
     // ---- S^T tile: 4 fragments of 16 keys x 16 queries
     f32x4 s[4];
