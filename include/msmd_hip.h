@@ -364,6 +364,14 @@ int msmd_mean_time(const void* x, float* y, int B, int T, int C, int dtype, msmd
 int msmd_dynamic_threshold(float* res, int N, int T_all, int L, int C, float ratio, float dt_min, float dt_max,
                            msmd_stream_t stream);
 
+/* Mixed-precision weight refresh, ONE launch per optimizer step: for each of n_weights (N, K) fp32 matrices inside
+ * the flat parameter arena `base`, write its bf16 cast (N, K) into cast_arena and its bf16 transpose (K, N) into
+ * transposed_arena.  meta (n_weights, 6) int64 device array: [src offset, N, K, cast offset, transposed offset, first
+ * tile index]; tiles are 32 x 32, total_tiles = sum of ceil(N/32) ceil(K/32).  Replaces the per-weight autocast copies
+ * an AMP training step of the reference would make (training_script.py:163-201 runs fp32; this build trains in bf16). */
+int msmd_cast_transpose_multi(const float* base, const long* meta, int n_weights, long total_tiles, void* cast_arena,
+                              void* transposed_arena, msmd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Training-batch assembly from an HBM-resident corpus: both consecutive L-frame windows of B samples in one launch
  * (reference DatasetPickle.__getitem__ + collate_fn, datasets.py:251-368, 424-503).

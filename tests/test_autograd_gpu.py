@@ -254,3 +254,33 @@ def test_fused_linear_activation_dropout_epilogue(act_name, with_res):
             assert rel(rq.grad, rf.grad) < 1e-2
     finally:
         ag.TrainNoise.active, ag.TrainNoise.state = old
+
+
+@pytest.mark.gpu
+def test_weight_arena_refresh_matches_per_weight_casts():
+    """msmd_cast_transpose_multi: one launch == the per-weight bf16 cast + transpose, bit for bit, and LinearFn
+    picks the arena views up through CACHE.persistent."""
+    from msmd_amd import autograd as ag, dp
+    torch.manual_seed(3)
+    shapes = [(64, 32), (8, 8), (3072, 768), (40, 104), (512, 356), (7, 16), (768, 3072)]
+    params = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes] + \
+             [torch.nn.Parameter(torch.randn(5, 16, 3, device="cuda"))]
+    flat = dp.flatten_parameters(params)
+    arena = ag.WeightArena(flat, params)
+    assert arena.n == 5                                     # (512, 356), (7, 16) and the 3-D tensor are skipped
+    for p in params[:5]:
+        if p.shape in [(512, 356), (7, 16)]:
+            continue
+        wc, wct = ag.CACHE.get(p, torch.bfloat16)
+        assert wc.data_ptr() >= arena.cast.data_ptr() and wc.data_ptr() < arena.cast.data_ptr() + arena.cast.numel() * 2
+        assert torch.equal(wc, p.detach().bfloat16())
+        assert torch.equal(wct, p.detach().bfloat16().t().contiguous())
+    with torch.no_grad():
+        flat.mul_(0.5)
+    arena.refresh()
+    wc, wct = ag.CACHE.get(params[2], torch.bfloat16)
+    assert torch.equal(wc, params[2].detach().bfloat16()) and torch.equal(wct, params[2].detach().bfloat16().t())
+    # a dead parameter's entry is dropped, not served to a new tensor that recycles its id()
+    key = (id(params[0]), torch.bfloat16)
+    assert key in ag.CACHE.persistent
+    ag.CACHE.persistent.clear()

@@ -2,7 +2,7 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from msmd_amd import dp
+from msmd_amd import dp, autograd as ag
 from msmd_amd.config import default_args
 from msmd_amd.model import get_diffusion_model
 from msmd_amd.style_encoder import get_style_encoder
@@ -22,6 +22,9 @@ if os.environ.get('TRAIN_MODE'):
 else:
     model.eval(); se.eval()
 tr = Trainer(args, model, se, use_graph=bool(os.environ.get('GRAPH')))
+if os.environ.get('ARENA') == '0':
+    tr.weight_arena = None
+    ag.CACHE.persistent.clear()
 if os.environ.get('DIRECT') is not None:
     tr.direct_grad = bool(int(os.environ['DIRECT']))
 batch = synthetic_batch(B, rank, dev)

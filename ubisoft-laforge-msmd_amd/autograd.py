@@ -19,16 +19,23 @@ ACT_NONE, ACT_GELU, ACT_ELU = ops.ACT_NONE, ops.ACT_GELU, ops.ACT_ELU
 
 
 class WeightCache:
-    """Per-optimizer-step cache of compute-dtype weight copies and their transposes (like AMP's cast cache)."""
+    """Per-optimizer-step cache of compute-dtype weight copies and their transposes (like AMP's cast cache).
+    `persistent` entries are views into arenas a Trainer refreshes with ONE launch per step (WeightArena)."""
 
     def __init__(self):
         self.store = {}
+        self.persistent = {}
 
     def clear(self):
         self.store.clear()
 
     def get(self, w: torch.Tensor, dtype):
         key = (id(w), dtype)
+        e = self.persistent.get(key)
+        if e is not None:
+            if e[0]() is w and e[1] == (w.data_ptr(), tuple(w.shape)):
+                return e[2], e[3]
+            del self.persistent[key]            # the parameter died or moved: drop the stale views
         e = self.store.get(key)
         # id() values are recycled once a tensor dies: an entry is valid only for the SAME live tensor object (weak
         # reference), at the same version and storage address
@@ -43,6 +50,44 @@ class WeightCache:
 
 
 CACHE = WeightCache()
+
+
+class WeightArena:
+    """bf16 casts and transposes of all 8-aligned 2-D trainable weights living in one flat fp32 parameter arena, kept
+    in two bf16 arenas and rewritten by ONE kernel launch (msmd_cast_transpose_multi) after every optimizer step;
+    LinearFn finds them through CACHE.persistent, so an iteration issues no per-weight cast / transpose launches."""
+
+    def __init__(self, flat_param, params):
+        self.flat = flat_param
+        rows, self.views = [], []
+        off = tiles = 0
+        base = flat_param.data_ptr()
+        for p in params:
+            if p.ndim != 2 or not p.requires_grad or p.shape[0] % 8 or p.shape[1] % 8 or not p.is_contiguous():
+                continue
+            src = (p.data_ptr() - base) // 4
+            if src < 0 or src + p.numel() > flat_param.numel():
+                continue
+            N, K = p.shape
+            rows.append((src, N, K, off, off, tiles))
+            self.views.append((p, off, N, K))
+            off += (N * K + 63) // 64 * 64
+            tiles += ((N + 31) // 32) * ((K + 31) // 32)
+        self.n, self.tiles = len(rows), tiles
+        if not rows:
+            return
+        dev = flat_param.device
+        self.meta = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self.cast = torch.empty(off, device=dev, dtype=torch.bfloat16)
+        self.tr = torch.empty(off, device=dev, dtype=torch.bfloat16)
+        for p, o, N, K in self.views:
+            CACHE.persistent[(id(p), torch.bfloat16)] = (weakref.ref(p), (p.data_ptr(), tuple(p.shape)),
+                                                         self.cast[o:o + N * K].view(N, K), self.tr[o:o + N * K].view(K, N))
+        self.refresh()
+
+    def refresh(self):
+        if self.n:
+            ops.cast_transpose_multi(self.flat, self.meta, self.n, self.tiles, self.cast, self.tr)
 
 
 USE_GEMM_TN = True

@@ -554,3 +554,52 @@ extern "C" int msmd_act_bwd_dropout(const void* dy, const void* z, void* dz, lon
                        (const bf16_t*)z, (bf16_t*)dz, n, act, p, rng_state, site);
   MSMD_RETURN_LAST();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Once-per-step weight refresh for mixed-precision training: every trainable (N, K) Linear weight of the flat fp32
+// parameter arena is cast to bf16 AND written transposed (K, N) (the data-gradient GEMM's operand) by ONE launch --
+// the ~240 per-weight cast / transpose launches of an iteration collapse into this.  meta (n_w, 6) int64:
+// [src offset in the fp32 arena, N, K, dst offset in the cast arena, dst offset in the transposed arena, first tile];
+// N, K multiples of 8; 32 x 32 tiles through LDS (coalesced on both sides).
+__global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const float* __restrict__ base,
+                                                                   const long* __restrict__ meta, int n_w,
+                                                                   bf16_t* __restrict__ cast, bf16_t* __restrict__ tr) {
+  __shared__ float tile[32][33];
+  // which weight owns this tile: binary search over the tile prefix
+  int lo = 0, hi = n_w - 1;
+  const long t = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (meta[mid * 6 + 5] <= t) lo = mid; else hi = mid - 1;
+  }
+  const long* m = meta + lo * 6;
+  const long src = m[0], N = m[1], K = m[2], dc = m[3], dt = m[4];
+  const long lt = t - m[5];
+  const int tk = (int)((K + 31) / 32);
+  const int n0 = (int)(lt / tk) * 32, k0 = (int)(lt % tk) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n0 + ty + 8 * r, k = k0 + tx;
+    float v = 0.f;
+    if (n < N && k < K) {
+      v = base[src + (long)n * K + k];
+      cast[dc + (long)n * K + k] = (bf16_t)v;
+    }
+    tile[ty + 8 * r][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = k0 + ty + 8 * r, n = n0 + tx;
+    if (n < N && k < K) tr[dt + (long)k * N + n] = (bf16_t)tile[tx][ty + 8 * r];
+  }
+}
+
+extern "C" int msmd_cast_transpose_multi(const float* base, const long* meta, int n_weights, long total_tiles,
+                                         void* cast_arena, void* transposed_arena, msmd_stream_t stream) {
+  if (n_weights <= 0 || total_tiles <= 0 || total_tiles > 0x7fffffffL) return 1;
+  hipLaunchKernelGGL(cast_transpose_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, base,
+                     meta, n_weights, (bf16_t*)cast_arena, (bf16_t*)transposed_arena);
+  MSMD_RETURN_LAST();
+}

@@ -547,6 +547,13 @@ def act_fwd(z, act):
     return y
 
 
+def cast_transpose_multi(flat, meta, n, tiles, cast_arena, t_arena):
+    """One launch: bf16 cast + bf16 transpose of n (N, K) matrices of the flat fp32 arena (meta: see msmd_hip.h)."""
+    _need_cuda(flat, meta, cast_arena, t_arena)
+    _lib.check(_lib.load().msmd_cast_transpose_multi(_p(flat), _p(meta), int(n), int(tiles), _p(cast_arena),
+                                                     _p(t_arena), _stream()), "msmd_cast_transpose_multi")
+
+
 def act_bwd_dropout(dy, z, act, p, rng_state, site):
     """dz = dropout_mask(dy) * act'(z) (one pass; mask of the forward msmd_gemm_ex / msmd_dropout)."""
     dz = torch.empty_like(z)

@@ -152,6 +152,7 @@ class Trainer:
                  [p for p in model.parameters() if p.requires_grad]
         self.flat_param = dp.flatten_parameters(params)
         self.reducer = dp.GradBucketReducer(params, bucket_mb=bucket_mb, process_group=process_group)
+        self.weight_arena = (ag.WeightArena(self.flat_param, params) if model.compute_dtype == torch.bfloat16 else None)
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
         self.opt_step = 0
@@ -230,6 +231,8 @@ class Trainer:
 
     def _invalidate_caches(self):
         ag.CACHE.clear()
+        if self.weight_arena is not None:
+            self.weight_arena.refresh()   # ONE launch: bf16 casts + transposes of every trainable Linear weight
         self.model.denoising_net._packed = None
         self.model._afm = None
         self.style_enc._packed = None
