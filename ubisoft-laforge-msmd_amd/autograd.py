@@ -89,6 +89,20 @@ class WeightArena:
         if self.n:
             ops.cast_transpose_multi(self.flat, self.meta, self.n, self.tiles, self.cast, self.tr)
 
+    def release(self):
+        """Drop this arena's views from the cache (the bf16 arenas are freed with them)."""
+        for p, _, _, _ in self.views:
+            e = CACHE.persistent.get((id(p), torch.bfloat16))
+            if e is not None and e[0]() is p:
+                del CACHE.persistent[(id(p), torch.bfloat16)]
+        self.views, self.n = [], 0
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
 
 USE_GEMM_TN = True
 # Set by Trainer when bucket launches do not depend on per-parameter hooks (hipGraph mode / single process):
