@@ -132,7 +132,7 @@ def pmc_traffic():
         return None
 
 
-def cpu_baseline_leg(B=4):
+def cpu_baseline_leg(B=12):
     """Numpy oracle (parity-pinned port of the reference CPU path) on this host: MSMD.forward on B clips."""
     from msmd_amd import shapes, synth
     from msmd_amd.config import default_args

@@ -115,6 +115,16 @@ int msmd_attention(const void* Q, const void* K, const void* V, void* O, int B, 
                    long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
                    int dtype, msmd_stream_t stream);
 
+/* Person-token cross-attention query, projection + Tq = 1 attention fused (one wave per sequence and head):
+ *   out[n, h*64:(h+1)*64] = softmax(scale * (x[n] Wq_h^T + bq_h) K_h[n]^T) V_h[n]     (no mask, head_dim 64, Tk <= 512)
+ * x row n at x + n*x_seq_stride (d elements); Wq (d, d) row-major; K/V rows at base + n*kv_bstride + t*kv_tstride + h*64;
+ * out (N, d) contiguous; all of `dtype` (fp32 accumulation throughout).
+ * Replaces, for row 0 of the sequence (the person / diffusion-step token) under the diagonal alignment mask: the
+ * q-projection and softmax of nn.MultiheadAttention in the reference's TransformerDecoderLayer (model.py:874-878,956). */
+int msmd_person_query_attention(const void* x, long x_seq_stride, const void* Wq, const float* bq, const void* K,
+                                const void* V, long kv_bstride, long kv_tstride, void* out, int N, int H, int Tk, int d,
+                                float scale, int dtype, msmd_stream_t stream);
+
 /* Training-mode attention forward: as msmd_attention with attention-probability dropout p_drop (HF
  * attention_dropout, nn.MultiheadAttention(dropout=0.1) inside the decoder / encoder layers).  The keep mask is
  * Philox4x32-10(seed = rng_state[0], step = rng_state[1], site, (b, h, q, key / 4)); rng_state is DEVICE memory so a

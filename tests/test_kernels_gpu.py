@@ -392,3 +392,31 @@ def test_gemm_and_attention_fp16_storage(M, N, K):
         ln = o.layernorm(qkv[..., :d].contiguous(), torch.ones(d, device=DEV), torch.zeros(d, device=DEV))
         assert ln.dtype == torch.float16
         assert float((ln.float() - torch.nn.functional.layer_norm(qkv[..., :d].float(), (d,))).abs().max()) < 4e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,T,Tk,H", [(5, 111, 110, 8), (128, 111, 110, 8), (3, 1, 1, 8), (2, 7, 512, 4), (9, 4, 65, 12)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-2), (torch.float16, 3e-3)])
+def test_person_query_attention_matches_projection_plus_attention(N, T, Tk, H, dtype, tol):
+    """msmd_person_query_attention (one launch) == q-projection GEMM of row 0 + Tq = 1 msmd_attention + torch fp64
+    reference; fp32 tolerance 2e-6 (same arithmetic, different summation order), bf16 / fp16: storage rounding."""
+    O = ops()
+    torch.manual_seed(N * 1000 + Tk)
+    d = H * 64
+    x = torch.randn(N, T, d, device="cuda")
+    wq = torch.randn(d, d, device="cuda") / d ** 0.5
+    bq = torch.randn(d, device="cuda") * 0.1
+    kv = torch.randn(N, Tk, 2 * d, device="cuda")
+    scale = 64 ** -0.5
+    xd, wd, kvd = x.to(dtype), wq.to(dtype), kv.to(dtype)
+    got = O.person_query_attention(xd, wd, bq, kvd, H, scale).float()
+    # fp64 reference on the rounded operands
+    q = (xd[:, 0].double() @ wd.double().t() + bq.double()).view(N, H, 1, 64)
+    k = kvd[..., :d].double().view(N, Tk, H, 64).permute(0, 2, 1, 3)
+    v = kvd[..., d:].double().view(N, Tk, H, 64).permute(0, 2, 1, 3)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).permute(0, 2, 1, 3).reshape(N, d).float()
+    assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    # and the two-launch path it replaces
+    q0 = O.gemm(xd, wd, bq, M=N, K=d, lda=T * d)
+    two = O.attention(q0.view(N, 1, d), kvd[..., :d], kvd[..., d:], H, scale).view(N, d).float()
+    assert (got - two).abs().max().item() <= 2 * tol * max(1.0, ref.abs().max().item())

@@ -400,7 +400,8 @@ def test_diagonal_cross_attention_fast_path_equals_general_path():
     net.diag_fast_path = False
     try:
         slow = call()
-        assert maxabs(fast.cpu().numpy(), slow.cpu().numpy()) < 2e-6
+        # the person token's row goes through msmd_person_query_attention (fp32 VALU, its own summation order)
+        assert maxabs(fast.cpu().numpy(), slow.cpu().numpy()) < 1e-5
         old = model.diffusion_sched
         model.diffusion_sched = DiffusionSchedule(4, "cosine").to(DEV)
         xT = dev(synth.normalish("dg/xT", (3, 100, 67)))

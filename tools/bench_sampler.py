@@ -5,6 +5,8 @@ import torch
 from msmd_amd.config import default_args
 from msmd_amd.model import get_diffusion_model
 model = get_diffusion_model(default_args(compute_dtype=os.environ.get("DTYPE", "bf16")), "cuda").eval()
+if os.environ.get("PQA") == "0":
+    model.denoising_net.fused_person_query = False
 T = int(os.environ.get("T", "500"))
 for B in [int(b) for b in (sys.argv[1] if len(sys.argv) > 1 else "1,8,64").split(",")]:
     af = torch.randn(B, 100, 512, device="cuda"); shape = torch.zeros(B, 100, device="cuda"); style = torch.randn(B, 256, device="cuda")

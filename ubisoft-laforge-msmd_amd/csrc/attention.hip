@@ -271,3 +271,168 @@ extern "C" int msmd_attention_dropout(const void* Q, const void* K, const void* 
   return attention_impl(Q, K, V, O, B, H, Tq, Tk, q_bstride, q_tstride, k_bstride, k_tstride, v_bstride, v_tstride,
                         o_bstride, o_tstride, scale, mask, p_drop, rng_state, site, dtype, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Person-token cross-attention query (sampler fast path, diagonal alignment mask): row 0 of every sequence is the only
+// row of the denoiser's cross-attention with a real softmax (rows t >= 1 see exactly one key; model.py:874-878 mask),
+// so per layer and denoising step the path needs  a0[n] = softmax(scale (x[n,0] Wq^T + bq)_h K_h[n]^T) V_h[n]  for N
+// sequences: a 1-row projection GEMM + a Tq = 1 attention launch, both latency-bound (16 us together inside the
+// sampler's graph).  Here ONE wave per (sequence, head) does both on the vector ALU in fp32, all loads issued up front.
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&o)[8]) {
+  if constexpr (sizeof(T) == 4) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+  } else {
+    const typename Vec8T<T>::type v = *(const typename Vec8T<T>::type*)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+  }
+}
+__device__ __forceinline__ float group8_sum(float v) {   // over the 8 lanes that share lane / 8
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+  return v;
+}
+
+// Lane = (g = lane / 8, c = lane % 8): every global access is 8 rows x 128 contiguous bytes (8 lanes x 8 elements).
+//   projection: row block rb -> row rb*8+g of Wq_h, the lane's chunks c, c+8, ... of the row against x0's; group sum
+//   scores:     iteration it -> key it*8+g, chunk c of the 64-wide head; group sum -> all 8 lanes hold the score
+//   output:     the same lanes hold p for their key and read chunk c of its V row; sum over g at the end
+// NIT = key iterations held in registers (Tk <= 8 NIT).
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void person_query_attention_kernel(const T* __restrict__ x, long x_seq_stride,
+                                                                     const T* __restrict__ Wq, const float* __restrict__ bq,
+                                                                     const T* __restrict__ K, const T* __restrict__ V,
+                                                                     long kv_bstride, long kv_tstride, T* __restrict__ out,
+                                                                     int N, int H, int Tk, int d, float scale) {
+  __shared__ float sq[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int g = lane >> 3, c = lane & 7;
+  const int w = blockIdx.x * 4 + wid;
+  if (w >= N * H) return;
+  const int n = w / H, h = w - n * H;
+  const T* x0 = x + (long)n * x_seq_stride;
+  const int nch = d >> 6;                      // chunks of 8 per lane along a d-long row (d = 64 H)
+  const T* kbase = K + (long)n * kv_bstride + h * 64 + c * 8;
+  const T* vbase = V + (long)n * kv_bstride + h * 64 + c * 8;
+  // 2-byte storage, Tk <= 128: the K / V stream (the only HBM-sized traffic here) does not depend on the query, so all
+  // of it is requested before the projection starts and lands behind it
+  constexpr bool PRE = sizeof(T) == 2 && NIT <= 16;
+  u32x4 kraw[PRE ? NIT : 1], vraw[PRE ? NIT : 1];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      if (it * 8 < Tk) {
+        const long ro = (long)min(it * 8 + g, Tk - 1) * kv_tstride;
+        kraw[it] = *(const u32x4*)(kbase + ro);
+        vraw[it] = *(const u32x4*)(vbase + ro);
+      }
+  }
+  float qv[8];
+#pragma unroll
+  for (int rb = 0; rb < 8; ++rb) qv[rb] = 0.f;
+  for (int i = 0; i < nch; ++i) {
+    float xv[8];
+    load8<T>(x0 + (c + 8 * i) * 8, xv);
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb) {
+      float wv[8];
+      load8<T>(Wq + (long)(h * 64 + rb * 8 + g) * d + (c + 8 * i) * 8, wv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[rb] = fmaf(xv[e], wv[e], qv[rb]);
+    }
+  }
+#pragma unroll
+  for (int rb = 0; rb < 8; ++rb) {
+    const float t = group8_sum(qv[rb]);
+    if (c == 0) sq[wid][rb * 8 + g] = (t + (bq ? bq[h * 64 + rb * 8 + g] : 0.f)) * scale;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float q8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) q8[e] = sq[wid][c * 8 + e];
+
+  float sc[NIT];
+  float m = -INFINITY;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int key = it * 8 + g;
+    sc[it] = -INFINITY;
+    if (it * 8 < Tk) {                         // wave-uniform
+      float kvv[8];
+      if constexpr (PRE) {
+        const typename Vec8T<T>::type v8 = __builtin_bit_cast(typename Vec8T<T>::type, kraw[it]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kvv[e] = (float)v8[e];
+      } else {
+        load8<T>(kbase + (long)min(key, Tk - 1) * kv_tstride, kvv);
+      }
+      float a = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a = fmaf(q8[e], kvv[e], a);
+      a = group8_sum(a);
+      if (key < Tk) { sc[it] = a; m = fmaxf(m, a); }
+    }
+  }
+  m = wave_max(m);
+  float l = 0.f, o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int key = it * 8 + g;
+    if (it * 8 < Tk) {
+      const float pv = key < Tk ? (sizeof(T) == 4 ? expf(sc[it] - m) : __expf(sc[it] - m)) : 0.f;
+      l += pv;
+      float vv[8];
+      if constexpr (PRE) {
+        const typename Vec8T<T>::type v8 = __builtin_bit_cast(typename Vec8T<T>::type, vraw[it]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[e] = (float)v8[e];
+      } else {
+        load8<T>(vbase + (long)min(key, Tk - 1) * kv_tstride, vv);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = fmaf(pv, vv[e], o[e]);
+    }
+  }
+  l = wave_sum(l) * 0.125f;                    // every key was counted by its 8 lanes
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float t = o[e];
+    t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+    o[e] = t / l;
+  }
+  if (g == 0) {
+    T* op = out + (long)n * d + h * 64 + c * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) op[e] = from_f32<T>(o[e]);
+  }
+}
+
+extern "C" int msmd_person_query_attention(const void* x, long x_seq_stride, const void* Wq, const float* bq,
+                                           const void* K, const void* V, long kv_bstride, long kv_tstride, void* out,
+                                           int N, int H, int Tk, int d, float scale, int dtype, msmd_stream_t stream) {
+  if (N <= 0 || H <= 0 || Tk <= 0 || Tk > 512 || d != H * 64 || !x || !Wq || !K || !V || !out) return 1;
+  const int E = 8;
+  if (x_seq_stride % E || kv_bstride % E || kv_tstride % E || ((uintptr_t)x & 15) || ((uintptr_t)Wq & 15) ||
+      ((uintptr_t)K & 15) || ((uintptr_t)V & 15))
+    return 1;
+  const dim3 grid((N * H + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_PQA(T)                                                                                                  \
+  do {                                                                                                                 \
+    if (Tk <= 128)                                                                                                     \
+      hipLaunchKernelGGL((person_query_attention_kernel<T, 16>), grid, block, 0, st, (const T*)x, x_seq_stride,         \
+                         (const T*)Wq, bq, (const T*)K, (const T*)V, kv_bstride, kv_tstride, (T*)out, N, H, Tk, d, scale); \
+    else                                                                                                               \
+      hipLaunchKernelGGL((person_query_attention_kernel<T, 64>), grid, block, 0, st, (const T*)x, x_seq_stride,         \
+                         (const T*)Wq, bq, (const T*)K, (const T*)V, kv_bstride, kv_tstride, (T*)out, N, H, Tk, d, scale); \
+  } while (0)
+  if (dtype == MSMD_F32) LAUNCH_PQA(float);
+  else if (dtype == MSMD_BF16) LAUNCH_PQA(bf16_t);
+  else if (dtype == MSMD_F16) LAUNCH_PQA(f16_t);
+  else return 1;
+#undef LAUNCH_PQA
+  MSMD_RETURN_LAST();
+}

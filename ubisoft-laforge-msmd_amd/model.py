@@ -309,8 +309,13 @@ class DenoisingNetwork_MSMD(nn.Module):
             if diag:
                 # only the person token (row 0) has a real softmax; rows t >= 1 come from the precomputed R
                 R = cross_list[li]
-                q0 = ops.gemm(x, L.ca_qw, L.ca_qb, M=N, K=d, lda=Tn * d)                        # (N, d) from x[:, 0]
-                a0 = ops.attention(q0.view(N, 1, d), kv[..., :d], kv[..., d:], H, scale)         # (N, 1, d)
+                # same-box A/B in the sampler graph: fused -1 % at N = 192 sequences, +1.5 % at N = 3 (a longer serial
+                # chain per wave than the two more parallel launches), so it is used from 64 sequences up
+                if getattr(self, "fused_person_query", N >= 64):
+                    a0 = ops.person_query_attention(x, L.ca_qw, L.ca_qb, kv, H, scale)           # (N, d), one launch
+                else:
+                    q0 = ops.gemm(x, L.ca_qw, L.ca_qb, M=N, K=d, lda=Tn * d)                    # (N, d) from x[:, 0]
+                    a0 = ops.attention(q0.view(N, 1, d), kv[..., :d], kv[..., d:], H, scale)     # (N, 1, d)
                 ops.gemm(a0, L.ca_ow, L.ca_ob, None, ops.ACT_NONE, out=R, M=N, K=d, ldc=Tn * d)  # -> R[:, 0]
                 x = ops.layernorm(x, *L.n2, residual=R)
             else:

@@ -547,6 +547,23 @@ def act_fwd(z, act):
     return y
 
 
+def person_query_attention(x, wq, bq, kv, n_heads, scale):
+    """Row 0 of every sequence of x (N, T, d): softmax(scale (x0 Wq^T + bq)_h K_h^T) V_h against kv (N, Tk, 2d) =
+    [K | V]; returns (N, d).  One launch for the projection and the Tq = 1 attention (msmd_person_query_attention)."""
+    _need_cuda(x, wq, kv)
+    N, _, d = x.shape
+    Tk = kv.shape[1]
+    if kv.shape[2] != 2 * d or wq.shape[0] != d or wq.shape[1] != d or x.stride(2) != 1 or kv.stride(2) != 1:
+        raise ValueError("person_query_attention: shapes")
+    if not (x.dtype == wq.dtype == kv.dtype):
+        raise TypeError("person_query_attention: x, wq, kv must share a dtype")
+    out = torch.empty(N, d, device=x.device, dtype=x.dtype)
+    _lib.check(_lib.load().msmd_person_query_attention(_p(x), x.stride(0), _p(wq), _p(bq), _p(kv), _p(kv[..., d:]),
+                                                       kv.stride(0), kv.stride(1), _p(out), N, n_heads, Tk, d,
+                                                       float(scale), _dt(x), _stream()), "msmd_person_query_attention")
+    return out
+
+
 def cast_transpose_multi(flat, meta, n, tiles, cast_arena, t_arena):
     """One launch: bf16 cast + bf16 transpose of n (N, K) matrices of the flat fp32 arena (meta: see msmd_hip.h)."""
     _need_cuda(flat, meta, cast_arena, t_arena)
