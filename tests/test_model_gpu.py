@@ -395,12 +395,16 @@ def test_diagonal_cross_attention_fast_path_equals_general_path():
     call = lambda: net(dev(x["motion"]), dev(x["audio_feat"]), person, dev(x["style"])[:, None], dev(x["prev_motion"]),
                        dev(x["prev_audio"]), [7, 250, 499], dev(x["indicator"]))
     net.diag_single_pass = True
-    fast = call()
+    fast2 = call()                              # small batch: q-projection GEMM + Tq = 1 attention for the person row
+    net.fused_person_query = True
+    fast = call()                               # large-batch form: msmd_person_query_attention
+    del net.fused_person_query
     net.diag_single_pass = False
     net.diag_fast_path = False
     try:
         slow = call()
-        # the person token's row goes through msmd_person_query_attention (fp32 VALU, its own summation order)
+        assert maxabs(fast2.cpu().numpy(), slow.cpu().numpy()) < 2e-6
+        # msmd_person_query_attention: fp32 VALU, its own summation order
         assert maxabs(fast.cpu().numpy(), slow.cpu().numpy()) < 1e-5
         old = model.diffusion_sched
         model.diffusion_sched = DiffusionSchedule(4, "cosine").to(DEV)

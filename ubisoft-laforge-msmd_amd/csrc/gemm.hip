@@ -412,6 +412,115 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const GemmArgs p) {
   gemm_epilogue<TO, FM, FN>(p, acc, z, m0 + wm, n0 + wn, fr, fq);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K-split wave layout of the same 128x128 / 8-wave / 2-stage tile: the default kernel above is LDS-bandwidth bound
+// (per K tile a workgroup reads 96 KB of fragments + 32 KB of LDS-DMA writes = 1024 clk at 128 B/clk against 512 clk
+// of MFMA issue per SIMD; tools/gemm_big.py).  Here the 8 waves are 2 x 2 spatial x 2 along K: a wave owns a 64 x 64
+// output block and ONE 32-deep half of every K tile, i.e. 8 fragment reads per 16 MFMAs instead of 12 (64 KB per K
+// tile).  The two K halves meet once per tile: each wave parks the 32 rows its partner finishes in the (then idle)
+// stage buffers, adds the partner's half to the rows it keeps, and runs the usual 32 x 64 epilogue.
+template <typename TO, typename TI = bf16_t>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm2k_kernel(const GemmArgs p) {
+  constexpr int BM = 128, BN = 128, NW = 8, NT = 512;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int LPT = (BM + BN) * 8 / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int pid = blockIdx.x;
+  const int xcd = pid & 7, slot = pid >> 3;
+  const int m_tile = (slot / p.nt) * 8 + xcd, n_tile = slot % p.nt;
+  if (m_tile >= p.mt) return;
+  const int z = blockIdx.z;
+  const int zo = z / p.batch_inner, zi = z % p.batch_inner;
+  const bf16_t* __restrict__ A = (const bf16_t*)p.A + zo * p.strideA + zi * p.strideA2;
+  const bf16_t* __restrict__ W = (const bf16_t*)p.W + zo * p.strideW + zi * p.strideW2;
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+  const bf16_t* src[LPT];
+#pragma unroll
+  for (int i = 0; i < LPT; ++i) {
+    const int id = (i * NW + wid) * 64 + lane;
+    const int row = id >> 3, phys = id & 7;
+    const int c = phys ^ ((row >> 1) & 7);
+    if (row < BM) src[i] = A + a_row_offset(p, min(m0 + row, p.M - 1)) + c * 8;
+    else src[i] = W + (long)min(n0 + row - BM, p.N - 1) * p.ldw + c * 8;
+  }
+  auto issue = [&](int kt, int stage) {
+#pragma unroll
+    for (int i = 0; i < LPT; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[i] + kt * 64),
+                                       (lds_void_t*)(smem + stage * STAGE + (i * NW + wid) * 1024), 16, 0, 0);
+  };
+
+  const int wk = wid & 1, wn = ((wid >> 1) & 1) * 64, wm = (wid >> 2) * 64;
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / 64;
+  issue(0, 0);
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) issue(kt + 1, stage ^ 1);
+    const unsigned char* sa = smem + stage * STAGE;
+    const unsigned char* sw = sa + BM * 128;
+    u32x4 fx[4], fw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fx[j] = *(const u32x4*)(sa + lds_off(wm + j * 16 + fr, wk * 4 + fq));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fw[i] = *(const u32x4*)(sw + lds_off(wn + i * 16 + fr, wk * 4 + fq));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Mfma<TI>::run(fw[i], fx[j], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+    stage ^= 1;
+  }
+  // meet the partner's K half: wave wk finishes rows [wk*32, wk*32+32) of the pair's 64 x 64 block.  The selects work
+  // on laundered VALUES: left alone, hipcc folds "wk ? acc[a] : acc[b]" into a dynamically indexed stack array.
+  __syncthreads();
+  f32x4* park = (f32x4*)smem + (wid ^ 1) * (8 * 64) + lane;    // read back by the partner as ITS region
+  const f32x4* mine = (const f32x4*)smem + wid * (8 * 64) + lane;
+  f32x4 fin[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      f32x4 lo = acc[i][jj], hi = acc[i][2 + jj];
+      asm volatile("" : "+v"(lo), "+v"(hi));
+      park[(i * 2 + jj) * 64] = wk ? lo : hi;
+      fin[i][jj] = wk ? hi : lo;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) fin[i][jj] += mine[(i * 2 + jj) * 64];
+  gemm_epilogue<TO, 2, 4>(p, fin, z, m0 + wm + wk * 32, n0 + wn, fr, fq);
+}
+
+template <typename TO, typename TI = bf16_t>
+static int launch_gemm2k(GemmArgs& p, int batch, hipStream_t st) {
+  constexpr int lds = 2 * 256 * 128;
+  static bool attr_done = false;
+  auto kfn = gemm2k_kernel<TO, TI>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  p.mt = (p.M + 127) / 128; p.nt = (p.N + 127) / 128;
+  dim3 grid(((p.mt + 7) / 8) * 8 * p.nt, 1, batch);
+  hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, p);
+  MSMD_RETURN_LAST();
+}
+
 int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // shared with gemm_tn.hip (key 2 = forced contraction splits)
 extern "C" int msmd_set_tuning(int key, int value) {
   if (key < 0 || key >= 8) return 1;
@@ -464,6 +573,7 @@ static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
     case 25: return launch_gemm2<TO, 256, 256, 4, 2, 2, true>(p, batch, st);
     case 26: return launch_gemm2<TO, 128, 256, 2, 4, 3, true>(p, batch, st);
     case 27: return launch_gemm2<TO, 256, 128, 4, 2, 2, true>(p, batch, st);
+    case 28: return launch_gemm2k<TO>(p, batch, st);
     default: return -1;
   }
 }
