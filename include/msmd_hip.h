@@ -305,7 +305,8 @@ int msmd_rotation_convert(int op, const float* in, const float* in2, float* out,
 /* out[0] = scale * mean over valid (n, t) of mean_{c in [c_lo, c_hi)} crit(D^order gt, D^order pred)
  *   gt, pred: (N, T, C) fp32; D^order = order-th temporal difference (0 = value, 1 = velocity, 2 = smoothness);
  *   frame t of the differenced sequence is valid when mask[t + order] holds, mask[tm] = tm < prefix ||
- *   tm - prefix < end_idx[n] (end_idx NULL: all valid).  criterion 0 = squared error, 1 = absolute error.
+ *   tm - prefix < end_idx[n] (end_idx NULL: all valid); a NEGATIVE prefix masks the first |prefix| frames OUT instead
+ *   (--no_constrain_prev, utils/common.py:382-385).  criterion 0 = squared error, 1 = absolute error.
  *   mode 1: compare D^order pred against 0 (the smoothness term).  acc_ws: 2 doubles of scratch.
  *   out is NaN when no frame is valid (the reference returns None there). */
 int msmd_masked_seq_loss(const float* gt, const float* pred, const int* end_idx, float* out, double* acc_ws,

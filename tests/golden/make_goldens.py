@@ -576,6 +576,44 @@ def g4_rotations(M, SE, mc):
     save("g4_rotations", **out)
 
 
+def g5_losses_no_constrain_prev(M, SE, mc):
+    """The reference's (deprecated but live) --no_constrain_prev mode of both loss functions (utils/common.py:245,
+    382, 481, 561): the previous-window part of the prediction is replaced by ground truth and masked out."""
+    from utils import common as C
+    from utils import flame as FL
+    args = ref_args(no_constrain_prev=True)
+    N = 3
+    gt = synth.normalish("loss/gt", (N, 100, 67))
+    prev = synth.normalish("loss/prev", (N, 10, 67))
+    target = synth.normalish("loss/target", (N, 110, 67))
+    end_idx = torch.tensor([100, 37, 1])
+    out = {}
+    for start in (True, False):
+        for use_end in (False, True):
+            r = C.compute_loss_no_vert(args, start, None, t(gt), None, t(target), t(prev), None, None,
+                                       end_idx=end_idx if use_end else None)
+            out[f"nv_{int(start)}_{int(use_end)}"] = np.array([np.nan if v is None else float(v) for v in r], np.float64)
+    with tempfile.TemporaryDirectory() as td:
+        pkl, npy = write_flame_asset(td)
+        cfg = FL.FLAMEConfig
+        cfg.flame_model_path, cfg.flame_lmk_embedding_path = pkl, npy
+        fl = FL.FLAME(cfg).eval()
+    L = 12
+    argsv = ref_args(n_motions=L, n_prev_motions=4, no_constrain_prev=True)
+    gt54 = (0.5 * synth.normalish("loss/gt54", (2, L, 54))).astype(np.float32)
+    prev54 = (0.5 * synth.normalish("loss/prev54", (2, 4, 54))).astype(np.float32)
+    tgt54 = (0.5 * synth.normalish("loss/tgt54", (2, L + 4, 54))).astype(np.float32)
+    shape = (0.5 * synth.normalish("loss/shape", (2, 100))).astype(np.float32)
+    stats = {"exp_mean": t(0.1 * synth.normalish("st/em", (50,))), "exp_std": t(1 + 0.1 * np.abs(synth.normalish("st/es", (50,)))),
+             "pose_mean": t(0.05 * synth.normalish("st/pm", (6,))), "pose_std": t(1 + 0.1 * np.abs(synth.normalish("st/ps", (6,)))),
+             "shape_mean": t(np.zeros(100, np.float32)), "shape_std": t(np.ones(100, np.float32))}
+    for start in (True, False):
+        r = C.compute_loss(argsv, start, t(shape), t(gt54), None, t(tgt54), t(prev54), stats, fl,
+                           end_idx=torch.tensor([L, 5]))
+        out[f"vert_{int(start)}"] = np.array([np.nan if v is None else float(v) for v in r], np.float64)
+    save("g5_losses_no_constrain_prev", **out)
+
+
 # --------------------------------------------------------------------------- G5 losses / scheduler
 def g5_losses(M, SE, mc):
     from utils import common as C
@@ -758,7 +796,8 @@ def g1_specaug(M, SE, mc):
 
 ALL = dict(g1_specaug=g1_specaug, g7_dataset=g7_dataset, g2_lr_schedule=g2_lr_schedule, g3_audio_large=g3_audio_large, g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
            g3_forward=g3_forward, g3_style=g3_style, g3_sample=g3_sample, g3_infer=g3_infer,
-           g4_flame=g4_flame, g4_rotations=g4_rotations, g5_losses=g5_losses, g6_train=g6_train)
+           g4_flame=g4_flame, g4_rotations=g4_rotations, g5_losses=g5_losses, g6_train=g6_train,
+           g5_losses_no_constrain_prev=g5_losses_no_constrain_prev)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -127,3 +127,48 @@ def test_truncation_scheduler_adam():
     for i in range(3):
         ops.adam_step_(w, dev(synth.normalish(f"adam/g{i}", (1000,))), m1, v1, 2e-3, i + 1)
     assert maxabs(w.cpu().numpy(), g["adam_w3"]) < 2e-6
+
+
+def test_no_constrain_prev_losses_match_reference():
+    """--no_constrain_prev (deprecated in the reference but live, utils/common.py:245, 382, 481, 561): the previous
+    window's part of the prediction is replaced by ground truth and its frames are masked OUT of every term; both loss
+    functions against goldens from the reference, and the differentiable training restatement against the forward one."""
+    from msmd_amd.utils import common as C
+    from msmd_amd import train_graph as tg
+    g = load_golden("g5_losses_no_constrain_prev")
+    args = default_args(no_constrain_prev=True)
+    N = 3
+    gt = dev(synth.normalish("loss/gt", (N, 100, 67)))
+    prev = dev(synth.normalish("loss/prev", (N, 10, 67)))
+    target = dev(synth.normalish("loss/target", (N, 110, 67)))
+    end_idx = torch.tensor([100, 37, 1], device=DEV)
+    for start in (True, False):
+        for use_end in (False, True):
+            e = end_idx if use_end else None
+            r = C.compute_loss_no_vert(args, start, None, gt, None, target, prev, None, None, end_idx=e)
+            ref, got = g[f"nv_{int(start)}_{int(use_end)}"], vals(r)
+            assert np.array_equal(np.isnan(got), np.isnan(ref)), (start, use_end)
+            assert np.nanmax(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))) < 2e-6, (start, use_end, got, ref)
+            rt = vals(tg.loss_no_vert_train(args, start, gt, target, prev, end_idx=e))
+            assert np.nanmax(np.abs(rt - ref) / np.maximum(1.0, np.abs(ref))) < 2e-6, (start, use_end, rt, ref)
+    # differs from the constrained mode (the masked frames carried loss there)
+    r0 = vals(C.compute_loss_no_vert(default_args(), False, None, gt, None, target, prev, None, None, end_idx=end_idx))
+    assert abs(r0[0] - g["nv_0_1"][0]) > 1e-3
+    fl = _flame()
+    L = 12
+    argsv = default_args(n_motions=L, n_prev_motions=4, no_constrain_prev=True)
+    gt54 = dev((0.5 * synth.normalish("loss/gt54", (2, L, 54))).astype(np.float32))
+    prev54 = dev((0.5 * synth.normalish("loss/prev54", (2, 4, 54))).astype(np.float32))
+    tgt54 = dev((0.5 * synth.normalish("loss/tgt54", (2, L + 4, 54))).astype(np.float32))
+    shape = dev((0.5 * synth.normalish("loss/shape", (2, 100))).astype(np.float32))
+    stats = {"exp_mean": dev(0.1 * synth.normalish("st/em", (50,))),
+             "exp_std": dev(1 + 0.1 * np.abs(synth.normalish("st/es", (50,)))),
+             "pose_mean": dev(0.05 * synth.normalish("st/pm", (6,))),
+             "pose_std": dev(1 + 0.1 * np.abs(synth.normalish("st/ps", (6,)))),
+             "shape_mean": dev(np.zeros(100, np.float32)), "shape_std": dev(np.ones(100, np.float32))}
+    for start in (True, False):
+        r = C.compute_loss(argsv, start, shape, gt54, None, tgt54, prev54, stats, fl,
+                           end_idx=torch.tensor([L, 5], device=DEV))
+        ref, got = g[f"vert_{int(start)}"], vals(r)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), start
+        assert np.nanmax(np.abs(got - ref) / np.maximum(1e-6, np.abs(ref))) < 2e-3, (start, got, ref)

@@ -27,10 +27,13 @@ __global__ __launch_bounds__(256) void masked_seq_loss_kernel(const LossArgs p) 
   for (long row = blockIdx.x; row < rows; row += gridDim.x) {
     const int n = (int)(row / Td), t = (int)(row % Td);
     const int tm = t + p.order;  // mask index: mask[:, order:]
-    bool valid = tm < p.prefix;
-    if (!valid) {
-      const int e = p.end_idx ? p.end_idx[n] : (p.T - p.prefix);
-      valid = (tm - p.prefix) < e;
+    // prefix >= 0: the first `prefix` frames (previous window) always count; prefix < 0: they never do
+    // (--no_constrain_prev, reference utils/common.py:382-385)
+    const int pf = p.prefix < 0 ? -p.prefix : p.prefix;
+    bool valid = p.prefix > 0 && tm < pf;
+    if (!valid && tm >= pf) {
+      const int e = p.end_idx ? p.end_idx[n] : (p.T - pf);
+      valid = (tm - pf) < e;
     }
     if (!valid) continue;  // block-uniform
     const float* g = p.gt + ((long)n * p.T + t) * p.C + p.c_lo;

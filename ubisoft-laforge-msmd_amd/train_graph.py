@@ -348,13 +348,16 @@ def loss_no_vert_train(args, is_starting_sample, motion_coef_gt, target, prev_mo
         target = target[:, n_prev:]
     else:
         motion_coef_gt = torch.cat([prev_motion_coef, motion_coef_gt], dim=1)
+        if getattr(args, "no_constrain_prev", False):     # reference utils/common.py:245-246
+            target = torch.cat([prev_motion_coef, target[:, n_prev:]], dim=1)
     N = target.shape[0]
     if end_idx is None:
         mask = torch.ones((N, args.n_motions), dtype=torch.bool, device=target.device)
     else:
         mask = torch.arange(args.n_motions, device=target.device).expand(N, -1) < end_idx.unsqueeze(1)
     if not is_starting_sample:
-        mask = torch.cat([torch.ones_like(mask[:, :n_prev]), mask], dim=1)
+        lead = torch.zeros_like if getattr(args, "no_constrain_prev", False) else torch.ones_like   # common.py:382-385
+        mask = torch.cat([lead(mask[:, :n_prev]), mask], dim=1)
     d1 = lambda x: x[:, 1:] - x[:, :-1]
     gt, pr = motion_coef_gt, target
     loss_noise = _masked_mean(crit(gt, pr), mask)

@@ -126,8 +126,7 @@ def compute_loss_no_vert(args, is_starting_sample, shape_coef, motion_coef_gt, n
         gt, pr, prefix = _prep(args, is_starting_sample, motion_coef_gt, target, prev_motion_coef)
         C = gt.shape[-1]
         if args.no_constrain_prev and not is_starting_sample:
-            # the mask prefix is zeros in this deprecated mode: shift end_idx instead (frames < prefix invalid)
-            raise NotImplementedError("no_constrain_prev is deprecated in the reference and not built")
+            prefix = -prefix   # previous-window frames are masked OUT (reference utils/common.py:382-385)
         ms = lambda c_lo, c_hi, order, mode=0: ops.masked_seq_loss(gt, pr, e32, c_lo, c_hi, order, prefix, crit, mode)
         loss_noise = ms(0, C, 0)
         if args.l_vel > 0:
@@ -186,7 +185,7 @@ def compute_loss(args, is_starting_sample, shape_coef, motion_coef_gt, noise, ta
     elif args.target == "sample":
         gt, pr, prefix = _prep(args, is_starting_sample, motion_coef_gt, target, prev_motion_coef)
         if args.no_constrain_prev and not is_starting_sample:
-            raise NotImplementedError("no_constrain_prev is deprecated in the reference and not built")
+            prefix = -prefix   # reference utils/common.py:561-563
         C = gt.shape[-1]
         loss_noise = ops.masked_seq_loss(gt, pr, e32, 0, C, 0, prefix, crit)
         if args.l_vert > 0 or args.l_vel > 0:
