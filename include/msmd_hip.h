@@ -211,7 +211,8 @@ int msmd_add_pe_token(void* x, const float* pe, const void* tok0, const void* ro
 
 /* out (N, L, dm) fp32 = dyn[:, :, :dm] + sum_b alpha_b * static_b (face dims) / sum_b static_b (last 3 dims)
  * dec: (N, L, dm+nb) decoder head output (row stride ld_dec); stat: (Ns, nb, dm) static bases, Ns in {N, N/entries}.
- * (model.py:961-996, use_head_alpha=False.) */
+ * (model.py:961-996.)  use_head_alpha bit 0: weight the last 3 (head pose) dims too; bit 1: alpha = sigmoid(alpha)
+ * (regularize_alpha = 'sigmoid', model.py:973-974). */
 int msmd_heads_static_mix(const void* dec, long ld_dec, const void* stat, float* out, int N, int L, int dm,
                           int nb, int stat_batch, int use_head_alpha, int dtype, msmd_stream_t stream);
 

@@ -108,10 +108,12 @@ def _mlp2(sd, p, x):
 def denoising_net(sd, motion_feat, audio_feat, person_feat, static_style_feat, prev_motion_feat,
                   prev_audio_feat, step, indicator=None, *, prefix="denoising_net.", n_heads=8,
                   n_prev=10, num_of_basis=4, n_diff_steps=500, align_mask_width=1,
-                  use_head_alpha=False, keep_separate=False):
-    """reference model.py:914-996 (architecture='decoder', learnable PE, use_indicator)."""
+                  use_head_alpha=False, keep_separate=False, regularize_alpha="None"):
+    """reference model.py:914-996 (architecture='decoder', use_indicator).  Learnable PE when the state dict holds
+    `PE`; otherwise the sinusoidal module's eval forward, which adds the single table row pe[seq_len] to every position
+    (utils/model_common.py:99-101).  regularize_alpha='sigmoid': model.py:973-974."""
     P = prefix
-    d = sd[P + "PE"].shape[-1]
+    d = sd[P + "person_proj.weight"].shape[0]
     te = nn.sinusoid_table(n_diff_steps + 1, d)  # TE.pe
     step = np.asarray(step, dtype=np.int64)
     diff_emb = _mlp2(sd, P + "diff_step_map.", te[0, step])[:, None]  # (N,1,d)
@@ -122,7 +124,11 @@ def denoising_net(sd, motion_feat, audio_feat, person_feat, static_style_feat, p
         ind = np.concatenate([np.zeros((N, n_prev), F32), nn.f32(indicator)], axis=1)[..., None]
         feats = np.concatenate([feats, ind], axis=-1)
     feats = nn.linear(feats, sd[P + "feature_proj.weight"], sd[P + "feature_proj.bias"])
-    feats = np.concatenate([person, feats], axis=1) + nn.f32(sd[P + "PE"])
+    feats = np.concatenate([person, feats], axis=1)
+    if P + "PE" in sd:
+        feats = feats + nn.f32(sd[P + "PE"])
+    else:
+        feats = feats + nn.sinusoid_table(600, d)[0, feats.shape[1]]
     mem = np.concatenate([prev_audio_feat, audio_feat], axis=1)
     L = mem.shape[1]
     mask = alignment_mask(n_prev, L - n_prev, align_mask_width) if align_mask_width > 0 else None
@@ -139,6 +145,8 @@ def denoising_net(sd, motion_feat, audio_feat, person_feat, static_style_feat, p
         static.append(np.tile(sb, (1, Lm, 1))[:, :, None])
     static = np.concatenate(static, axis=2)  # (N, L, nb, dm)
     alphas = target[:, :, -num_of_basis:]
+    if regularize_alpha == "sigmoid":
+        alphas = (F32(1) / (F32(1) + np.exp(-alphas))).astype(F32)
     dynamic = target[:, :, :-num_of_basis]
     if use_head_alpha:
         summed = (static * alphas[..., None]).sum(axis=2)

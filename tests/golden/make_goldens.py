@@ -361,6 +361,26 @@ def g3_denoiser(M, SE, mc):
     save("g3_denoiser", **out)
 
 
+def g3_denoiser_options(M, SE, mc):
+    """Two non-default switches of the denoiser the reference still reads: regularize_alpha='sigmoid'
+    (model.py:13-17, 973-974) and no_use_learnable_pe (sinusoidal PE module, model.py:862-866, 950-953)."""
+    B = 2
+    out = {}
+    step = torch.tensor([7, 433])
+    for name, kw in (("sigmoid", dict(regularize_alpha="sigmoid")), ("sinpe", dict(no_use_learnable_pe=True))):
+        model, args = build_ref_model(M, **kw)
+        x = denoiser_inputs(B, args)
+        person = torch.cat([t(x["shape"])[:, None], t(x["style"])[:, None]], dim=-1)
+        net = model.denoising_net
+        a = (t(x["motion"]), t(x["audio_feat"]), person, t(x["style"])[:, None], t(x["prev_motion"]),
+             t(x["prev_audio"]), step, t(x["indicator"]))
+        out[f"target_{name}"] = net(*a).numpy()
+        dyn, stat, al = net(*a, keep_separate=True)
+        out[f"alphas_{name}"] = al.numpy()
+    out["step"] = step.numpy()
+    save("g3_denoiser_options", **out)
+
+
 def g3_forward(M, SE, mc):
     model, args = build_ref_model(M)
     B = 2
@@ -797,7 +817,7 @@ def g1_specaug(M, SE, mc):
 ALL = dict(g1_specaug=g1_specaug, g7_dataset=g7_dataset, g2_lr_schedule=g2_lr_schedule, g3_audio_large=g3_audio_large, g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
            g3_forward=g3_forward, g3_style=g3_style, g3_sample=g3_sample, g3_infer=g3_infer,
            g4_flame=g4_flame, g4_rotations=g4_rotations, g5_losses=g5_losses, g6_train=g6_train,
-           g5_losses_no_constrain_prev=g5_losses_no_constrain_prev)
+           g5_losses_no_constrain_prev=g5_losses_no_constrain_prev, g3_denoiser_options=g3_denoiser_options)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -87,6 +87,31 @@ def test_denoiser_fp32():
                             dev(x["prev_motion"]), dev(x["prev_audio"]), dev(g["step"]), None)
 
 
+@pytest.mark.parametrize("name,kw", [("sigmoid", dict(regularize_alpha="sigmoid")), ("sinpe", dict(no_use_learnable_pe=True))])
+def test_denoiser_options_fp32(name, kw):
+    """regularize_alpha='sigmoid' (msmd_heads_static_mix flag) and the sinusoidal PE module (one table row on every
+    position): HIP forward vs goldens from the reference built with each switch (1e-4), the differentiable training
+    graph in eval mode vs the same goldens, and the sampler running through the same switches."""
+    from msmd_amd import train_graph as tg
+    g = load_golden("g3_denoiser_options")
+    model, args = get_model("wav2vec2", "fp32", **kw)
+    net = model.denoising_net
+    assert ("PE" in dict(net.named_parameters())) == (name != "sinpe")
+    x = denoiser_inputs(2, args)
+    person = torch.cat([dev(x["shape"])[:, None], dev(x["style"])[:, None]], dim=-1)
+    a = (dev(x["motion"]), dev(x["audio_feat"]), person, dev(x["style"])[:, None], dev(x["prev_motion"]),
+         dev(x["prev_audio"]), dev(g["step"]), dev(x["indicator"]))
+    y = net(*a)
+    assert maxabs(y.cpu().numpy(), g[f"target_{name}"]) < 1e-4
+    _, _, al = net(*a, keep_separate=True)
+    assert maxabs(al.cpu().numpy(), g[f"alphas_{name}"]) < 1e-4
+    with torch.no_grad():
+        yt = tg.denoiser_train(net, a[0], a[1], person, a[3], a[4], a[5], a[6], a[7], torch.float32)
+    assert maxabs(yt.cpu().numpy(), g[f"target_{name}"]) < 1e-4
+    out, _, _ = model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]), indicator=dev(x["indicator"]))
+    assert out.shape == (2, 100, 67) and bool(torch.isfinite(out).all())
+
+
 def test_msmd_forward_fp32():
     g = load_golden("g3_forward")
     model, args = get_model("wav2vec2", "fp32")

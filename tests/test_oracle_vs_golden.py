@@ -141,6 +141,25 @@ def test_denoiser():
     assert maxabs(stat[:, :2], g["static"]) <= 5e-5
 
 
+def test_denoiser_options():
+    """regularize_alpha='sigmoid' and the sinusoidal PE module (no_use_learnable_pe): both still read by the reference
+    (model.py:13-17, 862-866, 950-953, 973-974); goldens from the reference built with each switch."""
+    g = load_golden("g3_denoiser_options")
+    for name, kw, okw in (("sigmoid", dict(regularize_alpha="sigmoid"), dict(regularize_alpha="sigmoid")),
+                          ("sinpe", dict(no_use_learnable_pe=True), {})):
+        sd, args = msmd_state_dict("wav2vec2", **kw)
+        assert ("denoising_net.PE" in sd) == (name != "sinpe")
+        x = denoiser_inputs(2, args)
+        person = np.concatenate([x["shape"][:, None], x["style"][:, None]], axis=-1)
+        a = (sd, x["motion"], x["audio_feat"], person, x["style"][:, None], x["prev_motion"], x["prev_audio"], g["step"],
+             x["indicator"])
+        assert maxabs(od.denoising_net(*a, **okw), g[f"target_{name}"]) <= 5e-5, name
+        _, _, al = od.denoising_net(*a, keep_separate=True, **okw)
+        assert maxabs(al, g[f"alphas_{name}"]) <= 5e-5, name
+        if name == "sigmoid":
+            assert al.min() > 0 and al.max() < 1
+
+
 def test_msmd_forward():
     g = load_golden("g3_forward")
     sd, args = msmd_state_dict("wav2vec2")

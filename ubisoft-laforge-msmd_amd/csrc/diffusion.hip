@@ -81,7 +81,8 @@ extern "C" int msmd_add_pe_token(void* x, const float* pe, const void* tok0, con
   MSMD_RETURN_LAST();
 }
 
-// out = dyn + sum_b alpha_b * static_b (dims < dm-3, or all dims when use_head_alpha) ; + sum_b static_b (last 3 dims)
+// out = dyn + sum_b alpha_b * static_b (dims < dm-3, or all dims when use_head_alpha & 1) ; + sum_b static_b (last 3
+// dims); use_head_alpha & 2: alpha_b = sigmoid(raw alpha_b)
 template <typename T>
 __global__ void heads_mix_kernel(const T* __restrict__ dec, long ld_dec, const T* __restrict__ stat,
                                  float* __restrict__ out, int L, int dm, int nb, int stat_batch, int use_head_alpha) {
@@ -91,10 +92,12 @@ __global__ void heads_mix_kernel(const T* __restrict__ dec, long ld_dec, const T
     const int t = i / dm, k = i % dm;
     const T* row = dec + ((long)n * L + t) * ld_dec;
     float v = 0.f;
-    const bool weighted = use_head_alpha || (k < dm - 3);
+    const bool weighted = (use_head_alpha & 1) || (k < dm - 3);
     for (int b = 0; b < nb; ++b) {
       const float s = to_f32(stat[((long)ns * nb + b) * dm + k]);
-      v += weighted ? s * to_f32(row[dm + b]) : s;
+      float a = to_f32(row[dm + b]);
+      if (use_head_alpha & 2) a = 1.0f / (1.0f + expf(-a));   // regularize_alpha = 'sigmoid' (model.py:973-974)
+      v += weighted ? s * a : s;
     }
     out[((long)n * L + t) * dm + k] = to_f32(row[k]) + v;
   }

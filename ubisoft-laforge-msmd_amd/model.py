@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import ops, shapes, synth
-from .utils.model_common import ParamTree, enc_dec_mask, sinusoid_table  # noqa: F401  (enc_dec_mask re-exported)
+from .utils.model_common import ParamTree, PositionalEncoding, enc_dec_mask, sinusoid_table  # noqa: F401  (enc_dec_mask re-exported)
 
 
 def _cd(args) -> torch.dtype:
@@ -143,12 +143,8 @@ class DenoisingNetwork_MSMD(nn.Module):
         self.compute_dtype = _cd(args)
         if self.architecture != "decoder":
             raise ValueError(f"Unknown architecture: {self.architecture}")
-        if not self.use_learnable_pe:
-            raise NotImplementedError("only the learnable PE (reference default) is built")
         if self.feature_dim // self.n_heads != 64:
             raise NotImplementedError("attention kernels are specialised for head_dim 64")
-        if self.regularize_alpha == "sigmoid":
-            raise NotImplementedError("regularize_alpha='sigmoid' is not built (reference default is 'None')")
 
         self.TE = _TE(self.feature_dim, args.n_diff_steps + 1)
         tree = ParamTree(shapes.denoiser_shapes(args, self.motion_feat_dim))
@@ -156,6 +152,10 @@ class DenoisingNetwork_MSMD(nn.Module):
             self.register_parameter(name, p)
         for name, m in tree._modules.items():
             self.add_module(name, m)
+        if not self.use_learnable_pe:
+            # reference model.py:866: sinusoidal table under the key PE.pe; its forward adds the ONE row pe[seq_len]
+            # to every position (utils/model_common.py:99-101) and applies dropout 0.1 in train mode
+            self.PE = PositionalEncoding(self.feature_dim)
         if self.align_mask_width > 0:
             motion_len = self.n_prev_motions + self.n_motions
             mask = enc_dec_mask(motion_len, motion_len, 1, self.align_mask_width - 1, device="cpu")
@@ -203,7 +203,11 @@ class DenoisingNetwork_MSMD(nn.Module):
             return cd(out)
         P = SimpleNamespace()
         P.te = f32(sd["TE.pe"][0])
-        P.pe = f32(sd["PE"][0])
+        if self.use_learnable_pe:
+            P.pe = f32(sd["PE"][0])
+        else:
+            T = 1 + self.n_prev_motions + self.n_motions
+            P.pe = f32(sd["PE.pe"][0, T]).expand(T, -1).contiguous()
         P.ds0 = (cd(sd["diff_step_map.0.weight"]), f32(sd["diff_step_map.0.bias"]))
         P.ds2 = (cd(sd["diff_step_map.2.weight"]), f32(sd["diff_step_map.2.bias"]))
         P.pp = (padk(sd["person_proj.weight"]), f32(sd["person_proj.bias"]))
@@ -352,11 +356,14 @@ class DenoisingNetwork_MSMD(nn.Module):
         if keep_separate:
             dynamic = dec[:, :, :dm]
             alphas = dec[:, :, dm:]
+            if self.regularize_alpha == "sigmoid":
+                alphas = torch.sigmoid(alphas.float()).to(alphas.dtype)
             static = stat.float()[:, None].expand(-1, Lp + L, -1, -1)
             if static.shape[0] != N:
                 static = static.repeat(N // static.shape[0], 1, 1, 1)
             return dynamic, static, alphas
-        return ops.heads_static_mix(dec, stat.float().contiguous(), Lp + L, dm, nb, self.use_head_alpha)
+        return ops.heads_static_mix(dec, stat.float().contiguous(), Lp + L, dm, nb, self.use_head_alpha,
+                                    self.regularize_alpha == "sigmoid")
 
 
 class MSMD(nn.Module):

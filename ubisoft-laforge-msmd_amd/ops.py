@@ -333,12 +333,13 @@ def add_pe_token(x, pe, tok0, row0_add=None):
     return x
 
 
-def heads_static_mix(dec, stat, L, dm, nb, use_head_alpha=False):
+def heads_static_mix(dec, stat, L, dm, nb, use_head_alpha=False, sigmoid_alpha=False):
     lib = _lib.load()
     N = dec.shape[0]
     out = torch.empty(N, L, dm, device=dec.device, dtype=torch.float32)
     _lib.check(lib.msmd_heads_static_mix(_p(dec), dec.stride(1), _p(stat), _p(out), N, L, dm, nb, stat.shape[0],
-                                         int(use_head_alpha), _dt(dec), _stream()), "msmd_heads_static_mix")
+                                         int(bool(use_head_alpha)) | (2 if sigmoid_alpha else 0), _dt(dec), _stream()),
+               "msmd_heads_static_mix")
     return out
 
 

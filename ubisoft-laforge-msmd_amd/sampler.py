@@ -160,7 +160,7 @@ def sample(model, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=N
         ops.denoiser_pack_input(x_in, prev_m, ind_in, feats)
         dec = net.trunk(feats, tok_person, mem, dtype, kv_list=kv_list, row0_add=emb_all[t], cross_list=cross_list)
         if separate is None:
-            res = ops.heads_static_mix(dec, stat, Lp + L, dm, nb, net.use_head_alpha)
+            res = ops.heads_static_mix(dec, stat, Lp + L, dm, nb, net.use_head_alpha, net.regularize_alpha == "sigmoid")
         else:
             # diagnostic variant: stream bookkeeping in host-library tensor algebra on (N, 110, 4, 67)-sized data
             dyn, alpha_t = dec[..., :dm], dec[..., dm:]
@@ -231,7 +231,8 @@ class _StepGraph:
             ops.denoiser_pack_input(self.x, self.prev_m, self.ind, self.feats)
             dec = net.trunk(self.feats, self.tok, self.mem, dtype, kv_list=self.kv, row0_add=self.emb_row,
                             cross_list=self.cross)
-            res = ops.heads_static_mix(dec, self.stat, Lp + L, dm, nb, net.use_head_alpha)
+            res = ops.heads_static_mix(dec, self.stat, Lp + L, dm, nb, net.use_head_alpha,
+                                       net.regularize_alpha == "sigmoid")
             if dyn:
                 res = ops.dynamic_threshold_(res.float().contiguous(), L, *dyn)
             z = torch.randn_like(self.x)  # graph-safe philox stream; sigma_1 = 0 reproduces z = 0 at t = 1

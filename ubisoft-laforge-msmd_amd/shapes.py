@@ -60,7 +60,8 @@ def denoiser_shapes(args, motion_dim: int = 67) -> "OrderedDict[str, tuple]":
     L = 1 + args.n_prev_motions + args.n_motions
     person_dim = 100 + args.d_style
     s = OrderedDict()
-    s["PE"] = (1, L, d)
+    if not getattr(args, "no_use_learnable_pe", False):
+        s["PE"] = (1, L, d)   # learnable PE; the sinusoidal variant holds a computed buffer instead (model.py:862-866)
     for i in (0, 2):
         s[f"diff_step_map.{i}.weight"] = (d, d)
         s[f"diff_step_map.{i}.bias"] = (d,)

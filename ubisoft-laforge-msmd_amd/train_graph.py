@@ -215,7 +215,11 @@ def denoiser_train(net, motion_noisy, audio_feat, person_feat, static_style_feat
         ind = torch.cat([torch.zeros(N, net.n_prev_motions, device=feats.device), indicator.float()], dim=1)
         feats = torch.cat([feats, ind.unsqueeze(-1)], dim=-1)
     x = ag.linear(feats.to(dtype), g("feature_proj.weight"), g("feature_proj.bias"))
-    x = torch.cat([person.unsqueeze(1), x], dim=1) + g("PE").to(dtype)
+    x = torch.cat([person.unsqueeze(1), x], dim=1)
+    if net.use_learnable_pe:
+        x = x + g("PE").to(dtype)
+    else:   # sinusoidal: the single row pe[seq_len] on every position, then dropout 0.1 (utils/model_common.py:99-101)
+        x = ag.dropout(x + net.PE.pe[0, x.shape[1]].to(dtype), net.PE.p_drop)
     mem = torch.cat([prev_audio_feat.to(dtype), audio_feat.to(dtype)], dim=1)
     scale = (d // H) ** -0.5
     mask = net.alignment_mask
@@ -244,6 +248,8 @@ def denoiser_train(net, motion_noisy, audio_feat, person_feat, static_style_feat
                                   g(f"static_feature_mapping.{b}.2.weight"), g(f"static_feature_mapping.{b}.2.bias"))
                         for b in range(nb)], dim=1).float()                       # (N, nb, dm)
     dyn, alpha = dec[..., :dm], dec[..., dm:]
+    if net.regularize_alpha == "sigmoid":        # model.py:973-974
+        alpha = torch.sigmoid(alpha)
     if net.use_head_alpha:
         static = (stat[:, None] * alpha.unsqueeze(-1)).sum(dim=2)
     else:
