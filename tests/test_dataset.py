@@ -106,6 +106,54 @@ def test_trainer_consumes_resident_dataset_batches():
 
 
 @pytest.mark.gpu
+def test_train_function_keeps_the_reference_call_signature(tmp_path):
+    """training_script.train(args, model, style_enc, train_loader, val_loader, optimizer, save_dir, scheduler, writer,
+    ...) as the reference's main() calls it (training_script.py:49-50, 628-629): torch optimizer object and a
+    tensorboard-like writer accepted, loader items in the reference's tuple format, checkpoints in its format."""
+    import torch
+    from msmd_amd.config import default_args
+    from msmd_amd.datasets import ResidentDataset
+    from msmd_amd.model import get_diffusion_model
+    from msmd_amd.style_encoder import get_style_encoder
+    from msmd_amd.training_script import count_parameters, train
+    raw = raw_clips()
+    ds = ResidentDataset(raw, list(raw), coef_stats=None, random_crop=True, seed=5)
+    args = default_args(compute_dtype="bf16", encoder_layers=1, n_layers=1, lr=1e-3, warm_iter=0, max_iter=3, save_iter=2,
+                        val_iter=3, log_iter=1, batch_size=2)
+    model = get_diffusion_model(args, "cuda")
+    se = get_style_encoder(args, "vae2").to("cuda")
+    assert count_parameters(model) > 0
+
+    class Loader:
+        dataset = ds
+
+        def __iter__(self):
+            rng = np.random.RandomState(1)
+            for _ in range(2):                       # a finite epoch: train() must wrap around it
+                yield ds.batch(rng.randint(0, len(ds), size=2))
+
+    class Writer:
+        def __init__(self):
+            self.tags = []
+
+        def add_scalar(self, tag, value, it):
+            assert np.isfinite(value)
+            self.tags.append((tag, it))
+
+    opt = torch.optim.Adam([{"params": se.parameters(), "lr": 2e-4}, {"params": model.parameters(), "lr": 2e-4}])
+    w = Writer()
+    val = [ds.batch([0, 1])]
+    tr = train(args, model, se, Loader(), val, opt, tmp_path / "ck", scheduler=None, writer=w, start_iter=0)
+    torch.cuda.synchronize()
+    assert tr.opt_step == 4 and abs(tr.current_lr() - 2e-4) < 1e-12       # the optimizer's lr seeded the base lr
+    assert sorted(p.name for p in (tmp_path / "ck").glob("*.pt")) == ["iter_0000002.pt", "iter_0000003.pt"]
+    ck = torch.load(tmp_path / "ck" / "iter_0000003.pt", weights_only=False)
+    assert {"args", "model", "style_enc", "iter"} <= set(ck) and ck["iter"] == 3
+    tags = {t for t, _ in w.tags}
+    assert {"train/loss", "opt/lr", "val/loss"} <= tags
+
+
+@pytest.mark.gpu
 def test_validation_pass_over_resident_batches(tmp_path):
     """training_script.test (reference l.243-403): loss_log keys / aggregation, cross-style rule, model mode restored;
     the per-batch total equals the weighted sum of its parts."""

@@ -26,7 +26,7 @@ DEFAULTS = dict(
     l_kl_div=1e-7, use_vertex_space=False,
     # training (reference training_script.py:488-513, training_specs.sh)
     lr=2e-5, warm_iter=5000, scheduler="Warmup", cos_max_iter=1_000_000, min_lr_ratio=0.1, batch_size=16, max_iter=2_000_000,
-    gradient_accumulation_steps=1, trunc_prob1=0.5, trunc_prob2=0.4,
+    gradient_accumulation_steps=1, log_iter=100, save_iter=10000, val_iter=10000, log_smooth_win=50, trunc_prob1=0.5, trunc_prob2=0.4,
     prob_cross_style=0.3, use_cross_style=True,
     # engine (new in this build)
     compute_dtype="bf16",       # "bf16" speed mode | "fp32" parity mode

@@ -469,6 +469,81 @@ _FLAGS = [
 ]
 
 
+def infinite_data_loader(data_loader):
+    """reference training_script.py:28-31."""
+    while True:
+        for data in data_loader:
+            yield data
+
+
+def count_parameters(model):
+    """reference training_script.py:441-443."""
+    return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
+def train(args, model, style_enc, train_loader, val_loader, optimizer, save_dir, scheduler=None, writer=None, flame=None,
+          out_abc_dir=None, start_iter=0, trainer=None, use_graph=False):
+    """Drop-in for the reference's train() (training_script.py:49-243): same positional arguments, same loop --
+    infinite loader, one two-window iteration per step, smoothed loss log, `writer.add_scalar` hooks, checkpoints
+    `iter_%07d.pt` with {args, model, style_enc, iter} every save_iter, validation every val_iter.
+
+    The iteration itself is `Trainer.step` (HIP forward / backward, fused Adam on the flat parameter arena, bucketed
+    RCCL all-reduce).  `optimizer` and `scheduler` are accepted for call-site compatibility: the optimizer's lr (when
+    given) seeds the base learning rate; Adam's moments and the args.scheduler rule (training_script.py:590-621) live
+    in the Trainer, so the objects themselves are not stepped.  Loader items are the reference's
+    (audio_pair, coef_pair, extra) tuples (datasets.py:230-323) or already-unpacked batches."""
+    import time
+    from pathlib import Path
+    rank = dp.env_rank()[0]
+    if trainer is None:
+        if optimizer is not None:
+            args.lr = float(optimizer.param_groups[0]["lr"]) if scheduler is None else float(args.lr)
+        trainer = Trainer(args, model, style_enc, use_graph=use_graph)
+    save_dir = Path(save_dir)
+    if rank == 0:
+        save_dir.mkdir(parents=True, exist_ok=True)
+    model.train()
+    lw = load_loss_weights(args)
+    dataset = getattr(train_loader, "dataset", None)
+    if len(args.dataset_type.split("+")) > 1 and hasattr(dataset, "datasets"):   # ConcatDataset (reference l.60-63)
+        dataset = dataset.datasets[0]
+    coef_stats = getattr(dataset, "coef_stats", None)
+    data = infinite_data_loader(train_loader)
+    log, t0 = [], time.time()
+    for it in range(start_iter, args.max_iter + 1):
+        item = next(data)
+        batch = batch_from_loader(item) if isinstance(item[0], (list, tuple)) and isinstance(item[1][0], dict) else item
+        out = trainer.step(batch, it=it)
+        log.append(out["loss"])
+        if rank == 0 and it % args.log_iter == 0 and it != start_iter:
+            val = torch.stack(log[-args.log_smooth_win:]).mean().item()   # the only host sync, once per log interval
+            if writer is not None:
+                writer.add_scalar("train/loss", val, it)
+                writer.add_scalar("opt/lr", trainer.current_lr(), it)
+            print(f"iter {it}: loss {val:.5f}  lr {trainer.current_lr():.3e}  "
+                  f"{(time.time() - t0) / max(1, it - start_iter) * 1e3:.1f} ms/it")
+            log = log[-args.log_smooth_win:]
+        if rank == 0 and ((it % args.save_iter == 0 and it not in (0, start_iter)) or it == args.max_iter):
+            trainer.save_checkpoint(save_dir / f"iter_{it:07}.pt", it)
+        if val_loader is not None and ((it % args.val_iter == 0 and it not in (0, start_iter)) or it == args.max_iter):
+            res = test(args, lw, model, style_enc, val_loader, it, 1, "val", writer, coef_stats=coef_stats)
+            if rank == 0:
+                print(f"iter {it}: val loss {np.mean(res['loss']):.5f}")
+    return trainer
+
+
+class _ResidentLoader:
+    """Loader facade over datasets.ResidentDataset: `.dataset` as the reference's DataLoader exposes it, batches of
+    args.batch_size random items per iteration (index draws from a per-rank numpy stream)."""
+
+    def __init__(self, dataset, batch_size, seed):
+        self.dataset, self.batch_size, self.rng = dataset, batch_size, np.random.RandomState(seed)
+
+    def __iter__(self):
+        while True:
+            yield self.dataset.batch(self.rng.randint(0, len(self.dataset), size=self.batch_size))
+
+
 def build_parser():
     """argparse parser with the reference's flag names, types and defaults, plus this build's knobs."""
     import argparse
@@ -537,23 +612,8 @@ def main(argv=None):
     if rank == 0:
         ckpt_dir.mkdir(parents=True, exist_ok=True)
         save_args(args, exp_dir)
-    model.train()
-    sampler = np.random.RandomState(99 + rank)
-    t0, log = time.time(), []
-    for it in range(start_iter, args.max_iter + 1):
-        batch = batch_from_loader(train_set.batch(sampler.randint(0, len(train_set), size=args.batch_size)))
-        log.append(trainer.step(batch, it=it)["loss"])
-        if rank == 0 and it % args.log_iter == 0 and it != start_iter:
-            vals = torch.stack(log[-args.log_smooth_win:]).mean().item()   # the only host sync, once per log interval
-            print(f"iter {it}: loss {vals:.5f}  lr {trainer.current_lr():.3e}  {(time.time() - t0) / max(1, it - start_iter) * 1e3:.1f} ms/it")
-            log = log[-args.log_smooth_win:]
-        if rank == 0 and ((it % args.save_iter == 0 and it not in (0, start_iter)) or it == args.max_iter):
-            trainer.save_checkpoint(ckpt_dir / f"iter_{it:07}.pt", it)
-        if (it % args.val_iter == 0 and it not in (0, start_iter)) or it == args.max_iter:
-            res = test(args, lw, model, style_enc, val_loader, it, 1, "val", coef_stats=train_set.coef_stats)
-            if rank == 0:
-                print(f"iter {it}: val loss {np.mean(res['loss']):.5f}")
-    return trainer
+    return train(args, model, style_enc, _ResidentLoader(train_set, args.batch_size, 99 + rank), val_loader, None,
+                 ckpt_dir, start_iter=start_iter, trainer=trainer)
 
 
 if __name__ == "__main__":
