@@ -252,3 +252,24 @@ def test_style_clip_ingestion_and_denormalisation():
         ex, hr = denormalize_coeffs(m, stats)
         if fps == 25:
             assert np.abs(ex.numpy() - e).max() < 1e-5 and np.abs(hr.numpy() - h).max() < 1e-5
+
+
+def test_common_script_plumbing():
+    """NullableArgs / count_parameters / get_option_text (reference utils/common.py:9-27, 94-106): host-only helpers."""
+    import argparse
+    import torch
+    from msmd_amd.utils.common import NullableArgs, count_parameters, get_option_text
+    ns = argparse.Namespace(use_alignment_mask=True, predict_head_pose=False, use_learnable_pe=True, lr=1e-3)
+    a = NullableArgs(ns)
+    assert a.lr == 1e-3 and a.align_mask_width == 1 and a.no_head_pose is True and a.no_use_learnable_pe is False
+    assert a.never_saved is None
+    assert NullableArgs(argparse.Namespace()).align_mask_width == 0
+    lin = torch.nn.Linear(3, 2)
+    lin.bias.requires_grad = False
+    assert count_parameters(lin) == 6
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--alpha", type=int, default=1)
+    ap.add_argument("--beta", type=str, default="x")
+    txt = get_option_text(ap.parse_args(["--alpha", "5"]), ap)
+    assert txt.splitlines()[0].strip().startswith("alpha: 5") and "[default: 1]" in txt.splitlines()[0]
+    assert "default" not in txt.splitlines()[1]

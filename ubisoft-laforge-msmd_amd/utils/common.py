@@ -14,6 +14,52 @@ import torch
 from .. import ops
 
 
+# ----------------------------------------------------------------------------- script plumbing (host only)
+class NullableArgs:
+    """Namespace view for checkpoints saved by older configs (reference utils/common.py:9-27): absent attributes
+    read as None, except three renamed switches that are derived from their predecessors."""
+
+    _DERIVED = {
+        "align_mask_width": lambda d: (1 if d["use_alignment_mask"] else 0) if "use_alignment_mask" in d else 0,
+        "no_head_pose": lambda d: not d.get("predict_head_pose"),
+        "no_use_learnable_pe": lambda d: not d.get("use_learnable_pe"),
+    }
+
+    def __init__(self, namespace):
+        self.__dict__.update(vars(namespace))
+
+    def __getattr__(self, key):            # reached only when normal lookup fails
+        rule = NullableArgs._DERIVED.get(key)
+        return rule(self.__dict__) if rule is not None else None
+
+
+def count_parameters(model):
+    """Trainable parameter count (reference utils/common.py:94-95)."""
+    return sum(int(p.numel()) for p in model.parameters() if p.requires_grad)
+
+
+def get_option_text(args, parser):
+    """One line per option, sorted, with the parser default noted where the value differs
+    (reference utils/common.py:98-106; same column layout)."""
+    lines = []
+    for key in sorted(vars(args)):
+        value, default = getattr(args, key), parser.get_default(key)
+        note = f"\t[default: {default}]" if value != default else ""
+        lines.append(f"{key:>30}: {str(value):<30}{note}\n")
+    return "".join(lines)
+
+
+def get_model_path(exp_name, iteration, model_type="DPT"):
+    """(checkpoint path, experiment dir relative to the experiments root) for experiments/<model_type>/<exp_name>*
+    (reference utils/common.py:109-115): an exact directory match wins, else the first one with that prefix."""
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent / "experiments" / model_type
+    exp_dir = root / exp_name
+    if not exp_dir.exists():
+        exp_dir = next(root.glob(f"{exp_name}*"))
+    return exp_dir / "checkpoints" / f"iter_{iteration:07}.pt", exp_dir.relative_to(root)
+
+
 # ----------------------------------------------------------------------------- coefficient glue (host views)
 def get_pose_input(coef_dict, rot_repr, with_global_pose):
     """reference utils/common.py:118-125."""
