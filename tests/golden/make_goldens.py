@@ -561,6 +561,39 @@ def g4_flame(M, SE, mc):
     save("g4_flame", **out)
 
 
+def g4_lbs_blocks(M, SE, mc):
+    """The building blocks of the reference's utils/lbs.py on the synthetic FLAME asset: blend_shapes, vertices2joints,
+    transform_mat, batch_rigid_transform, find_dynamic_lmk_idx_and_bcoords."""
+    from utils import flame as FL, lbs as LBS
+    with tempfile.TemporaryDirectory() as td:
+        pkl, npy = write_flame_asset(td)
+        cfg = FL.FLAMEConfig
+        cfg.flame_model_path, cfg.flame_lmk_embedding_path = pkl, npy
+        fl = FL.FLAME(cfg).eval()
+    B = 4
+    x = flame_inputs(B, tag="blocks")
+    x["pose"][1, :3] = [0.0, 1.2, 0.0]
+    x["pose"][2, :3] = [0.0, -0.4, 0.0]
+    betas = torch.cat([t(x["shape"]), t(x["exp"])], dim=1)
+    out = {}
+    bs = LBS.blend_shapes(betas, fl.shapedirs)
+    out["blend_sub"] = bs.numpy()[:, ::79]
+    v_shaped = fl.v_template.unsqueeze(0) + bs
+    J = LBS.vertices2joints(fl.J_regressor, v_shaped)
+    out["joints"] = J.numpy()
+    full_pose = torch.cat([t(x["pose"])[:, :3], fl.neck_pose.expand(B, -1), t(x["pose"])[:, 3:], fl.eye_pose.expand(B, -1)], dim=1)
+    rot = LBS.batch_rodrigues(full_pose.view(-1, 3)).view(B, -1, 3, 3)
+    posed, rel = LBS.batch_rigid_transform(rot, J, fl.parents)
+    out["full_pose"], out["posed"], out["rel"] = full_pose.numpy(), posed.numpy(), rel.numpy()
+    out["tmat"] = LBS.transform_mat(rot[:, 1], J[:, 1].unsqueeze(-1)).numpy()
+    # the module-level function only runs at batch size 1 (its bmm against a (1, 3, 3) identity, utils/lbs.py:83)
+    pairs = [LBS.find_dynamic_lmk_idx_and_bcoords(v_shaped[b:b + 1], full_pose[b:b + 1], fl.dynamic_lmk_faces_idx,
+                                                  fl.dynamic_lmk_bary_coords, fl.neck_kin_chain) for b in range(B)]
+    out["dyn_idx"] = torch.cat([p[0] for p in pairs]).numpy()
+    out["dyn_bary"] = torch.cat([p[1] for p in pairs]).numpy()
+    save("g4_lbs_blocks", **out)
+
+
 def g4_rotations(M, SE, mc):
     from utils import rotation_conversions as RC
     n = 32
@@ -817,7 +850,7 @@ def g1_specaug(M, SE, mc):
 ALL = dict(g1_specaug=g1_specaug, g7_dataset=g7_dataset, g2_lr_schedule=g2_lr_schedule, g3_audio_large=g3_audio_large, g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
            g3_forward=g3_forward, g3_style=g3_style, g3_sample=g3_sample, g3_infer=g3_infer,
            g4_flame=g4_flame, g4_rotations=g4_rotations, g5_losses=g5_losses, g6_train=g6_train,
-           g5_losses_no_constrain_prev=g5_losses_no_constrain_prev, g3_denoiser_options=g3_denoiser_options)
+           g5_losses_no_constrain_prev=g5_losses_no_constrain_prev, g3_denoiser_options=g3_denoiser_options, g4_lbs_blocks=g4_lbs_blocks)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -420,3 +420,39 @@ def test_person_query_attention_matches_projection_plus_attention(N, T, Tk, H, d
     q0 = O.gemm(xd, wd, bq, M=N, K=d, lda=T * d)
     two = O.attention(q0.view(N, 1, d), kvd[..., :d], kvd[..., d:], H, scale).view(N, d).float()
     assert (got - two).abs().max().item() <= 2 * tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_lbs_building_blocks_match_reference():
+    """utils/lbs.py's pieces under the reference's names (blend_shapes, vertices2joints, transform_mat,
+    batch_rigid_transform, find_dynamic_lmk_idx_and_bcoords) against goldens from the reference on the synthetic FLAME
+    asset; fp32 tolerance 5e-6 on coordinates (exact-fp32 MFMA contraction vs einsum), LUT rows exact."""
+    from msmd_amd.utils import lbs as L
+    from msmd_amd.utils.flame import FLAME, FLAMEConfig
+    from types import SimpleNamespace
+    g = load_golden("g4_lbs_blocks")
+    cfg = SimpleNamespace(**vars(FLAMEConfig))
+    cfg.asset = synth.flame_asset()
+    fl = FLAME(cfg).to(DEV)
+    B = 4
+    x = flame_inputs(B, tag="blocks")
+    betas = torch.cat([dev(x["shape"]), dev(x["exp"])], dim=1)
+    bs = L.blend_shapes(betas, fl.shapedirs)
+    assert bs.shape == (B, fl.v_template.shape[0], 3) and maxabs(bs.cpu().numpy()[:, ::79], g["blend_sub"]) <= 5e-6
+    v_shaped = fl.v_template.unsqueeze(0) + bs
+    J = L.vertices2joints(fl.J_regressor, v_shaped)
+    assert maxabs(J.cpu().numpy(), g["joints"]) <= 5e-6
+    full_pose = dev(g["full_pose"])
+    rot = L.batch_rodrigues(full_pose.view(-1, 3)).view(B, -1, 3, 3)
+    posed, rel = L.batch_rigid_transform(rot, J, fl.parents)
+    assert maxabs(posed.cpu().numpy(), g["posed"]) <= 5e-6 and maxabs(rel.cpu().numpy(), g["rel"]) <= 5e-6
+    tm = L.transform_mat(rot[:, 1], J[:, 1].unsqueeze(-1))
+    assert maxabs(tm.cpu().numpy(), g["tmat"]) <= 5e-6
+    fi, bc = L.find_dynamic_lmk_idx_and_bcoords(v_shaped, full_pose, fl.dynamic_lmk_faces_idx,
+                                                fl.dynamic_lmk_bary_coords, fl.neck_kin_chain)
+    assert np.array_equal(fi.cpu().numpy(), g["dyn_idx"]) and np.array_equal(bc.cpu().numpy(), g["dyn_bary"])
+    from msmd_amd.utils.wav2vec2 import _compute_mask_indices, compute_mask_indices
+    np.random.seed(4)
+    a = _compute_mask_indices((3, 199), 0.05, 10, None, 2)
+    np.random.seed(4)
+    assert np.array_equal(a, compute_mask_indices((3, 199), 0.05, 10, 2))

@@ -106,3 +106,68 @@ def rot_mat_to_euler(rot_mats):
     """reference utils/lbs.py:26-32 (host-side helper on tiny tensors; the LUT path uses the fused kernel)."""
     sy = torch.sqrt(rot_mats[:, 0, 0] * rot_mats[:, 0, 0] + rot_mats[:, 1, 0] * rot_mats[:, 1, 0])
     return torch.atan2(-rot_mats[:, 2, 0], sy)
+
+
+# ----------------------------------------------------------------------------- the reference's building blocks
+# `lbs()` above never calls these (its two kernels fuse them); they keep the reference's names and results for code
+# that uses the pieces directly.  The two contractions over vertices / coefficients run on the exact-fp32 MFMA GEMM;
+# the 4x4 joint chain is a few hundred bytes per frame of host-library glue.
+def _pad4(x):
+    k = x.shape[-1]
+    return x if k % 4 == 0 else ops.pad_cols(x.contiguous(), (k + 3) // 4 * 4)
+
+
+def blend_shapes(betas, shape_disps):
+    """(B, L) coefficients x (V, 3, L) directions -> (B, V, 3) displacements (reference utils/lbs.py:246-267)."""
+    V, _, L = shape_disps.shape
+    out = ops.gemm(_pad4(betas.float().contiguous()), _pad4(shape_disps.float().reshape(V * 3, L).contiguous()))
+    return out.view(betas.shape[0], V, 3)
+
+
+def vertices2joints(J_regressor, vertices):
+    """(J, V) regressor applied to (B, V, 3) vertices -> (B, J, 3) joints (reference utils/lbs.py:226-243)."""
+    B, V, _ = vertices.shape
+    vt = vertices.float().transpose(1, 2).contiguous().view(B * 3, V)        # rows (b, xyz), V contiguous
+    out = ops.gemm(_pad4(vt), _pad4(J_regressor.float().contiguous()))       # (B*3, J)
+    return out.view(B, 3, -1).transpose(1, 2).contiguous()
+
+
+def transform_mat(R, t):
+    """(B, 3, 3) rotations + (B, 3, 1) translations -> (B, 4, 4) homogeneous transforms (utils/lbs.py:304-314)."""
+    T = torch.zeros(R.shape[0], 4, 4, device=R.device, dtype=R.dtype)
+    T[:, :3, :3] = R
+    T[:, :3, 3:] = t
+    T[:, 3, 3] = 1
+    return T
+
+
+def batch_rigid_transform(rot_mats, joints, parents, dtype=torch.float32):
+    """Pose the kinematic tree (reference utils/lbs.py:317-375): returns the posed joints (B, N, 3) and each joint's
+    transform relative to its rest position (B, N, 4, 4)."""
+    B, N = joints.shape[:2]
+    rel = joints.clone()
+    rel[:, 1:] = joints[:, 1:] - joints[:, parents[1:]]
+    local = transform_mat(rot_mats.reshape(-1, 3, 3), rel.reshape(-1, 3, 1)).view(B, N, 4, 4)
+    world = [local[:, 0]]
+    for i in range(1, N):
+        world.append(torch.matmul(world[int(parents[i])], local[:, i]))
+    world = torch.stack(world, dim=1)
+    posed = world[:, :, :3, 3]
+    # subtract the rest-pose joint carried through the rotation: only the translation column changes
+    rest = torch.matmul(world[:, :, :, :3], joints.unsqueeze(-1))            # (B, N, 4, 1); row 3 is zero
+    rel_t = world.clone()
+    rel_t[:, :, :, 3:] = world[:, :, :, 3:] - rest
+    return posed, rel_t
+
+
+def find_dynamic_lmk_idx_and_bcoords(vertices, pose, dynamic_lmk_faces_idx, dynamic_lmk_b_coords, neck_kin_chain,
+                                     dtype=torch.float32):
+    """Contour-landmark faces / barycentric weights for the current neck yaw (reference utils/lbs.py:35-99): the
+    yaw -> table-row lookup is msmd_dynamic_lmk_row.  This module-level function looks the table up at MINUS the yaw
+    (utils/lbs.py:86-87), unlike FLAME's own method (utils/flame.py:158-160, what the model uses): the kernel's row
+    for +yaw is mirrored here (0 -> 0, r <= 39 -> r + 39, r > 39 -> r - 39; exact, clamps included)."""
+    B = vertices.shape[0]
+    chain = torch.as_tensor(neck_kin_chain, device=pose.device).to(torch.int32).contiguous()
+    row = ops.dynamic_lmk_row(pose.reshape(B, -1).float().contiguous(), chain).long()
+    row = torch.where(row == 0, row, torch.where(row <= 39, row + 39, row - 39))
+    return dynamic_lmk_faces_idx[row], dynamic_lmk_b_coords[row]

@@ -55,6 +55,14 @@ def compute_mask_indices(shape, mask_prob, mask_length, min_masks=0, rng=None):
     return mask
 
 
+def _compute_mask_indices(shape, mask_prob, mask_length, attention_mask=None, min_masks=0):
+    """The reference's name and argument order (utils/wav2vec2.py:17-18).  attention_mask is never passed on the
+    reference's path (its model calls the encoder without one, model.py:257), so only that case is built."""
+    if attention_mask is not None:
+        raise NotImplementedError("attention_mask is never passed on the reference's path (model.py:257)")
+    return compute_mask_indices(shape, mask_prob, mask_length, min_masks)
+
+
 def compute_mask_indices_hf(shape, mask_prob, mask_length, min_masks=0, rng=None):
     """transformers' `_compute_mask_indices` (modeling_wav2vec2.py, used by HubertModel._mask_hidden_states, which the
     reference's HuBERT wrapper calls at utils/hubert.py:35), no attention_mask: one epsilon draw, then one
