@@ -244,3 +244,57 @@ def test_training_cli_end_to_end_on_a_decoded_corpus(tmp_path):
     exp = pickle.load(open(out[0], "rb"))
     rot = pickle.load(open(out[1], "rb"))
     assert exp.shape == (int(52000 / 16000 * 25), 64) and rot.shape == (exp.shape[0], 3) and np.isfinite(exp).all()
+
+
+@pytest.mark.gpu
+def test_dataset_pickle_adapter_keeps_reference_constructor(tmp_path):
+    """datasets.DatasetPickle(pkl_file, split_file, coef_stats_file, ...) with the reference's arguments
+    (datasets.py:167-169): split / valid-id filtering, chunked pickle, stats file, SE items, and get_collate_fn
+    reproducing ResidentDataset.batch from an item list."""
+    import pickle
+    import torch
+    from msmd_amd.datasets import DatasetPickle, ResidentDataset
+    raw = raw_clips()
+    names = list(raw)
+    pkl = tmp_path / "corpus.pkl"
+    with open(pkl, "wb") as f:
+        pickle.dump({k: raw[k] for k in names[:2]}, f)
+        pickle.dump({k: raw[k] for k in names[2:]}, f)
+    split = tmp_path / "train.txt"
+    split.write_text("\n".join(names[:4]) + "\n")
+    ds = DatasetPickle(pkl, split, None, celebv_text=False, full_dataset=True, seed=7)
+    ref = ResidentDataset(raw, names[:4], seed=7)
+    assert ds.file_names == names[:4] and len(ds) == 4
+    for k in ("exp_mean", "exp_std", "pose_mean", "pose_std"):
+        assert torch.equal(ds.coef_stats[k], ref.coef_stats[k])
+    a, b = ds[1], ref[1]
+    assert all(torch.equal(x, y) for x, y in zip(a[0], b[0])) and torch.equal(a[1][1]["motion"], b[1][1]["motion"])
+    # collate(item list) == the one-launch batch for the same crop draws
+    ds2 = DatasetPickle(pkl, split, None, celebv_text=False, full_dataset=True, seed=11)
+    ref2 = ResidentDataset(raw, names[:4], coef_stats=ds2.coef_stats, seed=11)
+    ref2.rng = np.random.RandomState(5)
+    ds2.rng = np.random.RandomState(5)
+    got = DatasetPickle.get_collate_fn(False)([ds2[i] for i in (0, 2, 3)])
+    want = ref2.batch([0, 2, 3])
+    assert torch.equal(got[0][0], want[0][0]) and torch.equal(got[0][1], want[0][1])
+    assert torch.equal(got[1][0]["motion"], want[1][0]["motion"]) and torch.equal(got[1][1]["shape"], want[1][1]["shape"])
+    assert abs(float(got[2][0]) - float(want[2][0])) < 1e-7 and abs(float(got[2][1]) - float(want[2][1])) < 1e-7
+    # stats file + style-encoder items + valid-id filter + over-fit truncation
+    np.savez(tmp_path / "stats.npz", **{k: v.numpy() for k, v in ds.coef_stats.items()})
+    keys = tmp_path / "keys.txt"
+    keys.write_text("\n".join([names[0], names[3], "not_in_split"]) + "\n")
+    old = DatasetPickle.VALID_ID_FILE
+    DatasetPickle.VALID_ID_FILE = str(keys)
+    try:
+        se = DatasetPickle(pkl, split, tmp_path / "stats.npz", SE=True, celebv_text=True, full_dataset=True, seed=3)
+    finally:
+        DatasetPickle.VALID_ID_FILE = old
+    assert se.file_names == [names[0], names[3]]
+    item = se[0]
+    assert len(item) == 2 and item[0].shape == (100, 67)
+    pair = DatasetPickle.get_collate_fn(True)([se[0], se[1]])
+    assert pair[0].shape == (2, 100, 67) and pair[1].shape == (2, 100, 67)
+    one = DatasetPickle(pkl, split, tmp_path / "stats.npz", celebv_text=False, pre_loaded_raw_dataset=raw,
+                        batch_overfit_size=1)
+    assert len(one) == 1
+    assert len(list(DatasetPickle.load_dict_in_chunks_static(pkl))) == 2

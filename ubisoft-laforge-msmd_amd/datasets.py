@@ -175,3 +175,74 @@ def incremental_mean_and_std(dataset):
     mean = s / n
     std = torch.sqrt(ss / n - mean ** 2)
     return mean[:E].cpu(), std[:E].cpu(), mean[E:].cpu(), std[E:].cpu()
+
+
+class DatasetPickle(ResidentDataset):
+    """The reference's dataset class name and constructor (datasets.py:141-250) over the HBM-resident corpus: split
+    file -> clip names (optionally filtered by a valid-id list, truncated for batch over-fitting), single or chunked
+    pickle (or an already loaded dict), optional statistics file (.npz of exp/pose mean/std), 30 -> 25 fps resampling.
+    Items and batches come from ResidentDataset (one gather launch per batch); `get_collate_fn` keeps the reference's
+    DataLoader contract for callers that still collate item lists."""
+
+    VALID_ID_FILE = "/data/celebv-text/keys.txt"   # the path the reference hard-codes (datasets.py:175)
+
+    @staticmethod
+    def load_dict_in_chunks_static(file_path):
+        return load_dict_in_chunks(file_path)
+
+    def load_dict_in_chunks(self, file_path):
+        return load_dict_in_chunks(file_path)
+
+    def __init__(self, pkl_file, split_file, coef_stats_file=None, original_fps=30, coef_fps=25, n_motions=100,
+                 rot_repr="aa", no_head_pose=False, clip_len=100, device="cuda", SE=False, full_dataset=False,
+                 pre_loaded_raw_dataset=None, celebv_text=True, random_crop=True, batch_overfit_size=-1, seed=None):
+        import pickle
+        self.split_file, self.pkl_file = split_file, pkl_file
+        self.rot_representation, self.no_head_pose, self.SE = rot_repr, no_head_pose, False   # SE set after the stats
+        self.valid_id = []
+        if celebv_text:
+            with open(self.VALID_ID_FILE, "r") as f:
+                self.valid_id = [line.strip() for line in f]
+        valid = set(self.valid_id)
+        with open(split_file, "r") as f:
+            names = [line.strip() for line in f]
+        self.file_names = [n for n in names if (not celebv_text or n in valid)]
+        if batch_overfit_size > 0:
+            self.file_names = self.file_names[:batch_overfit_size]
+        if pre_loaded_raw_dataset is not None:
+            raw = pre_loaded_raw_dataset
+        elif not full_dataset:
+            with open(pkl_file, "rb") as f:
+                raw = pickle.load(f)
+        else:
+            raw = {}
+            for chunk in load_dict_in_chunks(pkl_file):
+                raw.update(chunk)
+        stats = None
+        if coef_stats_file is not None:
+            stats = {k: torch.tensor(v) for k, v in dict(np.load(coef_stats_file)).items()}
+        super().__init__(raw, self.file_names, coef_stats=stats, original_fps=original_fps, coef_fps=coef_fps,
+                         n_motions=n_motions, clip_len=clip_len, device=device, random_crop=random_crop, seed=seed,
+                         compute_stats=coef_stats_file is None)
+        self.SE = SE
+
+    def __getitem__(self, index):
+        item = super().__getitem__(index)
+        return [item[1][0]["motion"], item[1][1]["motion"]] if self.SE else item
+
+    @staticmethod
+    def get_collate_fn(SE):
+        """reference datasets.py:424-503: stack an item list; audio windows zero-padded / trimmed to 64000 samples,
+        clip statistics averaged over the batch."""
+        def collate_fn(batch):
+            if SE:
+                return [torch.stack([b[0] for b in batch], 0), torch.stack([b[1] for b in batch], 0)]
+            n = 64000
+            fit = lambda a: torch.nn.functional.pad(a, (0, n - a.shape[0])) if a.shape[0] < n else a[:n]
+            audio = [torch.stack([fit(b[0][w]) for b in batch], 0) for w in range(2)]
+            coef = [{"shape": torch.stack([b[1][w]["shape"] for b in batch], 0),
+                     "motion": torch.stack([b[1][w]["motion"] for b in batch], 0)} for w in range(2)]
+            mean = torch.tensor([float(b[2][0]) for b in batch]).float().mean()
+            std = torch.tensor([float(b[2][1]) for b in batch]).float().mean()
+            return audio, coef, (mean, std)
+        return collate_fn
