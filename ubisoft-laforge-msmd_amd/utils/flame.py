@@ -25,6 +25,22 @@ def _np(a, dtype=np.float32):
     return np.array(a, dtype=dtype)
 
 
+# the reference module's loader helpers, under its names (utils/flame.py:28-42)
+to_np = _np
+
+
+def to_tensor(array, dtype=torch.float32):
+    """Array-like -> tensor; a value that already is a torch tensor yields None, as in the reference (l.28-30)."""
+    return None if "torch.tensor" in str(type(array)) else torch.tensor(array, dtype=dtype)
+
+
+class Struct(object):
+    """Attribute bag over the pickle's dict (reference l.39-42)."""
+
+    def __init__(self, **kwargs):
+        self.__dict__.update(kwargs)
+
+
 class FLAME(nn.Module):
     """Same buffers, constructor argument and forward signature as the reference class.
     ``config`` may also carry ``asset`` (a dict with the pickle's arrays + 'lmk') so tests can
