@@ -30,7 +30,8 @@ to_np = _np
 
 
 def to_tensor(array, dtype=torch.float32):
-    """Array-like -> tensor; a value that already is a torch tensor yields None, as in the reference (l.28-30)."""
+    """Array-like -> tensor (reference l.28-30; its lower-case type-name test never matches "torch.Tensor", so
+    tensors are copied like any other input -- kept)."""
     return None if "torch.tensor" in str(type(array)) else torch.tensor(array, dtype=dtype)
 
 
