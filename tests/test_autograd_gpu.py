@@ -280,6 +280,14 @@ def test_weight_arena_refresh_matches_per_weight_casts():
     arena.refresh()
     wc, wct = ag.CACHE.get(params[2], torch.bfloat16)
     assert torch.equal(wc, params[2].detach().bfloat16()) and torch.equal(wct, params[2].detach().bfloat16().t())
+    # an in-place write behind the arena's back (e.g. load_state_dict) is noticed: fresh cast until the next refresh
+    with torch.no_grad():
+        params[0].add_(1.0)
+    wc0, _ = ag.CACHE.get(params[0], torch.bfloat16)
+    assert torch.equal(wc0, params[0].detach().bfloat16()) and wc0.data_ptr() != arena.cast.data_ptr()
+    arena.refresh()
+    wc0, _ = ag.CACHE.get(params[0], torch.bfloat16)
+    assert torch.equal(wc0, params[0].detach().bfloat16()) and wc0.data_ptr() == arena.cast.data_ptr()
     # a dead parameter's entry is dropped, not served to a new tensor that recycles its id()
     key = (id(params[0]), torch.bfloat16)
     assert key in ag.CACHE.persistent

@@ -34,8 +34,12 @@ class WeightCache:
         e = self.persistent.get(key)
         if e is not None:
             if e[0]() is w and e[1] == (w.data_ptr(), tuple(w.shape)):
-                return e[2], e[3]
-            del self.persistent[key]            # the parameter died or moved: drop the stale views
+                if e[4][0] == w._version:
+                    return e[2], e[3]
+                # written in place behind the arena's back (load_state_dict, manual edits): cast afresh below until
+                # the owner's next refresh() picks the new values up
+            else:
+                del self.persistent[key]        # the parameter died or moved: drop the stale views
         e = self.store.get(key)
         # id() values are recycled once a tensor dies: an entry is valid only for the SAME live tensor object (weak
         # reference), at the same version and storage address
@@ -80,14 +84,20 @@ class WeightArena:
         self.meta = torch.tensor(rows, dtype=torch.int64, device=dev)
         self.cast = torch.empty(off, device=dev, dtype=torch.bfloat16)
         self.tr = torch.empty(off, device=dev, dtype=torch.bfloat16)
+        self.versions = []
         for p, o, N, K in self.views:
+            box = [p._version]
+            self.versions.append(box)
             CACHE.persistent[(id(p), torch.bfloat16)] = (weakref.ref(p), (p.data_ptr(), tuple(p.shape)),
-                                                         self.cast[o:o + N * K].view(N, K), self.tr[o:o + N * K].view(K, N))
+                                                         self.cast[o:o + N * K].view(N, K), self.tr[o:o + N * K].view(K, N),
+                                                         box)
         self.refresh()
 
     def refresh(self):
         if self.n:
             ops.cast_transpose_multi(self.flat, self.meta, self.n, self.tiles, self.cast, self.tr)
+            for (p, _, _, _), box in zip(self.views, self.versions):
+                box[0] = p._version
 
     def release(self):
         """Drop this arena's views from the cache (the bf16 arenas are freed with them)."""
