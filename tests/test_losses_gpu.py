@@ -172,3 +172,32 @@ def test_no_constrain_prev_losses_match_reference():
         ref, got = g[f"vert_{int(start)}"], vals(r)
         assert np.array_equal(np.isnan(got), np.isnan(ref)), start
         assert np.nanmax(np.abs(got - ref) / np.maximum(1e-6, np.abs(ref))) < 2e-3, (start, got, ref)
+
+
+def test_vertex_space_metrics_against_numpy_flame():
+    """vertex_space_metrics (HIP FLAME pass + on-device reductions) against the numpy oracle's LBS / landmarks on the
+    same coefficients: fp32, relative tolerance 1e-4 on metre-scale errors; truncated sequences via end_idx."""
+    from msmd_amd.utils import common as C
+    from oracle import flame as ofl
+    fl = _flame()
+    N, L = 2, 6
+    pred = (0.5 * synth.normalish("vm/pred", (N, L, 54))).astype(np.float32)
+    gt = (0.5 * synth.normalish("vm/gt", (N, L, 54))).astype(np.float32)
+    shape = (0.5 * synth.normalish("vm/shape", (N, 100))).astype(np.float32)
+    end_idx = torch.tensor([L, 4], device=DEV)
+    got = C.vertex_space_metrics(dev(pred), dev(gt), dev(shape), fl, end_idx=end_idx, flame_batch_size=5)
+    orc = ofl.FlameOracle(synth.flame_asset())
+
+    def numpy_side(m):
+        cd = C.get_coef_dict(torch.from_numpy(m), torch.from_numpy(shape), None, with_global_pose=False)
+        flat = {k: v.reshape(-1, v.shape[-1]).numpy() for k, v in cd.items()}
+        v, _, lm = orc.forward(flat["shape"], flat["exp"], flat["pose"], return_lm2d=False, return_lm3d=True)
+        return v.reshape(N, L, -1, 3), lm.reshape(N, L, -1, 3)
+    (vp, lp), (vg, lg) = numpy_side(pred), numpy_side(gt)
+    valid = np.arange(L)[None] < np.array([L, 4])[:, None]
+    dv, dl = np.linalg.norm(vp - vg, axis=-1), np.linalg.norm(lp - lg, axis=-1)
+    ref = {"mve": dv.mean(-1)[valid].mean(), "lmk3d": dl.mean(-1)[valid].mean(),
+           "mouth_lmk": dl[..., 48:68].mean(-1)[valid].mean(), "mouth_max": dl[..., 48:68].max(-1)[valid].mean()}
+    for k, r in ref.items():
+        assert abs(float(got[k]) - r) <= 1e-4 * abs(r) + 1e-7, (k, float(got[k]), r)
+    assert float(got["mouth_max"]) >= float(got["mouth_lmk"]) > 0

@@ -305,3 +305,44 @@ def truncate_coef_dict_and_audio(audio, coef_dict, n_motions, audio_unit=640, pa
     end_idx = torch.randint(1, n_motions, (batch_size,), device=audio.device)
     audio_trunc = _truncate_audio(audio, (end_idx * audio_unit).long(), pad_mode=pad_mode)
     return audio_trunc, _truncate_coef_dict(coef_dict, end_idx, pad_mode=pad_mode), end_idx
+
+
+# ----------------------------------------------------------------------------- vertex-space evaluation
+@torch.no_grad()
+def vertex_space_metrics(motion_pred, motion_gt, shape_coef, flame, coef_stats=None, rot_repr="aa", end_idx=None,
+                         flame_batch_size=512):
+    """Evaluation of predicted against ground-truth motion in FLAME vertex space, on the device the sampler left its
+    output on (no host round trip): coefficients -> `get_coef_dict` -> one FLAME pass per chunk (the HIP LBS + landmark
+    kernels) for both sequences -> per-frame Euclidean errors.  motion_*: (N, L, 54) legacy layout (50 expression + 4
+    pose, as `compute_loss` consumes, utils/common.py:486-489); shape_coef (N, 100); end_idx (N,) optional valid length.
+
+    Returns 0-dim fp32 tensors (metres, the FLAME asset's unit):
+      mve        mean over valid frames and vertices of |v_pred - v_gt|
+      lmk3d      the same over the 68 3-D landmarks
+      mouth_lmk  over landmarks 48..67 (outer + inner lip contours)
+      mouth_max  mean over valid frames of the per-frame maximum mouth-landmark error (a lip-sync worst case per frame)
+    The reference stops at `coef_dict_to_vertices` (utils/common.py:176-196); these four reductions are this build's
+    extension of that export step."""
+    N, L = motion_pred.shape[:2]
+    verts, lmks = [], []
+    for m in (motion_pred, motion_gt):
+        cd = get_coef_dict(m.float(), shape_coef, coef_stats, with_global_pose=False, rot_repr=rot_repr)
+        flat = {k: v.reshape(-1, v.shape[-1]).contiguous() for k, v in cd.items()}
+        vs, ls = [], []
+        for i in range(0, N * L, flame_batch_size):
+            v, _, l3 = flame(flat["shape"][i:i + flame_batch_size], flat["exp"][i:i + flame_batch_size],
+                             flat["pose"][i:i + flame_batch_size], return_lm2d=False, return_lm3d=True)
+            vs.append(v)
+            ls.append(l3)
+        verts.append(torch.cat(vs).view(N, L, -1, 3))
+        lmks.append(torch.cat(ls).view(N, L, -1, 3))
+    valid = torch.ones(N, L, dtype=torch.bool, device=motion_pred.device) if end_idx is None else \
+        torch.arange(L, device=motion_pred.device).expand(N, -1) < end_idx.to(motion_pred.device).unsqueeze(1)
+    w = valid.float()
+    cnt = w.sum().clamp(min=1.0)
+    dv = (verts[0] - verts[1]).norm(dim=-1)          # (N, L, V)
+    dl = (lmks[0] - lmks[1]).norm(dim=-1)            # (N, L, 68)
+    mouth = dl[..., 48:68]
+    per_frame = lambda x: (x * w).sum() / cnt
+    return {"mve": per_frame(dv.mean(-1)), "lmk3d": per_frame(dl.mean(-1)), "mouth_lmk": per_frame(mouth.mean(-1)),
+            "mouth_max": per_frame(mouth.max(-1).values)}
