@@ -247,6 +247,43 @@ def test_infer_coeffs_fp32():
         model.diffusion_sched = old
 
 
+def test_infer_coeffs_edge_lengths():
+    """Edge lengths of the window driver, following the reference's integer arithmetic (inference.py:38-45, 71-72):
+    an EMPTY clip and a 100-sample clip (0 frames at 25 fps) pad to one window and trim to (n_rep, 0, 67); 641 samples
+    yield exactly one frame; exactly one window needs no padding; one sample over is still one window (clip_len stays
+    100, the encoder sees 64001 samples); 102 frames' worth starts a second window trimmed to 102 frames."""
+    import math
+    from msmd_amd.inference import infer_coeffs, infer_coeffs_batch, window_plan
+    from msmd_amd.model import DiffusionSchedule
+    model, args = get_model("wav2vec2", "fp32")
+    old = model.diffusion_sched
+    model.diffusion_sched = DiffusionSchedule(2, "cosine").to(DEV)
+    style = dev(synth.normalish("edge/style", (1, args.d_style)))
+    shape = torch.zeros(1, 1, 100, device=DEV)
+    try:
+        outs = {}
+        for S in (0, 100, 641, 64000, 64001, 65280):
+            clip_len = int(S / 16000 * args.fps)
+            n_sub = 1 if clip_len <= args.n_motions else math.ceil(clip_len / args.n_motions)
+            n_pad = 64000 * n_sub - S
+            n_pad_frames = math.ceil(n_pad / 640.0)
+            assert list(window_plan(S, args.fps, args.n_motions, 640.0))[2:] == [n_sub, n_pad, n_pad_frames]
+            audio = dev(synth.audio_clips(1, max(S, 1), tag="edge")[0][:S])
+            y = infer_coeffs(model, args, audio, shape, 640.0, style.expand(2, -1), n_repetitions=2,
+                             dynamic_threshold=None)
+            want = n_sub * args.n_motions - (n_pad_frames if n_pad_frames > 0 else 0)
+            assert y.shape == (2, want, 67) and bool(torch.isfinite(y).all()), (S, y.shape)
+            outs[S] = want
+        assert outs == {0: 0, 100: 0, 641: 1, 64000: 100, 64001: 100, 65280: 102}
+        # the batched driver takes the same ragged lengths in one call
+        auds = [dev(synth.audio_clips(1, S, tag="edge")[0]) for S in (641, 65280, 32000)]
+        ys = infer_coeffs_batch(model, args, auds, torch.zeros(3, 100, device=DEV), 640.0, style.expand(3, -1),
+                                dynamic_threshold=None)
+        assert [tuple(v.shape) for v in ys] == [(1, 1, 67), (1, 102, 67), (1, 50, 67)]
+    finally:
+        model.diffusion_sched = old
+
+
 def test_bf16_mode_tolerance():
     """Speed mode (bf16 storage, fp32 accumulate).  Stated tolerance vs the fp32 reference goldens:
     max-abs-err <= 0.08 on O(1) outputs after 12 encoder + 8 decoder layers (about 2^-4 relative)."""
