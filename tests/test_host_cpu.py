@@ -273,3 +273,16 @@ def test_common_script_plumbing():
     txt = get_option_text(ap.parse_args(["--alpha", "5"]), ap)
     assert txt.splitlines()[0].strip().startswith("alpha: 5") and "[default: 1]" in txt.splitlines()[0]
     assert "default" not in txt.splitlines()[1]
+
+
+def test_window_plan_edge_lengths():
+    """inference.window_plan against the reference's integer arithmetic (inference.py:38-43) at the edges: empty clip,
+    sub-frame clip, one frame, exact window, one sample over, and a long ragged clip."""
+    import math
+    from msmd_amd.inference import window_plan
+    for S in (0, 1, 100, 639, 640, 641, 63999, 64000, 64001, 64640, 65280, 128000, 1000003):
+        clip_len = int(S / 16000 * 25)
+        n_sub = 1 if clip_len <= 100 else math.ceil(clip_len / 100)
+        n_pad = 64000 * n_sub - S
+        got = window_plan(S, 25, 100, 640.0)
+        assert (got[0], got[2], got[3], got[4]) == (clip_len, n_sub, n_pad, math.ceil(n_pad / 640.0)), S
