@@ -26,6 +26,7 @@ struct GemmArgs {
   // training epilogue (msmd_gemm_ex): optional pre-activation copy Z (layout of C) and dropout on act(.) before the
   // residual add; the keep mask is Philox(rng, site, (m * N + n) / 4), i.e. msmd_dropout's on a contiguous (M, N) C
   void* Z; float p_drop; const unsigned long* rng; unsigned site;
+  int xn;  // XCDs along N (1, 2 or 4): the 8 XCDs form an (8 / xn) x xn grid over (M tiles, N tiles)
 };
 
 template <typename T> struct Mfma;
@@ -322,8 +323,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const GemmArgs p) {
 
   const int pid = blockIdx.x;
   const int xcd = pid & 7, slot = pid >> 3;
-  const int m_tile = (slot / p.nt) * 8 + xcd, n_tile = slot % p.nt;
-  if (m_tile >= p.mt) return;
+  // XCD grid (8 / xn) x xn over (M, N) tiles: an XCD's L2 then holds 1 / xn of the weight matrix instead of all of it
+  const int xm_n = 8 / p.xn, ntx = (p.nt + p.xn - 1) / p.xn;
+  const int m_tile = (slot / ntx) * xm_n + (xcd % xm_n), n_tile = (slot % ntx) * p.xn + xcd / xm_n;
+  if (m_tile >= p.mt || n_tile >= p.nt) return;
   const int z = blockIdx.z;
   const int zo = z / p.batch_inner, zi = z % p.batch_inner;
   const bf16_t* __restrict__ A = (const bf16_t*)p.A + zo * p.strideA + zi * p.strideA2;
@@ -538,7 +541,13 @@ static int launch_gemm2(GemmArgs& p, int batch, hipStream_t st) {
     attr_done = true;
   }
   p.mt = (p.M + BM - 1) / BM; p.nt = (p.N + BN - 1) / BN;
-  dim3 grid(((p.mt + 7) / 8) * 8 * p.nt, 1, batch);
+  // 4 x 2 XCD grid by default: with all 8 XCDs striped along M every L2 streams its own copy of the whole weight
+  // matrix from HBM; halving that is worth -2.4 % on the forward step (same-graph A/B, both orders), 2 x 4 only -0.5 %
+  // (the activation rows then replicate instead).  tuning key 7: 1 = 8 x 1 (the old mapping), 4 = 2 x 4.
+  const int want_xn = g_tuning[7] == 1 ? 1 : (g_tuning[7] == 4 ? 4 : 2);
+  p.xn = p.nt >= want_xn ? want_xn : 1;
+  const int xm_n = 8 / p.xn;
+  dim3 grid(((p.mt + xm_n - 1) / xm_n) * ((p.nt + p.xn - 1) / p.xn) * 8, 1, batch);
   hipLaunchKernelGGL(kfn, grid, dim3(WM * WN * 64), lds, st, p);
   MSMD_RETURN_LAST();
 }
@@ -625,7 +634,7 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
   p.inv_rpb = 1.0f / (float)rows_per_batch;
   p.strideA = strideA; p.strideW = strideW; p.strideC = strideC; p.strideBias = strideBias; p.strideR = strideR;
   p.batch_inner = batch_inner; p.strideA2 = strideA2; p.strideW2 = strideW2; p.strideC2 = strideC2;
-  p.Z = z_out; p.p_drop = p_drop; p.rng = rng; p.site = site;
+  p.Z = z_out; p.p_drop = p_drop; p.rng = rng; p.site = site; p.xn = 1;
   if (p_drop != 0.f && (!(p_drop > 0.f && p_drop < 1.f) || !rng || (N & 3) || ldc != N || batch != 1 || batch_inner != 1))
     return 1;  // the mask index assumes one contiguous (M, N) output
   const int osz = out_dtype == MSMD_F32 ? 4 : 2;
