@@ -541,10 +541,22 @@ static int launch_gemm2(GemmArgs& p, int batch, hipStream_t st) {
     attr_done = true;
   }
   p.mt = (p.M + BM - 1) / BM; p.nt = (p.N + BN - 1) / BN;
-  // 4 x 2 XCD grid by default: with all 8 XCDs striped along M every L2 streams its own copy of the whole weight
-  // matrix from HBM; halving that is worth -2.4 % on the forward step (same-graph A/B, both orders), 2 x 4 only -0.5 %
-  // (the activation rows then replicate instead).  tuning key 7: 1 = 8 x 1 (the old mapping), 4 = 2 x 4.
-  const int want_xn = g_tuning[7] == 1 ? 1 : (g_tuning[7] == 4 ? 4 : 2);
+  // XCD grid over (M, N) tiles.  With all 8 XCDs striped along M every L2 streams its own copy of the whole weight
+  // matrix from HBM, while the activation rows (the previous kernel's output) are still warm: an XCD of an
+  // (8 / xn) x xn grid reads 1 / xn of W and xn / 8 of A, so xn is picked per problem from  0.7 xn |A| + (8 / xn) |W|
+  // (the 0.7 fitted on the qkv shape, where 2 x 4 ties with 8 x 1 and both trail 4 x 2).  Forward step, same-graph A/B
+  // in both orders: 8 x 1 4.96 ms, 4 x 2 everywhere 4.89, this rule 4.88.  tuning key 7 forces xn = 1 / 2 / 4.
+  int want_xn = 1;
+  if (g_tuning[7] == 1 || g_tuning[7] == 2 || g_tuning[7] == 4) {
+    want_xn = g_tuning[7];
+  } else {
+    const double a_bytes = 2.0 * p.M * (double)(p.rows_per_batch < p.M ? p.lda : p.K), w_bytes = 2.0 * p.N * (double)p.K;
+    double best = 1e30;
+    for (int xn = 1; xn <= 4; xn *= 2) {
+      const double c = 0.7 * xn * a_bytes + (8.0 / xn) * w_bytes;
+      if (c < best && p.nt >= xn) { best = c; want_xn = xn; }
+    }
+  }
   p.xn = p.nt >= want_xn ? want_xn : 1;
   const int xm_n = 8 / p.xn;
   dim3 grid(((p.mt + xm_n - 1) / xm_n) * ((p.nt + p.xn - 1) / p.xn) * 8, 1, batch);
