@@ -121,7 +121,9 @@ def pmc_traffic():
     WRITE_SIZE collected in SEPARATE runs of this same command; KB units; FETCH_SIZE doubled per the gfx950
     correction of MI355X_MICROARCH.md section HBM).  PMC counters cannot be read from inside this process, so the
     figure comes from profiles/ (null when the file is absent)."""
-    path = os.path.join(ROOT, "profiles", "r01d_pmc_hbm_fetch_write_per_kernel.json")
+    path = os.path.join(ROOT, "profiles", "r01e_pmc_hbm_fetch_write_per_kernel.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r01d_pmc_hbm_fetch_write_per_kernel.json")
     if not os.path.exists(path):
         path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_fetch_write_per_kernel.json")
     try:
@@ -182,6 +184,10 @@ def main():
 
     from msmd_amd.config import default_args
     from msmd_amd.model import get_diffusion_model
+    if os.environ.get("MSMD_TUNE"):   # developer A/B knob, e.g. MSMD_TUNE="7=1" (msmd_set_tuning key=value pairs)
+        from msmd_amd import ops as _ops
+        for kv in os.environ["MSMD_TUNE"].split(","):
+            _ops.set_tuning(*(int(v) for v in kv.split("=")))
     args = default_args(compute_dtype=a.dtype)
     model = get_diffusion_model(args, device).eval()
     b = synth_batch(a.batch, rank, device)
