@@ -38,6 +38,7 @@ struct TnArgs {
   long b_wstride;
   float inv_rpw;
   int accumulate;  // C += product, colsum += sums (gradient accumulation straight into .grad)
+  int plain_order; // tuning key 1 = 1: items in (tile, split) launch order instead of XCD-contiguous eighths
 };
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -89,9 +90,21 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnArgs p) {
   constexpr int STAGE = 2 * 64 * 256;  // A image [64 m][128 n] + B image [64 m][128 k], bf16
   constexpr int LPT = 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tile = blockIdx.x;
-  const int n_tile = tile / p.nt_k, k_tile = tile % p.nt_k;
-  const int split = blockIdx.y, z = blockIdx.z;
+  // Work item = (n tile, k tile, M split).  Workgroups are dealt to the 8 XCDs round-robin by blockIdx.x, so XCD x takes
+  // the x-th CONTIGUOUS eighth of the item list ordered with the larger operand's tile index slowest: the items that
+  // re-read one 128-column slab of that operand then share one L2 instead of pulling it into all eight.
+  int n_tile, k_tile, split;
+  {
+    const int items = p.nt_n * p.nt_k * p.splits;
+    const int per_xcd = (items + 7) >> 3;
+    const int lin = p.plain_order ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (lin >= items || (!p.plain_order && (int)(blockIdx.x >> 3) >= per_xcd)) return;
+    split = lin % p.splits;
+    const int t = lin / p.splits;
+    if (p.nt_n >= p.nt_k) { n_tile = t / p.nt_k; k_tile = t % p.nt_k; }
+    else { k_tile = t / p.nt_n; n_tile = t % p.nt_n; }
+  }
+  const int z = blockIdx.z;
   const bf16_t* __restrict__ A = p.A + z * p.strideA;
   const bf16_t* __restrict__ B = p.B + z * p.strideB;
   const int n0 = n_tile * 128, k0 = k_tile * 128;
@@ -316,6 +329,7 @@ extern "C" int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsu
   p.b_wstride = b_window_stride; p.inv_rpw = p.b_rpw ? 1.0f / (float)p.b_rpw : 0.f;
   if (p.b_rpw && ((b_window_stride & 7) || M >= (1 << 24))) return 1;
   p.accumulate = accumulate ? 1 : 0;
+  p.plain_order = g_tuning[1] == 1;
   if (p.splits > 1 && colsum && !accumulate) {
     hipError_t e = hipMemsetAsync(colsum, 0, sizeof(float) * N, st);
     if (e != hipSuccess) return (int)e;
@@ -330,7 +344,7 @@ extern "C" int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsu
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kfn, dim3(p.nt_n * p.nt_k, p.splits, batch), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(kfn, dim3(((p.nt_n * p.nt_k * p.splits + 7) / 8) * 8, 1, batch), dim3(512), lds, st, p);
   if (p.splits > 1) {
     const long quads = (long)N * (K / 4);
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((quads + 255) / 256), batch), dim3(256), 0, st, p.ws, C,
