@@ -34,8 +34,11 @@ typedef void* msmd_stream_t; /* hipStream_t */
 
 /* Library / device probe: returns the ABI version; safe to call without a GPU. */
 int msmd_abi_version(void);
-/* Developer knob: key 0 = force a bf16 GEMM kernel variant (0 = built-in heuristic, -1 = register-staged v1
- * kernels only).  Used by tools/bench_gemm.py; not part of the drop-in surface. */
+/* Developer knobs for A/B measurements (tools/ab_graph.py, tools/bench_gemm.py); not part of the drop-in surface.
+ * key 0: force a bf16 GEMM kernel variant (0 = built-in heuristic, -1 = register-staged v1 kernels only);
+ * key 1: msmd_gemm_tn work items in plain launch order (1) instead of XCD-contiguous eighths; key 2: its split count;
+ * key 4: 13 instead of 17 for the 128x128 tile; keys 5 / 6: variant for M >= 20000 / the other 128x128 problems;
+ * key 7: XCDs along N for the GEMM tile map (1, 2, 4; 0 = chosen per problem from the operand sizes). */
 int msmd_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------------------------------------
