@@ -276,8 +276,15 @@ __global__ __launch_bounds__(256) void lbs_skin_bf16x3_kernel(const bf16_t* __re
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
-  const int v = blockIdx.x * 64 + wid * 16 + i;
-  const int f_begin = blockIdx.y * frames_per_block;
+  // 1-D grid, vertex tile = (L % 8) + 8 * ((L / 8) % ceil(vt / 8)): every frame split of one 64-vertex slice runs on
+  // the SAME XCD (workgroups go to XCDs round-robin), so the slice's 147 KB of blendshape directions is fetched into one
+  // L2 once and re-read from there by the other splits instead of bouncing through all eight
+  const int vt8 = (Vp / 64 + 7) >> 3;
+  const int L = blockIdx.x;
+  const int v_tile = (L & 7) + 8 * ((L >> 3) % vt8);
+  if (v_tile * 64 >= Vp) return;
+  const int v = v_tile * 64 + wid * 16 + i;
+  const int f_begin = ((L >> 3) / vt8) * frames_per_block;
   const int f_end = min(B, f_begin + frames_per_block);
 
   u32x4 dh[3][KG], dl[3][KG];
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(256) void lbs_skin_bf16x3_kernel(const bf16_t* __re
   issue(f_begin, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tile: nothing younger than the loads yet
   // a wave issues exactly 4 vertex-store instructions per tile unless ALL its vertices are padding
-  const bool wave_stores = __builtin_amdgcn_readfirstlane(blockIdx.x * 64 + wid * 16) < V;
+  const bool wave_stores = __builtin_amdgcn_readfirstlane(v_tile * 64 + wid * 16) < V;
   for (int f0 = f_begin; f0 < f_end; f0 += 16) {
     // vmcnt counts stores too: waiting for 0 would serialise on the previous tile's vertex stores (the 4 youngest
     // VMEM ops of this wave).  Leave them in flight and wait only for this tile's 4 LDS-DMA loads, which are older.
@@ -389,7 +396,7 @@ extern "C" int msmd_lbs_skin_bf16x3(const void* coef_hl, const float* A, const f
   int splits = max(1, min((B + 63) / 64, (2048 + vt - 1) / vt));
   int fpb = (((B + splits - 1) / splits) + 15) / 16 * 16;
   splits = (B + fpb - 1) / fpb;
-  dim3 grid(vt, splits), block(256);
+  dim3 grid(((vt + 7) / 8) * 8 * splits), block(256);
   hipLaunchKernelGGL((lbs_skin_bf16x3_kernel<6, 5>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)coef_hl, A,
                      v_template, (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb);
   MSMD_RETURN_LAST();
