@@ -25,6 +25,14 @@ extern "C" {
 #define MSMD_F32 0
 #define MSMD_BF16 1
 #define MSMD_F16 2 /* IEEE half storage, fp32 accumulate: inference kernels (GEMM, attention, norm, audio, diffusion) */
+/* "split pair" storage of fp32-grade values for the parity-grade speed mode (inference kernels): x ~= hi + lo * 2^-11
+ * with hi = RN_f16(x), lo = RN_f16((x - hi) * 2^11), |err| <= 2^-22 |x| + 2^-35 (typically 2^-24 |x|) for |x| < 65504.  A logical row of C values
+ * (C % 32 == 0) is stored as 2 C fp16 numbers in 32-element blocks [hi x 32 | lo x 32]; all sizes / leading
+ * dimensions / strides in this header stay in LOGICAL elements.  Contractions run as three f16 MFMAs per k-step
+ * (hi.hi, hi.lo, lo.hi; fp32 accumulate), i.e. at 1/3 of the f16 MFMA rate instead of the 1/16 of the exact-fp32
+ * MFMA.  The reference computes in fp32 everywhere (training_script.py:548-551: no autocast); this is the mode that
+ * meets its 1e-4 tolerance at speed. */
+#define MSMD_F16X2 3
 
 #define MSMD_ACT_NONE 0
 #define MSMD_ACT_GELU 1 /* exact erf GELU */
@@ -49,6 +57,9 @@ int msmd_set_tuning(int key, int value);
  *   W: (N, K) row-major, leading dimension ldw (torch Linear layout; conv weights repacked (N, k*C_in)).
  *   bias: fp32 (N) or NULL.  residual: (M, N) ld ldr or NULL.  C: (M, N) ld ldc.
  *   in_dtype: dtype of A and W.  out_dtype: dtype of C and residual.
+ *   in_dtype MSMD_F16X2 (split storage, the parity-grade speed mode): three f16 MFMAs per k-step, fp32-grade result;
+ *   out_dtype MSMD_F32 or MSMD_F16X2; K, lda, ldw, a_batch_stride and the A / W strides must be multiples of 32, and
+ *   for split output also N % 4 == 0 and ldc / ldr / strideC / strideR multiples of 32.
  *   batch > 1 launches independent problems with the given element strides (grouped conv).
  *   act: MSMD_ACT_* in bits 0-7; bits 8-15 may carry a kernel-variant hint chosen by a host-side autotuner (0 = the
  *   library's own shape heuristic; every variant computes bit-identical results).
@@ -105,6 +116,20 @@ int msmd_layernorm(const void* x, const void* residual, const float* gamma, cons
                    const float* post_add, void* y, int rows, int cols, float eps, int act,
                    int in_dtype, int out_dtype, msmd_stream_t stream);
 
+/* msmd_layernorm on fp32 input with the row ALSO written in MSMD_F16X2 split storage (y_split; cols % 32 == 0):
+ * in the parity-grade speed mode a LayerNorm output is the next contraction's A operand (split) and the residual of
+ * the block after it (fp32, y; may be NULL when no fp32 copy is needed).  Same reference lines as msmd_layernorm. */
+int msmd_layernorm_f16x2(const float* x, const float* residual, const float* gamma, const float* beta,
+                         const float* post_add, float* y, void* y_split, int rows, int cols, float eps, int act,
+                         msmd_stream_t stream);
+
+/* fp32 (rows, cols) with leading dimension ldx -> MSMD_F16X2 split rows of cols_out >= cols logical columns
+ * (cols_out % 32 == 0; the padding columns are zero), and back.  Streaming conversions for tensors that enter the
+ * parity-grade speed mode from fp32 producers (weights at pack time, small glue tensors); the hot producers
+ * (msmd_layernorm_f16x2, msmd_gemm with out_dtype MSMD_F16X2, msmd_conv0_gn_gelu) write split rows themselves. */
+int msmd_split_f16x2(const float* x, void* y, long rows, int cols, long ldx, int cols_out, msmd_stream_t stream);
+int msmd_unsplit_f16x2(const void* x, float* y, long rows, int cols, int cols_in, long ldy, msmd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused softmax attention for short sequences (Tk <= 512), head_dim 64:
  *   O[b, t, h*64:(h+1)*64] = softmax(scale * Q_h K_h^T  (masked -> -inf)) V_h
@@ -117,6 +142,14 @@ int msmd_attention(const void* Q, const void* K, const void* V, void* O, int B, 
                    long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
                    long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
                    int dtype, msmd_stream_t stream);
+
+/* msmd_attention on MSMD_F16X2 split operands (the parity-grade speed mode): Q / K / V as written by msmd_gemm with
+ * out_dtype MSMD_F16X2, both products as three f16 MFMAs per k-step, softmax in fp32 (expf); O in fp32 or in split
+ * storage (out_dtype) for the out-projection GEMM.  Strides in logical elements, multiples of 32. */
+int msmd_attention_f16x2(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
+                         long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
+                         long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
+                         int out_dtype, msmd_stream_t stream);
 
 /* Person-token cross-attention query, projection + Tq = 1 attention fused (one wave per sequence and head):
  *   out[n, h*64:(h+1)*64] = softmax(scale * (x[n] Wq_h^T + bq_h) K_h[n]^T) V_h[n]     (no mask, head_dim 64, Tk <= 512)
@@ -193,9 +226,11 @@ int msmd_conv0_ln_gelu(const float* audio, const float* w0, const float* bias, c
 int msmd_interp_linear(const void* x, void* y, int B, int T_in, int T_crop, int T_out, int C, int dtype,
                        msmd_stream_t stream);
 
-/* Regroup (B, T, G*Cg) channels-last into the zero-padded group-major layout (B, G, T + 2*pad, Cg)
- * the positional grouped conv reads as G windowed GEMMs. */
-int msmd_group_pad(const void* x, void* y, int B, int T, int G, int Cg, int pad, int dtype, msmd_stream_t stream);
+/* Regroup (B, T, G*Cg) channels-last into the zero-padded group-major layout (B, G, T + 2*pad, Cg_out >= Cg; the
+ * extra channels are zero) the positional grouped conv reads as G windowed GEMMs.  out_dtype = dtype, or MSMD_F16X2
+ * from fp32 input (Cg_out % 32 == 0: split storage keeps 32-element blocks whole, so 48 channels are padded to 64). */
+int msmd_group_pad(const void* x, void* y, int B, int T, int G, int Cg, int Cg_out, int pad, int dtype, int out_dtype,
+                   msmd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Denoiser glue (reference model.py:931-951, 961-996, 231-236, 404-432).

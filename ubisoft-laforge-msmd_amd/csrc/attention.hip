@@ -220,6 +220,175 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const AttnArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// MSMD_F16X2 (split pair, common.h) attention for the parity-grade speed mode: Q / K / V arrive in split storage
+// straight from the QKV GEMM's epilogue (a 64-wide head = two 32-element blocks = one 256-byte row [hi0|lo0|hi1|lo1]),
+// both products run as three f16 MFMAs per k-step (S = Kh.Qh + (Kh.Ql + Kl.Qh) / 2048; the fp32 probabilities are
+// split in registers for O = Vh.Ph + (Vh.Pl + Vl.Ph) / 2048), softmax in fp32 (exp_neg_accurate: ~1 ulp, 7 VALU).
+// Same structure as attn_kernel (S computed swapped, V^T operand by ds_read_b64_tr_b16 from the row-major image);
+// LDS rows are 256 bytes: K chunks XOR (row & 15) (conflict-free ds_read_b128), V chunks XOR the dual-use pattern of
+// cdna_hip_programming.md T10 (b).  TO = float (fp32 O) or f16_t (O in split storage for the out-projection GEMM).
+__device__ __forceinline__ int vsw(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+template <typename TO, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_split_kernel(const AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 64 * 256];
+  unsigned char* sK = smem;
+  unsigned char* sV = smem + 64 * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  constexpr int NT = 64 * NW;
+  const int query = blockIdx.x * (16 * NW) + wid * 16 + fr;
+  const int qrow = query < p.Tq ? query : p.Tq - 1;
+  const f16_t* Qp = (const f16_t*)p.Q + 2 * ((long)b * p.qb + (long)qrow * p.qt) + h * 128;
+  const f16_t* Kb = (const f16_t*)p.K + 2 * (long)b * p.kb + h * 128;
+  const f16_t* Vb = (const f16_t*)p.V + 2 * (long)b * p.vb + h * 128;
+
+  u32x4 qh[2], ql[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    qh[g] = *(const u32x4*)(Qp + 64 * g + 8 * fq);
+    ql[g] = *(const u32x4*)(Qp + 64 * g + 32 + 8 * fq);
+  }
+  f32x4 o0[4], o1[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) o0[d] = o1[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  constexpr int NPF = (64 * 16 + NT - 1) / NT;
+  u32x4 pk[NPF], pv[NPF];
+  auto prefetch = [&](int kv0) {
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int c = tid + i * NT;
+      const int row = c >> 4, ch = c & 15;
+      const int key = kv0 + row;
+      pk[i] = pv[i] = u32x4{0, 0, 0, 0};
+      if (c < 64 * 16 && key < p.Tk) {
+        pk[i] = *(const u32x4*)(Kb + 2 * (long)key * p.kt + ch * 8);
+        pv[i] = *(const u32x4*)(Vb + 2 * (long)key * p.vt + ch * 8);
+      }
+    }
+  };
+  prefetch(0);
+  for (int kv0 = 0; kv0 < p.Tk; kv0 += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int c = tid + i * NT;
+      if (c < 64 * 16) {
+        const int row = c >> 4, ch = c & 15;
+        *(u32x4*)(sK + row * 256 + ((ch ^ (row & 15)) << 4)) = pk[i];
+        *(u32x4*)(sV + row * 256 + ((ch ^ vsw(row)) << 4)) = pv[i];
+      }
+    }
+    __syncthreads();
+    if (kv0 + 64 < p.Tk) prefetch(kv0 + 64);
+
+    f32x4 s[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+      const int row = 16 * f + fr;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const u32x4 kh = *(const u32x4*)(sK + row * 256 + (((8 * g + fq) ^ (row & 15)) << 4));
+        const u32x4 kl = *(const u32x4*)(sK + row * 256 + (((8 * g + 4 + fq) ^ (row & 15)) << 4));
+        s0 = mfma16<f16_t>(kh, qh[g], s0);
+        s1 = mfma16<f16_t>(kh, ql[g], s1);
+        s1 = mfma16<f16_t>(kl, qh[g], s1);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[f][e] = fmaf(s1[e], MSMD_SPLIT_INV, s0[e]);
+    }
+
+    float mx = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = kv0 + 16 * f + 4 * fq + e;
+        float v = s[f][e] * p.scale;
+        bool dead = key >= p.Tk;
+        if (p.mask && !dead) dead = p.mask[(long)qrow * p.Tk + key] != 0;
+        v = dead ? -INFINITY : v;
+        s[f][e] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = (m_run == -INFINITY) ? 0.f : exp_neg_accurate(m_run - m_use);
+    float ps = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pe = exp_neg_accurate(s[f][e] - m_use);
+        s[f][e] = pe;
+        ps += pe;
+      }
+    ps += __shfl_xor(ps, 16, 64);
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o0[d][e] *= alpha; o1[d][e] *= alpha; }
+
+    const int qp = fr >> 2, pp = fr & 3;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const int f0 = 2 * pr, f1 = 2 * pr + 1;
+      f16x8 phv, plv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f16_t hh, ll;
+        split_f16x2(s[f0][e], hh, ll); phv[e] = hh; plv[e] = ll;
+        split_f16x2(s[f1][e], hh, ll); phv[4 + e] = hh; plv[4 + e] = ll;
+      }
+      const u32x4 ph = __builtin_bit_cast(u32x4, phv), pl = __builtin_bit_cast(u32x4, plv);
+      const int r0 = 16 * f0 + 4 * fq + qp, r1 = 16 * f1 + 4 * fq + qp;
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      typedef s16x4 __attribute__((address_space(3)))* lds_s16x4_ptr;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int ch = (d >> 1) * 8 + (d & 1) * 2 + (pp >> 1);   // hi chunk of this d block; lo is 4 chunks further
+        const int b8 = (pp & 1) * 8;
+        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sV + r0 * 256 + ((ch ^ vsw(r0)) << 4) + b8));
+        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sV + r1 * 256 + ((ch ^ vsw(r1)) << 4) + b8));
+        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sV + r0 * 256 + (((ch + 4) ^ vsw(r0)) << 4) + b8));
+        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sV + r1 * 256 + (((ch + 4) ^ vsw(r1)) << 4) + b8));
+        const u32x4 vh = __builtin_bit_cast(u32x4, (s16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]}));
+        const u32x4 vl = __builtin_bit_cast(u32x4, (s16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]}));
+        o0[d] = mfma16<f16_t>(vh, ph, o0[d]);
+        o1[d] = mfma16<f16_t>(vh, pl, o1[d]);
+        o1[d] = mfma16<f16_t>(vl, ph, o1[d]);
+      }
+    }
+  }
+
+  if (query < p.Tq) {
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaf(o1[d][e], MSMD_SPLIT_INV, o0[d][e]) * inv;
+      if constexpr (sizeof(TO) == 4) {
+        float* Op = (float*)p.O + (long)b * p.ob + (long)query * p.ot + h * 64;
+        *(f32x4*)(Op + 16 * d + 4 * fq) = f32x4{o[0], o[1], o[2], o[3]};
+      } else {
+        f16_t* Op = (f16_t*)p.O + 2 * ((long)b * p.ob + (long)query * p.ot);
+        store4_split(Op, h * 64 + 16 * d + 4 * fq, o);
+      }
+    }
+  }
+}
+
 static int attention_impl(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
                           long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
                           long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
@@ -270,6 +439,36 @@ extern "C" int msmd_attention_dropout(const void* Q, const void* K, const void* 
                                       unsigned int site, int dtype, msmd_stream_t stream) {
   return attention_impl(Q, K, V, O, B, H, Tq, Tk, q_bstride, q_tstride, k_bstride, k_tstride, v_bstride, v_tstride,
                         o_bstride, o_tstride, scale, mask, p_drop, rng_state, site, dtype, stream);
+}
+
+// Split-pair attention (inference): Q / K / V in MSMD_F16X2 storage, O in fp32 (out_dtype MSMD_F32) or split storage.
+// Strides in logical elements, multiples of 32.
+extern "C" int msmd_attention_f16x2(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
+                                    long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
+                                    long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
+                                    int out_dtype, msmd_stream_t stream) {
+  if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || !Q || !K || !V || !O) return 1;
+  if (out_dtype != MSMD_F32 && out_dtype != MSMD_F16X2) return 1;
+  if (q_tstride % 32 || k_tstride % 32 || v_tstride % 32 || q_bstride % 32 || k_bstride % 32 || v_bstride % 32) return 1;
+  if (out_dtype == MSMD_F16X2 ? (o_tstride % 32 || o_bstride % 32) : (o_tstride % 4 || o_bstride % 4)) return 1;
+  if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)V & 15) || ((uintptr_t)O & 15)) return 1;
+  AttnArgs p{Q, K, V, O, B, H, Tq, Tk, q_bstride, q_tstride, k_bstride, k_tstride, v_bstride, v_tstride,
+             o_bstride, o_tstride, scale, mask, 0.f, nullptr, 0u};
+  const int need = (Tq + 15) / 16;
+  const int nw = need <= 4 ? 4 : (need <= 7 ? 7 : (need <= 13 ? 13 : 16));
+  dim3 grid((Tq + 16 * nw - 1) / (16 * nw), H, B), block(64 * nw);
+  hipStream_t st = (hipStream_t)stream;
+#define MSMD_ATTN_S(TO)                                                                                \
+  do {                                                                                                 \
+    if (nw == 4) hipLaunchKernelGGL((attn_split_kernel<TO, 4>), grid, block, 0, st, p);                \
+    else if (nw == 7) hipLaunchKernelGGL((attn_split_kernel<TO, 7>), grid, block, 0, st, p);           \
+    else if (nw == 13) hipLaunchKernelGGL((attn_split_kernel<TO, 13>), grid, block, 0, st, p);         \
+    else hipLaunchKernelGGL((attn_split_kernel<TO, 16>), grid, block, 0, st, p);                       \
+  } while (0)
+  if (out_dtype == MSMD_F32) MSMD_ATTN_S(float);
+  else MSMD_ATTN_S(f16_t);
+#undef MSMD_ATTN_S
+  MSMD_RETURN_LAST();
 }
 
 // ---------------------------------------------------------------------------------------------------

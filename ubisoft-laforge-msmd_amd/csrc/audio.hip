@@ -142,7 +142,8 @@ extern "C" int msmd_conv0_stats(const float* audio, const float* w0, float* stat
 }
 
 // out (B, T0, C) = GELU(GN(conv0)); thread = 4 consecutive channels, block = 2 frame rows x 128 channel quads
-template <typename TO>
+// SPLIT: out is MSMD_F16X2 split storage (TO = f16_t): exact erf GELU, hi / lo 16-byte stores
+template <typename TO, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restrict__ audio,
                                                             const float* __restrict__ w0,
                                                             const float* __restrict__ stats,
@@ -176,10 +177,12 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
         float y = 0.f;
 #pragma unroll
         for (int k = 0; k < C0_K; ++k) y = fmaf(w[e][k], xs[t * C0_S + k], y);
-        o[e] = sizeof(TO) == 2 ? gelu_fast(fmaf(y, sc[e], sh[e])) : gelu_erf(fmaf(y, sc[e], sh[e]));
+        o[e] = (sizeof(TO) == 2 && !SPLIT) ? gelu_fast(fmaf(y, sc[e], sh[e])) : gelu_erf(fmaf(y, sc[e], sh[e]));
       }
       TO* op = out + ((long)b * T0 + t0 + t) * C + c0;
-      if constexpr (sizeof(TO) == 4) {
+      if constexpr (SPLIT) {
+        store8_split((f16_t*)out + ((long)b * T0 + t0 + t) * 2 * C, c0, o);
+      } else if constexpr (sizeof(TO) == 4) {
         *(f32x4*)op = f32x4{o[0], o[1], o[2], o[3]};
         *(f32x4*)(op + 4) = f32x4{o[4], o[5], o[6], o[7]};
       } else {
@@ -197,7 +200,11 @@ extern "C" int msmd_conv0_gn_gelu(const float* audio, const float* w0, const flo
   const int Lp = L + 4 * reflect_len + 2 * replicate_len;
   const int T0 = (Lp - C0_K) / C0_S + 1;
   dim3 grid((T0 + 63) / 64, B), block(256);
-  if (out_dtype == MSMD_F32)
+  if (out_dtype == MSMD_F16X2) {
+    if (C & 31) return 1;
+    hipLaunchKernelGGL((conv0_gn_gelu_kernel<f16_t, true>), grid, block, 0, (hipStream_t)stream, audio, w0, stats, gamma,
+                       beta, (f16_t*)out, L, reflect_len, replicate_len, C, T0);
+  } else if (out_dtype == MSMD_F32)
     hipLaunchKernelGGL(conv0_gn_gelu_kernel<float>, grid, block, 0, (hipStream_t)stream, audio, w0, stats, gamma, beta,
                        (float*)out, L, reflect_len, replicate_len, C, T0);
   else if (out_dtype == MSMD_F16)
@@ -327,33 +334,48 @@ extern "C" int msmd_interp_linear(const void* x, void* y, int B, int T_in, int T
   MSMD_RETURN_LAST();
 }
 
-// (B, T, G*Cg) -> zero-padded group-major (B, G, T + 2*pad, Cg)
-template <typename T>
-__global__ void group_pad_kernel(const T* __restrict__ x, T* __restrict__ y, int Tn, int G, int Cg, int pad) {
+// (B, T, G*Cg) -> zero-padded group-major (B, G, T + 2*pad, Cgo) with Cgo >= Cg (extra channels zero).  Output in
+// the input's dtype, or (fp32 input, Cgo % 32 == 0) in MSMD_F16X2 split storage for the parity-grade speed mode, where
+// the grouped positional conv reads its overlapping windows in place and 32-element blocks must stay whole (48 -> 64).
+template <typename T, bool SPLIT>
+__global__ void group_pad_kernel(const T* __restrict__ x, void* __restrict__ yv, int Tn, int G, int Cg, int Cgo,
+                                 int pad) {
   const int b = blockIdx.z, g = blockIdx.y;
   const int Tp = Tn + 2 * pad;
-  const long n = (long)Tp * Cg;
-  T* yo = y + ((long)b * G + g) * n;
+  const long n = (long)Tp * Cgo;
   for (long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const int tp = (int)(i / Cg), c = (int)(i % Cg);
+    const int tp = (int)(i / Cgo), c = (int)(i % Cgo);
     const int t = tp - pad;
-    yo[i] = (t >= 0 && t < Tn) ? x[((long)b * Tn + t) * (G * Cg) + g * Cg + c] : from_f32<T>(0.f);
+    const bool in = t >= 0 && t < Tn && c < Cg;
+    if constexpr (SPLIT) {
+      f16_t hi, lo;
+      split_f16x2(in ? to_f32(x[((long)b * Tn + t) * (G * Cg) + g * Cg + c]) : 0.f, hi, lo);
+      f16_t* row = (f16_t*)yv + (((long)b * G + g) * Tp + tp) * 2 * Cgo + split_col(c);
+      row[0] = hi;
+      row[32] = lo;
+    } else {
+      T* yo = (T*)yv + ((long)b * G + g) * n;
+      yo[i] = in ? x[((long)b * Tn + t) * (G * Cg) + g * Cg + c] : from_f32<T>(0.f);
+    }
   }
 }
 
-extern "C" int msmd_group_pad(const void* x, void* y, int B, int T, int G, int Cg, int pad, int dtype,
-                              msmd_stream_t stream) {
-  if (B <= 0 || T <= 0 || G <= 0 || Cg <= 0 || pad < 0) return 1;
-  const long n = (long)(T + 2 * pad) * Cg;
+extern "C" int msmd_group_pad(const void* x, void* y, int B, int T, int G, int Cg, int Cg_out, int pad, int dtype,
+                              int out_dtype, msmd_stream_t stream) {
+  if (B <= 0 || T <= 0 || G <= 0 || Cg <= 0 || Cg_out < Cg || pad < 0) return 1;
+  const long n = (long)(T + 2 * pad) * Cg_out;
   dim3 grid((unsigned)min((n + 255) / 256, (long)64), G, B), block(256);
-  if (dtype == MSMD_F32)
-    hipLaunchKernelGGL(group_pad_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)x, (float*)y, T, G,
-                       Cg, pad);
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == MSMD_F16X2) {
+    if (dtype != MSMD_F32 || (Cg_out & 31)) return 1;
+    hipLaunchKernelGGL((group_pad_kernel<float, true>), grid, block, 0, st, (const float*)x, y, T, G, Cg, Cg_out, pad);
+  } else if (out_dtype != dtype) {
+    return 1;
+  } else if (dtype == MSMD_F32)
+    hipLaunchKernelGGL((group_pad_kernel<float, false>), grid, block, 0, st, (const float*)x, y, T, G, Cg, Cg_out, pad);
   else if (dtype == MSMD_F16)
-    hipLaunchKernelGGL(group_pad_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)x, (f16_t*)y, T,
-                       G, Cg, pad);
+    hipLaunchKernelGGL((group_pad_kernel<f16_t, false>), grid, block, 0, st, (const f16_t*)x, y, T, G, Cg, Cg_out, pad);
   else
-    hipLaunchKernelGGL(group_pad_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, T,
-                       G, Cg, pad);
+    hipLaunchKernelGGL((group_pad_kernel<bf16_t, false>), grid, block, 0, st, (const bf16_t*)x, y, T, G, Cg, Cg_out, pad);
   MSMD_RETURN_LAST();
 }

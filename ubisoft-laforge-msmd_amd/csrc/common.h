@@ -75,6 +75,48 @@ template <typename T> __device__ __forceinline__ f32x4 mfma16(const u32x4 a, con
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// MSMD_F16X2 ("split pair") storage: a logical fp32 value x is kept as two fp16 numbers
+//   hi = RN_f16(x),  lo = RN_f16((x - hi) * 2^11)          x ~= hi + lo * 2^-11   (|err| <= 2^-22 |x| + 2^-35, |x| < 65504)
+// A logical row of C values (C % 32 == 0) is a row of 2 C fp16 numbers in 32-element blocks [hi x 32 | lo x 32]:
+// one 128-byte line = one 32-deep MFMA k-step of both planes, so tiles are staged by the same LDS-DMA / LDS image as
+// plain 16-bit tiles.  A product sum is three f16 MFMAs per k-step (hi.hi -> acc0; hi.lo + lo.hi -> acc1) and
+// acc0 + acc1 * 2^-11 at the end: fp32-grade results at one third of the f16 MFMA rate instead of the 1/16 of
+// v_mfma_f32_16x16x4_f32 (the dropped lo.lo term is <= 2^-22 relative).
+#define MSMD_SPLIT_SCALE 2048.0f
+#define MSMD_SPLIT_INV 4.8828125e-4f
+__device__ __forceinline__ void split_f16x2(float x, f16_t& hi, f16_t& lo) {
+  hi = (f16_t)x;
+  lo = (f16_t)((x - (float)hi) * MSMD_SPLIT_SCALE);
+}
+__device__ __forceinline__ float unsplit_f16x2(f16_t hi, f16_t lo) { return fmaf((float)lo, MSMD_SPLIT_INV, (float)hi); }
+// physical fp16 offset of logical column c inside a split row (hi; lo is 32 further)
+__device__ __forceinline__ long split_col(int c) { return ((long)(c >> 5) << 6) + (c & 31); }
+// 4 consecutive logical columns c .. c+3 (c % 4 == 0) of a split row
+__device__ __forceinline__ void store4_split(f16_t* row, int c, const float* v) {
+  f16_t h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split_f16x2(v[e], h[e], l[e]);
+  f16_t* p = row + split_col(c);
+  *(f16x4*)p = f16x4{h[0], h[1], h[2], h[3]};
+  *(f16x4*)(p + 32) = f16x4{l[0], l[1], l[2], l[3]};
+}
+__device__ __forceinline__ void load4_split(const f16_t* row, int c, float* v) {
+  const f16_t* p = row + split_col(c);
+  const f16x4 h = *(const f16x4*)p, l = *(const f16x4*)(p + 32);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = unsplit_f16x2(h[e], l[e]);
+}
+// 8 consecutive logical columns (c % 8 == 0): two 16-byte stores
+__device__ __forceinline__ void store8_split(f16_t* row, int c, const float* v) {
+  f16_t h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) split_f16x2(v[e], h[e], l[e]);
+  f16_t* p = row + split_col(c);
+  *(f16x8*)p = f16x8{h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]};
+  *(f16x8*)(p + 32) = f16x8{l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]};
+}
+
 // Exact erf GELU (HF ACT2FN['gelu'] / torch F.gelu(approximate='none')).
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
@@ -90,6 +132,18 @@ __device__ __forceinline__ float erf_fast(float x) {
   return copysignf(y, x);
 }
 __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+
+// exp(x) for x <= 0 (softmax numerators) at ~1 ulp from ONE v_exp_f32: t = x log2(e) with the product's rounding error
+// and log2(e)'s own fp32 rounding carried separately (r) and applied as exp2(t) (1 + r ln 2).  libm's expf is ~25
+// VALU instructions, this is 7; __expf alone (x * log2e rounded once) is off by up to |x| * 2^-24 relative.
+__device__ __forceinline__ float exp_neg_accurate(float x) {
+  x = fmaxf(x, -200.0f);                       // -inf (masked keys) -> exp2(-288) = 0 without NaNs in the residual
+  const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.92596299112661746e-8f;
+  const float t = x * L2E_HI;
+  const float r = fmaf(x, L2E_HI, -t) + x * L2E_LO;
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e * r, 0.693147180559945309f, e);
+}
 
 __device__ __forceinline__ float apply_act(float x, int act) {
   if (act == MSMD_ACT_GELU) return gelu_erf(x);

@@ -524,6 +524,130 @@ static int launch_gemm2k(GemmArgs& p, int batch, hipStream_t st) {
   MSMD_RETURN_LAST();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// MSMD_F16X2 ("split pair", common.h) kernel: the parity-grade speed mode.  Operands are rows of 2K fp16 numbers in
+// 32-element blocks [hi x 32 | lo x 32], so ONE 128-byte line = one 32-deep k-step of both planes and the LDS-DMA
+// ring, LDS image, swizzle and fragment reads are those of gemm2_kernel (chunks 0-3 of a row = hi, 4-7 = lo).  Per
+// k-step and fragment pair: acc0 += Wh.Ah, acc1 += Wh.Al + Wl.Ah (three v_mfma_f32_16x16x32_f16), result
+// acc0 + acc1 / 2048.  The launcher passes lda / ldw / strides of A and W already doubled (fp16 units); K stays logical.
+// TO = float (fp32 C and residual) or f16_t (C and residual in split storage).
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue_split(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int z, int m_base,
+                                                    int n_base, int fr, int fq) {
+  f16_t* __restrict__ C = (f16_t*)p.C + 2 * ((z / p.batch_inner) * p.strideC + (z % p.batch_inner) * p.strideC2);
+  const f16_t* __restrict__ R = p.R ? (const f16_t*)p.R + 2 * (z * p.strideR) : nullptr;
+  const float* __restrict__ bias = p.bias ? p.bias + z * p.strideBias : nullptr;
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+    const int n = n_base + i * 16 + fq * 4;
+    if (n >= p.N) continue;   // N % 4 == 0 (launcher)
+    const f32x4 bv = bias ? *(const f32x4*)(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = m_base + j * 16 + fr;
+      if (m >= p.M) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = act_out<float>(acc[i][j][e] + bv[e], p.act);
+      if (R) {
+        float r[4];
+        load4_split(R + (long)m * 2 * p.ldr, n, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
+      }
+      store4_split(C + (long)m * 2 * p.ldc, n, v);
+    }
+  }
+}
+
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(WM * WN * 64) void gemm2s_kernel(const GemmArgs p) {
+  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int LPT = (BM + BN) * 8 / NT;
+  constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+  static_assert((BM + BN) * 8 % NT == 0, "tile chunks must divide over the threads");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int pid = blockIdx.x;
+  const int xcd = pid & 7, slot = pid >> 3;
+  const int xm_n = 8 / p.xn, ntx = (p.nt + p.xn - 1) / p.xn;
+  const int m_tile = (slot / ntx) * xm_n + (xcd % xm_n), n_tile = (slot % ntx) * p.xn + xcd / xm_n;
+  if (m_tile >= p.mt || n_tile >= p.nt) return;
+  const int z = blockIdx.z;
+  const int zo = z / p.batch_inner, zi = z % p.batch_inner;
+  const f16_t* __restrict__ A = (const f16_t*)p.A + zo * p.strideA + zi * p.strideA2;
+  const f16_t* __restrict__ W = (const f16_t*)p.W + zo * p.strideW + zi * p.strideW2;
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+  const f16_t* src[LPT];
+#pragma unroll
+  for (int i = 0; i < LPT; ++i) {
+    const int id = (i * NW + wid) * 64 + lane;
+    const int row = id >> 3, phys = id & 7;
+    const int c = phys ^ ((row >> 1) & 7);
+    if (row < BM) src[i] = A + a_row_offset(p, min(m0 + row, p.M - 1)) + c * 8;
+    else src[i] = W + (long)min(n0 + row - BM, p.N - 1) * p.ldw + c * 8;
+  }
+  auto issue = [&](int kt, int stage) {
+#pragma unroll
+    for (int i = 0; i < LPT; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[i] + kt * 64),
+                                       (lds_void_t*)(smem + stage * STAGE + (i * NW + wid) * 1024), 16, 0, 0);
+  };
+
+  const int wm = (wid / WN) * (BM / WM), wn = (wid % WN) * (BN / WN);
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4 acc0[FN][FM], acc1[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc0[i][j] = acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / 32;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) issue(s, s);
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + NSTAGE - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, (stage + NSTAGE - 1) % NSTAGE);
+    const unsigned char* sa = smem + stage * STAGE;
+    const unsigned char* sw = sa + BM * 128;
+    u32x4 ah[FM], al[FM], wh[FN], wl[FN];
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      ah[j] = *(const u32x4*)(sa + lds_off(wm + j * 16 + fr, fq));
+      al[j] = *(const u32x4*)(sa + lds_off(wm + j * 16 + fr, 4 + fq));
+    }
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      wh[i] = *(const u32x4*)(sw + lds_off(wn + i * 16 + fr, fq));
+      wl[i] = *(const u32x4*)(sw + lds_off(wn + i * 16 + fr, 4 + fq));
+    }
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        Mfma<f16_t>::run(wh[i], ah[j], acc0[i][j]);
+        Mfma<f16_t>::run(wh[i], al[j], acc1[i][j]);
+        Mfma<f16_t>::run(wl[i], ah[j], acc1[i][j]);
+      }
+    stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
+  }
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc0[i][j][e] = fmaf(acc1[i][j][e], MSMD_SPLIT_INV, acc0[i][j][e]);
+  if constexpr (sizeof(TO) == 4) gemm_epilogue<float, FM, FN>(p, acc0, z, m0 + wm, n0 + wn, fr, fq);
+  else gemm_epilogue_split<FM, FN>(p, acc0, z, m0 + wm, n0 + wn, fr, fq);
+}
+
 int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // shared with gemm_tn.hip (key 2 = forced contraction splits)
 extern "C" int msmd_set_tuning(int key, int value) {
   if (key < 0 || key >= 8) return 1;
@@ -562,6 +686,51 @@ static int launch_gemm2(GemmArgs& p, int batch, hipStream_t st) {
   dim3 grid(((p.mt + xm_n - 1) / xm_n) * ((p.nt + p.xn - 1) / p.xn) * 8, 1, batch);
   hipLaunchKernelGGL(kfn, grid, dim3(WM * WN * 64), lds, st, p);
   MSMD_RETURN_LAST();
+}
+
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE>
+static int launch_gemm2s(GemmArgs& p, int batch, hipStream_t st) {
+  constexpr int lds = NSTAGE * (BM + BN) * 128;
+  static bool attr_done = false;
+  auto kfn = gemm2s_kernel<TO, BM, BN, WM, WN, NSTAGE>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  p.mt = (p.M + BM - 1) / BM; p.nt = (p.N + BN - 1) / BN;
+  int want_xn = 1;
+  if (g_tuning[7] == 1 || g_tuning[7] == 2 || g_tuning[7] == 4) {
+    want_xn = g_tuning[7];
+  } else {   // same cost model as launch_gemm2 (bytes are 4 per logical element here; the ratio is what matters)
+    const double a_bytes = 4.0 * p.M * (double)(p.rows_per_batch < p.M ? p.lda / 2 : p.K), w_bytes = 4.0 * p.N * (double)p.K;
+    double best = 1e30;
+    for (int xn = 1; xn <= 4; xn *= 2) {
+      const double c = 0.7 * xn * a_bytes + (8.0 / xn) * w_bytes;
+      if (c < best && p.nt >= xn) { best = c; want_xn = xn; }
+    }
+  }
+  p.xn = p.nt >= want_xn ? want_xn : 1;
+  const int xm_n = 8 / p.xn;
+  dim3 grid(((p.mt + xm_n - 1) / xm_n) * ((p.nt + p.xn - 1) / p.xn) * 8, 1, batch);
+  hipLaunchKernelGGL(kfn, grid, dim3(WM * WN * 64), lds, st, p);
+  MSMD_RETURN_LAST();
+}
+
+template <typename TO>
+static int dispatch_gemm2s(GemmArgs& p, int batch, hipStream_t st, int variant) {
+  switch (variant) {
+    case 1: return launch_gemm2s<TO, 128, 128, 4, 2, 2>(p, batch, st);   // 64 KB
+    case 2: return launch_gemm2s<TO, 128, 128, 4, 2, 4>(p, batch, st);   // 128 KB, deep ring
+    case 3: return launch_gemm2s<TO, 128, 128, 2, 2, 2>(p, batch, st);   // 4 waves of 64 x 64
+    case 4: return launch_gemm2s<TO, 256, 128, 4, 2, 3>(p, batch, st);   // 144 KB, 64 x 64 wave tiles
+    case 5: return launch_gemm2s<TO, 64, 64, 2, 2, 4>(p, batch, st);
+    case 6: return launch_gemm2s<TO, 128, 64, 2, 2, 3>(p, batch, st);
+    case 7: return launch_gemm2s<TO, 64, 128, 2, 2, 3>(p, batch, st);
+    case 8: return launch_gemm2s<TO, 128, 128, 2, 2, 4>(p, batch, st);
+    case 9: return launch_gemm2s<TO, 128, 128, 4, 2, 3>(p, batch, st);   // 96 KB
+    case 10: return launch_gemm2s<TO, 128, 256, 2, 4, 3>(p, batch, st);  // 144 KB
+    default: return -1;
+  }
 }
 
 template <typename TO>
@@ -633,6 +802,42 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch_inner <= 0 || !A || !W || !C) return 1;
   const int hint = (act >> 8) & 0xff;  // caller-chosen kernel variant (host-side autotune), 0 = heuristic below
   act &= 0xff;
+  if (in_dtype == MSMD_F16X2) {
+    // split-pair operands: logical sizes in, fp16 strides (x 2) into the kernel; 32-element blocks must stay whole
+    if (out_dtype != MSMD_F32 && out_dtype != MSMD_F16X2) return 1;
+    if (K % 32 || lda % 32 || ldw % 32 || a_batch_stride % 32 || strideA % 32 || strideW % 32 || strideA2 % 32 ||
+        strideW2 % 32 || z_out || p_drop != 0.f)
+      return 1;
+    if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 15)) return 1;
+    if (rows_per_batch <= 0) rows_per_batch = M;
+    GemmArgs p;
+    p.A = A; p.W = W; p.bias = bias; p.R = residual; p.C = C;
+    p.M = M; p.N = N; p.K = K;
+    p.lda = 2 * lda; p.rows_per_batch = rows_per_batch; p.a_batch_stride = 2 * a_batch_stride;
+    p.ldw = 2 * ldw; p.ldc = ldc; p.ldr = ldr; p.act = act;
+    p.inv_rpb = 1.0f / (float)rows_per_batch;
+    p.strideA = 2 * strideA; p.strideW = 2 * strideW; p.strideC = strideC; p.strideBias = strideBias; p.strideR = strideR;
+    p.batch_inner = batch_inner; p.strideA2 = 2 * strideA2; p.strideW2 = 2 * strideW2; p.strideC2 = strideC2;
+    p.Z = nullptr; p.p_drop = 0.f; p.rng = nullptr; p.site = 0; p.xn = 1;
+    if (out_dtype == MSMD_F16X2) {
+      if ((N & 3) || ldc % 32 || strideC % 32 || strideC2 % 32 || (residual && (ldr % 32 || strideR % 32))) return 1;
+      if (bias && (((uintptr_t)bias & 15) || (strideBias & 3))) return 1;
+      p.vec_ok = 1;
+    } else {
+      p.vec_ok = (ldc % 4 == 0) && (strideC % 4 == 0) && (strideC2 % 4 == 0) && (((uintptr_t)C % 16) == 0) &&
+                 (!residual || ((ldr % 4 == 0) && (strideR % 4 == 0) && (((uintptr_t)residual % 16) == 0)));
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nz = batch * batch_inner;
+    int variant = g_tuning[3] > 0 ? g_tuning[3] : hint;
+    if (variant == 0) {
+      const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nz;
+      variant = (N > 64 && tiles128 >= 192) ? 1 : 5;
+    }
+    const int r = out_dtype == MSMD_F32 ? dispatch_gemm2s<float>(p, nz, st, variant)
+                                        : dispatch_gemm2s<f16_t>(p, nz, st, variant);
+    return r >= 0 ? r : 1;
+  }
   const int E = in_dtype == MSMD_F32 ? 4 : 8;
   if (K % E || lda % E || ldw % E || a_batch_stride % E || strideA % E || strideW % E || strideA2 % E || strideW2 % E)
     return 1;

@@ -27,12 +27,13 @@ template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, const float*
 }
 
 // cols % 4 == 0, cols <= 4 * 64 * MAXC
-template <typename TI, typename TO, int MAXC>
+// SPLIT2: additionally (y may then be NULL) write the row in MSMD_F16X2 split storage to y2 (cols % 32 == 0)
+template <typename TI, typename TO, int MAXC, bool SPLIT2 = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, const TI* __restrict__ res,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         const float* __restrict__ post, TO* __restrict__ y, int rows,
-                                                        int cols, float eps, int act) {
+                                                        int cols, float eps, int act, f16_t* __restrict__ y2 = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] += pa[e];
       }
-      store4<TO>(y + (long)row * cols + c * 4, o);
+      if (!SPLIT2 || y) store4<TO>(y + (long)row * cols + c * 4, o);
+      if constexpr (SPLIT2) store4_split(y2 + (long)row * 2 * cols, c * 4, o);
     }
   }
 }
@@ -111,6 +113,29 @@ static int launch_ln(const void* x, const void* res, const float* g, const float
   else if (cols <= 4 * 64 * 16)
     hipLaunchKernelGGL((layernorm_kernel<TI, TO, 16>), grid, block, 0, st, (const TI*)x, (const TI*)res, g, b, post,
                        (TO*)y, rows, cols, eps, act);
+  else
+    return 1;
+  MSMD_RETURN_LAST();
+}
+
+// fp32 in; y (fp32, may be NULL) and / or y2 (split storage): the LayerNorm output is both the next GEMM's A operand
+// (split) and the residual of the block after it (fp32) -- one pass writes both.
+extern "C" int msmd_layernorm_f16x2(const float* x, const float* residual, const float* gamma, const float* beta,
+                                    const float* post_add, float* y, void* y_split, int rows, int cols, float eps,
+                                    int act, msmd_stream_t stream) {
+  if (rows <= 0 || cols <= 0 || (cols & 31) || !x || !y_split || !gamma || !beta || ((uintptr_t)y_split & 15)) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((rows + 3) / 4), block(256);
+  f16_t* y2 = (f16_t*)y_split;
+  if (cols <= 4 * 64 * 2)
+    hipLaunchKernelGGL((layernorm_kernel<float, float, 2, true>), grid, block, 0, st, x, residual, gamma, beta, post_add,
+                       y, rows, cols, eps, act, y2);
+  else if (cols <= 4 * 64 * 4)
+    hipLaunchKernelGGL((layernorm_kernel<float, float, 4, true>), grid, block, 0, st, x, residual, gamma, beta, post_add,
+                       y, rows, cols, eps, act, y2);
+  else if (cols <= 4 * 64 * 16)
+    hipLaunchKernelGGL((layernorm_kernel<float, float, 16, true>), grid, block, 0, st, x, residual, gamma, beta,
+                       post_add, y, rows, cols, eps, act, y2);
   else
     return 1;
   MSMD_RETURN_LAST();

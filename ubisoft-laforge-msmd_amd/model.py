@@ -25,9 +25,18 @@ def _cd(args) -> torch.dtype:
         return torch.bfloat16
     if name in ("fp32", "float32", torch.float32):
         return torch.float32
+    if name in ("f16x2", "split"):   # parity-grade speed mode: fp32 activations in HBM, contractions on split pairs
+        return torch.float32
     if name in ("fp16", "float16", "half", torch.float16):   # inference only: the training kernels are bf16 / fp32
         return torch.float16
     raise ValueError(f"Unknown compute dtype {name}!")
+
+
+def _is_split(args) -> bool:
+    """compute_dtype "f16x2": fp32-grade results (reference arithmetic is fp32, training_script.py:548-551) at 1/3 of
+    the f16 MFMA rate -- every contraction runs on MSMD_F16X2 split pairs (three f16 MFMAs per k-step), everything
+    else (LayerNorm, softmax, GELU, residuals) in fp32 exactly as in the "fp32" parity mode."""
+    return getattr(args, "compute_dtype", "bf16") in ("f16x2", "split")
 
 
 def get_diffusion_model(args, device="cuda"):
@@ -141,6 +150,7 @@ class DenoisingNetwork_MSMD(nn.Module):
         self.n_motions = args.n_motions
         self.n_diff_steps = args.n_diff_steps
         self.compute_dtype = _cd(args)
+        self.split_mode = _is_split(args)
         if self.architecture != "decoder":
             raise ValueError(f"Unknown architecture: {self.architecture}")
         if self.feature_dim // self.n_heads != 64:
@@ -188,20 +198,22 @@ class DenoisingNetwork_MSMD(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def pack(self, dtype):
-        if self._packed is not None and self._packed_dtype == dtype:
+        split = bool(getattr(self, "split_mode", False)) and dtype == torch.float32
+        if self._packed is not None and self._packed_dtype == (dtype, split):
             return self._packed
         sd = {k: v.detach() for k, v in self.state_dict().items()}
         d, nb, dm = self.feature_dim, self.num_of_basis, self.motion_feat_dim
         f32 = lambda t: t.float().contiguous()
-        cd = lambda t: t.to(dtype).contiguous()
+        cd = (lambda t: ops.to_split(t.float().contiguous())) if split else (lambda t: t.to(dtype).contiguous())
 
-        def padk(w, mult=8):
+        def padk(w, mult=32 if split else 8):
             K = w.shape[1]
             Kp = (K + mult - 1) // mult * mult
             out = torch.zeros(w.shape[0], Kp, device=w.device, dtype=torch.float32)
             out[:, :K] = w.float()
             return cd(out)
         P = SimpleNamespace()
+        P.split = split
         P.te = f32(sd["TE.pe"][0])
         if self.use_learnable_pe:
             P.pe = f32(sd["PE"][0])
@@ -226,6 +238,7 @@ class DenoisingNetwork_MSMD(nn.Module):
             L.sa_ow, L.sa_ob = cd(sd[p + "self_attn.out_proj.weight"]), f32(sd[p + "self_attn.out_proj.bias"])
             w, b = sd[p + "multihead_attn.in_proj_weight"], sd[p + "multihead_attn.in_proj_bias"]
             L.ca_qw, L.ca_qb = cd(w[:d]), f32(b[:d])
+            L.ca_qw_valu = f32(w[:d]) if split else L.ca_qw   # person_query_attention multiplies on the vector ALU
             L.ca_kvw, L.ca_kvb = cd(w[d:]), f32(b[d:])
             L.ca_ow, L.ca_ob = cd(sd[p + "multihead_attn.out_proj.weight"]), f32(sd[p + "multihead_attn.out_proj.bias"])
             L.l1 = (cd(sd[p + "linear1.weight"]), f32(sd[p + "linear1.bias"]))
@@ -241,7 +254,7 @@ class DenoisingNetwork_MSMD(nn.Module):
                  f32(torch.cat([sd[f"static_feature_mapping.{b}.0.bias"] for b in range(nb)], 0)))
         P.st2 = (cd(torch.stack([sd[f"static_feature_mapping.{b}.2.weight"] for b in range(nb)], 0)),
                  f32(torch.stack([sd[f"static_feature_mapping.{b}.2.bias"] for b in range(nb)], 0)))
-        self._packed, self._packed_dtype = P, dtype
+        self._packed, self._packed_dtype = P, (dtype, split)
         return P
 
     # ------------------------------------------------------------------ pieces (shared with the sampler)
@@ -282,6 +295,8 @@ class DenoisingNetwork_MSMD(nn.Module):
             N, Tk, _ = kv.shape
             R = torch.empty(N, Tk + 1, d, device=kv.device, dtype=dtype)
             v = kv[..., d:]
+            if P.split:
+                v = ops.to_split(kv)[..., d:]   # same (N, Tk, 2d) layout in split storage, then the V half
             # one batched launch (batch = sequence) writes straight into rows 1.. of every sequence
             ops.gemm(v, L.ca_ow, L.ca_ob, None, ops.ACT_NONE, out=R[:, 1:, :], M=Tk, N=d, K=d, lda=2 * d, ldc=d, batch=N,
                      strideA=Tk * 2 * d, strideW=0, strideC=(Tk + 1) * d)
@@ -297,6 +312,8 @@ class DenoisingNetwork_MSMD(nn.Module):
         x = ops.gemm(feats, *P.fp)
         ops.add_pe_token(x, P.pe, tok0, row0_add)
         scale = (d // H) ** -0.5
+        if P.split:
+            return self._trunk_split(P, x, mem, kv_list, cross_list, scale)
         # the fast path pays when R is hoisted over many calls (the sampler passes cross_list); for a single forward
         # the general masked kernels are as fast (measured 5.37 vs 5.46 ms on the bench step), so it stays opt-in there
         diag = P.diag and getattr(self, "diag_fast_path", True) and (cross_list is not None or
@@ -316,7 +333,7 @@ class DenoisingNetwork_MSMD(nn.Module):
                 # same-box A/B in the sampler graph: fused -1 % at N = 192 sequences, +1.5 % at N = 3 (a longer serial
                 # chain per wave than the two more parallel launches), so it is used from 64 sequences up
                 if getattr(self, "fused_person_query", N >= 64):
-                    a0 = ops.person_query_attention(x, L.ca_qw, L.ca_qb, kv, H, scale)           # (N, d), one launch
+                    a0 = ops.person_query_attention(x, L.ca_qw_valu, L.ca_qb, kv, H, scale)      # (N, d), one launch
                 else:
                     q0 = ops.gemm(x, L.ca_qw, L.ca_qb, M=N, K=d, lda=Tn * d)                    # (N, d) from x[:, 0]
                     a0 = ops.attention(q0.view(N, 1, d), kv[..., :d], kv[..., d:], H, scale)     # (N, 1, d)
@@ -331,7 +348,44 @@ class DenoisingNetwork_MSMD(nn.Module):
         # motion_dec on rows 1.. (windowed view of x, no copy)
         Lm = Tn - 1
         h = torch.empty(N, Lm, d // 2, device=x.device, dtype=dtype)
-        ops.gemm(x[:, 1:], *P.md0, None, ops.ACT_GELU, out=h, M=N * Lm, K=d, lda=d, rows_per_batch=Lm,
+        xs = ops.to_split(x) if P.split else x
+        ops.gemm(xs[:, 1:], *P.md0, None, ops.ACT_GELU, out=h, M=N * Lm, K=d, lda=d, rows_per_batch=Lm,
+                 a_batch_stride=Tn * d)
+        return ops.gemm(h, *P.md2, out_dtype=torch.float32)
+
+    def _trunk_split(self, P, x, mem, kv_list, cross_list, scale):
+        """The decoder layers + motion_dec head of `trunk` in the parity-grade speed mode (x: fp32 (N, Tn, d) after the
+        PE / token add).  LayerNorms write fp32 (residual) and split (next GEMM operand) rows in one pass; Q / K / V,
+        attention outputs and the FFN hidden layer move between kernels in split storage.  With the diagonal mask and a
+        hoisted cross_list (sampler) only the person row runs a real cross-attention, as in the other modes."""
+        d, H = self.feature_dim, self.n_heads
+        N, Tn, _ = x.shape
+        diag = P.diag and getattr(self, "diag_fast_path", True) and cross_list is not None
+        xs = ops.to_split(x)
+        mem_s = None
+        for li, L in enumerate(P.layers):
+            qkv = ops.gemm(xs, L.sa_w, L.sa_b, out_dtype=ops.SPLIT)
+            a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale)
+            x, xs = ops.layernorm(ops.gemm(a, L.sa_ow, L.sa_ob, residual=x), *L.n1, split="both")
+            if diag:
+                R, kv = cross_list[li], kv_list[li]                                      # fp32 R (N, Tn, d); kv fp32
+                a0 = ops.person_query_attention(x, L.ca_qw_valu, L.ca_qb, kv, H, scale)   # (N, d) fp32, vector ALU
+                ops.gemm(a0, L.ca_ow, L.ca_ob, None, ops.ACT_NONE, out=R, M=N, K=d, ldc=Tn * d)
+                x, xs = ops.layernorm(x, *L.n2, residual=R, split="both")
+            else:
+                if kv_list is not None:
+                    kv = ops.to_split(kv_list[li])
+                else:
+                    mem_s = ops.to_split(mem) if mem_s is None else mem_s
+                    kv = ops.gemm(mem_s, L.ca_kvw, L.ca_kvb, out_dtype=ops.SPLIT)
+                q = ops.gemm(xs, L.ca_qw, L.ca_qb, out_dtype=ops.SPLIT)
+                c = ops.attention(q, kv[..., :d], kv[..., d:], H, scale, mask=P.mask)
+                x, xs = ops.layernorm(ops.gemm(c, L.ca_ow, L.ca_ob, residual=x), *L.n2, split="both")
+            f = ops.gemm(xs, *L.l1, act=ops.ACT_GELU, out_dtype=ops.SPLIT)
+            x, xs = ops.layernorm(ops.gemm(f, *L.l2, residual=x), *L.n3, split="both")
+        Lm = Tn - 1
+        h = ops.empty((N, Lm, d // 2), x.device, ops.SPLIT)
+        ops.gemm(xs[:, 1:], *P.md0, None, ops.ACT_GELU, out=h, M=N * Lm, K=d, lda=d, rows_per_batch=Lm,
                  a_batch_stride=Tn * d)
         return ops.gemm(h, *P.md2, out_dtype=torch.float32)
 
@@ -384,6 +438,7 @@ class MSMD(nn.Module):
         self.n_motions = args.n_motions
         self.n_prev_motions = args.n_prev_motions
         self.compute_dtype = _cd(args)
+        self.split_mode = _is_split(args)
         if self.use_style:
             self.style_feat_dim = args.d_style
         self.audio_model = args.audio_model
@@ -432,6 +487,7 @@ class MSMD(nn.Module):
         if "audio" in self.guiding_conditions:
             self.null_audio_feat = nn.Parameter(torch.zeros(1, 1, args.feature_dim))
         synth.load_synthetic(self)  # deterministic init (no pretrained assets offline); checkpoints overwrite it
+        self.audio_encoder.split_mode = self.split_mode
         self._afm = None
         self.to(device)
 
@@ -448,13 +504,18 @@ class MSMD(nn.Module):
         return super()._load_from_state_dict(state_dict, prefix, *a, **k)
 
     def set_compute_dtype(self, dtype):
-        self.compute_dtype = _cd(SimpleNamespace(compute_dtype=dtype))
+        ns = SimpleNamespace(compute_dtype=dtype)
+        self.compute_dtype = _cd(ns)
+        self.split_mode = _is_split(ns)
         self.denoising_net.compute_dtype = self.compute_dtype
+        self.denoising_net.split_mode = self.audio_encoder.split_mode = self.split_mode
         return self
 
     def _afm_packed(self, dtype):
-        if self._afm is None or self._afm[0] != dtype:
-            self._afm = (dtype, self.audio_feature_map.weight.detach().to(dtype).contiguous(),
+        split = self.split_mode and dtype == torch.float32
+        if self._afm is None or self._afm[0] != (dtype, split):
+            w = self.audio_feature_map.weight.detach()
+            self._afm = ((dtype, split), ops.to_split(w.float().contiguous()) if split else w.to(dtype).contiguous(),
                          self.audio_feature_map.bias.detach().float().contiguous())
         return self._afm[1], self._afm[2]
 

@@ -14,7 +14,109 @@ import torch
 
 from . import _lib
 
-F32, BF16, F16 = 0, 1, 2
+F32, BF16, F16, F16X2 = 0, 1, 2, 3
+SPLIT = "f16x2"   # dtype token of the parity-grade speed mode (MSMD_F16X2 split storage, include/msmd_hip.h)
+
+
+class Split:
+    """A tensor in MSMD_F16X2 split storage: logical shape (..., C) fp32-grade values, physically `.t` = (..., 2 C)
+    fp16 in 32-element blocks [hi x 32 | lo x 32] (x ~= hi + lo / 2048).  Only what the call sites need: logical shape /
+    strides, slicing (last-dim slices on multiples of 32), the device pointer.  `.float()` converts back."""
+    __slots__ = ("t",)
+    dtype = SPLIT
+    is_cuda = True
+
+    def __init__(self, t):
+        if t.dtype != torch.float16 or t.shape[-1] % 64 or t.stride(-1) != 1:
+            raise TypeError("Split wraps an fp16 tensor whose last dim is 2 x (a multiple of 32)")
+        self.t = t
+
+    @property
+    def shape(self):
+        return torch.Size((*self.t.shape[:-1], self.t.shape[-1] // 2))
+
+    @property
+    def device(self):
+        return self.t.device
+
+    def dim(self):
+        return self.t.dim()
+
+    def numel(self):
+        return self.t.numel() // 2
+
+    def stride(self, i):
+        i = i % self.t.dim()
+        return 1 if i == self.t.dim() - 1 else self.t.stride(i) // 2
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+    def is_contiguous(self):
+        return self.t.is_contiguous()
+
+    def __getitem__(self, idx):
+        if not isinstance(idx, tuple):
+            idx = (idx,)
+        if Ellipsis in idx:
+            k = idx.index(Ellipsis)
+            idx = idx[:k] + (slice(None),) * (self.t.dim() - (len(idx) - 1)) + idx[k + 1:]
+        if len(idx) == self.t.dim():
+            last = idx[-1]
+            if not isinstance(last, slice) or last.step not in (None, 1):
+                raise IndexError("Split: only contiguous slices along the last dim")
+            C = self.shape[-1]
+            a, b, _ = last.indices(C)
+            if a % 32 or (b % 32 and b != C):
+                raise IndexError("Split: last-dim slices must fall on multiples of 32")
+            idx = idx[:-1] + (slice(2 * a, 2 * b),)
+        return Split(self.t[idx])
+
+    def view(self, *shape):
+        shape = shape[0] if len(shape) == 1 and not isinstance(shape[0], int) else shape
+        return Split(self.t.view(*shape[:-1], 2 * shape[-1]))
+
+    reshape = view
+
+    def float(self):
+        return unsplit(self)
+
+
+def empty(shape, device, dtype):
+    """torch.empty that understands the SPLIT token (last dim must then be a multiple of 32)."""
+    if dtype == SPLIT:
+        if shape[-1] % 32:
+            raise ValueError("split storage needs a last dim that is a multiple of 32")
+        return Split(torch.empty(*shape[:-1], 2 * shape[-1], device=device, dtype=torch.float16))
+    return torch.empty(*shape, device=device, dtype=dtype)
+
+
+def to_split(x, cols_out=None):
+    """fp32 (..., C) -> Split (..., cols_out) (zero-padded to a multiple of 32); rows may be strided (last dim
+    contiguous, uniform row stride)."""
+    if isinstance(x, Split):
+        return x
+    _need_cuda(x)
+    if x.dtype != torch.float32:
+        x = x.float()
+    C = x.shape[-1]
+    cols_out = (C + 31) // 32 * 32 if cols_out is None else cols_out
+    if not x.is_contiguous():
+        x = x.contiguous()
+    rows = x.numel() // C
+    out = torch.empty(*x.shape[:-1], 2 * cols_out, device=x.device, dtype=torch.float16)
+    _lib.check(_lib.load().msmd_split_f16x2(_p(x), _p(out), rows, C, C, cols_out, _stream()), "msmd_split_f16x2")
+    return Split(out)
+
+
+def unsplit(s, cols=None):
+    C = s.shape[-1]
+    cols = C if cols is None else cols
+    t = s.t if s.t.is_contiguous() else s.t.contiguous()
+    rows = t.numel() // (2 * C)
+    out = torch.empty(*s.shape[:-1], cols, device=t.device, dtype=torch.float32)
+    _lib.check(_lib.load().msmd_unsplit_f16x2(_p(t), _p(out), rows, cols, C, cols, _stream()), "msmd_unsplit_f16x2")
+    return out
 ACT_NONE, ACT_GELU, ACT_ELU = 0, 1, 2
 CONV0_SPLITS = 16
 
@@ -24,6 +126,8 @@ GEMM_TRACE = None
 
 
 def _dt(t: torch.Tensor) -> int:
+    if t.dtype == SPLIT:
+        return F16X2
     if t.dtype == torch.float32:
         return F32
     if t.dtype == torch.bfloat16:
@@ -43,6 +147,8 @@ def _stream():
 
 def _need_cuda(*ts):
     for t in ts:
+        if isinstance(t, Split):
+            t = t.t
         if t is not None and not t.is_cuda:
             raise RuntimeError("msmd_amd ops need tensors on the MI355X (cuda) device; there is no CPU path")
 
@@ -88,6 +194,16 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
     w: (N, K) (or (batch, N, K) with strideW).  Returns C with a's leading dims + (N,)."""
     _need_cuda(a, w, bias, residual)
     lib = _lib.load()
+    if isinstance(w, Split) and not isinstance(a, Split):
+        # parity-grade speed mode with an fp32 producer: convert here (hot producers hand over Split tensors directly).
+        # Only whole contiguous tensors: the caller's lda / strides describe the ORIGINAL layout.
+        if not a.is_contiguous() or a.shape[-1] % 32:
+            raise ValueError("split GEMM: pass a contiguous fp32 tensor with a last dim % 32 == 0, or a Split")
+        a = to_split(a)
+    if isinstance(a, Split) and not isinstance(w, Split):
+        raise TypeError("split activations need split weights")
+    if isinstance(a, Split) and out_dtype is None and out is None:
+        out_dtype = torch.float32
     if K is None:
         K = a.shape[-1]
     if M is None:
@@ -101,7 +217,7 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
     out_dtype = out_dtype or a.dtype
     if out is None:
         lead = a.shape[:-1] if a.numel() // a.shape[-1] == M and batch == 1 else (M,)
-        out = torch.empty(*lead, N, device=a.device, dtype=out_dtype)
+        out = empty((*lead, N), a.device, out_dtype)
     if ldc is None:
         ldc = N
     ldr = residual.stride(-2) if residual is not None and residual.dim() >= 2 else N
@@ -169,18 +285,28 @@ def conv1d_cl(x, w_packed, bias=None, *, kernel, stride, act=ACT_NONE, out_dtype
     w_packed: (Cout, kernel*C) with K index = kk*C + c."""
     B, T, C = x.shape
     T_out = (T - kernel) // stride + 1
-    out = torch.empty(B, T_out, w_packed.shape[0], device=x.device, dtype=out_dtype or x.dtype)
+    out = empty((B, T_out, w_packed.shape[0]), x.device, out_dtype or x.dtype)
     gemm(x, w_packed, bias, None, act, out=out, M=B * T_out, K=kernel * C, lda=stride * C, rows_per_batch=T_out,
          a_batch_stride=T * C)
     return out
 
 
-def layernorm(x, gamma, beta, residual=None, post_add=None, act=ACT_NONE, eps=1e-5, out_dtype=None, post_act=ACT_NONE):
-    """y = post_act(LayerNorm(act(x + residual)) * gamma + beta) + post_add."""
+def layernorm(x, gamma, beta, residual=None, post_add=None, act=ACT_NONE, eps=1e-5, out_dtype=None, post_act=ACT_NONE,
+              split=None):
+    """y = post_act(LayerNorm(act(x + residual)) * gamma + beta) + post_add.
+    split="both": returns (y fp32, y Split) from ONE pass; split="only": the Split alone (fp32 input, cols % 32 == 0)."""
     _need_cuda(x, gamma, beta)
     lib = _lib.load()
     cols = x.shape[-1]
     rows = x.numel() // cols
+    if split:
+        if x.dtype != torch.float32 or (residual is not None and residual.dtype != torch.float32):
+            raise TypeError("layernorm(split=...) takes fp32 input")
+        y = torch.empty(x.shape, device=x.device, dtype=torch.float32) if split == "both" else None
+        ys = empty(tuple(x.shape), x.device, SPLIT)
+        _lib.check(lib.msmd_layernorm_f16x2(_p(x), _p(residual), _p(gamma), _p(beta), _p(post_add), _p(y), _p(ys), rows,
+                                            cols, eps, act | (post_act << 8), _stream()), "msmd_layernorm_f16x2")
+        return (y, ys) if split == "both" else ys
     y = torch.empty(x.shape, device=x.device, dtype=out_dtype or x.dtype)
     _lib.check(lib.msmd_layernorm(_p(x), _p(residual), _p(gamma), _p(beta), _p(post_add), _p(y), rows, cols, eps,
                                   act | (post_act << 8),
@@ -201,13 +327,28 @@ def dropout(x, p, rng_state, site, residual=None, out=None):
     return out
 
 
-def attention(q, k, v, n_heads, scale, mask=None, out=None, p_drop=0.0, rng_state=None, site=0):
-    """q: (B, Tq, H*64) view, k/v: (B, Tk, H*64) views (last dim contiguous; may be slices of a packed QKV)."""
+def attention(q, k, v, n_heads, scale, mask=None, out=None, p_drop=0.0, rng_state=None, site=0, out_dtype=None):
+    """q: (B, Tq, H*64) view, k/v: (B, Tk, H*64) views (last dim contiguous; may be slices of a packed QKV).
+    Split q / k / v (parity-grade speed mode): msmd_attention_f16x2; out_dtype SPLIT (default) or torch.float32."""
     _need_cuda(q, k, v)
     lib = _lib.load()
     B, Tq, d = q.shape
     Tk = k.shape[1]
     assert d == n_heads * 64 and q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1
+    if isinstance(q, Split):
+        if not (isinstance(k, Split) and isinstance(v, Split)) or p_drop > 0.0:
+            raise TypeError("split attention: q, k, v must all be Split (inference only)")
+        if out is None:
+            out = empty((B, Tq, d), q.device, out_dtype or SPLIT)
+        m = None
+        if mask is not None:
+            assert mask.dtype in (torch.bool, torch.uint8) and mask.shape == (Tq, Tk) and mask.is_contiguous()
+            m = mask
+        _lib.check(lib.msmd_attention_f16x2(_p(q), _p(k), _p(v), _p(out), B, n_heads, Tq, Tk, q.stride(0), q.stride(1),
+                                            k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0),
+                                            out.stride(1), float(scale), _p(m), _dt(out), _stream()),
+                   "msmd_attention_f16x2")
+        return out
     if out is None:
         out = torch.empty(B, Tq, d, device=q.device, dtype=q.dtype)
     m = None
@@ -277,7 +418,7 @@ def conv0_gn_gelu(audio, w0, gamma, beta, reflect_len, replicate_len, out_dtype,
     ws = torch.empty(B, CONV0_SPLITS, 66, device=audio.device, dtype=torch.float32)
     _lib.check(lib.msmd_conv0_stats(_p(audio), _p(w0), _p(stats), _p(ws), B, L, reflect_len, replicate_len, C, eps,
                                     _stream()), "msmd_conv0_stats")
-    out = torch.empty(B, T0, C, device=audio.device, dtype=out_dtype)
+    out = empty((B, T0, C), audio.device, out_dtype)
     _lib.check(lib.msmd_conv0_gn_gelu(_p(audio), _p(w0), _p(stats), _p(gamma), _p(beta), _p(out), B, L, reflect_len,
                                       replicate_len, C, _dt(out), _stream()), "msmd_conv0_gn_gelu")
     return out
@@ -305,11 +446,16 @@ def interp_linear(x, t_out, t_crop=None):
     return y
 
 
-def group_pad(x, groups, pad):
+def group_pad(x, groups, pad, cg_out=None, split=False):
+    """(B, T, G*Cg) -> zero-padded group-major (B, G, T + 2 pad, cg_out >= Cg); split=True writes MSMD_F16X2 rows
+    (fp32 input, cg_out % 32 == 0)."""
     lib = _lib.load()
     B, T, C = x.shape
-    y = torch.empty(B, groups, T + 2 * pad, C // groups, device=x.device, dtype=x.dtype)
-    _lib.check(lib.msmd_group_pad(_p(x), _p(y), B, T, groups, C // groups, pad, _dt(x), _stream()), "msmd_group_pad")
+    cg = C // groups
+    cg_out = cg if cg_out is None else cg_out
+    y = empty((B, groups, T + 2 * pad, cg_out), x.device, SPLIT if split else x.dtype)
+    _lib.check(lib.msmd_group_pad(_p(x), _p(y), B, T, groups, cg, cg_out, pad, _dt(x), _dt(y), _stream()),
+               "msmd_group_pad")
     return y
 
 

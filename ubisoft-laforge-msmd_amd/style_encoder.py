@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from . import ops, shapes, synth
-from .model import _cd
+from .model import _cd, _is_split
 from .utils.model_common import ParamTree, sinusoid_table
 
 
@@ -38,6 +38,7 @@ class StyleEncoder_VAE2(nn.Module):
         self.conv_feature_dim = 512
         self.output_size = args.d_style * 2
         self.compute_dtype = _cd(args)
+        self.split_mode = _is_split(args)
         tree = ParamTree(shapes.style_encoder_shapes(args, self.input_dim, self.conv_feature_dim))
         for name, p in tree._parameters.items():
             self.register_parameter(name, p)
@@ -57,13 +58,15 @@ class StyleEncoder_VAE2(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def pack(self, dtype):
-        if self._packed is not None and self._packed_dtype == dtype:
+        split = bool(self.split_mode) and dtype == torch.float32
+        if self._packed is not None and self._packed_dtype == (dtype, split):
             return self._packed
         sd = {k: v.detach() for k, v in self.state_dict().items()}
         f32 = lambda t: t.float().contiguous()
-        cd = lambda t: t.to(dtype).contiguous()
+        cd = (lambda t: ops.to_split(t.float().contiguous())) if split else (lambda t: t.to(dtype).contiguous())
         P = SimpleNamespace()
-        self.cin_pad = (self.input_dim + 7) // 8 * 8
+        mult = 32 if split else 8
+        self.cin_pad = (self.input_dim + mult - 1) // mult * mult
 
         def conv_w(w, cpad=None):  # (Cout, Cin, 3) -> (Cout, 3*Cpad), K = kk*Cpad + c
             Cout, Cin, k = w.shape
@@ -85,7 +88,7 @@ class StyleEncoder_VAE2(nn.Module):
         P.c3 = (conv_w(sd["output_layers.1.weight"]), f32(sd["output_layers.1.bias"]))
         P.n3 = (f32(sd["output_layers.5.weight"]), f32(sd["output_layers.5.bias"]))
         P.c4 = (conv_w(sd["output_layers.7.weight"]), f32(sd["output_layers.7.bias"]))
-        self._packed, self._packed_dtype = P, dtype
+        self._packed, self._packed_dtype = P, (dtype, split)
         return P
 
     @staticmethod

@@ -138,6 +138,7 @@ class Wav2Vec2Model(nn.Module):
             self.add_module(name, m)
         self._packed = None
         self._packed_dtype = None
+        self.split_mode = False   # set by MSMD for compute_dtype "f16x2" (contractions on MSMD_F16X2 split pairs)
 
     @classmethod
     def from_pretrained(cls, name=None, cache_dir=None, **kw):
@@ -157,13 +158,15 @@ class Wav2Vec2Model(nn.Module):
 
     # ------------------------------------------------------------------ weight packing (load time)
     def pack(self, dtype):
-        if self._packed is not None and self._packed_dtype == dtype:
+        split = bool(self.split_mode) and dtype == torch.float32
+        if self._packed is not None and self._packed_dtype == (dtype, split):
             return self._packed
         c = self.config
         sd = {k: v.detach() for k, v in self.state_dict().items()}
         P = SimpleNamespace()
+        P.split = split
         f32 = lambda t: t.float().contiguous()
-        cd = lambda t: t.to(dtype).contiguous()
+        cd = (lambda t: ops.to_split(t.float().contiguous())) if split else (lambda t: t.to(dtype).contiguous())
         fe = "feature_extractor.conv_layers."
         P.w0 = f32(sd[fe + "0.conv.weight"].reshape(c.conv_dim, CONV_KERNEL[0]))
         P.gn_g, P.gn_b = f32(sd[fe + "0.layer_norm.weight"]), f32(sd[fe + "0.layer_norm.bias"])
@@ -182,7 +185,11 @@ class Wav2Vec2Model(nn.Module):
         G = c.num_conv_pos_embedding_groups
         cg = c.hidden_size // G
         kpos = c.num_conv_pos_embeddings
-        P.pos_w = cd(w.reshape(G, cg, cg, kpos).permute(0, 1, 3, 2).reshape(G, cg, kpos * cg))  # K = kk*cg + ci
+        # split storage keeps 32-element blocks whole, so the per-group channel count is zero-padded 48 -> 64 there
+        P.pos_cg = (cg + 31) // 32 * 32 if split else cg
+        wp = torch.zeros(G, cg, kpos, P.pos_cg, device=w.device, dtype=torch.float32)
+        wp[..., :cg] = w.reshape(G, cg, cg, kpos).permute(0, 1, 3, 2)
+        P.pos_w = cd(wp.reshape(G, cg, kpos * P.pos_cg))  # K = kk*cg_pad + ci
         P.pos_b = f32(sd["encoder.pos_conv_embed.conv.bias"])
         P.enc_ln = (f32(sd["encoder.layer_norm.weight"]), f32(sd["encoder.layer_norm.bias"]))
         P.layers = []
@@ -197,7 +204,7 @@ class Wav2Vec2Model(nn.Module):
             L.w2, L.b2 = cd(sd[p + "feed_forward.output_dense.weight"]), f32(sd[p + "feed_forward.output_dense.bias"])
             L.ln2 = (f32(sd[p + "final_layer_norm.weight"]), f32(sd[p + "final_layer_norm.bias"]))
             P.layers.append(L)
-        self._packed, self._packed_dtype = P, dtype
+        self._packed, self._packed_dtype = P, (dtype, split)
         return P
 
     # ------------------------------------------------------------------ forward pieces
@@ -216,6 +223,16 @@ class Wav2Vec2Model(nn.Module):
                 z = ops.conv1d_cl(x, w, P.conv_b[i + 1], kernel=CONV_KERNEL[i + 1], stride=CONV_STRIDE[i + 1])
                 x = ops.layernorm(z, *P.conv_ln[i + 1], post_act=ops.ACT_GELU, eps=eps)
             return x
+        if P.split:
+            # parity-grade speed mode: the stack's activations stay in split storage between the convs (conv0 and
+            # every GEMM epilogue write [hi | lo] rows), the last conv hands fp32 to the crop / resample / LayerNorm
+            x = ops.conv0_gn_gelu(audio.float().contiguous(), P.w0, P.gn_g, P.gn_b, reflect_len, replicate_len,
+                                  ops.SPLIT, eps)
+            for i, w in enumerate(P.conv_w):
+                last = i == len(P.conv_w) - 1
+                x = ops.conv1d_cl(x, w, P.conv_b[i + 1], kernel=CONV_KERNEL[i + 1], stride=CONV_STRIDE[i + 1],
+                                  act=ops.ACT_GELU, out_dtype=torch.float32 if last else ops.SPLIT)
+            return x
         x = ops.conv0_gn_gelu(audio.float().contiguous(), P.w0, P.gn_g, P.gn_b, reflect_len, replicate_len, dtype, eps)
         for i, w in enumerate(P.conv_w):
             x = ops.conv1d_cl(x, w, P.conv_b[i + 1], kernel=CONV_KERNEL[i + 1], stride=CONV_STRIDE[i + 1],
@@ -229,15 +246,18 @@ class Wav2Vec2Model(nn.Module):
         B, T, _ = x.shape
         H = c.num_attention_heads
         d = c.hidden_size
+        if P.split and not c.do_stable_layer_norm:
+            return self._encode_features_split(x, P)
         h = ops.layernorm(x, *P.fp_ln, eps=c.layer_norm_eps)
         h = ops.gemm(h, P.fp_w, P.fp_b)
         # positional grouped conv (k=128, pad=64, drop last frame) as G windowed GEMMs + GELU + residual
         G, cg, kpos = c.num_conv_pos_embedding_groups, d // c.num_conv_pos_embedding_groups, c.num_conv_pos_embeddings
-        xp = ops.group_pad(h, G, kpos // 2)  # (B, G, T + kpos, cg)
+        cgp = P.pos_cg
+        xp = ops.group_pad(h, G, kpos // 2, cg_out=cgp, split=P.split)  # (B, G, T + kpos, cgp)
         Tp = T + kpos
         y = torch.empty_like(h)
-        ops.gemm(xp, P.pos_w, P.pos_b, h, ops.ACT_GELU, out=y, M=B * T, N=cg, K=kpos * cg, lda=cg, rows_per_batch=T,
-                 a_batch_stride=G * Tp * cg, ldw=kpos * cg, ldc=d, batch=G, strideA=Tp * cg, strideW=cg * kpos * cg,
+        ops.gemm(xp, P.pos_w, P.pos_b, h, ops.ACT_GELU, out=y, M=B * T, N=cg, K=kpos * cgp, lda=cgp, rows_per_batch=T,
+                 a_batch_stride=G * Tp * cgp, ldw=kpos * cgp, ldc=d, batch=G, strideA=Tp * cgp, strideW=cg * kpos * cgp,
                  strideC=cg, strideBias=cg, strideR=cg)
         if c.do_stable_layer_norm:
             # HubertEncoderStableLayerNorm: pre-LN blocks, ONE LayerNorm after the last layer
@@ -256,6 +276,37 @@ class Wav2Vec2Model(nn.Module):
             h = ops.layernorm(ops.gemm(a, L.wo, L.bo, residual=h), *L.ln1, eps=c.layer_norm_eps)
             f = ops.gemm(h, L.w1, L.b1, act=ops.ACT_GELU)
             h = ops.layernorm(ops.gemm(f, L.w2, L.b2, residual=h), *L.ln2, eps=c.layer_norm_eps)
+        return h
+
+    def _encode_features_split(self, x, P):
+        """encode_features (post-LN encoder) in the parity-grade speed mode.  Data flow per layer: LayerNorm writes the
+        row twice in one pass (fp32 = the next residual, split = the next GEMM's A operand); the QKV GEMM writes split
+        Q / K / V, the split attention writes split O, the FFN's GELU output goes GEMM -> GEMM in split storage; every
+        residual add and LayerNorm input stays fp32.  No standalone conversion pass."""
+        c = self.config
+        B, T, _ = x.shape
+        H, d, eps = c.num_attention_heads, c.hidden_size, c.layer_norm_eps
+        h = ops.gemm(ops.layernorm(x, *P.fp_ln, eps=eps, split="only"), P.fp_w, P.fp_b)          # fp32 (B, T, d)
+        G, cg, kpos = c.num_conv_pos_embedding_groups, d // c.num_conv_pos_embedding_groups, c.num_conv_pos_embeddings
+        cgp = P.pos_cg
+        xp = ops.group_pad(h, G, kpos // 2, cg_out=cgp, split=True)
+        Tp = T + kpos
+        y = torch.empty_like(h)
+        ops.gemm(xp, P.pos_w, P.pos_b, h, ops.ACT_GELU, out=y, M=B * T, N=cg, K=kpos * cgp, lda=cgp, rows_per_batch=T,
+                 a_batch_stride=G * Tp * cgp, ldw=kpos * cgp, ldc=d, batch=G, strideA=Tp * cgp, strideW=cg * kpos * cgp,
+                 strideC=cg, strideBias=cg, strideR=cg)
+        h, hs = ops.layernorm(y, *P.enc_ln, eps=eps, split="both")
+        scale = (d // H) ** -0.5
+        for li, L in enumerate(P.layers):
+            qkv = ops.gemm(hs, L.wqkv, L.bqkv, out_dtype=ops.SPLIT)
+            a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale)           # split out
+            h, hs = ops.layernorm(ops.gemm(a, L.wo, L.bo, residual=h), *L.ln1, eps=eps, split="both")
+            f = ops.gemm(hs, L.w1, L.b1, act=ops.ACT_GELU, out_dtype=ops.SPLIT)
+            t = ops.gemm(f, L.w2, L.b2, residual=h)
+            if li + 1 < len(P.layers):
+                h, hs = ops.layernorm(t, *L.ln2, eps=eps, split="both")
+            else:
+                h = ops.layernorm(t, *L.ln2, eps=eps)
         return h
 
     def encode(self, audio, output_fps=25, frame_num=None, dtype=torch.bfloat16, pad=True):
