@@ -1,24 +1,36 @@
 #!/usr/bin/env python3
-"""Headline benchmark: motion frames/s of the audio -> motion-coefficient forward on MI355X.
+"""Headline benchmark: motion frames/s of the audio -> motion-coefficient hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): one step = MSMD.forward on a batch of 32 synthetic 4 s / 16 kHz clips
-(raw audio -> wav2vec2-base encoder -> audio_feature_map -> q-sample -> 8-layer denoiser -> heads), bf16
-storage with fp32 accumulation, eval-mode arithmetic, random-init (closed-form synthetic) weights.
-100 motion frames per clip, so one step produces 3200 frames per GPU.  N > 1: one process per GPU,
-clips are independent (no data-path collective), weak scaling.
+Workload of `value` (BASELINE.json configs[1]): one step = MSMD.forward on a batch of 32 synthetic 4 s / 16 kHz clips
+(raw audio -> wav2vec2-base encoder -> audio_feature_map -> q-sample -> 8-layer denoiser -> heads), bf16 storage with
+fp32 accumulation, eval-mode arithmetic, closed-form synthetic weights.  100 motion frames per clip, 3200 frames per
+GPU and step.  N > 1: one process per GPU (RCCL), clips are independent (no data-path collective), weak scaling.
+`python bench.py --gpus N` without WORLD_SIZE in the environment starts the N ranks itself (torch.distributed.run,
+from a parent that never touches the GPU) and relays rank 0's line; `n_gpus` is what torch.distributed saw.
 
-Prints ONE JSON line (rank 0) with the contract fields plus:
-  roofline     -- the dominant kernel (bf16 MFMA GEMM, csrc/gemm.hip, 128x128 tile): algorithmic FLOPs
-                  (2*M*N*K per launch, summed over the launches of one step) / their summed durations, measured
-                  live with HIP events on the launch stream in a separate traced pass.
-  cpu_baseline -- the numpy oracle (a parity-checked port of the reference's CPU path) timed on this host's
-                  cores on a bounded sample of the same workload.
+One JSON line (rank 0) with the contract fields plus
+  max_abs_err_vs_oracle  the headline dtype's output against the CPU restatement of the reference on ALL clips of the
+                         batch (the reference's tolerance is 1e-4: bf16 does not meet it, it is the throughput mode);
+  parity_mode            the modes that DO meet 1e-4, each timed the same way: "f16x2" (contractions on fp16 split
+                         pairs, three MFMAs per k-step: the parity-grade speed mode) and "fp32" (exact-fp32 MFMA), with
+                         ms_per_step, frames_per_s, max_abs_err_vs_oracle and the dominant kernel's roofline;
+  roofline               dominant kernel of the headline mode: algorithmic FLOPs / launch durations measured live with
+                         HIP events on the launch stream; the event pair's overhead is calibrated in-run on a kernel of
+                         known duration (msmd_spin_us), NOT assumed; profiles/ holds the rocprofv3 summary of this command;
+  legs                   the other BASELINE configs, measured in this run: sampler (B=64, T=500, 3 CFG entries, fp16,
+                         hipGraph) + LBS (6400 / 25600 frames, HBM fraction), training step (B=32), HuBERT-large 10 s clips;
+  cpu_baseline           oracle/torch_cpu.py (torch-CPU restatement of the reference's fp32 path, pinned to the same
+                         reference goldens as the numpy oracle) on this host's cores: median of 5 after 2 warm-ups.
+`--mode train` times the configs[2] step instead (local batch 32 x 2 windows: fwd + bwd + bucketed gradient all-reduce +
+fused Adam) and adds allreduce_ms / overlap_frac.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,14 +39,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
+import torch  # noqa: E402  (importing torch does not initialise the GPU)
 
-PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
-FLOP_PER_FRAME = 0.6512e9  # MSMD.forward from raw audio = 65.12 GFLOP / 100-frame clip
+PEAK_MFMA_TFLOPS = 2500.0   # dense bf16 / f16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_F32_TFLOPS = 157.3     # v_mfma_f32_16x16x4_f32 (same table)
+PEAK_HBM_GBS = 8000.0
+FLOP_PER_FRAME = 0.6512e9   # MSMD.forward from raw audio = 65.12 GFLOP per 100-frame clip
+DENOISER_FLOP = 7.886e9     # per call and sequence
+TRAIN_FLOP_PER_SAMPLE = 317e9
+HUBERT_LARGE_FLOP_PER_CLIP = 384e9
+LBS_BYTES_PER_FRAME = 60936
 
 
+# ----------------------------------------------------------------------------------------------- workload
 def synth_batch(B, rank, device):
-    """SURVEY.md section 8(d) inputs: z-normalised pseudo-gaussian audio, motion, zero shape, style, ones indicator."""
+    """SURVEY.md 8(d) inputs: z-normalised pseudo-gaussian audio, motion, zero shape, style, ones indicator."""
     from msmd_amd import synth
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
     return dict(
@@ -54,13 +73,9 @@ def step(model, b):
 
 
 def graphed_step(model, b):
-    """The step as ONE hipGraph replay (MSMD.capture_forward): static shapes, so the ~300 launches are captured once
-    and re-issued by the GPU's command processor (host-side launch jitter -- 8 ranks share one host in the scaling
-    runs -- no longer shows up in the step time).  Every replay runs all kernels on inputs refreshed by
-    device-to-device copies into the captured buffers (new data arriving in HBM); capture_forward checks a replay on
-    perturbed inputs against the eager forward, bit for bit.
-    (Capturing the batch as two concurrent sub-batch branches looked 4 % faster but replayed one branch against stale
-    buffers -- a multi-stream capture hazard -- and two independent graphs on two streams gain nothing: not used.)"""
+    """The step as ONE hipGraph replay (MSMD.capture_forward): static shapes, every replay runs all kernels on inputs
+    refreshed by device-to-device copies into the captured buffers; capture_forward checks a replay on perturbed inputs
+    against the eager forward, bit for bit."""
     ts = torch.tensor(b["time_step"], device=b["audio"].device, dtype=torch.long)
     run = model.capture_forward(b["motion"], b["audio"], b["shape"], b["style"], ts, b["indicator"], b["eps"])
     fresh = dict(motion_feat=b["motion"], audio=b["audio"], shape_feat=b["shape"], style_feat=b["style"], time_step=ts,
@@ -68,32 +83,40 @@ def graphed_step(model, b):
     return lambda: run(**fresh)
 
 
-def roofline_leg(model, b, steps=3):
-    """Per-launch HIP-event timing of every msmd_gemm launch (the dominant kernel family) over `steps` steps."""
+# ----------------------------------------------------------------------------------------------- roofline
+def event_pair_overhead_us():
+    """Overhead of ONE HIP event pair around ONE launch, measured on a kernel that reports its own duration."""
+    from msmd_amd import _lib
+    lib = _lib.load()
+    ticks = torch.zeros(1, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    over = []
+    for us in (20.0, 60.0) * 12:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lib.msmd_spin_us(us, ticks.data_ptr(), st)
+        e1.record()
+        torch.cuda.synchronize()
+        over.append(e0.elapsed_time(e1) * 1e3 - float(ticks.item()) / 100.0)
+    over.sort()
+    return over[len(over) // 2]
+
+
+def roofline_leg(model, b, mode, steps=3):
+    """Per-launch HIP-event timing of every msmd_gemm launch of `steps` eager steps; the dominant kernel is the
+    128x128-tile kernel of the mode (bf16: gemm2_kernel, f16x2: gemm2s_kernel; fp32: gemm_kernel<float>)."""
     from msmd_amd import ops
     step(model, b)
     torch.cuda.synchronize()
+    overhead = event_pair_overhead_us() * 1e-3   # ms
     ops.GEMM_TRACE = []
     for _ in range(steps):
         step(model, b)
     torch.cuda.synchronize()
     trace, ops.GEMM_TRACE = ops.GEMM_TRACE, None
-    # an event pair around NOTHING still measures the record-to-record latency of the queue; subtract it so that the
-    # per-launch figure is the kernel's duration (what rocprofv3 --kernel-trace reports in profiles/)
-    empt = []
-    for _ in range(200):
-        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a0.record()
-        a1.record()
-        empt.append((a0, a1))
-    torch.cuda.synchronize()
-    gaps = sorted(x.elapsed_time(y) for x, y in empt)
-    overhead = gaps[len(gaps) // 2]
-    flops = 0.0
-    ms = 0.0
-    n_launch = 0
-    big_f = big_ms = 0.0
-    big_n = 0
+    flops = ms = big_f = big_ms = 0.0
+    n_launch = big_n = 0
+    kq = 32 if mode == "f16x2" else 64
     for (M, N, K, batch, dt, e0, e1) in trace:
         f = 2.0 * M * N * K * batch
         d = max(e0.elapsed_time(e1) - overhead, 1e-4)
@@ -101,64 +124,372 @@ def roofline_leg(model, b, steps=3):
         ms += d
         n_launch += 1
         tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
-        if N > 64 and tiles >= 192 and K % 64 == 0:  # launches that run the 128x128 LDS-DMA kernel (csrc/gemm.hip)
+        if N > 64 and tiles >= 192 and (mode == "fp32" or K % kq == 0):
             big_f += f
             big_ms += d
             big_n += 1
+    peak = PEAK_F32_TFLOPS if mode == "fp32" else PEAK_MFMA_TFLOPS
     achieved = big_f / (big_ms * 1e-3) / 1e12 if big_ms > 0 else 0.0
-    return dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=pmc_traffic(),
-                kernel="gemm2_kernel<bf16,128,128,4,2,2,pipelined> (csrc/gemm.hip)",
-                launches_per_step=big_n // steps, gflop_per_step=round(big_f / steps / 1e9, 1),
-                ms_per_step_in_kernel=round(big_ms / steps, 3),
-                all_gemm_tflops=round(flops / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
-                all_gemm_launches_per_step=n_launch // steps, all_gemm_ms_per_step=round(ms / steps, 3),
-                event_overhead_us=round(overhead * 1e3, 2))
+    kernel = {"bf16": "gemm2_kernel<bf16,128,128,4,2,2,pipelined>", "fp16": "gemm2_kernel<f16,128,128,4,2,2,pipelined>",
+              "f16x2": "gemm2s_kernel<128,128,4,2,2> (three f16 MFMAs per algorithmic product)",
+              "fp32": "gemm_kernel<float,128,128> (v_mfma_f32_16x16x4_f32)"}[mode]
+    out = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
+               traffic=pmc_traffic(mode), kernel=kernel + " (csrc/gemm.hip)", launches_per_step=big_n // steps,
+               gflop_per_step=round(big_f / steps / 1e9, 1), ms_per_step_in_kernel=round(big_ms / steps, 3),
+               avg_launch_us=round(big_ms / max(big_n, 1) * 1e3, 2),
+               all_gemm_tflops=round(flops / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
+               all_gemm_launches_per_step=n_launch // steps, all_gemm_ms_per_step=round(ms / steps, 3),
+               event_pair_overhead_us=round(overhead * 1e3, 2),
+               note="achieved = algorithmic 2MNK of the dominant kernel's launches / their HIP-event durations minus the "
+                    "calibrated event-pair overhead (msmd_spin_us); rocprofv3 summary of this command: profiles/; "
+                    "traffic is a constant from this round's --pmc passes in profiles/, not this run")
+    if mode == "f16x2":
+        out["mfma_issue_frac"] = round(3.0 * achieved / peak, 4)   # the MFMA pipe executes 3 products per algorithmic one
+    return out
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE collected in SEPARATE runs of this same command; KB units; FETCH_SIZE doubled per the gfx950
-    correction of MI355X_MICROARCH.md section HBM).  PMC counters cannot be read from inside this process, so the
-    figure comes from profiles/ (null when the file is absent)."""
-    path = os.path.join(ROOT, "profiles", "r01e_pmc_hbm_fetch_write_per_kernel.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r01d_pmc_hbm_fetch_write_per_kernel.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_fetch_write_per_kernel.json")
-    try:
-        d = json.load(open(path))
-        k = [v for name, v in d.items() if "gemm2_kernel" in name and "Li128ELi128ELi4ELi2ELi2E" in name][0]  # same tile / traffic as the pipelined variant
-        return round((2.0 * k["fetch_kb_avg"] + k["write_kb_avg"]) * 1024.0)
-    except Exception:
-        return None
+def pmc_traffic(mode):
+    """HBM bytes per launch of the dominant kernel from this round's committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE in SEPARATE runs; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC counters
+    cannot be read from inside this process: the figure is a constant from profiles/ (null when absent), not this run."""
+    for name in ("r02_pmc_hbm_fetch_write_per_kernel.json", "r01e_pmc_hbm_fetch_write_per_kernel.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        try:
+            d = json.load(open(path))
+            want = {"bf16": "gemm2_kernel", "fp16": "gemm2_kernel", "f16x2": "gemm2s_kernel", "fp32": "gemm_kernel"}[mode]
+            ks = [v for n, v in d.items() if want + "I" in n.replace("<", "I") and "128ELi128E" in n.replace(", ", "ELi").replace("<", "I")]
+            ks = ks or [v for n, v in d.items() if want in n and "128" in n and ("gemm2s" in n) == (mode == "f16x2")]
+            if ks:
+                k = max(ks, key=lambda v: v.get("launches", 0))
+                return round((2.0 * k["fetch_kb_avg"] + k["write_kb_avg"]) * 1024.0)
+        except Exception:
+            pass
+    return None
 
 
-def cpu_baseline_leg(B=12):
-    """Numpy oracle (parity-pinned port of the reference CPU path) on this host: MSMD.forward on B clips."""
+# ----------------------------------------------------------------------------------------------- CPU baseline / oracle
+def cpu_baseline_leg(B, want_lbs=True):
+    """oracle/torch_cpu.py on this host (reference arithmetic: fp32 torch CPU, eval mode).  Returns (json dict, the
+    forward's `target` (B, 110, 67) as the in-run checker of the GPU modes)."""
     from msmd_amd import shapes, synth
     from msmd_amd.config import default_args
-    from oracle import diffusion as od
+    from oracle import diffusion as od, flame as ofl, torch_cpu as tc
+    ncpu = os.cpu_count() or 1
     args = default_args()
-    sd = synth.fill_state_dict(shapes.msmd_shapes(args))
+    sd = tc.to_torch(synth.fill_state_dict(shapes.msmd_shapes(args)))
     sched = od.diffusion_schedule(500, "cosine")
-    audio = synth.audio_clips(B, 64000, tag="bench_audio_r0")
-    motion = synth.motion_clips(B, tag="bench_motion_r0")
-    style = synth.normalish("bench_style_r0", (B, 256))
-    eps = synth.normalish("bench_eps_r0", (B, 100, 67))
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).float()
+    audio, motion = t(synth.audio_clips(B, 64000, tag="bench_audio_r0")), t(synth.motion_clips(B, tag="bench_motion_r0"))
+    style, eps = t(synth.normalish("bench_style_r0", (B, 256))), t(synth.normalish("bench_eps_r0", (B, 100, 67)))
     ts = [(37 * i + 11) % 500 + 1 for i in range(B)]
-    t0 = time.time()
-    od.msmd_forward(sd, sched, motion, audio, np.zeros((B, 100), np.float32), style, ts, eps,
-                    indicator=np.ones((B, 100), np.float32))
-    dt = time.time() - t0
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    return dict(value=round(B * 100 / dt, 1), unit="frames/s", cores=int(cores), kind="port",
-                sample=f"oracle.diffusion.msmd_forward (numpy fp32) on {B} clips of the same synthetic workload, "
-                       f"{dt:.1f} s wall")
+    shape, ind = torch.zeros(B, 100), torch.ones(B, 100)
+
+    def med(fn, warm=2, reps=5):
+        for _ in range(warm):
+            out = fn()
+        tt = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = fn()
+            tt.append(time.perf_counter() - t0)
+        return sorted(tt)[len(tt) // 2], out
+    # torch's intra-op pool does not scale to every core of a 2-socket host on this path (128 threads ran SLOWER than 16
+    # on the EPYC 9575F box): scan thread counts on an 8-clip slice and time the batch at the best one
+    scan = {}
+    for thr in [c for c in (8, 16, 32, 64, 128, 256) if c <= ncpu] or [ncpu]:
+        torch.set_num_threads(thr)
+        sl = slice(0, min(8, B))
+        scan[thr], _ = med(lambda: tc.msmd_forward(sd, sched, motion[sl], audio[sl], shape[sl], style[sl], ts[:sl.stop],
+                                                   eps[sl], ind[sl]), 1, 1)
+    threads = min(scan, key=scan.get)
+    torch.set_num_threads(threads)
+    t_fwd, (_, target, _) = med(lambda: tc.msmd_forward(sd, sched, motion, audio, shape, style, ts, eps, ind))
+    af = t(synth.normalish("bench_cpu_af", (B, 100, 512)))
+    t_den, _ = med(lambda: tc.denoise_step(sd, motion, af, shape, style, 250, ind), 1, 3)
+    out = dict(value=round(B * 100 / t_fwd, 1), unit="frames/s", cores=int(threads), kind="port",
+               sample=f"oracle/torch_cpu.py msmd_forward (torch fp32 CPU restatement of the reference path, pinned to the "
+                      f"reference goldens) on the SAME {B}-clip batch: median of 5 after 2 warm-ups = {t_fwd:.2f} s; "
+                      f"host {ncpu} logical CPUs, torch threads {threads} (best of a scan on an 8-clip slice: "
+                      + ", ".join(f"{k}: {min(8, B) * 100 / v:.0f} f/s" for k, v in scan.items()) + ")",
+               denoise_step_3entries=dict(ms=round(t_den * 1e3, 1), frames_per_s_at_T500=round(B * 100 / (t_den * 500), 2),
+                                          sample=f"one sampler loop body on 3 x {B} sequences, median of 3"))
+    if want_lbs:
+        fl = tc.FlameTorch(ofl.FlameOracle(synth.flame_asset()))
+        n = 800
+        g = torch.Generator().manual_seed(7)
+        ex, po = 0.5 * torch.randn(n, 50, generator=g), 0.2 * torch.randn(n, 6, generator=g)
+        t_lbs, _ = med(lambda: fl.forward(torch.zeros(n, 100), ex, po), 1, 3)
+        out["lbs"] = dict(frames_per_s=round(n / t_lbs, 1), sample=f"{n} frames, FLAME vertices only, median of 3")
+    return out, target.numpy()
+
+
+# ----------------------------------------------------------------------------------------------- legs (other configs)
+def leg_sampler(device, B=64, T=500, dtype="fp16"):
+    from msmd_amd import synth
+    from msmd_amd.config import default_args
+    from msmd_amd.model import get_diffusion_model
+    model = get_diffusion_model(default_args(compute_dtype=dtype), device).eval()
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
+    af, style = t(synth.normalish("leg_samp_af", (B, 100, 512))), t(synth.normalish("leg_samp_style", (B, 256)))
+    shape, ind = torch.zeros(B, 100, device=device), torch.ones(B, 100, device=device)
+    model.sample(af, shape, style, indicator=ind, cfg_scale=1.15)      # warm-up: packs, captures the step graph
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x0, _, _ = model.sample(af, shape, style, indicator=ind, cfg_scale=1.15)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tf = B * 3 * DENOISER_FLOP * T / dt / 1e12
+    out = dict(config=f"configs[4]: sample() B={B}, T={T} DDPM steps x 3 CFG entries, {dtype}, one hipGraph replay per step",
+               ms_per_step=round(dt / T * 1e3, 3), frames_per_s=round(B * 100 / dt, 1), tflops=round(tf, 1),
+               mfma_frac=round(tf / PEAK_MFMA_TFLOPS, 4), finite=bool(torch.isfinite(x0).all()))
+    del model
+    return out
+
+
+def leg_lbs(device, frames_list=(6400, 25600)):
+    """FLAME blendshapes + LBS (5023 vertices) on N frames: algorithmic bytes 60 936 per frame."""
+    from types import SimpleNamespace
+    from msmd_amd import synth
+    from msmd_amd.utils.flame import FLAME, FLAMEConfig
+    cfg = SimpleNamespace(**vars(FLAMEConfig))
+    cfg.asset = synth.flame_asset()
+    fl = FLAME(cfg).to(device)
+    out = {}
+    for n in frames_list:
+        g = torch.Generator(device="cpu").manual_seed(n)
+        exp = (0.5 * torch.randn(n, 50, generator=g)).to(device)
+        pose = (0.2 * torch.randn(n, 6, generator=g)).to(device)
+        shape = torch.zeros(n, 100, device=device)
+        for _ in range(3):
+            fl(shape, exp, pose, return_lm2d=False, return_lm3d=False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        R = 20
+        e0.record()
+        for _ in range(R):
+            fl(shape, exp, pose, return_lm2d=False, return_lm3d=False)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / R
+        gbs = n * LBS_BYTES_PER_FRAME / ms / 1e6
+        out[f"lbs_{n}"] = dict(ms=round(ms, 4), frames_per_s=round(n / ms * 1e3), gb_per_s=round(gbs, 1),
+                               hbm_frac=round(gbs / PEAK_HBM_GBS, 4), precision=fl.lbs_precision or "bf16x3 (split-bf16 MFMA, fp32 accumulate)",
+                               bytes_per_frame=LBS_BYTES_PER_FRAME)
+    return out
+
+
+def leg_train(device, B=32, steps=5):
+    from msmd_amd.config import default_args
+    from msmd_amd.model import get_diffusion_model
+    from msmd_amd.style_encoder import get_style_encoder
+    from msmd_amd.training_script import Trainer, synthetic_batch
+    args = default_args(compute_dtype="bf16", lr=2e-5, warm_iter=5000)
+    model = get_diffusion_model(args, device).train()
+    se = get_style_encoder(args, "vae2").to(device).train()
+    tr = Trainer(args, model, se, use_graph=True)
+    batch = synthetic_batch(B, 0, device)
+    tr.capture_all(batch)
+    for _ in range(2):
+        tr.step(batch, it=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(batch, it=1)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tf = TRAIN_FLOP_PER_SAMPLE * B / dt / 1e12
+    return dict(config=f"configs[2] per-GPU shape: local batch {B} x 2 windows, fwd + bwd + fused Adam, bf16, train-mode "
+                       f"noise on, whole-iteration hipGraph", ms_per_step=round(dt * 1e3, 2),
+                frames_per_s=round(B * 200 / dt), tflops=round(tf, 1), mfma_frac=round(tf / PEAK_MFMA_TFLOPS, 4))
+
+
+def leg_hubert_large(device, B=32, steps=5):
+    from msmd_amd import synth
+    from msmd_amd.config import default_args
+    from msmd_amd.model import get_diffusion_model
+    args = default_args(audio_model="hubert_large", compute_dtype="bf16", n_motions=250)
+    model = get_diffusion_model(args, device).eval()
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
+    audio = t(synth.audio_clips(B, 160000, tag="hl_bench"))
+    motion, style = t(synth.normalish("hl_motion", (B, 250, 67))), t(synth.normalish("hl_style", (B, 256)))
+    eps = t(synth.normalish("hl_eps", (B, 250, 67)))
+    ts = [(37 * i + 11) % 500 + 1 for i in range(B)]
+    shape, ind = torch.zeros(B, 100, device=device), torch.ones(B, 250, device=device)
+    run = lambda: model(motion, audio, shape, style, time_step=ts, indicator=ind, train_with_CFG=False, eps=eps)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tf = B * HUBERT_LARGE_FLOP_PER_CLIP / dt / 1e12
+    return dict(config=f"configs[3]: HuBERT-large encoder (24 layers, 1024 wide), B={B} x 10 s clips, bf16, MSMD.forward, eager",
+                ms_per_step=round(dt * 1e3, 2), frames_per_s=round(B * 250 / dt), encoder_tflops=round(tf, 1),
+                mfma_frac=round(tf / PEAK_MFMA_TFLOPS, 4))
+
+
+def run_legs(device):
+    legs = {}
+    for name, fn in (("sampler_b64_t500", leg_sampler), ("lbs", leg_lbs), ("train_step_b32", leg_train),
+                     ("hubert_large_10s_b32", leg_hubert_large)):
+        try:
+            r = fn(device)
+            if name == "lbs":
+                legs.update(r)
+            else:
+                legs[name] = r
+        except Exception as e:   # a leg must never take the headline line down with it
+            legs[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return legs
+
+
+# ----------------------------------------------------------------------------------------------- modes
+def run_forward(a, rank, world, device):
+    from msmd_amd import dp
+    from msmd_amd.config import default_args
+    from msmd_amd.model import get_diffusion_model
+    args = default_args(compute_dtype=a.dtype)
+    model = get_diffusion_model(args, device).eval()
+    b = synth_batch(a.batch, rank, device)
+
+    def timed(mode):
+        model.set_compute_dtype(mode)
+        for _ in range(2):
+            out = step(model, b)   # lazy packing / allocator warm-up before any capture
+        target = out[1].float().cpu().numpy()
+        launch, run = "eager", (lambda: step(model, b))
+        if not a.eager:
+            try:
+                run = graphed_step(model, b)
+                launch = "one hipGraph replay per step (inputs refreshed by D2D copies)"
+            except Exception as e:
+                print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
+                torch.cuda.synchronize()
+        elapsed = dp.timed_steps(run, a.steps, a.warmup, sync=torch.cuda.synchronize, device=device)
+        return elapsed, launch, target
+    elapsed, launch, target = timed(a.dtype)
+    if rank != 0:
+        return None
+    n = world
+    value = a.batch * 100 * a.steps * n / elapsed
+    out = {
+        "metric": "FLAME frames/sec on 4s@16kHz clips (whole job; MSMD.forward motion-coefficient frames)",
+        "value": round(value, 1), "unit": "frames/s", "n_gpus": n, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "configs[1]: MSMD.forward, batch=32 x 4 s clips per GPU, wav2vec2-base encoder + "
+                               "8-layer motion decoder, eval-mode, synthetic closed-form weights",
+                   "batch_per_gpu": a.batch, "clip_seconds": 4, "frames_per_clip": 100,
+                   "parallelism": f"dp{n} (independent clips, no collective)", "launch": launch,
+                   "inputs": "resident in HBM when the timed region starts (H2D of the 8.2 MB batch excluded)"},
+        "end_to_end_tflops": round(value * FLOP_PER_FRAME / 1e12 / n, 1),
+    }
+    if n > 1:
+        return out
+    ref = None
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"], ref = cpu_baseline_leg(a.batch)
+    err = lambda t: None if ref is None else float(np.abs(t - ref).max())
+    out["max_abs_err_vs_oracle"] = err(target)
+    out["tolerance"] = "reference parity bound: 1e-4 max-abs on the motion coefficients (north_star); see parity_mode"
+    if not a.no_roofline:
+        out["roofline"] = roofline_leg(model, b, a.dtype)
+    if not a.no_parity:
+        pm = []
+        for mode in [m for m in ("f16x2", "fp32") if m != a.dtype]:
+            el, _, tg = timed(mode)
+            ent = dict(dtype=mode, ms_per_step=round(el / a.steps * 1e3, 3), frames_per_s=round(a.batch * 100 * a.steps / el, 1),
+                       max_abs_err_vs_oracle=err(tg),
+                       end_to_end_tflops=round(a.batch * 100 * a.steps / el * FLOP_PER_FRAME / 1e12, 1))
+            if ent["max_abs_err_vs_oracle"] is not None:
+                ent["meets_1e-4"] = bool(ent["max_abs_err_vs_oracle"] < 1e-4)
+            if not a.no_roofline:
+                ent["roofline"] = roofline_leg(model, b, mode)
+            pm.append(ent)
+        out["parity_mode"] = pm
+        model.set_compute_dtype(a.dtype)
+    del model
+    torch.cuda.empty_cache()
+    if a.legs != "none":
+        out["legs"] = run_legs(device)
+    return out
+
+
+def run_train(a, rank, world, device):
+    """configs[2]: per-GPU local batch (default 32) x 2 windows; fwd + bwd + gradient all-reduce (RCCL, ~32 MB buckets on
+    a side stream) + fused Adam."""
+    from msmd_amd import dp
+    from msmd_amd.config import default_args
+    from msmd_amd.model import get_diffusion_model
+    from msmd_amd.style_encoder import get_style_encoder
+    from msmd_amd.training_script import Trainer, synthetic_batch
+    args = default_args(compute_dtype="bf16", lr=2e-5, warm_iter=5000)
+    model = get_diffusion_model(args, device).train()
+    se = get_style_encoder(args, "vae2").to(device).train()
+    tr = Trainer(args, model, se, use_graph=not a.eager)
+    batch = synthetic_batch(a.batch, rank, device)
+    if tr.use_graph:
+        tr.capture_all(batch)
+    run = lambda: tr.step(batch, it=1)
+    warm = max(a.warmup, 2)
+    elapsed = dp.timed_steps(run, a.steps, warm, sync=torch.cuda.synchronize, device=device)
+    extra = {}
+    if world > 1:
+        # the exchange alone (all buckets, nothing to overlap with) and the step without any exchange
+        ar = dp.timed_steps(tr.reducer.exchange_only, 5, 2, sync=torch.cuda.synchronize, device=device) / 5
+        tr.reducer.mute = True
+        solo = dp.timed_steps(run, a.steps, 1, sync=torch.cuda.synchronize, device=device) / a.steps
+        tr.reducer.mute = False
+        exposed = max(elapsed / a.steps - solo, 0.0)
+        extra = dict(allreduce_ms=round(ar * 1e3, 3), step_without_exchange_ms=round(solo * 1e3, 3),
+                     overlap_frac=round(max(0.0, min(1.0, 1.0 - exposed / ar)), 3) if ar > 0 else None,
+                     gradient_bytes=int(tr.reducer.arena.numel() * 4), buckets=len(tr.reducer.buckets))
+    if rank != 0:
+        return None
+    value = a.batch * 200 * a.steps * world / elapsed
+    out = {
+        "metric": "FLAME frames/sec on 4s@16kHz clips (whole job; training step, 2 windows x 100 frames per sample)",
+        "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": warm,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"configs[2]: training_script step, local batch {a.batch} (global {a.batch * world}), 2 windows, "
+                               "fwd + bwd + bucketed RCCL gradient all-reduce + fused Adam, train-mode noise on",
+                   "batch_per_gpu": a.batch, "parallelism": f"dp{world}",
+                   "launch": tr.launch_description()},
+        "end_to_end_tflops": round(value / 200 * TRAIN_FLOP_PER_SAMPLE / 1e12 / world, 1),
+    }
+    out.update(extra)
+    return out
+
+
+def spawn(a, argv):
+    """`--gpus N` without a launcher: start N ranks with torch.distributed.run from THIS process, which has not touched
+    the GPU (no exec after HIP init anywhere), and relay rank 0's JSON line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+        return p.returncode
+    return p.returncode or 1
 
 
 def main():
@@ -168,64 +499,35 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32", "f16x2"])
+    ap.add_argument("--mode", default="forward", choices=["forward", "train"])
+    ap.add_argument("--legs", default="all", choices=["all", "none"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of one hipGraph replay")
+    ap.add_argument("--no-parity", action="store_true", help="skip the f16x2 / fp32 parity-mode timings")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of hipGraph replays")
     a = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn(a, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = world > 1
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from msmd_amd import dp
     dp.init("nccl", device)
-
-    from msmd_amd.config import default_args
-    from msmd_amd.model import get_diffusion_model
+    if world > 1:
+        import torch.distributed as td
+        world = td.get_world_size()    # what RCCL actually sees
     if os.environ.get("MSMD_TUNE"):   # developer A/B knob, e.g. MSMD_TUNE="7=1" (msmd_set_tuning key=value pairs)
         from msmd_amd import ops as _ops
         for kv in os.environ["MSMD_TUNE"].split(","):
             _ops.set_tuning(*(int(v) for v in kv.split("=")))
-    args = default_args(compute_dtype=a.dtype)
-    model = get_diffusion_model(args, device).eval()
-    b = synth_batch(a.batch, rank, device)
-    for _ in range(2):
-        step(model, b)   # lazy packing / allocator warm-up before any capture
-    launch = "eager"
-    run = lambda: step(model, b)  # noqa: E731
-    if not a.eager:
-        try:
-            run = graphed_step(model, b)
-            launch = "one hipGraph replay per step (inputs refreshed by D2D copies)"
-        except Exception as e:  # capture unsupported on this stack: keep the host-launched step (same kernels)
-            print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
-            torch.cuda.synchronize()
-    elapsed = dp.timed_steps(run, a.steps, a.warmup, sync=torch.cuda.synchronize, device=device)
-
-    if rank == 0:
-        n = max(world, a.gpus) if dist else 1
-        frames = a.batch * 100 * a.steps * n
-        value = frames / elapsed
-        out = {
-            "metric": "FLAME frames/sec on 4s@16kHz clips (whole job; MSMD.forward motion-coefficient frames)",
-            "value": round(value, 1), "unit": "frames/s", "n_gpus": n, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "configs[1]: MSMD.forward, batch=32 x 4 s clips per GPU, wav2vec2-base encoder + "
-                                   "8-layer motion decoder, eval-mode, synthetic closed-form weights",
-                       "batch_per_gpu": a.batch, "clip_seconds": 4, "frames_per_clip": 100,
-                       "parallelism": f"dp{n} (independent clips, no collective)",
-                       "launch": launch},
-            "end_to_end_tflops": round(value * FLOP_PER_FRAME / 1e12 / n, 1),
-        }
-        if not a.no_roofline:
-            out["roofline"] = roofline_leg(model, b)
-        if not a.no_cpu_baseline and n == 1:
-            out["cpu_baseline"] = cpu_baseline_leg()
+    out = run_train(a, rank, world, device) if a.mode == "train" else run_forward(a, rank, world, device)
+    if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
-    if dist:
+    if world > 1:
         import torch.distributed as td
         td.barrier()
         td.destroy_process_group()

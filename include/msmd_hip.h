@@ -49,6 +49,11 @@ int msmd_abi_version(void);
  * key 7: XCDs along N for the GEMM tile map (1, 2, 4; 0 = chosen per problem from the operand sizes). */
 int msmd_set_tuning(int key, int value);
 
+/* Measurement aid: one wavefront that spins for `us` microseconds of the 100 MHz constant clock (s_memrealtime) and
+ * optionally stores the ticks it actually spun.  bench.py times it at two lengths to calibrate the overhead of a HIP
+ * event pair around ONE launch, so that its per-launch roofline figures agree with rocprofv3 --kernel-trace. */
+int msmd_spin_us(float us, long* ticks_out, msmd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Dense contraction on MFMA:  C = act(A . W^T + bias) + residual
  *   A: (M, K) activations, row m at  A + (m / rows_per_batch) * a_batch_stride + (m % rows_per_batch) * lda

@@ -206,6 +206,83 @@ def test_grad_bucket_reducer_world_2_gloo(tmp_path):
     assert out["err"] < 1e-6 and out["unused"] == 0.0 and out["n"] == 512 + 64 + 256 + 64 + 64  # 64-element aligned slots
 
 
+def test_grad_bucket_reducer_accumulation_rearm_and_write_sequence_world_2_gloo(tmp_path):
+    """(1) Gradient accumulation with a parameter that is unused in micro-step 1: the arrival counters are re-armed
+    per backward (`begin_backward`), so no bucket is reduced before the stepping micro-step's backward has finished
+    adding into it, and the result equals the mean over ranks of the accumulated single-rank gradients.
+    (2) The write-sequence tracker (what hipGraph mode cuts its backward segments on): with parameters written once
+    per "window" (two uses of the same weights in one backward), `on_bucket_final` fires after the LAST write of a
+    bucket, never at its first complete arrival, and every bucket fires exactly once."""
+    script = tmp_path / "acc.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, json
+        sys.path.insert(0, {ROOT!r})
+        import torch, torch.distributed as td
+        from msmd_amd import dp
+        rank, world = dp.init("gloo")
+        torch.manual_seed(0)
+        a, b = torch.nn.Linear(16, 32), torch.nn.Linear(32, 8)
+        side = torch.nn.Linear(16, 8)                         # only used in micro-step 2 (e.g. a LayerDrop-skipped layer)
+        params = list(a.parameters()) + list(b.parameters()) + list(side.parameters())
+        red = dp.GradBucketReducer(params, bucket_mb=0.0005)
+        launched_during = []
+        orig = red._launch
+        def spy(bk):
+            launched_during.append((phase[0], bk))
+            return orig(bk)
+        red._launch = spy
+        phase = ["m1"]
+        x = torch.randn(8, 16)[list(dp.shard_clips(8, rank, world))]
+        red.zero_grad()
+        red.enabled = False; red.begin_backward()
+        b(torch.nn.functional.gelu(a(x))).pow(2).mean().backward()            # micro-step 1: `side` unused
+        phase[0] = "m2"
+        red.enabled = True; red.begin_backward()
+        (b(torch.nn.functional.gelu(a(x))) + side(x)).pow(2).mean().backward()   # stepping micro-step
+        phase[0] = "finish"
+        flat, scale = red.finish()
+        got = [(p.grad * scale).clone() for p in params]
+        # reference: accumulate the same two micro-steps on every rank's shard in one process, then average
+        full = torch.randn(8, 16) if False else None
+        torch.manual_seed(0); _ = torch.nn.Linear(16, 32), torch.nn.Linear(32, 8), torch.nn.Linear(16, 8)
+        xs = torch.randn(8, 16)
+        acc = [torch.zeros_like(p) for p in params]
+        for r in range(world):
+            for p in params: p.grad = None
+            xr = xs[list(dp.shard_clips(8, r, world))]
+            b(torch.nn.functional.gelu(a(xr))).pow(2).mean().backward()
+            (b(torch.nn.functional.gelu(a(xr))) + side(xr)).pow(2).mean().backward()
+            for t, p in zip(acc, params): t += p.grad / world
+        err = max(float((g - t).abs().max()) for g, t in zip(got, acc))
+        early = [e for e in launched_during if e[0] == "m1"]
+        # ---- (2) write-sequence tracking: two "windows" through the same weights in ONE backward
+        red.mute = True
+        red.zero_grad()
+        red.trace_begin()
+        (b(torch.nn.functional.gelu(a(x))).pow(2).mean() + b(torch.nn.functional.gelu(a(2 * x))).pow(2).mean()).backward()
+        pos = red.trace_end()
+        fired = []
+        red.on_bucket_final = lambda bk: fired.append((red.write_count, bk))
+        red.zero_grad()
+        (b(torch.nn.functional.gelu(a(x))).pow(2).mean() + b(torch.nn.functional.gelu(a(2 * x))).pow(2).mean()).backward()
+        used = sorted(set(bk for bks in pos.values() for bk in bks))
+        if rank == 0:
+            print(json.dumps(dict(err=err, early=len(early), fired=sorted(bk for _, bk in fired), used=used,
+                                  n_pos=len(pos))))
+        td.destroy_process_group()
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29619")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29619", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["err"] < 1e-6, out
+    assert out["early"] == 0, "a bucket was reduced on a non-stepping micro-step"
+    assert out["fired"] == out["used"] and len(out["used"]) >= 2, out
+
+
 def test_lr_schedule_matches_reference_scheduler_sequences():
     """utils.scheduler.LrSchedule (what Trainer feeds the fused Adam kernel) against learning-rate sequences recorded
     from the reference's GradualWarmupScheduler (+ CosineAnnealingLR) stepped as its training loop steps them."""

@@ -310,3 +310,42 @@ def test_audio_encoder_hubert_large_architecture():
     a2 = synth.audio_clips(1, 32000, tag="audio30")
     y = oa.audio_encoder(sd, "audio_encoder.", oa.pad_audio(a2), 30, frame_num=60, n_heads=16, stable_layer_norm=True)
     assert maxabs(y, g["hidden_fps30_60"]) <= 1e-4
+
+
+def test_torch_cpu_restatement_matches_reference_goldens():
+    """oracle/torch_cpu.py (the restatement bench.py's cpu_baseline leg times on the GPU box's host cores) against the
+    SAME reference goldens the numpy oracle is pinned to: MSMD.forward from raw audio at full depth (g3_forward), one
+    sampler-step denoiser call vs the numpy oracle, FLAME vertices (g4_flame)."""
+    import torch
+    from oracle import torch_cpu as tc
+    g = load_golden("g3_forward")
+    sd, args = msmd_state_dict("wav2vec2")
+    tsd = tc.to_torch(sd)
+    sched = od.diffusion_schedule(500, "cosine")
+    x = denoiser_inputs(2, args, tag="fw")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()
+    audio = synth.audio_clips(2, 64000, tag="fw_audio")
+    _, target, afeat = tc.msmd_forward(tsd, sched, t(x["motion"]), t(audio), t(x["shape"]), t(x["style"]), [3, 499],
+                                       t(g["a_eps"]), t(x["indicator"]))
+    assert maxabs(afeat.numpy()[:, ::2, ::3], g["a_audio_feat"]) <= 1e-4
+    assert maxabs(target.numpy(), g["a_target"]) <= 1e-4
+    # one loop body of the sampler (3 CFG entries) vs the numpy denoiser on the same stacked inputs
+    B = 2
+    xt = synth.normalish("tc/xt", (B, 100, 67))
+    got = tc.denoise_step(tsd, t(xt), t(x["audio_feat"]), t(x["shape"]), t(x["style"]), 250, t(x["indicator"])).numpy()
+    null_a = np.broadcast_to(sd["null_audio_feat"], x["audio_feat"].shape)
+    null_s = np.broadcast_to(sd["null_style_feat"], (B, 1, 256))
+    st, sh = x["style"][:, None], x["shape"][:, None]
+    rep = lambda v: np.concatenate([v] * 3, 0)
+    want = od.denoising_net(sd, rep(xt), np.concatenate([null_a, x["audio_feat"], x["audio_feat"]], 0),
+                            np.concatenate([np.concatenate([sh, s], -1) for s in (null_s, null_s, st)], 0), rep(st),
+                            rep(np.broadcast_to(sd["start_motion_feat"], (B, 10, 67))),
+                            rep(np.broadcast_to(sd["start_audio_feat"], (B, 10, 512))), np.full(3 * B, 250),
+                            rep(x["indicator"]))
+    assert maxabs(got, want) <= 1e-4
+    # FLAME vertices
+    gf = load_golden("g4_flame")
+    fo = ofl.FlameOracle(synth.flame_asset())
+    fx = flame_inputs(8)
+    v = tc.FlameTorch(fo).forward(t(fx["shape"]), t(fx["exp"]), t(gf["pose"])).numpy()
+    assert maxabs(v[:, ::79], gf["verts_sub"]) <= 2e-6

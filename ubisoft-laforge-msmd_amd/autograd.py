@@ -118,6 +118,10 @@ USE_GEMM_TN = True
 # Set by Trainer when bucket launches do not depend on per-parameter hooks (hipGraph mode / single process):
 # LinearFn.backward then adds weight / bias gradients directly into the pre-allocated .grad arena views.
 DIRECT_GRAD = False
+# Called with every leaf parameter whose gradient a backward kernel has just added STRAIGHT into its .grad arena view
+# (no autograd accumulation, hence no post-accumulate hook): dp.GradBucketReducer.on_write, which is how the reducer
+# knows in hipGraph mode when a gradient bucket is final.
+GRAD_WRITTEN = None
 
 
 class LinearFn(torch.autograd.Function):
@@ -177,6 +181,10 @@ class LinearFn(torch.autograd.Function):
                 if b_leaf is not None and b_leaf.grad is not None and b_leaf.grad.is_contiguous():
                     bgrad = b_leaf.grad
             ops.gemm_tn(dz2, xin.reshape(M, Kp), out=w.grad.view(N, Kp), colsum_out=bgrad, accumulate=True)
+            if GRAD_WRITTEN is not None:
+                GRAD_WRITTEN(w)
+                if bgrad is not None:
+                    GRAD_WRITTEN(ctx.b_ref)
             if want_b and bgrad is None:
                 db = ops.colsum(dz2)
         elif ctx.needs_input_grad[1] and dtype == torch.bfloat16 and N % 8 == 0 and USE_GEMM_TN:
@@ -225,6 +233,9 @@ class LayerNormFn(torch.autograd.Function):
                 and all(r.grad is not None and r.grad.is_contiguous() and r.grad.dtype == torch.float32 for r in refs)):
             # the kernel accumulates dgamma / dbeta: aim it at the parameters' .grad views of the gradient arena
             dx, _, _ = ops.layernorm_bwd(dy.contiguous(), x, g, dg_out=refs[0].grad.view(-1), db_out=refs[1].grad.view(-1))
+            if GRAD_WRITTEN is not None:
+                GRAD_WRITTEN(refs[0])
+                GRAD_WRITTEN(refs[1])
             return dx, None, None, None
         dx, dg, db = ops.layernorm_bwd(dy.contiguous(), x, g)
         return dx, dg, db, None

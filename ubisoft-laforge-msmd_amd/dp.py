@@ -126,6 +126,16 @@ class GradBucketReducer:
         self.side = torch.cuda.Stream(device=dev) if self.cuda else None
         self.works = []
         self.enabled = True  # set False on gradient-accumulation micro-steps (reference training_script.py:199)
+        self.mute = False    # measurement switch (bench.py --mode train): run the step with NO exchange at all
+        # Completion tracking that does not depend on autograd hooks alone: every gradient WRITE of a parameter -- an
+        # autograd accumulation (hook below) or a kernel that adds straight into the arena view (autograd.GRAD_WRITTEN)
+        # -- is noted in order.  `trace_begin()` / `trace_end()` record one backward's write sequence; afterwards
+        # `on_write` fires `on_bucket_final(b)` at the write after which bucket b receives nothing more this backward
+        # (parameters are written once per window, so "first arrival" is not "final").
+        self.trace = None
+        self.final_pos = None
+        self.write_count = 0
+        self.on_bucket_final = None
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._hook)
 
@@ -136,21 +146,79 @@ class GradBucketReducer:
     def zero_grad(self):
         """Zero the arena (grads are views) and re-arm the arrival counters."""
         self.arena.zero_()
+        self.begin_backward()
+
+    def begin_backward(self):
+        """Re-arm the arrival counters.  Called before EVERY backward (Trainer.step), not only after an optimizer step:
+        with gradient accumulation a bucket that received only part of its gradients in an earlier micro-step (a
+        LayerDrop-skipped layer, an unused null token) must not reach zero early in the stepping micro-step and be
+        reduced while backward is still adding into it."""
         self.pending = [len(m) for _, _, m in self.buckets]
         self.launched = [False] * len(self.buckets)
         self.works = []
+        self.write_count = 0
+
+    # ---- write-sequence tracking (hipGraph segments; see __init__)
+    def trace_begin(self):
+        self.trace, self.final_pos, self.write_count = [], None, 0
+
+    def trace_end(self):
+        """-> {write position: [buckets final after that write]} of the traced backward."""
+        last = {}
+        for i, b in enumerate(self.trace):
+            last[b] = i
+        self.trace = None
+        self.final_pos = {}
+        for b, i in last.items():
+            self.final_pos.setdefault(i, []).append(b)
+        self.write_count = 0
+        return self.final_pos
+
+    def on_write(self, p):
+        """A gradient of parameter p was just accumulated into / written to the arena (stream order = call order)."""
+        ent = self.slot.get(id(p))
+        if ent is None:
+            return
+        if self.trace is not None:
+            self.trace.append(ent[0])
+            return
+        if self.final_pos is not None and self.on_bucket_final is not None:
+            done = self.final_pos.get(self.write_count)
+            self.write_count += 1
+            if done:
+                for b in done:
+                    self.on_bucket_final(b)
 
     def _hook(self, p):
         b, off, n = self.slot[id(p)]
         if p.grad.data_ptr() != self.arena[off:off + n].data_ptr():  # autograd replaced the view: copy back
             self.arena[off:off + n].copy_(p.grad.reshape(-1))
             p.grad = self.arena[off:off + n].view_as(p)
+        self.on_write(p)
         self.pending[b] -= 1
         if self.pending[b] == 0 and self.enabled:
             self._launch(b)
 
+    def exchange_only(self):
+        """All buckets' all-reduce with nothing to overlap with (bench.py: the exchange's own duration).  The arena's
+        contents are scaled back afterwards so repeated calls do not overflow."""
+        self.begin_backward()
+        for b in range(len(self.buckets)):
+            self._launch(b)
+        self._join()
+        self.arena.mul_(1.0 / self.world)
+        self.begin_backward()
+
+    def _join(self):
+        for w in self.works:
+            if w is not None:
+                w.wait()   # NCCL: the CURRENT STREAM waits for the collective (no host block); gloo: host wait
+        self.works = []
+        if self.cuda and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.side)
+
     def _launch(self, b):
-        if self.launched[b] or self.world == 1:
+        if self.launched[b] or self.world == 1 or self.mute:
             self.launched[b] = True
             return
         self.launched[b] = True
@@ -170,11 +238,7 @@ class GradBucketReducer:
         for b in range(len(self.buckets)):
             if not self.launched[b]:
                 self._launch(b)
-        for w in self.works:
-            if w is not None:
-                w.wait()
-        if self.cuda and self.world > 1:
-            torch.cuda.current_stream().wait_stream(self.side)
+        self._join()
         return self.arena, 1.0 / self.world
 
 

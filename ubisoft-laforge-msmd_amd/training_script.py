@@ -163,6 +163,12 @@ class Trainer:
         self.sched_step = 0
         self._build_lr_schedule()
         self.use_graph = bool(use_graph)
+        # truncation geometry as the reference's train() takes it from the dataset / args (training_script.py:67,125)
+        self.audio_unit = float(getattr(args, "audio_unit", None) or 16000.0 / float(args.fps))
+        pad_mode = getattr(args, "pad_mode", "zero")
+        if pad_mode not in ("zero", "replicate"):
+            raise ValueError(f"Unknown pad mode {pad_mode}!")   # reference utils/common.py:777
+        self.pad_replicate = pad_mode == "replicate"
         self._graphs, self._graph_pool, self._flag_table = {}, None, None
         # weight gradients are added straight into the arena by the wgrad GEMM when bucket launches do not hang
         # on per-parameter autograd hooks (graph mode launches them from finish(); world 1 launches nothing)
@@ -276,20 +282,21 @@ class Trainer:
                 else:
                     end_idx = torch.randint(1, args.n_motions, (B,), device=self.device) if trunc[i] else None
                 if end_idx is not None:
+                    # reference utils/common.py:816-832: audio is cut at (end_idx * audio_unit).long() with the DATASET's
+                    # audio_unit = 16000 / fps (a float: 533.33 at 30 fps) and both tensors padded per args.pad_mode
                     e32 = end_idx.to(torch.int32).contiguous()
-                    audio_in = ops.truncate_rows_(audio.float().clone().contiguous(), e32, 640, False)
-                    motion_in = ops.truncate_rows_(motion.float().clone().contiguous(), e32, 1, False)
+                    a32 = (end_idx.to(torch.float32) * self.audio_unit).long().to(torch.int32).contiguous()
+                    audio_in = ops.truncate_rows_(audio.float().clone().contiguous(), a32, 1, self.pad_replicate)
+                    motion_in = ops.truncate_rows_(motion.float().clone().contiguous(), e32, 1, self.pad_replicate)
                     indicator = (torch.arange(args.n_motions, device=self.device).expand(B, -1) < end_idx.unsqueeze(1)).float()
                 else:
                     audio_in, motion_in = audio, motion
                     indicator = torch.ones(B, args.n_motions, device=self.device)
                 ts = draws["t"][i] if "t" in draws else model.diffusion_sched.uniform_sample_t_device(B)
                 eps = draws["eps"][i] if "eps" in draws else torch.randn_like(motion_in)
-                # CFG masking (incremental mode, model.py:205-218): one uniform draw per sample
-                flag = draws["cfg_flag"][i] if "cfg_flag" in draws else torch.rand(B, device=self.device)
-                ns = (flag > 0.55) if flag is not None else None
-                na = (flag > 0.9) if flag is not None else None
-                _, target, _, audio_feat = tg.msmd_forward_train(model, motion_in, audio_in, shape, style, prev_motion,
+                ns, na = self._cfg_masks(draws, i, B)
+                shape_in = torch.zeros_like(shape) if getattr(args, "do_ignore_shape", False) else shape
+                _, target, _, audio_feat = tg.msmd_forward_train(model, motion_in, audio_in, shape_in, style, prev_motion,
                                                                  prev_audio, ts, indicator, eps, ns, na)
                 if i == 0:
                     if end_idx is not None:  # truncated: hand over the COMPLETE clip's features (training_script.py:152-155)
@@ -313,6 +320,38 @@ class Trainer:
         out = {k: v.detach() for k, v in losses.items()}
         out["loss"] = loss.detach()
         return out
+
+    def _cfg_masks(self, draws, i, B):
+        """Null-style / null-audio masks of the training forward (reference model.py:190-218, switched off by
+        --do_ignore_cfg, training_script.py:146): incremental mode draws ONE uniform per sample (style nulled above
+        0.55, audio above 0.9); a single condition or cfg_mode 'independent' draws one uniform PER condition against
+        0.1 / 0.5.  Injected draws: cfg_flag[i] = tensor (incremental) or (style_u, audio_u) (independent)."""
+        model, args = self.model, self.args
+        conds = model.guiding_conditions
+        if getattr(args, "do_ignore_cfg", False) or len(conds) == 0:
+            return None, None
+        if len(conds) > 2:
+            raise AssertionError("Only support 1 or 2 CFG conditions!")
+        inj = draws["cfg_flag"][i] if "cfg_flag" in draws else None
+        if "cfg_flag" in draws and inj is None:
+            return None, None
+        if len(conds) == 1 or model.cfg_mode == "independent":
+            p = 0.5 if len(conds) >= 2 else 0.1
+            us = ua = None
+            if inj is not None:
+                us, ua = inj if isinstance(inj, (tuple, list)) else (inj, inj)
+            ns = ((us if us is not None else torch.rand(B, device=self.device)) < p) if "style" in conds else None
+            na = ((ua if ua is not None else torch.rand(B, device=self.device)) < p) if "audio" in conds else None
+            return ns, na
+        if model.cfg_mode != "incremental":
+            raise NotImplementedError(f"Unknown cfg_mode {model.cfg_mode}")
+        flag = inj if inj is not None else torch.rand(B, device=self.device)
+        return ((flag > 0.55) if "style" in conds else None), ((flag > 0.9) if "audio" in conds else None)
+
+    def launch_description(self):
+        if not self.use_graph:
+            return "eager launches; bucket all-reduces from post-accumulate-grad hooks on a side stream"
+        return "whole-iteration hipGraph; all-reduce buckets launched after the replay"
 
     def _host_choices(self, draws):
         """The reference's host-side coin flips (training_script.py:99-141): cross-style per window, truncation."""
@@ -347,6 +386,7 @@ class Trainer:
         self.noise_state[1] += 1
         ag.TrainNoise.graph_safe = self.use_graph
         ag.TrainNoise.spec_masks = None
+        self.reducer.begin_backward()         # re-arm per backward, not per optimizer step (gradient accumulation)
         if self.use_graph:
             self.reducer.enabled = False      # python hooks do not run on replay: buckets are launched by finish()
             out = self._graph_fwd_bwd(batch, draws, trunc, cross)
