@@ -293,3 +293,34 @@ def test_sampler_split():
         assert out.shape == (2, 100, 67) and bool(torch.isfinite(out).all())
     finally:
         model.diffusion_sched = old
+
+
+def test_bench_batch_b32_matches_cpu_restatement_in_parity_modes():
+    """The bench workload itself (configs[1]: B = 32 x 4 s clips, 12 + 8 layers), not only 2-clip goldens: MSMD.forward
+    in the f16x2 and fp32 modes against the torch-CPU restatement of the reference (oracle/torch_cpu.py, pinned to the
+    reference goldens) on 3 sampled clips of the batch -- every op is row-independent, so the oracle runs those 3 rows
+    only -- plus the hipGraph replay of the full batch equal to the eager forward."""
+    import bench
+    from oracle import diffusion as od, torch_cpu as tc
+    from msmd_amd import shapes
+    model, args = get_model("wav2vec2")
+    b = bench.synth_batch(32, 0, DEV)
+    rows = [0, 13, 31]
+    sd = tc.to_torch(synth.fill_state_dict(shapes.msmd_shapes(args)))
+    sched = od.diffusion_schedule(500, "cosine")
+    cpu = lambda t: t[rows].float().cpu()
+    _, ref, _ = tc.msmd_forward(sd, sched, cpu(b["motion"]), cpu(b["audio"]), cpu(b["shape"]), cpu(b["style"]),
+                                [b["time_step"][r] for r in rows], cpu(b["eps"]), cpu(b["indicator"]))
+    ref = ref.numpy()
+    for mode in ("f16x2", "fp32"):
+        model.set_compute_dtype(mode)
+        _, target, _, _ = bench.step(model, b)
+        err = maxabs(target[rows].cpu().numpy(), ref)
+        print(f"B=32 bench batch, {mode}: max-abs-err vs CPU restatement on rows {rows} = {err:.2e}")
+        assert err < 1e-4, (mode, err)
+        if mode == "f16x2":
+            run = bench.graphed_step(model, b)     # capture_forward verifies replay == eager on perturbed inputs
+            out = run()
+            torch.cuda.synchronize()
+            assert torch.equal(out[1], target)
+    model.set_compute_dtype("f16x2")

@@ -177,6 +177,53 @@ def test_trainer_hipgraph_step_matches_eager():
     assert len(trg._graphs) >= 2
 
 
+def test_trainer_segmented_hipgraph_matches_single_graph(monkeypatch):
+    """hipGraph mode for more than one rank (forced here on one): the iteration is captured as SEGMENTS that end where a
+    gradient bucket receives its last write of the backward (autograd accumulations AND the wgrad GEMM's direct arena
+    writes, two windows per weight), so each bucket's all-reduce can start under the rest of the backward.  Same
+    injected draws: losses and the applied Adam update equal the one-graph mode bit for bit; every bucket is handed to
+    the reducer exactly once per step, in a segment that precedes the last one for most of the bytes."""
+    from msmd_amd.model import get_diffusion_model
+    from msmd_amd.style_encoder import get_style_encoder
+    from msmd_amd.training_script import Trainer, synthetic_batch
+    args = default_args(compute_dtype="bf16", encoder_layers=2, n_layers=2, lr=1e-3, warm_iter=0,
+                        gradient_accumulation_steps=1)
+    B = 2
+    batch = synthetic_batch(B, 0, DEV)
+    draws = dict(cross=[False, True], end_idx=[torch.tensor([60, 100], device=DEV), None], t=[[5, 400], [250, 20]],
+                 eps=[dev(synth.normalish(f"tr/eps{i}", (B, 100, 67))) for i in range(2)],
+                 style_eps=[dev(synth.normalish(f"tr/se{i}", (B, 256))) for i in range(2)],
+                 cfg_flag=[dev(np.array([0.1, 0.7], np.float32)), dev(np.array([0.95, 0.3], np.float32))])
+    res = []
+    for seg in (False, True):
+        monkeypatch.setenv("MSMD_SEGMENT_GRAPHS", "1" if seg else "0")
+        torch.manual_seed(0)
+        model = get_diffusion_model(args, DEV).eval()
+        se = get_style_encoder(args, "vae2").to(DEV).eval()
+        tr = Trainer(args, model, se, use_graph=True, bucket_mb=4.0)
+        assert tr.segment_graphs == seg
+        launched = []
+        orig = tr.reducer._launch
+        tr.reducer._launch = lambda b, _o=orig, _l=launched: (_l.append(b), _o(b))[1]
+        outs = [tr.step(batch, it=it, draws=draws) for it in (1, 2)]
+        torch.cuda.synchronize()
+        res.append((outs, tr.flat_param.clone(), tr, list(launched)))
+    (o1, p1, tr1, _), (o2, p2, tr2, l2) = res
+    for a, b in zip(o1, o2):
+        for k in a:
+            assert float(a[k]) == float(b[k]), k
+    d = (p1 - p2).abs()          # split-contraction wgrad kernels reduce through workspaces: last-bit differences only
+    assert float(d.max()) < 2e-5 and float((d > 1e-6).float().mean()) < 1e-3, (float(d.max()), float((d > 1e-6).float().mean()))
+    (segs,) = [ent[3] for ent in tr2._graphs.values()]
+    nb = len(tr2.reducer.buckets)
+    assert len(segs) >= 3 and nb >= 4
+    per_step = l2[: len(l2) // 2]
+    assert sorted(set(per_step)) == list(range(nb))            # every bucket handed over (finish() re-visits are no-ops)
+    early = [b for _, bks in segs[:-1] for b in bks]
+    early_bytes = sum(tr2.reducer.buckets[b][1] - tr2.reducer.buckets[b][0] for b in early)
+    assert early_bytes >= 0.5 * tr2.reducer.arena.numel(), (early_bytes, tr2.reducer.arena.numel())
+
+
 def test_trainer_train_mode_noise_eager_and_graph():
     """model.train(): dropout / LayerDrop / SpecAugment are live (losses differ from eval mode and from step to
     step on a fixed batch with fixed draws), in eager mode and under hipGraph replay; eval mode is unaffected."""

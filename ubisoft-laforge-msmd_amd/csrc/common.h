@@ -86,6 +86,12 @@ template <typename T> __device__ __forceinline__ f32x4 mfma16(const u32x4 a, con
 #define MSMD_SPLIT_SCALE 2048.0f
 #define MSMD_SPLIT_INV 4.8828125e-4f
 __device__ __forceinline__ void split_f16x2(float x, f16_t& hi, f16_t& lo) {
+  // Pin x to ONE register value first.  Under -ffp-contract=fast hipcc may duplicate the expression that produced x
+  // into both uses below and contract the copies differently (a (1 + b) as a + a b in one, fma(a, b, a) in the other):
+  // two values one fp32 ulp apart.  When x sits on an fp16 rounding tie, hi then comes from one neighbour and the
+  // residual from the other: lo gets the wrong sign and the pair is off by a whole fp16 ulp (found by the conv0 test:
+  // 14 of 1.3 M GELU outputs).
+  asm volatile("" : "+v"(x));
   hi = (f16_t)x;
   lo = (f16_t)((x - (float)hi) * MSMD_SPLIT_SCALE);
 }

@@ -14,6 +14,7 @@
 // columns of one row: 16-B (fp32) / 8-B (bf16) epilogue stores and a float4 bias load.
 // bf16: v_mfma_f32_16x16x32_bf16; fp32 parity mode: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
 #include "common.h"
+#include <utility>
 
 struct GemmArgs {
   const void* A; const void* W; const float* bias; const void* R; void* C;
@@ -548,7 +549,9 @@ __device__ __forceinline__ void gemm_epilogue_split(const GemmArgs& p, const f32
       if (m >= p.M) continue;
       float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = act_out<float>(acc[i][j][e] + bv[e], p.act);
+      // GELU through the 12-instruction erf (|abs err| <= 1.5e-7, i.e. <= 0.5 |x| 1.5e-7 on the output: the size of an
+      // fp32 rounding error at these magnitudes); libm's erff would be ~15 % of an FFN1 launch
+      for (int e = 0; e < 4; ++e) v[e] = act_out<f16_t>(acc[i][j][e] + bv[e], p.act);
       if (R) {
         float r[4];
         load4_split(R + (long)m * 2 * p.ldr, n, r);
@@ -648,6 +651,239 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2s_kernel(const GemmArgs p) 
   else gemm_epilogue_split<FM, FN>(p, acc0, z, m0 + wm, n0 + wn, fr, fq);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// gemm3: ONE workgroup per CU (8 waves, 2 per SIMD, up to 256 VGPRs), large tiles, fragment reads software-pipelined
+// ACROSS ring stages.  Why: the 128x128 kernels above stage 32 KB per 2.1 MFLOP (bf16) -- at 2 workgroups per CU the
+// MFMA rate would need 64 B/clk/CU of L2 -> LDS traffic (34 TB/s chip-wide), and they top out where the LDS-DMA stream
+// does (10-12 TB/s measured: 700-850 TF).  A 256x128 tile needs 2/3 of those bytes per FLOP, 256x256 half.  With one
+// workgroup per CU nothing else covers a wave's read -> wait -> multiply chain, so the chain is broken here instead:
+// the work is a sequence of UNITS (one 32-deep k-step; bf16: two per 128-byte stage row, split pairs: one), and while
+// the MFMAs of unit u issue from one register set, the fragments of unit u+1 are already being read into the other --
+// also when u+1 lives in the NEXT ring stage (its DMA was retired by the counted vmcnt + barrier at the stage entry,
+// where the stage just drained is immediately refilled NB stages ahead).  One barrier per stage, none per unit.
+//   NPL = 1: bf16 / f16 operands (MFMA per fragment pair and unit: 1); NPL = 2: MSMD_F16X2 split pairs (3, two accumulators).
+// Fragment reads as inline asm: through plain loads hipcc waits lgkmcnt(0) in front of the MFMAs of unit u for the
+// reads of unit u + 1 it has just issued (the loop-carried register sets defeat its counted waits), which is exactly
+// the serialisation this kernel exists to remove.  The counted wait is placed by hand (wait_units) and tied to the
+// registers it guards so no consumer can be scheduled above it (cdna_hip_programming.md 5.7 items 1 and 3).
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read128(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int BASE, int C, int NPL, int... Rs>
+__device__ __forceinline__ void lds_read_rows(u32x4 (&dst)[sizeof...(Rs)][NPL], unsigned addr,
+                                              std::integer_sequence<int, Rs...>) {
+  ((dst[Rs][C] = lds_read128<BASE + Rs * 2048>(addr)), ...);
+}
+template <int N>
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void pin(u32x4& v) { asm volatile("" : "+v"(v)); }
+
+//   NL = 0: every wave stages its share of each ring stage itself.  NL = 4: four extra LOADER waves (one per SIMD) issue
+//   all LDS-DMA; the eight consumer waves only read fragments and multiply.  An LDS-DMA wave-instruction costs the wave
+//   that issues it on the order of 100+ cycles (MI355X_MICROARCH.md cycle constants) during which it cannot issue MFMAs:
+//   at 48-64 pieces per stage that is more than the stage's MFMA time, so it is moved off the multiplying waves.
+template <typename TO, typename TI, int NPL, int BM, int BN, int WM, int WN, int NB, int NL = 0>
+__global__ __launch_bounds__(512 + 64 * NL) __attribute__((amdgpu_waves_per_eu(NL ? 3 : 2, NL ? 3 : 2))) void gemm3_kernel(const GemmArgs p) {
+  static_assert(WM * WN == 8, "8 waves");
+  constexpr int NW = NL ? NL : 8, NT = NW * 64;   // waves / threads that stage
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int LPT = (BM + BN) * 8 / NT;
+  static_assert((BM + BN) * 8 % NT == 0, "stage chunks must divide over the staging threads");
+  constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+  constexpr int UPS = NPL == 1 ? 2 : 1;   // units per stage
+  constexpr int NACC = NPL;               // accumulator sets
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int pid = blockIdx.x;
+  const int xcd = pid & 7, slot = pid >> 3;
+  const int xm_n = 8 / p.xn, ntx = (p.nt + p.xn - 1) / p.xn;
+  const int m_tile = (slot / ntx) * xm_n + (xcd % xm_n), n_tile = (slot % ntx) * p.xn + xcd / xm_n;
+  if (m_tile >= p.mt || n_tile >= p.nt) return;
+  const int z = blockIdx.z;
+  const int zo = z / p.batch_inner, zi = z % p.batch_inner;
+  const uint16_t* __restrict__ A = (const uint16_t*)p.A + zo * p.strideA + zi * p.strideA2;
+  const uint16_t* __restrict__ W = (const uint16_t*)p.W + zo * p.strideW + zi * p.strideW2;
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = NL > 0 && wid_all >= 8;
+  const int wid = NL > 0 ? (loader ? wid_all - 8 : wid_all) : wid_all;   // index among the stagers / among the consumers
+  const int nk = NPL == 1 ? p.K / 64 : p.K / 32;   // ring stages
+
+  const uint16_t* src[LPT];
+#pragma unroll
+  for (int i = 0; i < LPT; ++i) {
+    const int id = (i * NW + (NL > 0 && !loader ? 0 : wid)) * 64 + lane;
+    const int row = id >> 3, phys = id & 7;
+    const int c = phys ^ ((row >> 1) & 7);
+    if (row < BM) src[i] = A + a_row_offset(p, min(m0 + row, p.M - 1)) + c * 8;
+    else src[i] = W + (long)min(n0 + row - BM, p.N - 1) * p.ldw + c * 8;
+  }
+  auto issue = [&](int st) {   // stage st -> ring slot st % NB
+    unsigned char* dst = smem + (st % NB) * STAGE + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < LPT; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[i] + st * 64), (lds_void_t*)(dst + i * NW * 1024), 16, 0, 0);
+  };
+
+  if constexpr (NL > 0) {
+    if (loader) {   // same barrier cadence as the consumers' enter_stage(S), S = 0 .. nk - 1
+#pragma unroll
+      for (int s = 0; s < NB; ++s)
+        if (s < nk) issue(s);
+      for (int S = 0; S < nk; ++S) {
+        if (S + NB - 2 < nk && S >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * LPT) : "memory");
+        else if (S == 0 && NB - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 1) * LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (S >= 1 && S - 1 + NB < nk) issue(S - 1 + NB);
+      }
+      return;
+    }
+  }
+  const int wm = (wid / WN) * (BM / WM), wn = (wid % WN) * (BN / WN);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw = (fr >> 1) & 7;
+  // fragment row r of the X (activation) block sits at byte (wm + 16 r + fr) * 128, of the W block BM * 128 further
+  const int xrow = (wm + fr) * 128, wrow = (BM + wn + fr) * 128;
+  const int ch0 = (fq ^ sw) << 4, ch1 = ((4 + fq) ^ sw) << 4;
+
+  f32x4 acc[NACC][FN][FM];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nu = nk * UPS;
+
+  struct Frags { u32x4 x[FM][NPL]; u32x4 w[FN][NPL]; };
+  constexpr int RPU = (FM + FN) * NPL;   // ds_read_b128 per unit and wave
+  static_assert(RPU <= 15, "lgkmcnt counts to 15");
+  auto read_unit = [&](int u, Frags& f) {
+    const unsigned sb = (unsigned)(((u / UPS) % NB) * STAGE);
+    if constexpr (NPL == 1) {
+      const unsigned ch = sb + ((u & 1) ? ch1 : ch0);
+      lds_read_rows<0, 0, NPL>(f.x, ch + xrow, std::make_integer_sequence<int, FM>{});
+      lds_read_rows<0, 0, NPL>(f.w, ch + wrow, std::make_integer_sequence<int, FN>{});
+    } else {
+      lds_read_rows<0, 0, NPL>(f.x, sb + xrow + ch0, std::make_integer_sequence<int, FM>{});
+      lds_read_rows<0, 1, NPL>(f.x, sb + xrow + ch1, std::make_integer_sequence<int, FM>{});
+      lds_read_rows<0, 0, NPL>(f.w, sb + wrow + ch0, std::make_integer_sequence<int, FN>{});
+      lds_read_rows<0, 1, NPL>(f.w, sb + wrow + ch1, std::make_integer_sequence<int, FN>{});
+    }
+  };
+  auto pin_unit = [&](Frags& f) {   // after a counted wait: the fragments are (re)defined HERE for the scheduler
+#pragma unroll
+    for (int j = 0; j < FM; ++j)
+#pragma unroll
+      for (int c = 0; c < NPL; ++c) pin(f.x[j][c]);
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int c = 0; c < NPL; ++c) pin(f.w[i][c]);
+  };
+  auto mfma_unit = [&](const Frags& f) {
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        if constexpr (NPL == 1) {
+          Mfma<TI>::run(f.w[i][0], f.x[j][0], acc[0][i][j]);
+        } else {
+          Mfma<f16_t>::run(f.w[i][0], f.x[j][0], acc[0][i][j]);
+          Mfma<f16_t>::run(f.w[i][0], f.x[j][1], acc[1][i][j]);
+          Mfma<f16_t>::run(f.w[i][1], f.x[j][0], acc[1][i][j]);
+        }
+      }
+  };
+  // entering ring stage S (its first unit's fragments are about to be read): retire its DMA, make sure every wave has
+  // finished READING stage S - 1 (its fragments are in registers), then refill that slot with stage S - 1 + NB
+  auto enter_stage = [&](int S) {
+    if constexpr (NL == 0) {
+      if (S + NB - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * LPT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    lds_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    if constexpr (NL == 0) {
+      if (S >= 1 && S - 1 + NB < nk) issue(S - 1 + NB);
+    }
+  };
+  auto step = [&](int u, Frags& cur, Frags& nxt) {
+    if (u + 1 < nu) {
+      if ((u + 1) % UPS == 0) enter_stage((u + 1) / UPS);
+      read_unit(u + 1, nxt);
+      lds_wait<RPU>();        // everything but the reads just issued: unit u's fragments have landed
+    } else {
+      lds_wait<0>();
+    }
+    pin_unit(cur);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    mfma_unit(cur);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if constexpr (NL == 0) {
+#pragma unroll
+    for (int s = 0; s < NB; ++s)
+      if (s < nk) issue(s);
+  }
+  Frags fa, fb;
+  enter_stage(0);
+  read_unit(0, fa);
+  for (int u = 0; u < nu; u += 2) {
+    step(u, fa, fb);
+    if (u + 1 < nu) step(u + 1, fb, fa);
+  }
+
+  if constexpr (NPL == 2) {
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[0][i][j][e] = fmaf(acc[1][i][j][e], MSMD_SPLIT_INV, acc[0][i][j][e]);
+  }
+  if constexpr (NPL == 2 && sizeof(TO) == 2) gemm_epilogue_split<FM, FN>(p, acc[0], z, m0 + wm, n0 + wn, fr, fq);
+  else gemm_epilogue<TO, FM, FN>(p, acc[0], z, m0 + wm, n0 + wn, fr, fq);
+}
+
+template <typename TO, typename TI, int NPL, int BM, int BN, int WM, int WN, int NB, int NL = 0>
+static int launch_gemm3(GemmArgs& p, int batch, hipStream_t st) {
+  constexpr int lds = NB * (BM + BN) * 128;
+  static_assert(lds <= 160 * 1024, "ring does not fit the CU's LDS");
+  static bool attr_done = false;
+  auto kfn = gemm3_kernel<TO, TI, NPL, BM, BN, WM, WN, NB, NL>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  p.mt = (p.M + BM - 1) / BM; p.nt = (p.N + BN - 1) / BN;
+  int want_xn = 1;
+  if (g_tuning[7] == 1 || g_tuning[7] == 2 || g_tuning[7] == 4) {
+    want_xn = g_tuning[7];
+  } else {
+    const double a_bytes = 2.0 * p.M * (double)(p.rows_per_batch < p.M ? p.lda : p.K * NPL), w_bytes = 2.0 * NPL * p.N * (double)p.K;
+    double best = 1e30;
+    for (int xn = 1; xn <= 4; xn *= 2) {
+      const double c = 0.7 * xn * a_bytes + (8.0 / xn) * w_bytes;
+      if (c < best && p.nt >= xn) { best = c; want_xn = xn; }
+    }
+  }
+  p.xn = p.nt >= want_xn ? want_xn : 1;
+  const int xm_n = 8 / p.xn;
+  dim3 grid(((p.mt + xm_n - 1) / xm_n) * ((p.nt + p.xn - 1) / p.xn) * 8, 1, batch);
+  hipLaunchKernelGGL(kfn, grid, dim3(512 + 64 * NL), lds, st, p);
+  MSMD_RETURN_LAST();
+}
+
 int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // shared with gemm_tn.hip (key 2 = forced contraction splits)
 extern "C" int msmd_set_tuning(int key, int value) {
   if (key < 0 || key >= 8) return 1;
@@ -729,6 +965,10 @@ static int dispatch_gemm2s(GemmArgs& p, int batch, hipStream_t st, int variant) 
     case 8: return launch_gemm2s<TO, 128, 128, 2, 2, 4>(p, batch, st);
     case 9: return launch_gemm2s<TO, 128, 128, 4, 2, 3>(p, batch, st);   // 96 KB
     case 10: return launch_gemm2s<TO, 128, 256, 2, 4, 3>(p, batch, st);  // 144 KB
+    case 11: return launch_gemm3<TO, f16_t, 2, 128, 128, 4, 2, 4>(p, batch, st);   // 1 workgroup / CU, pipelined reads
+    case 12: return launch_gemm3<TO, f16_t, 2, 128, 128, 4, 2, 3>(p, batch, st);
+    case 13: return launch_gemm3<TO, f16_t, 2, 128, 128, 2, 4, 4>(p, batch, st);
+    case 14: return launch_gemm3<TO, f16_t, 2, 128, 128, 4, 2, 4, 4>(p, batch, st);   // + 4 loader waves
     default: return -1;
   }
 }
@@ -764,6 +1004,13 @@ static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
     case 26: return launch_gemm2<TO, 128, 256, 2, 4, 3, true>(p, batch, st);
     case 27: return launch_gemm2<TO, 256, 128, 4, 2, 2, true>(p, batch, st);
     case 28: return launch_gemm2k<TO>(p, batch, st);
+    case 30: return launch_gemm3<TO, bf16_t, 1, 256, 128, 4, 2, 3>(p, batch, st);
+    case 31: return launch_gemm3<TO, bf16_t, 1, 256, 256, 2, 4, 2>(p, batch, st);
+    case 32: return launch_gemm3<TO, bf16_t, 1, 128, 128, 4, 2, 4>(p, batch, st);
+    case 33: return launch_gemm3<TO, bf16_t, 1, 128, 256, 2, 4, 3>(p, batch, st);
+    case 34: return launch_gemm3<TO, bf16_t, 1, 256, 128, 4, 2, 3, 4>(p, batch, st);   // + 4 loader waves
+    case 35: return launch_gemm3<TO, bf16_t, 1, 128, 128, 4, 2, 4, 4>(p, batch, st);
+    case 36: return launch_gemm3<TO, bf16_t, 1, 128, 256, 2, 4, 3, 4>(p, batch, st);
     default: return -1;
   }
 }

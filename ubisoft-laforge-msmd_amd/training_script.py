@@ -25,6 +25,9 @@ rows 17-18); `synthetic_batch` produces the loader's tensor contract (SURVEY.md 
 """
 from __future__ import annotations
 
+import contextlib
+import os
+
 import numpy as np
 import torch
 
@@ -170,6 +173,10 @@ class Trainer:
             raise ValueError(f"Unknown pad mode {pad_mode}!")   # reference utils/common.py:777
         self.pad_replicate = pad_mode == "replicate"
         self._graphs, self._graph_pool, self._flag_table = {}, None, None
+        # hipGraph mode with more than one rank: capture the iteration as bucket-aligned SEGMENTS so every bucket's
+        # all-reduce starts as soon as its gradients are final (MSMD_SEGMENT_GRAPHS=1 forces it on one rank: tests)
+        self.segment_graphs = self.use_graph and (self.reducer.world > 1 or os.environ.get("MSMD_SEGMENT_GRAPHS") == "1")
+        self._stepping = True
         # weight gradients are added straight into the arena by the wgrad GEMM when bucket launches do not hang
         # on per-parameter autograd hooks (graph mode launches them from finish(); world 1 launches nothing)
         self.direct_grad = self.use_graph or self.reducer.world == 1
@@ -351,7 +358,10 @@ class Trainer:
     def launch_description(self):
         if not self.use_graph:
             return "eager launches; bucket all-reduces from post-accumulate-grad hooks on a side stream"
-        return "whole-iteration hipGraph; all-reduce buckets launched after the replay"
+        if self.segment_graphs:
+            return ("hipGraph segments cut where a gradient bucket becomes final; each bucket's all-reduce is launched "
+                    "on a side stream between segment replays (overlaps the rest of the backward)")
+        return "whole-iteration hipGraph (one rank: nothing to exchange)"
 
     def _host_choices(self, draws):
         """The reference's host-side coin flips (training_script.py:99-141): cross-style per window, truncation."""
@@ -387,6 +397,7 @@ class Trainer:
         ag.TrainNoise.graph_safe = self.use_graph
         ag.TrainNoise.spec_masks = None
         self.reducer.begin_backward()         # re-arm per backward, not per optimizer step (gradient accumulation)
+        self._stepping = stepping
         if self.use_graph:
             self.reducer.enabled = False      # python hooks do not run on replay: buckets are launched by finish()
             out = self._graph_fwd_bwd(batch, draws, trunc, cross)
@@ -423,7 +434,12 @@ class Trainer:
                 if dst is not None:
                     dst.copy_(torch.as_tensor(src, device=self.device), non_blocking=True)
         flags.copy_(self._flag_table[int(cross[0]) * 2 + int(cross[1])], non_blocking=True)
-        g.replay()
+        stepping = self._stepping
+        for gseg, buckets in g:
+            gseg.replay()
+            if stepping:
+                for b in buckets:        # final for this backward: reduce it under the segments that follow
+                    self.reducer._launch(b)
         return {k: v.clone() for k, v in out.items()}
 
     def _draw_spec_mask(self, shape):
@@ -464,26 +480,83 @@ class Trainer:
             spec = [self._draw_spec_mask((B, 2 * self.model.n_motions)).to(dev) for _ in range(n_pass)]
         ag.TrainNoise.graph_safe = True
         saved = self.reducer.arena.clone()
-        # warm-up on a side stream (allocator / lazy init), then capture; gradients written by both are discarded
+        segmented = self.segment_graphs
+        red = self.reducer
+        # warm-up on a side stream (allocator / lazy init), then capture; gradients written by both are discarded.
+        # Segmented mode: the warm-up also RECORDS the backward's gradient-write sequence (autograd accumulations and
+        # direct arena writes), from which the capture knows after which write each bucket is final.
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
+        mt = torch.autograd.set_multithreading_enabled(False) if segmented else contextlib.nullcontext()
+        with mt:   # single-threaded backward: hooks run on THIS thread, so a capture can be ended / begun inside them
+            with torch.cuda.stream(s):
+                self._invalidate_caches()
+                ag.TrainNoise.spec_masks = spec or None
+                if segmented:
+                    red.trace_begin()
+                    ag.GRAD_WRITTEN = red.on_write
+                self._fwd_bwd(sb, sd, trunc, cross)
+                final_pos = red.trace_end() if segmented else None
+            torch.cuda.current_stream().wait_stream(s)
             self._invalidate_caches()
             ag.TrainNoise.spec_masks = spec or None
-            self._fwd_bwd(sb, sd, trunc, cross)
-        torch.cuda.current_stream().wait_stream(s)
-        self._invalidate_caches()
-        g = torch.cuda.CUDAGraph()
-        ag.TrainNoise.spec_masks = spec or None
-        with torch.cuda.graph(g, pool=self._graph_pool):
-            out = self._fwd_bwd(sb, sd, trunc, cross)
+            if not segmented:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self._graph_pool):
+                    out = self._fwd_bwd(sb, sd, trunc, cross)
+                if self._graph_pool is None:
+                    self._graph_pool = g.pool()
+                segs = [(g, [])]
+            else:
+                # One hipGraph per stretch of the iteration that ends where a gradient bucket becomes final: the replay
+                # loop launches that bucket's all-reduce on the side stream while the next segment (the rest of the
+                # backward) runs -- the overlap the eager mode gets from autograd hooks, without ~10^4 host launches.
+                segs, cur = [], [torch.cuda.CUDAGraph(), []]
+                torch.cuda.synchronize()
+                cs = torch.cuda.Stream(device=dev)
+                cs.wait_stream(torch.cuda.current_stream())
+
+                def begin(gr):
+                    if self._graph_pool is None:
+                        gr.capture_begin()
+                    else:
+                        gr.capture_begin(pool=self._graph_pool)
+
+                def cut(bucket):
+                    cur[1].append(bucket)
+                    if getattr(red, "_last_cut_count", None) == red.write_count:
+                        return                   # several buckets final at the same write: one cut
+                    red._last_cut_count = red.write_count
+                    cur[0].capture_end()
+                    if self._graph_pool is None:
+                        self._graph_pool = cur[0].pool()
+                    segs.append((cur[0], cur[1]))
+                    cur[0], cur[1] = torch.cuda.CUDAGraph(), []
+                    begin(cur[0])
+                red.final_pos, red.write_count, red._last_cut_count = final_pos, 0, None
+                red.on_bucket_final = cut
+                try:
+                    with torch.cuda.stream(cs):
+                        begin(cur[0])
+                        out = self._fwd_bwd(sb, sd, trunc, cross)
+                        cur[0].capture_end()
+                        if self._graph_pool is None:
+                            self._graph_pool = cur[0].pool()
+                        segs.append((cur[0], cur[1]))
+                finally:
+                    red.on_bucket_final, red.final_pos = None, None
+                    ag.GRAD_WRITTEN = None
+                torch.cuda.current_stream().wait_stream(cs)
+                # buckets whose cut coincided share the segment that ended there
+                merged = []
+                for gseg, bks in segs:
+                    merged.append((gseg, list(bks)))
+                segs = merged
         ag.TrainNoise.spec_masks = None
-        if self._graph_pool is None:
-            self._graph_pool = g.pool()
         self._invalidate_caches()             # cached casts now live in the graph's pool: eager code must re-make them
         self.reducer.arena.copy_(saved)
-        self.reducer.pending = [len(m) for _, _, m in self.reducer.buckets]
-        ent = (sb, sd, flags, g, out, spec)
+        self.reducer.begin_backward()
+        ent = (sb, sd, flags, segs, out, spec)
         self._graphs[key] = ent
         return ent
 
