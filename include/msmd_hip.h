@@ -293,7 +293,7 @@ int msmd_cfg_ddpm_step_dev(float* x, const float* res, const float* z, const flo
  * msmd_lbs_skin: verts (B, V, 3) = sum_j w[v][j] A[b][j] . [v_template + coef . dirs ; 1].
  */
 int msmd_lbs_prepare(const float* betas, const float* pose, const float* JS, const int* parents,
-                     float* coef, void* coef_hl, float* A, float* joints, int B, int NB, int J, int Kp,
+                     float* coef, void* coef_hl, float* A, float* joints, void* at_tiles, int B, int NB, int J, int Kp,
                      int pose_is_matrix, msmd_stream_t stream);
 int msmd_lbs_skin(const float* coef, const float* A, const float* v_template, const float* dirs,
                   const float* lbs_weights, float* verts, int B, int J, int V, int Vp, int Kp,
@@ -305,6 +305,15 @@ int msmd_lbs_skin(const float* coef, const float* A, const float* v_template, co
 int msmd_lbs_skin_bf16x3(const void* coef_hl, const float* A, const float* v_template, const void* dirs_hl,
                          const float* lbs_weights, float* verts, int B, int J, int V, int Vp, int Kp,
                          msmd_stream_t stream);
+
+/* msmd_lbs_skin_bf16x3 with the per-(vertex, frame) joint blend T = sum_j w_j A_j on the matrix pipe as well: for each
+ * of the 12 components of the 3x4 transforms ONE v_mfma_f32_16x16x32_f16 contracts the five joints (both sides split
+ * into fp16 hi + lo: 15 of the 32 K slots), its accumulator landing where the blendshape product puts p(vertex,
+ * frame).  at_tiles (ceil(B / 16), 12, 2, 16, 8) fp16 = the frame-side rows, written by msmd_lbs_prepare.  128 vertices
+ * per workgroup (8 waves), 16-frame tiles through a 3-deep LDS-DMA ring; Vp = padded vertex count of the constant
+ * planes (any value >= V).  HBM-bound target: 60 936 algorithmic bytes per frame.  Same reference lines. */
+int msmd_lbs_skin_v2(const void* coef_hl, const void* at_tiles, const float* v_template, const void* dirs_hl,
+                     const float* lbs_weights, float* verts, int B, int J, int V, int Vp, int Kp, msmd_stream_t stream);
 
 /* Landmarks by barycentric interpolation (utils/lbs.py:102-138): out (B, L, 3).
  * faces (F,3) int32; lmk_faces_idx (B or 1, L) int32 with batch stride idx_bstride (0 = shared);

@@ -191,10 +191,11 @@ def test_group_pad():
     assert np.array_equal(y[:, 1, 8:58], x[:, :, 48:])
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16x3_valu"])
 def test_flame_lbs_matches_oracle_and_golden(precision):
-    """fp32: exact-fp32 MFMA.  bf16x3: split-bf16 products with fp32 accumulation -- same 5e-6 tolerance on
-    FLAME-scale (|v| ~ 0.1) vertices."""
+    """fp32: exact-fp32 MFMA.  bf16x3: split-bf16 blendshape products with fp32 accumulation and the joint blend as one
+    fp16-split MFMA per transform component (msmd_lbs_skin_v2, the default); bf16x3_valu: the blend on the vector ALU
+    (the round-1 kernel) -- same 5e-6 tolerance on FLAME-scale (|v| ~ 0.1) vertices."""
     from msmd_amd.utils.flame import FLAME, FLAMEConfig
     from types import SimpleNamespace
     g = load_golden("g4_flame")
@@ -222,7 +223,7 @@ def test_flame_lbs_matches_oracle_and_golden(precision):
     row = ops().dynamic_lmk_row(dev(orc.full_pose(pose)), dev(orc.neck_kin_chain.astype(np.int32)))
     assert np.array_equal(row.cpu().numpy(), ofl.dynamic_lmk_index(orc.full_pose(pose), orc.neck_kin_chain))
     # ragged frame counts (not a multiple of the 16-frame tile) and a large batch
-    for B in (1, 17, 100):
+    for B in (1, 17, 100, 1000):
         xi = flame_inputs(B, tag=f"flame{B}")
         vi, _, _ = fl(dev(xi["shape"]), dev(xi["exp"]), dev(xi["pose"]), return_lm2d=False, return_lm3d=False)
         vr, _, _ = orc.forward(xi["shape"], xi["exp"], xi["pose"], return_lm2d=False, return_lm3d=False)

@@ -8,7 +8,7 @@ from msmd_amd.utils.flame import FLAME, FLAMEConfig
 cfg = SimpleNamespace(**vars(FLAMEConfig)); cfg.asset = synth.flame_asset()
 fl = FLAME(cfg).to("cuda")
 import msmd_amd.utils.lbs as L
-for prec in ("fp32", "bf16x3"):
+for prec in ("fp32", "bf16x3_valu", "bf16x3"):
   fl.lbs_precision = prec
   for B in (6400, 25600):
       torch.manual_seed(B); exp = (0.5 * torch.randn(B, 50, device="cuda")); pose = 0.2 * torch.randn(B, 6, device="cuda"); shape = torch.zeros(B, 100, device="cuda")

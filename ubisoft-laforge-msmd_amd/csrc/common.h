@@ -44,7 +44,7 @@ __device__ __forceinline__ Philox4 dropout_bits(const unsigned long* __restrict_
 // keep iff uniform [0,1) >= p  <=>  bits >= p * 2^32
 __device__ __forceinline__ unsigned dropout_threshold(float p) { return (unsigned)fminf(p * 4294967296.0f, 4294967295.0f); }
 
-extern int g_tuning[8];  // msmd_set_tuning knobs (gemm.hip)
+extern int g_tuning[16];  // msmd_set_tuning knobs (gemm.hip)
 #define MSMD_RETURN_LAST() return (int)hipGetLastError()
 
 __device__ __forceinline__ float to_f32(float x) { return x; }

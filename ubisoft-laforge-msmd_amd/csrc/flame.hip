@@ -48,114 +48,131 @@ extern "C" int msmd_batch_rodrigues(const float* rot_vecs, float* R, int N, msmd
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Per-frame kinematics: one wavefront per frame.
+// Per-frame kinematics: 16 frames per 256-thread workgroup, 16 lanes per frame.  (The first version ran one 64-thread
+// workgroup per frame with the joint chain serial in lane 0: latency bound, 110 us for 25 600 frames -- a sixth of the
+// whole FLAME pass.)  The joint-regression table (9 KB) is staged in LDS once per workgroup and shared by its frames;
+// the kinematic chain runs joint by joint (parents[i] < i) with 12 lanes computing the 3x4 entries of a transform.
 #define LBS_MAXJ 8
-__global__ __launch_bounds__(64) void lbs_prepare_kernel(const float* __restrict__ betas,
-                                                         const float* __restrict__ pose,
-                                                         const float* __restrict__ JS,
-                                                         const int* __restrict__ parents, float* __restrict__ coef,
-                                                         bf16_t* __restrict__ coef_hl, float* __restrict__ A,
-                                                         float* __restrict__ joints_out, int NB, int J, int Kp,
-                                                         int pose_is_matrix) {
-  __shared__ float sJ[LBS_MAXJ * 3];
-  __shared__ float sR[LBS_MAXJ * 9];
-  const int b = blockIdx.x, t = threadIdx.x;
-  const float* be = betas + (long)b * NB;
-  // joints = J_regressor . (template + sum_l beta_l shapedirs_l): linear, so use the precomputed JS table.
-  // 64 lanes = 4 slices of the beta range x 16 output slots (J*3 <= 16), combined with two shuffles.
-  __shared__ float sB[256];
-  for (int l = t; l < NB; l += 64) sB[l] = be[l];
-  __syncthreads();
-  {
-    const int slot = t & 15, slice = t >> 4;
-    float acc = 0.f;
-    if (slot < J * 3) {
-      const int per = (NB + 3) / 4, l0 = slice * per, l1 = min(NB, l0 + per);
-#pragma unroll 8
-      for (int l = l0; l < l1; ++l) acc = fmaf(sB[l], JS[(long)(1 + l) * J * 3 + slot], acc);
-    }
-    acc += __shfl_xor(acc, 16, 64);
-    acc += __shfl_xor(acc, 32, 64);
-    if (t < J * 3) sJ[t] = acc + JS[t];
-  }
-  if (t < J) {
+#define LBS_FPB 16
+__global__ __launch_bounds__(256) void lbs_prepare_kernel(const float* __restrict__ betas,
+                                                          const float* __restrict__ pose,
+                                                          const float* __restrict__ JS,
+                                                          const int* __restrict__ parents, float* __restrict__ coef,
+                                                          bf16_t* __restrict__ coef_hl, float* __restrict__ A,
+                                                          float* __restrict__ joints_out, int NB, int J, int Kp,
+                                                          int pose_is_matrix, f16_t* __restrict__ at_tiles, int B) {
+  __shared__ float sJS[257 * 15];
+  __shared__ float sB[LBS_FPB][260];
+  __shared__ float sJ[LBS_FPB][16];
+  __shared__ float sR[LBS_FPB][LBS_MAXJ * 9];
+  __shared__ float sT[LBS_FPB][LBS_MAXJ * 12];
+  __shared__ float sAo[LBS_FPB][LBS_MAXJ * 12];
+  const int tid = threadIdx.x, fl = tid >> 4, ln = tid & 15;
+  const int b = blockIdx.x * LBS_FPB + fl;
+  const bool valid = b < B;
+  const int bb = valid ? b : B - 1;
+  const int J3 = J * 3;
+  for (int k = tid; k < (NB + 1) * J3; k += 256) sJS[k] = JS[k];
+  const float* be = betas + (long)bb * NB;
+  for (int k = ln; k < NB; k += 16) sB[fl][k] = be[k];
+  if (ln < J) {
     float R[9];
     if (pose_is_matrix) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) R[k] = pose[((long)b * J + t) * 9 + k];
+      for (int k = 0; k < 9; ++k) R[k] = pose[((long)bb * J + ln) * 9 + k];
     } else {
-      const float r[3] = {pose[((long)b * J + t) * 3], pose[((long)b * J + t) * 3 + 1], pose[((long)b * J + t) * 3 + 2]};
+      const float r[3] = {pose[((long)bb * J + ln) * 3], pose[((long)bb * J + ln) * 3 + 1], pose[((long)bb * J + ln) * 3 + 2]};
       rodrigues(r, R);
     }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) sR[t * 9 + k] = R[k];
+    for (int k = 0; k < 9; ++k) sR[fl][ln * 9 + k] = R[k];
   }
   __syncthreads();
-  // coefficient row = [betas | pose_feature = (R[1:] - I) | 0 pad]
-  float* crow = coef + (long)b * Kp;
-  for (int k = t; k < Kp; k += 64) {
-    float v = 0.f;
-    if (k < NB) v = be[k];
-    else if (k < NB + (J - 1) * 9) {
-      const int pf = k - NB, j = 1 + pf / 9, rc = pf % 9;
-      v = sR[j * 9 + rc] - ((rc == 0 || rc == 4 || rc == 8) ? 1.0f : 0.0f);
+  // joints = J_regressor . (template + sum_l beta_l shapedirs_l): linear in the coefficients -> the JS table
+  if (ln < J3) {
+    float a0 = sJS[ln], a1 = 0.f;
+    int l = 0;
+    for (; l + 1 < NB; l += 2) {
+      a0 = fmaf(sB[fl][l], sJS[(1 + l) * J3 + ln], a0);
+      a1 = fmaf(sB[fl][l + 1], sJS[(2 + l) * J3 + ln], a1);
     }
-    crow[k] = v;
-    if (coef_hl) {  // bf16 hi/lo split for the 3-product MFMA form: v ~= hi + lo with 16 significant bits
-      const bf16_t hi = (bf16_t)v;
-      coef_hl[((long)b * 2 + 0) * Kp + k] = hi;
-      coef_hl[((long)b * 2 + 1) * Kp + k] = (bf16_t)(v - (float)hi);
+    if (l < NB) a0 = fmaf(sB[fl][l], sJS[(1 + l) * J3 + ln], a0);
+    sJ[fl][ln] = a0 + a1;
+  }
+  __syncthreads();
+  // kinematic chain (utils/lbs.py:317-371): T_0 = [R_0 | J_0]; T_i = T_parent . [R_i | J_i - J_parent]; entry (r, c) = lane
+  for (int i = 0; i < J; ++i) {
+    if (ln < 12) {
+      const int r = ln >> 2, c = ln & 3;
+      const int pa = i == 0 ? -1 : parents[i];
+      auto loc = [&](int rr) { return c < 3 ? sR[fl][i * 9 + rr * 3 + c] : sJ[fl][i * 3 + rr] - (pa >= 0 ? sJ[fl][pa * 3 + rr] : 0.f); };
+      float v;
+      if (pa < 0) {
+        v = loc(r);
+      } else {
+        const float* Tp = &sT[fl][pa * 12 + r * 4];
+        v = Tp[0] * loc(0) + Tp[1] * loc(1) + Tp[2] * loc(2);
+        if (c == 3) v += Tp[3];
+      }
+      sT[fl][i * 12 + ln] = v;
+    }
+    __syncthreads();
+  }
+  // A_i = [R | t - R J_i] (relative to the rest pose); posed joints = translation column of T_i
+  for (int e = ln; e < J * 12; e += 16) {
+    const int i = e / 12, rc = e - i * 12, r = rc >> 2, c = rc & 3;
+    const float* Tr = &sT[fl][i * 12 + r * 4];
+    float v = Tr[c];
+    if (c == 3) v -= Tr[0] * sJ[fl][i * 3] + Tr[1] * sJ[fl][i * 3 + 1] + Tr[2] * sJ[fl][i * 3 + 2];
+    sAo[fl][e] = v;
+    if (valid) {
+      A[(long)b * J * 12 + e] = v;
+      if (joints_out && c == 3) joints_out[((long)b * J + i) * 3 + r] = Tr[3];
     }
   }
-  if (t == 0) {
-    // kinematic chain (utils/lbs.py:317-371): T_0 = [R_0 | J_0]; T_i = T_parent . [R_i | J_i - J_parent]
-    float Tm[LBS_MAXJ][12];
-    for (int i = 0; i < J; ++i) {
-      float loc[12];
-      const int pa = i == 0 ? -1 : parents[i];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) loc[r * 4 + c] = sR[i * 9 + r * 3 + c];
-        loc[r * 4 + 3] = sJ[i * 3 + r] - (pa >= 0 ? sJ[pa * 3 + r] : 0.f);
+  // coefficient row = [betas | pose_feature = (R[1:] - I) | 0 pad]
+  if (valid) {
+    float* crow = coef + (long)b * Kp;
+    for (int k = ln; k < Kp; k += 16) {
+      float v = 0.f;
+      if (k < NB) v = sB[fl][k];
+      else if (k < NB + (J - 1) * 9) {
+        const int pf = k - NB, jj = 1 + pf / 9, rc = pf % 9;
+        v = sR[fl][jj * 9 + rc] - ((rc == 0 || rc == 4 || rc == 8) ? 1.0f : 0.0f);
       }
-      if (pa < 0) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) Tm[i][k] = loc[k];
-      } else {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            float v = Tm[pa][r * 4 + 0] * loc[0 * 4 + c] + Tm[pa][r * 4 + 1] * loc[1 * 4 + c] +
-                      Tm[pa][r * 4 + 2] * loc[2 * 4 + c];
-            if (c == 3) v += Tm[pa][r * 4 + 3];
-            Tm[i][r * 4 + c] = v;
-          }
-        }
+      crow[k] = v;
+      if (coef_hl) {  // bf16 hi/lo split for the 3-product MFMA form: v ~= hi + lo with 16 significant bits
+        asm volatile("" : "+v"(v));
+        const bf16_t hi = (bf16_t)v;
+        coef_hl[((long)b * 2 + 0) * Kp + k] = hi;
+        coef_hl[((long)b * 2 + 1) * Kp + k] = (bf16_t)(v - (float)hi);
       }
     }
-    for (int i = 0; i < J; ++i) {
-      float* Ao = A + ((long)b * J + i) * 12;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const float tj = Tm[i][r * 4] * sJ[i * 3] + Tm[i][r * 4 + 1] * sJ[i * 3 + 1] + Tm[i][r * 4 + 2] * sJ[i * 3 + 2];
-        Ao[r * 4 + 0] = Tm[i][r * 4 + 0];
-        Ao[r * 4 + 1] = Tm[i][r * 4 + 1];
-        Ao[r * 4 + 2] = Tm[i][r * 4 + 2];
-        Ao[r * 4 + 3] = Tm[i][r * 4 + 3] - tj;
-        if (joints_out) joints_out[((long)b * J + i) * 3 + r] = Tm[i][r * 4 + 3];
-      }
+  }
+  if (at_tiles) {
+    // Frame-side operand of the skinning kernel's blend MFMA (msmd_lbs_skin_v2): for component m of the 3x4 transforms,
+    // 16 fp16 K slots per frame = [Ah_0..4 | Al_0..4 | Ah_0..4 | 0] (A = Ah + Al, unscaled: |A| = O(1), so the lo
+    // halves keep 2^-25 absolute).  Tile layout [frame / 16][m][slot / 8][frame % 16][slot % 8]: one 16-byte chunk per
+    // (m, slot octet, frame), frames of a tile contiguous -> conflict-free ds_read_b128.  Frames beyond B - 1 of the
+    // last tile carry frame B - 1's rows (the kernel clamps them to that frame and stores identical values).
+    __syncthreads();
+    for (int idx = ln; idx < 12 * 16; idx += 16) {
+      const int m = idx >> 4, slot = idx & 15;
+      float a = slot < 15 ? sAo[fl][(slot % 5) * 12 + m] : 0.f;
+      asm volatile("" : "+v"(a));
+      const f16_t ah = (f16_t)a, al = (f16_t)(a - (float)ah);
+      const f16_t val = slot >= 15 ? (f16_t)0.f : ((slot >= 5 && slot < 10) ? al : ah);
+      at_tiles[((((long)blockIdx.x * 12 + m) * 2 + (slot >> 3)) * 16 + fl) * 8 + (slot & 7)] = val;
     }
   }
 }
 
 extern "C" int msmd_lbs_prepare(const float* betas, const float* pose, const float* JS, const int* parents,
-                                float* coef, void* coef_hl, float* A, float* joints, int B, int NB, int J, int Kp,
-                                int pose_is_matrix, msmd_stream_t stream) {
-  if (B <= 0 || NB <= 0 || NB > 256 || J <= 0 || J > 5 || Kp < NB + (J - 1) * 9) return 1;
-  hipLaunchKernelGGL(lbs_prepare_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, betas, pose, JS, parents, coef,
-                     (bf16_t*)coef_hl, A, joints, NB, J, Kp, pose_is_matrix);
+                                float* coef, void* coef_hl, float* A, float* joints, void* at_tiles, int B, int NB, int J,
+                                int Kp, int pose_is_matrix, msmd_stream_t stream) {
+  if (B <= 0 || NB <= 0 || NB > 256 || J <= 0 || J > 5 || Kp < NB + (J - 1) * 9 || (at_tiles && J != 5)) return 1;
+  hipLaunchKernelGGL(lbs_prepare_kernel, dim3((B + LBS_FPB - 1) / LBS_FPB), dim3(256), 0, (hipStream_t)stream, betas, pose,
+                     JS, parents, coef, (bf16_t*)coef_hl, A, joints, NB, J, Kp, pose_is_matrix, (f16_t*)at_tiles, B);
   MSMD_RETURN_LAST();
 }
 
@@ -399,6 +416,226 @@ extern "C" int msmd_lbs_skin_bf16x3(const void* coef_hl, const float* A, const f
   dim3 grid(((vt + 7) / 8) * 8 * splits), block(256);
   hipLaunchKernelGGL((lbs_skin_bf16x3_kernel<6, 5>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)coef_hl, A,
                      v_template, (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb);
+  MSMD_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Skinning, second form (msmd_lbs_skin_v2): the per-(vertex, frame) blend  T = sum_j w_j A_j  moves from the vector
+// ALU (60 FMAs + 60 broadcast LDS reads per lane and frame: the epilogue that bounded lbs_skin_bf16x3 at ~20 % of HBM)
+// onto the matrix pipe.  For component m of the 3x4 transforms, T_m(frame, vertex) = sum_j A_j[m](frame) w_j(vertex) is
+// a contraction over the FIVE joints: with both sides split into fp16 hi + lo it is 15 K slots of ONE
+// v_mfma_f32_16x16x32_f16 (frame-side rows [Ah | Al | Ah] written by lbs_prepare, vertex-side column [wh | wh | wl] held
+// in one VGPR quad), whose accumulator lands exactly where the blendshape product puts p(vertex, frame): vertex on the
+// lane, frames 4q + e in the registers.  12 MFMAs replace ~240 vector instructions per 16 x 16 tile; what is left on
+// the vector ALU is out_c = T_c0 px + T_c1 py + T_c2 pz + T_c3 (36 FMAs per lane and tile).
+// Workgroup = NWV waves = 16 NWV vertices (their `dirs` planes in registers, 144 VGPRs, as before); frame tiles of 16
+// arrive by LDS-DMA through an NS-deep ring (coefficients 12 KB + blend rows 6 KB per tile = 18 one-KiB pieces dealt
+// round-robin to the waves) behind counted vmcnt waits that leave younger tiles' loads AND the vertex stores in flight.
+// Stores: 12 bytes (x, y, z of the lane's vertex) per lane and frame, 16 lanes = 192 contiguous bytes.  (Turning each
+// wave's 16 x 48 floats through an LDS patch into plain dword stores of whole row slices was built and measured: the
+// 28 extra LDS instructions per lane and tile cost more than the narrower stores saved, 765 vs 695 us at 25 600 frames.)
+// No lane is ever masked: padding vertices (v >= V) and padding frames (f >= B) recompute and re-store vertex V - 1 /
+// frame B - 1 (identical bytes), so every wave issues exactly 4 store instructions per tile and the vmcnt arithmetic
+// is uniform.
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void vm_wait_n(int n) {   // n = (pieces per load group) a + 4 b, see the kernel
+  switch (n) {
+    case 1: vm_wait<1>(); break;    case 2: vm_wait<2>(); break;    case 3: vm_wait<3>(); break;
+    case 4: vm_wait<4>(); break;    case 5: vm_wait<5>(); break;    case 6: vm_wait<6>(); break;
+    case 7: vm_wait<7>(); break;    case 8: vm_wait<8>(); break;    case 9: vm_wait<9>(); break;
+    case 10: vm_wait<10>(); break;  case 11: vm_wait<11>(); break;  case 12: vm_wait<12>(); break;
+    case 13: vm_wait<13>(); break;  case 14: vm_wait<14>(); break;  case 15: vm_wait<15>(); break;
+    case 16: vm_wait<16>(); break;  case 17: vm_wait<17>(); break;  case 18: vm_wait<18>(); break;
+    case 19: vm_wait<19>(); break;  case 20: vm_wait<20>(); break;  case 21: vm_wait<21>(); break;
+    case 22: vm_wait<22>(); break;
+    default: vm_wait<0>(); break;
+  }
+}
+
+// NWV waves per workgroup (16 vertices each).  ABL (developer ablations, tuning key 8; 0 in the product): 1 = no vertex
+// stores, 2 = no blend MFMAs, 4 = no blendshape MFMAs, 8 = no LDS-DMA after the prologue (stale tiles) -- outputs are
+// then wrong by construction.
+template <int KG, int NS, int NWV, int ABL = 0>
+__global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void lbs_skin_v2_kernel(const bf16_t* __restrict__ coef_hl, const f16_t* __restrict__ at_tiles,
+                        const float* __restrict__ tmpl, const bf16_t* __restrict__ dirs_hl,
+                        const float* __restrict__ wts, float* __restrict__ verts, int B, int V, int Vp,
+                        int frames_per_block, int vtn) {
+  constexpr int Kp = KG * 32, J = 5, VPB = 16 * NWV;
+  constexpr int NCH = 2 * Kp / 8;            // 16-byte chunks per frame of coef_hl (hi then lo)
+  constexpr int COEF_BYTES = NCH * 256;      // [chunk][frame] 16 B
+  constexpr int AT_BYTES = 12 * 2 * 256;     // [m][slot octet][frame] 16 B
+  constexpr int STAGE = COEF_BYTES + AT_BYTES;
+  constexpr int NP = STAGE / 1024;           // 18 one-KiB LDS-DMA pieces per tile
+  static_assert(COEF_BYTES == 12 * 1024 && AT_BYTES == 6 * 1024, "piece map below");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int vt8 = (vtn + 7) >> 3;
+  const int L = blockIdx.x;
+  const int v_tile = (L & 7) + 8 * ((L >> 3) % vt8);   // all frame splits of a vertex slice on ONE XCD (its dirs stay in that L2)
+  if (v_tile >= vtn) return;
+  const int f_begin = ((L >> 3) / vt8) * frames_per_block;
+  if (f_begin >= B) return;
+  const int f_end = min(B, f_begin + frames_per_block);
+  const int ntiles = (f_end - f_begin + 15) >> 4;
+  const int ve = min(v_tile * VPB + wid * 16 + i, V - 1);
+
+  u32x4 dh[3][KG], dl[3][KG];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      const long off = (((long)c * (Kp / 8) + 4 * g + q) * Vp + ve) * 8;
+      dh[c][g] = *(const u32x4*)(dirs_hl + off);
+      dl[c][g] = *(const u32x4*)(dirs_hl + (long)3 * (Kp / 8) * Vp * 8 + off);
+    }
+  float t3[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) t3[c] = tmpl[(long)c * Vp + ve];
+  // vertex-side operand of the blend MFMA: K slots [wh_0..4 | wh_0..4 | wl_0..4 | 0 ...]; lane (i, q) holds slots 8q .. 8q+7
+  u32x4 wB;
+  {
+    f16_t wh[J], wl[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      float w = wts[(long)j * Vp + ve];
+      asm volatile("" : "+v"(w));
+      wh[j] = (f16_t)w;
+      wl[j] = (f16_t)(w - (float)wh[j]);
+    }
+    const f16_t z = (f16_t)0.f;
+    const f16x8 s0 = f16x8{wh[0], wh[1], wh[2], wh[3], wh[4], wh[0], wh[1], wh[2]};
+    const f16x8 s1 = f16x8{wh[3], wh[4], wl[0], wl[1], wl[2], wl[3], wl[4], z};
+    const f16x8 zz = f16x8{z, z, z, z, z, z, z, z};
+    wB = __builtin_bit_cast(u32x4, q == 0 ? s0 : (q == 1 ? s1 : zz));
+  }
+
+  typedef __attribute__((address_space(3))) void lds_t;
+  typedef __attribute__((address_space(1))) const void gbl_t;
+  // piece k of a tile -> wave k % NWV; a wave stages pieces wid, wid + NWV, ... (my_np of them: the vmcnt unit)
+  const int my_np = (NP - wid + NWV - 1) / NWV;
+  auto issue = [&](int t) {
+    unsigned char* base = smem + (t % NS) * STAGE;
+    const int f0 = f_begin + 16 * t;
+#pragma unroll
+    for (int r = 0; r < (NP + NWV - 1) / NWV; ++r) {
+      const int k = wid + NWV * r;
+      if (k < 12) {          // coefficient piece: LDS slot p = chunk * 16 + frame
+        const int p = k * 64 + lane;
+        const int fr = min(f0 + (p & 15), B - 1), ch = p >> 4;
+        __builtin_amdgcn_global_load_lds((gbl_t*)(coef_hl + (long)fr * 2 * Kp + ch * 8), (lds_t*)(base + k * 1024), 16, 0, 0);
+      } else if (k < NP) {   // blend rows: contiguous
+        __builtin_amdgcn_global_load_lds((gbl_t*)(at_tiles + (long)(f0 >> 4) * (AT_BYTES / 2) + (k - 12) * 512 + lane * 8),
+                                         (lds_t*)(base + k * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < ntiles) issue(s);
+  for (int t = 0; t < ntiles; ++t) {
+    // ops younger than tile t's loads, in issue order: min(NS-2, ntiles-1-t) load groups (my_np each) and min(NS-1, t)
+    // store groups (4 each)
+    vm_wait_n((ABL & 9) ? 0 : my_np * min(NS - 2, ntiles - 1 - t) + 4 * min(NS - 1, t));
+    __builtin_amdgcn_s_barrier();
+    if (t + NS - 1 < ntiles && !(ABL & 8)) issue(t + NS - 1);
+    const unsigned char* sc = smem + (t % NS) * STAGE;
+    const unsigned char* sat = sc + COEF_BYTES;
+    const int f0 = f_begin + 16 * t;
+
+    f32x4 accp[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) accp[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4*)(sc + ((4 * g + q) * 16 + i) * 16));
+      const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4*)(sc + ((Kp / 8 + 4 * g + q) * 16 + i) * 16));
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if constexpr (ABL & 4) {
+          if (g == 0) accp[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8, dh[c][g]), accp[c], 0, 0, 0);
+          asm volatile("" :: "v"(dh[c][g]), "v"(dl[c][g]), "v"(ah), "v"(al));
+        } else {
+          accp[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8, dh[c][g]), accp[c], 0, 0, 0);
+          accp[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, dl[c][g]), accp[c], 0, 0, 0);
+          accp[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, dh[c][g]), accp[c], 0, 0, 0);
+        }
+      }
+    }
+    float px[4], py[4], pz[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { px[e] = t3[0] + accp[0][e]; py[e] = t3[1] + accp[1][e]; pz[e] = t3[2] + accp[2][e]; }
+    float out[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      f32x4 T[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int m = 4 * c + k;
+        u32x4 fa = u32x4{0, 0, 0, 0};          // K slots 16 .. 31 are zero on both sides
+        if (q < 2) fa = *(const u32x4*)(sat + ((m * 2 + q) * 16 + i) * 16);
+        if constexpr (ABL & 2) {
+          T[k] = __builtin_bit_cast(f32x4, fa);
+          asm volatile("" :: "v"(wB));
+        } else {
+          T[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa), __builtin_bit_cast(f16x8, wB),
+                                                        f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[c][e] = fmaf(T[0][e], px[e], fmaf(T[1][e], py[e], fmaf(T[2][e], pz[e], T[3][e])));
+    }
+    struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int f = min(f0 + 4 * q + e, B - 1);
+      F3 o;
+      o.x = out[0][e]; o.y = out[1][e]; o.z = out[2][e];
+      if constexpr (ABL & 1) asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(f));
+      else *(F3*)(verts + ((long)f * V + ve) * 3) = o;   // 16 lanes = 192 contiguous bytes per frame
+    }
+  }
+}
+
+extern "C" int msmd_lbs_skin_v2(const void* coef_hl, const void* at_tiles, const float* v_template, const void* dirs_hl,
+                                const float* lbs_weights, float* verts, int B, int J, int V, int Vp, int Kp,
+                                msmd_stream_t stream) {
+  if (B <= 0 || V <= 0 || Vp < V || J != 5 || Kp != 192 || !at_tiles) return 1;
+  // tuning key 9: 1 = two 4-wave workgroups per CU (64 vertices each, 3-stage rings) instead of one 8-wave workgroup
+  // (128 vertices, 4-stage ring).  Measured at 25 600 frames: 783 vs 732 us -- the smaller workgroups double the
+  // staged bytes per vertex and their phase drift buys less than that costs.
+  const bool big = g_tuning[9] != 1;
+  const int vpb = big ? 128 : 64;
+  const int vt = (V + vpb - 1) / vpb;
+  int splits = max(1, min((B + 63) / 64, ((big ? 1024 : 2048) + vt - 1) / vt));   // >= 64 frames per workgroup amortise the dirs load
+  int fpb = (((B + splits - 1) / splits) + 15) / 16 * 16;
+  splits = (B + fpb - 1) / fpb;
+  dim3 grid(((vt + 7) / 8) * 8 * splits);
+#define LBS_V2_LAUNCH(NS, NWV, ABL)                                                                                    \
+  do {                                                                                                                 \
+    constexpr int lds = NS * 18 * 1024;                                                                                \
+    auto kfn = lbs_skin_v2_kernel<6, NS, NWV, ABL>;                                                                    \
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                       \
+    hipLaunchKernelGGL(kfn, grid, dim3(64 * NWV), lds, (hipStream_t)stream, (const bf16_t*)coef_hl,                     \
+                       (const f16_t*)at_tiles, v_template, (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb, vt); \
+  } while (0)
+  if (!big) {
+    LBS_V2_LAUNCH(3, 4, 0);
+  } else {
+    switch (g_tuning[8]) {
+      case 1: LBS_V2_LAUNCH(4, 8, 1); break;
+      case 2: LBS_V2_LAUNCH(4, 8, 2); break;
+      case 4: LBS_V2_LAUNCH(4, 8, 4); break;
+      case 8: LBS_V2_LAUNCH(4, 8, 8); break;
+      case 7: LBS_V2_LAUNCH(4, 8, 7); break;
+      case 15: LBS_V2_LAUNCH(4, 8, 15); break;
+      default: LBS_V2_LAUNCH(4, 8, 0); break;
+    }
+  }
+#undef LBS_V2_LAUNCH
   MSMD_RETURN_LAST();
 }
 

@@ -884,9 +884,9 @@ static int launch_gemm3(GemmArgs& p, int batch, hipStream_t st) {
   MSMD_RETURN_LAST();
 }
 
-int g_tuning[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // shared with gemm_tn.hip (key 2 = forced contraction splits)
+int g_tuning[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // shared with gemm_tn.hip (key 2 = forced contraction splits)
 extern "C" int msmd_set_tuning(int key, int value) {
-  if (key < 0 || key >= 8) return 1;
+  if (key < 0 || key >= 16) return 1;
   g_tuning[key] = value;
   return 0;
 }

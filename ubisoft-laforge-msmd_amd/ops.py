@@ -535,7 +535,9 @@ def mean_time(x):
 
 
 # ----------------------------------------------------------------------------- FLAME
-def lbs_prepare(betas, pose, JS, parents, Kp=192, pose_is_matrix=False, want_joints=True, want_split=False):
+def lbs_prepare(betas, pose, JS, parents, Kp=192, pose_is_matrix=False, want_joints=True, want_split=False,
+                want_blend_tiles=False):
+    """-> coef, coef_hl, A, joints[, at_tiles]: want_blend_tiles adds the fp16 frame-side rows of msmd_lbs_skin_v2."""
     lib = _lib.load()
     B, NB = betas.shape
     J = parents.shape[0]
@@ -543,9 +545,10 @@ def lbs_prepare(betas, pose, JS, parents, Kp=192, pose_is_matrix=False, want_joi
     coef_hl = torch.empty(B, 2, Kp, device=betas.device, dtype=torch.bfloat16) if want_split else None
     A = torch.empty(B, J, 12, device=betas.device, dtype=torch.float32)
     joints = torch.empty(B, J, 3, device=betas.device, dtype=torch.float32) if want_joints else None
+    at = torch.empty((B + 15) // 16, 12, 2, 16, 8, device=betas.device, dtype=torch.float16) if want_blend_tiles else None
     _lib.check(lib.msmd_lbs_prepare(_p(betas), _p(pose), _p(JS), _p(parents), _p(coef), _p(coef_hl), _p(A), _p(joints),
-                                    B, NB, J, Kp, int(pose_is_matrix), _stream()), "msmd_lbs_prepare")
-    return coef, coef_hl, A, joints
+                                    _p(at), B, NB, J, Kp, int(pose_is_matrix), _stream()), "msmd_lbs_prepare")
+    return (coef, coef_hl, A, joints, at) if want_blend_tiles else (coef, coef_hl, A, joints)
 
 
 def lbs_skin(coef, A, v_template_planes, dirs, weight_planes, V):
@@ -567,6 +570,17 @@ def lbs_skin_bf16x3(coef_hl, A, v_template_planes, dirs_hl, weight_planes, V):
     verts = torch.empty(B, V, 3, device=A.device, dtype=torch.float32)
     _lib.check(lib.msmd_lbs_skin_bf16x3(_p(coef_hl), _p(A), _p(v_template_planes), _p(dirs_hl), _p(weight_planes),
                                         _p(verts), B, J, V, Vp, Kp, _stream()), "msmd_lbs_skin_bf16x3")
+    return verts
+
+
+def lbs_skin_v2(coef_hl, at_tiles, v_template_planes, dirs_hl, weight_planes, V):
+    lib = _lib.load()
+    B, _, Kp = coef_hl.shape
+    J = weight_planes.shape[0]
+    Vp = dirs_hl.shape[-2]
+    verts = torch.empty(B, V, 3, device=coef_hl.device, dtype=torch.float32)
+    _lib.check(lib.msmd_lbs_skin_v2(_p(coef_hl), _p(at_tiles), _p(v_template_planes), _p(dirs_hl), _p(weight_planes),
+                                    _p(verts), B, J, V, Vp, Kp, _stream()), "msmd_lbs_skin_v2")
     return verts
 
 

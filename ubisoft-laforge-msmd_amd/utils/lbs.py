@@ -65,7 +65,9 @@ def _constants(v_template, shapedirs, posedirs, J_regressor, parents, lbs_weight
 
 
 # "bf16x3": split-bf16 MFMA products with fp32 accumulation (max-abs-err ~1e-6 on FLAME-scale vertices, 5x fewer
-# matrix cycles); "fp32": exact-fp32 MFMA.  Both far inside the 1e-4 budget of BASELINE.json.
+# matrix cycles), the joint blend as one fp16-split MFMA per transform component (msmd_lbs_skin_v2);
+# "bf16x3_valu": the same blendshape product with the blend on the vector ALU (msmd_lbs_skin_bf16x3, the round-1 kernel);
+# "fp32": exact-fp32 MFMA.  All far inside the 1e-4 budget of BASELINE.json.
 DEFAULT_PRECISION = "bf16x3"
 
 
@@ -79,12 +81,16 @@ def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_
     betas = betas.float().expand(B, -1).contiguous()
     pose = pose.float().reshape(pose.shape[0], -1).expand(B, -1).contiguous()
     precision = precision or DEFAULT_PRECISION
-    if precision not in ("bf16x3", "fp32"):
+    if precision not in ("bf16x3", "bf16x3_valu", "fp32"):
         raise ValueError(f"Unknown LBS precision {precision}!")
-    split = precision == "bf16x3"
-    coef, coef_hl, A, joints = ops.lbs_prepare(betas, pose, c.JS, c.parents, KP, pose_is_matrix=not pose2rot,
-                                               want_split=split)
-    if split:
+    split = precision != "fp32"
+    v2 = precision == "bf16x3" and c.J == 5
+    res = ops.lbs_prepare(betas, pose, c.JS, c.parents, KP, pose_is_matrix=not pose2rot, want_split=split,
+                          want_blend_tiles=v2)
+    coef, coef_hl, A, joints = res[:4]
+    if v2:
+        verts = ops.lbs_skin_v2(coef_hl, res[4], c.template_planes, c.dirs_hl, c.weight_planes, c.V)
+    elif split:
         verts = ops.lbs_skin_bf16x3(coef_hl, A, c.template_planes, c.dirs_hl, c.weight_planes, c.V)
     else:
         verts = ops.lbs_skin(coef, A, c.template_planes, c.dirs, c.weight_planes, c.V)
