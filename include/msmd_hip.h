@@ -315,6 +315,20 @@ int msmd_lbs_skin_bf16x3(const void* coef_hl, const float* A, const float* v_tem
 int msmd_lbs_skin_v2(const void* coef_hl, const void* at_tiles, const float* v_template, const void* dirs_hl,
                      const float* lbs_weights, float* verts, int B, int J, int V, int Vp, int Kp, msmd_stream_t stream);
 
+/* Training through FLAME (the reference's use_vertex_space branch: training_script.py:167-176 -> utils/common.py:486-513
+ * -> utils/lbs.py:141-223, differentiated by autograd there).
+ * msmd_lbs_skin_v2_train: msmd_lbs_skin_v2 that also stores the un-skinned vertices v_posed = template + coef . dirs.
+ * msmd_lbs_pack: (coef (B, Kp), A (B, 5, 12)) fp32 -> coef_hl / at_tiles, for per-frame kinematics computed elsewhere
+ *   (the differentiable pass builds them with autograd on (B, 5, 3, 3)-sized tensors).
+ * msmd_lbs_skin_bwd: given grad_verts (B, V, 3) and v_posed: dp_planes (B, 3, Vp) = (sum_j w_j R_j)^T g (the A operand
+ *   of dcoef = dp . dirs^T, an msmd_gemm) and dA (B, 5, 12) = sum_v w_j(v) g(v) [v_posed(v) ; 1]^T. */
+int msmd_lbs_skin_v2_train(const void* coef_hl, const void* at_tiles, const float* v_template, const void* dirs_hl,
+                           const float* lbs_weights, float* verts, float* v_posed, int B, int J, int V, int Vp, int Kp,
+                           msmd_stream_t stream);
+int msmd_lbs_pack(const float* coef, const float* A, void* coef_hl, void* at_tiles, int B, int Kp, msmd_stream_t stream);
+int msmd_lbs_skin_bwd(const float* grad_verts, const float* v_posed, const float* A, const float* lbs_weights,
+                      float* dp_planes, float* dA, int B, int J, int V, int Vp, msmd_stream_t stream);
+
 /* Landmarks by barycentric interpolation (utils/lbs.py:102-138): out (B, L, 3).
  * faces (F,3) int32; lmk_faces_idx (B or 1, L) int32 with batch stride idx_bstride (0 = shared);
  * bary (B or 1, L, 3) with batch stride bary_bstride. */
@@ -365,6 +379,12 @@ int msmd_rotation_convert(int op, const float* in, const float* in2, float* out,
 int msmd_masked_seq_loss(const float* gt, const float* pred, const int* end_idx, float* out, double* acc_ws,
                          int N, int T, int C, int c_lo, int c_hi, int order, int prefix, int criterion, int mode,
                          float scale, msmd_stream_t stream);
+/* d msmd_masked_seq_loss / d pred, ADDED into grad_pred (N, T, C) (channels outside [c_lo, c_hi) untouched): acc_ws is
+ * the forward call's workspace (its valid-row count), upstream the incoming 0-dim gradient on the device.  What the
+ * reference gets from autograd through utils/common.py:198-620 (training through the vertex-space loss). */
+int msmd_masked_seq_loss_bwd(const float* gt, const float* pred, const int* end_idx, const double* acc_ws,
+                             const float* upstream, float* grad_pred, int N, int T, int C, int c_lo, int c_hi, int order,
+                             int prefix, int criterion, int mode, float scale, msmd_stream_t stream);
 /* out[0] = -0.5 * sum(1 + logvar - mu^2 - exp(logvar)) over n elements. */
 int msmd_kl_loss(const float* mu, const float* logvar, float* out, double* acc_ws, long n, msmd_stream_t stream);
 /* In place: x (N, L, inner)[n, end_idx[n]*unit :, :] = 0 (or the last kept row when replicate != 0). */

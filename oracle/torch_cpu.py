@@ -6,7 +6,7 @@ The reference runs on CPU as fp32 torch modules (HF wav2vec2 + nn.TransformerDec
 `cpu_baseline` leg times THIS restatement on the host cores (torch.set_num_threads(all cores), fp32, eval arithmetic),
 as SURVEY.md section 8(d) prescribes.  It mirrors the numpy oracle function for function (oracle/audio_encoder.py,
 oracle/diffusion.py, oracle/flame.py -- each of which cites the reference lines it follows) and is pinned to it by
-tests/test_oracle_vs_golden.py::test_torch_cpu_restatement_matches_numpy_oracle.
+tests/test_oracle_vs_golden.py::test_torch_cpu_restatement_matches_reference_goldens.
 
   msmd_forward   reference model.py:146-248 (raw audio -> utils/wav2vec2.py:71-119 -> model.py:250-264 -> 820-996)
   denoise_step   one denoiser call on n_entries x B sequences = one step of model.py:283-440's loop body
@@ -197,6 +197,11 @@ class FlameTorch:
 
     @torch.no_grad()
     def forward(self, shape, exp, pose):
+        return self.forward_grad(shape, exp, pose)
+
+    def forward_grad(self, shape, exp, pose):
+        """Same arithmetic with autograd left on: the oracle of the differentiable FLAME pass (the reference trains
+        through utils/flame.py / utils/lbs.py with torch autograd, training_script.py:167-176)."""
         B = shape.shape[0]
         V = self.v_template.shape[0]
         betas = torch.cat([shape, exp], dim=1)
@@ -220,3 +225,54 @@ class FlameTorch:
         T = torch.matmul(self.lbs_weights[None], A.view(B, -1, 16)).view(B, V, 4, 4)
         vh = torch.cat([v_posed, torch.ones(B, V, 1)], dim=2)[..., None]
         return torch.matmul(T, vh)[:, :, :3, 0]
+
+
+def vertex_space_loss(args, is_starting_sample, shape_coef, motion_coef_gt, target, prev_motion_coef, coef_stats, flame,
+                      end_idx=None):
+    """Oracle restatement of reference utils/common.py:456-620 (target='sample', rot_repr='aa', legacy 54-d motion) with
+    torch autograd: dict of the eight terms (each already / 2 as the reference returns them; head_trans None for the
+    first window).  `flame` is a FlameTorch; coef_stats a dict of torch tensors (utils/common.py:140-173 de-normalises
+    exp / pose / shape with them and zeroes the global rotation)."""
+    l2 = args.criterion.lower() == "l2"
+    crit = (lambda a, b: (a - b) ** 2) if l2 else (lambda a, b: (a - b).abs())
+    P = args.n_prev_motions
+    if is_starting_sample:
+        target = target[:, P:]
+    else:
+        motion_coef_gt = torch.cat([prev_motion_coef, motion_coef_gt], dim=1)
+        if args.no_constrain_prev:
+            target = torch.cat([prev_motion_coef, target[:, P:]], dim=1)
+    N, T = target.shape[:2]
+
+    def coef_dict(m):
+        exp = m[..., :50] * coef_stats["exp_std"] + coef_stats["exp_mean"]
+        pose = torch.cat([torch.zeros_like(m[..., :3]), m[..., -1:], torch.zeros_like(m[..., :2])], dim=-1)
+        pose = pose * coef_stats["pose_std"] + coef_stats["pose_mean"]
+        pose = torch.cat([torch.zeros_like(pose[..., :3]), pose[..., 3:]], dim=-1)
+        shp = shape_coef[:, None].expand(-1, m.shape[1], -1) * coef_stats["shape_std"] + coef_stats["shape_mean"]
+        return shp.reshape(-1, 100), exp.reshape(-1, 50), pose.reshape(-1, 6)
+    vg = flame.forward_grad(*coef_dict(motion_coef_gt)).view(N, T, 5023, 3)
+    vp = flame.forward_grad(*coef_dict(target)).view(N, T, 5023, 3)
+    if end_idx is None:
+        mask = torch.ones(N, args.n_motions, dtype=torch.bool)
+    else:
+        mask = torch.arange(args.n_motions).expand(N, -1) < end_idx.unsqueeze(1)
+    if not is_starting_sample:
+        lead = torch.zeros_like if args.no_constrain_prev else torch.ones_like
+        mask = torch.cat([lead(mask[:, :P]), mask], dim=1)
+    d1 = lambda x: x[:, 1:] - x[:, :-1]
+    out = {"noise": crit(motion_coef_gt, target)[mask].mean() / 2,
+           "vert": crit(vg, vp)[mask].mean() / 2,
+           "vel": crit(d1(vg), d1(vp))[mask[:, 1:]].mean() / 2,
+           "smooth": crit(d1(vp)[:, 1:], d1(vp)[:, :-1])[mask[:, 2:]].mean() / 2}
+    hg, hp = motion_coef_gt[:, :, 50:53], target[:, :, 50:53]
+    out["head_angle"] = crit(hg, hp)[mask].mean() / 2
+    out["head_vel"] = crit(d1(hg), d1(hp))[mask[:, 1:]].mean() / 2
+    out["head_smooth"] = crit(d1(hp)[:, 1:], d1(hp)[:, :-1])[mask[:, 2:]].mean() / 2
+    out["head_trans"] = None
+    if not is_starting_sample and args.l_head_trans > 0:
+        seq = torch.cat([hg[:, P - 3:P], hp[:, P:P + 3]], dim=1)
+        v = d1(seq)
+        a = d1(v)
+        out["head_trans"] = crit(v[:, 2:4], v[:, 1:3])[mask[:, P:P + 2]].mean() + crit(a[:, 1:], a[:, :-1])[mask[:, P:P + 3]].mean()
+    return out

@@ -814,6 +814,58 @@ def g6_train(M, SE, mc):
             lambda cls, name, **kw: cls(Wav2Vec2Config(attn_implementation="eager")))
 
 
+def g8_vertex_grad(M, SE, mc):
+    """Gradient of the reference's vertex-space training loss (training_script.py:167-176 -> utils/common.py:456-620
+    -> utils/flame.py / utils/lbs.py, differentiated by the reference's own autograd) with respect to the predicted
+    motion coefficients, on the synthetic FLAME asset: both windows, truncated end indices, all loss weights > 0."""
+    from utils import common as C
+    from utils import flame as FL
+    with tempfile.TemporaryDirectory() as td:
+        pkl, npy = write_flame_asset(td)
+        cfg = FL.FLAMEConfig
+        cfg.flame_model_path, cfg.flame_lmk_embedding_path = pkl, npy
+        fl = FL.FLAME(cfg).eval()
+    L, P, N = 12, 4, 3
+    args = ref_args(n_motions=L, n_prev_motions=P, use_vertex_space=True)
+    gt = (0.5 * synth.normalish("vgrad/gt", (N, L, 54))).astype(np.float32)
+    prev = (0.5 * synth.normalish("vgrad/prev", (N, P, 54))).astype(np.float32)
+    tgt = (0.5 * synth.normalish("vgrad/tgt", (N, L + P, 54))).astype(np.float32)
+    shape = (0.5 * synth.normalish("vgrad/shape", (N, 100))).astype(np.float32)
+    stats = {"exp_mean": t(0.1 * synth.normalish("st/em", (50,))), "exp_std": t(1 + 0.1 * np.abs(synth.normalish("st/es", (50,)))),
+             "pose_mean": t(0.05 * synth.normalish("st/pm", (6,))), "pose_std": t(1 + 0.1 * np.abs(synth.normalish("st/ps", (6,)))),
+             "shape_mean": t(np.zeros(100, np.float32)), "shape_std": t(np.ones(100, np.float32))}
+    end_idx = torch.tensor([L, 5, 9])
+    wts = dict(noise=1.0, vert=args.l_vert, vel=args.l_vel, smooth=args.l_smooth, head_angle=args.l_head_angle,
+               head_vel=args.l_head_vel, head_smooth=args.l_head_smooth, head_trans=args.l_head_trans)
+    out = {"weights": np.array([wts[k] for k in ("noise", "vert", "vel", "smooth", "head_angle", "head_vel", "head_smooth",
+                                                   "head_trans")], np.float64)}
+    torch.set_grad_enabled(True)
+    try:
+        for start in (True, False):
+            for use_end in (False, True):
+                tg = t(tgt).clone().requires_grad_(True)
+                ld = C.compute_loss(args, start, t(shape), t(gt), None, tg, t(prev), stats, fl,
+                                    end_idx=end_idx if use_end else None, return_dict=True)
+                total = sum(wts[k] * v for k, v in ld.items() if v is not None and not isinstance(v, int))
+                total.backward()
+                key = f"{int(start)}_{int(use_end)}"
+                out["loss_" + key] = np.array([np.nan if (v is None) else float(v) for v in
+                                               (ld[k] for k in ("noise", "vert", "vel", "smooth", "head_angle", "head_vel",
+                                                                "head_smooth", "head_trans"))], np.float64)
+                out["grad_" + key] = tg.grad.numpy().copy()
+        # the FLAME pass alone: d(sum of verts * probe) / d(exp, pose)
+        B = 6
+        x = flame_inputs(B, tag="vgrad_flame")
+        ex, po = t(x["exp"]).clone().requires_grad_(True), t(x["pose"]).clone().requires_grad_(True)
+        probe = synth.normalish("vgrad/probe", (B, 5023, 3))
+        v, _, _ = fl(t(x["shape"]), ex, po, return_lm2d=False, return_lm3d=False)
+        (v * t(probe)).sum().backward()
+        out["flame_dexp"], out["flame_dpose"] = ex.grad.numpy().copy(), po.grad.numpy().copy()
+    finally:
+        torch.set_grad_enabled(False)
+    save("g8_vertex_grad", **out)
+
+
 class mock_randn_like:
     """Feed a fixed sequence of tensors to torch.randn_like (style VAE eps, then diffusion eps)."""
 
@@ -850,7 +902,8 @@ def g1_specaug(M, SE, mc):
 ALL = dict(g1_specaug=g1_specaug, g7_dataset=g7_dataset, g2_lr_schedule=g2_lr_schedule, g3_audio_large=g3_audio_large, g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
            g3_forward=g3_forward, g3_style=g3_style, g3_sample=g3_sample, g3_infer=g3_infer,
            g4_flame=g4_flame, g4_rotations=g4_rotations, g5_losses=g5_losses, g6_train=g6_train,
-           g5_losses_no_constrain_prev=g5_losses_no_constrain_prev, g3_denoiser_options=g3_denoiser_options, g4_lbs_blocks=g4_lbs_blocks)
+           g5_losses_no_constrain_prev=g5_losses_no_constrain_prev, g3_denoiser_options=g3_denoiser_options, g4_lbs_blocks=g4_lbs_blocks,
+           g8_vertex_grad=g8_vertex_grad)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

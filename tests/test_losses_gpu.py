@@ -201,3 +201,72 @@ def test_vertex_space_metrics_against_numpy_flame():
     for k, r in ref.items():
         assert abs(float(got[k]) - r) <= 1e-4 * abs(r) + 1e-7, (k, float(got[k]), r)
     assert float(got["mouth_max"]) >= float(got["mouth_lmk"]) > 0
+
+
+def _vgrad_case():
+    t = dev
+    L, P, N = 12, 4, 3
+    gt = (0.5 * synth.normalish("vgrad/gt", (N, L, 54))).astype(np.float32)
+    prev = (0.5 * synth.normalish("vgrad/prev", (N, P, 54))).astype(np.float32)
+    tgt = (0.5 * synth.normalish("vgrad/tgt", (N, L + P, 54))).astype(np.float32)
+    shape = (0.5 * synth.normalish("vgrad/shape", (N, 100))).astype(np.float32)
+    stats = {"exp_mean": t(0.1 * synth.normalish("st/em", (50,))), "exp_std": t(1 + 0.1 * np.abs(synth.normalish("st/es", (50,)))),
+             "pose_mean": t(0.05 * synth.normalish("st/pm", (6,))), "pose_std": t(1 + 0.1 * np.abs(synth.normalish("st/ps", (6,)))),
+             "shape_mean": t(np.zeros(100, np.float32)), "shape_std": t(np.ones(100, np.float32))}
+    return L, P, N, gt, prev, tgt, shape, stats
+
+
+def _flame():
+    from msmd_amd.utils.flame import FLAME, FLAMEConfig
+    cfg = SimpleNamespace(**vars(FLAMEConfig))
+    cfg.asset = synth.flame_asset()
+    return FLAME(cfg).to(DEV)
+
+
+def test_flame_differentiable_pass_matches_reference_autograd():
+    """d <verts, probe> / d (exp, pose) through the differentiable FLAME pass -- per-frame kinematics by autograd on
+    (B, 5, 3, 3)-sized tensors, per-vertex skinning forward (msmd_lbs_skin_v2_train) and backward (msmd_lbs_skin_bwd +
+    one GEMM) in HIP -- against gradients recorded from the reference's autograd through utils/flame.py / utils/lbs.py
+    (g8_vertex_grad): 2e-4 of the largest entry; the forward equals the inference kernel's vertices."""
+    from helpers import flame_inputs
+    g = load_golden("g8_vertex_grad")
+    fl = _flame()
+    x = flame_inputs(6, tag="vgrad_flame")
+    ex, po = dev(x["exp"]).requires_grad_(True), dev(x["pose"]).requires_grad_(True)
+    with torch.enable_grad():
+        v, _, _ = fl(dev(x["shape"]), ex, po, return_lm2d=False, return_lm3d=False)
+        (v * dev(synth.normalish("vgrad/probe", (6, 5023, 3)))).sum().backward()
+    v0, _, _ = fl(dev(x["shape"]), dev(x["exp"]), dev(x["pose"]), return_lm2d=False, return_lm3d=False)
+    assert maxabs(v.detach().cpu().numpy(), v0.cpu().numpy()) <= 2e-6
+    for got, key in ((ex.grad, "flame_dexp"), (po.grad, "flame_dpose")):
+        err, scale = maxabs(got.cpu().numpy(), g[key]), np.abs(g[key]).max()
+        assert err <= 2e-4 * scale, (key, err, scale)
+
+
+def test_vertex_space_training_loss_gradients_match_reference_autograd():
+    """train_graph.loss_vert_train (the use_vertex_space training branch, reference training_script.py:167-176 ->
+    utils/common.py:456-620): all eight terms and d(weighted total) / d(target) against the reference's autograd
+    (g8_vertex_grad), both windows, with and without truncation."""
+    from msmd_amd import train_graph as tg
+    g = load_golden("g8_vertex_grad")
+    L, P, N, gt, prev, tgt, shape, stats = _vgrad_case()
+    args = default_args(n_motions=L, n_prev_motions=P, use_vertex_space=True, dataset_type="flame_mead_ravdess")
+    fl = _flame()
+    keys = ("noise", "vert", "vel", "smooth", "head_angle", "head_vel", "head_smooth", "head_trans")
+    w = dict(zip(keys, g["weights"]))
+    end_idx = torch.tensor([L, 5, 9], device=DEV)
+    for start in (True, False):
+        for use_end in (False, True):
+            tgd = dev(tgt).clone().requires_grad_(True)
+            with torch.enable_grad():
+                ld = tg.loss_vert_train(args, start, dev(shape), dev(gt), tgd, dev(prev), stats, fl,
+                                        end_idx if use_end else None)
+                total = sum(w[k] * v for k, v in ld.items() if v is not None and not isinstance(v, int))
+                total.backward()
+            key = f"{int(start)}_{int(use_end)}"
+            want = g["loss_" + key]
+            got = np.array([np.nan if ld[k] is None else float(ld[k]) for k in keys])
+            ok = ~np.isnan(want)
+            assert np.allclose(got[ok], want[ok], rtol=2e-4, atol=1e-8), (key, got, want)
+            err, scale = maxabs(tgd.grad.cpu().numpy(), g["grad_" + key]), np.abs(g["grad_" + key]).max()
+            assert err <= 2e-4 * scale, (key, err, scale)

@@ -8,6 +8,7 @@ import pytest
 from oracle import audio_encoder as oa, diffusion as od, flame as ofl, infer as oi, nn as onn, rotations as orot
 from oracle import style as ost
 from msmd_amd import synth
+from msmd_amd.config import default_args
 
 from conftest import load_golden
 from helpers import denoiser_inputs, flame_inputs, maxabs, msmd_state_dict, style_state_dict
@@ -349,3 +350,44 @@ def test_torch_cpu_restatement_matches_reference_goldens():
     fx = flame_inputs(8)
     v = tc.FlameTorch(fo).forward(t(fx["shape"]), t(fx["exp"]), t(gf["pose"])).numpy()
     assert maxabs(v[:, ::79], gf["verts_sub"]) <= 2e-6
+
+
+def test_vertex_space_loss_gradient_oracle_matches_reference_autograd():
+    """oracle.torch_cpu.vertex_space_loss (+ FlameTorch.forward_grad) against gradients recorded from the reference's
+    own autograd through utils/common.py:456-620 and FLAME (g8_vertex_grad): losses to 1e-6 relative, d loss / d
+    target to 2e-5 of the largest gradient entry, and the FLAME pass alone (d <verts, probe> / d exp, pose)."""
+    import torch
+    from oracle import torch_cpu as tc
+    g = load_golden("g8_vertex_grad")
+    fo = ofl.FlameOracle(synth.flame_asset())
+    ft = tc.FlameTorch(fo)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()
+    L, P, N = 12, 4, 3
+    args = default_args(n_motions=L, n_prev_motions=P, use_vertex_space=True)
+    gt = (0.5 * synth.normalish("vgrad/gt", (N, L, 54))).astype(np.float32)
+    prev = (0.5 * synth.normalish("vgrad/prev", (N, P, 54))).astype(np.float32)
+    tgt = (0.5 * synth.normalish("vgrad/tgt", (N, L + P, 54))).astype(np.float32)
+    shape = (0.5 * synth.normalish("vgrad/shape", (N, 100))).astype(np.float32)
+    stats = {"exp_mean": t(0.1 * synth.normalish("st/em", (50,))), "exp_std": t(1 + 0.1 * np.abs(synth.normalish("st/es", (50,)))),
+             "pose_mean": t(0.05 * synth.normalish("st/pm", (6,))), "pose_std": t(1 + 0.1 * np.abs(synth.normalish("st/ps", (6,)))),
+             "shape_mean": t(np.zeros(100, np.float32)), "shape_std": t(np.ones(100, np.float32))}
+    end_idx = torch.tensor([L, 5, 9])
+    keys = ("noise", "vert", "vel", "smooth", "head_angle", "head_vel", "head_smooth", "head_trans")
+    w = dict(zip(keys, g["weights"]))
+    for start in (True, False):
+        for use_end in (False, True):
+            tg = t(tgt).clone().requires_grad_(True)
+            ld = tc.vertex_space_loss(args, start, t(shape), t(gt), tg, t(prev), stats, ft, end_idx if use_end else None)
+            total = sum(w[k] * v for k, v in ld.items() if v is not None)
+            total.backward()
+            key = f"{int(start)}_{int(use_end)}"
+            want = g["loss_" + key]
+            got = np.array([np.nan if ld[k] is None else float(ld[k]) for k in keys])
+            assert np.allclose(got[~np.isnan(want)], want[~np.isnan(want)], rtol=2e-5, atol=1e-9), (key, got, want)
+            assert maxabs(tg.grad.numpy(), g["grad_" + key]) <= 2e-5 * np.abs(g["grad_" + key]).max(), key
+    x = flame_inputs(6, tag="vgrad_flame")
+    ex, po = t(x["exp"]).clone().requires_grad_(True), t(x["pose"]).clone().requires_grad_(True)
+    v = ft.forward_grad(t(x["shape"]), ex, po)
+    (v * t(synth.normalish("vgrad/probe", (6, 5023, 3)))).sum().backward()
+    assert maxabs(ex.grad.numpy(), g["flame_dexp"]) <= 2e-5 * np.abs(g["flame_dexp"]).max()
+    assert maxabs(po.grad.numpy(), g["flame_dpose"]) <= 2e-5 * np.abs(g["flame_dpose"]).max()

@@ -224,6 +224,45 @@ def test_trainer_segmented_hipgraph_matches_single_graph(monkeypatch):
     assert early_bytes >= 0.5 * tr2.reducer.arena.numel(), (early_bytes, tr2.reducer.arena.numel())
 
 
+def test_trainer_vertex_space_branch_steps_through_flame():
+    """use_vertex_space on a legacy FLAME dataset type (reference training_script.py:167-176): Trainer.step runs the
+    vertex / velocity / smoothness terms through the differentiable FLAME pass; the vertex terms are live (their
+    weights change the gradient), the loss is finite and a few Adam steps on a fixed batch reduce it."""
+    from types import SimpleNamespace
+    from msmd_amd.model import get_diffusion_model
+    from msmd_amd.style_encoder import get_style_encoder
+    from msmd_amd.training_script import Trainer, synthetic_batch
+    from msmd_amd.utils.flame import FLAME, FLAMEConfig
+    cfg = SimpleNamespace(**vars(FLAMEConfig))
+    cfg.asset = synth.flame_asset()
+    fl = FLAME(cfg).to(DEV)
+    stats = {"exp_mean": np.zeros(50, np.float32), "exp_std": np.full(50, 0.3, np.float32),
+             "pose_mean": np.zeros(6, np.float32), "pose_std": np.full(6, 0.1, np.float32),
+             "shape_mean": np.zeros(100, np.float32), "shape_std": np.ones(100, np.float32)}
+    args = default_args(compute_dtype="bf16", encoder_layers=1, n_layers=1, lr=2e-4, warm_iter=0,
+                        gradient_accumulation_steps=1, use_vertex_space=True, dataset_type="flame_mead_ravdess",
+                        l_vert=2e5, l_vel=1e6, l_smooth=1e5)
+    B = 2
+    batch = synthetic_batch(B, 0, DEV)
+    draws = dict(cross=[False, False], end_idx=[torch.tensor([60, 100], device=DEV), None], t=[[5, 400], [250, 20]],
+                 eps=[dev(synth.normalish(f"tr/eps{i}", (B, 100, 67))) for i in range(2)],
+                 style_eps=[dev(synth.normalish(f"tr/se{i}", (B, 256))) for i in range(2)],
+                 cfg_flag=[None, None])
+    torch.manual_seed(0)
+    model = get_diffusion_model(args, DEV).eval()
+    se = get_style_encoder(args, "vae2").to(DEV).eval()
+    with pytest.raises(ValueError):
+        Trainer(args, model, se)
+    tr = Trainer(args, model, se, flame=fl, coef_stats=stats)
+    assert tr.vertex_space
+    outs = [tr.step(batch, it=i, draws=draws) for i in range(1, 9)]
+    torch.cuda.synchronize()
+    vert = [float(o["vert"]) for o in outs]
+    tot = [float(o["loss"]) for o in outs]
+    assert all(np.isfinite(v) for v in vert + tot) and vert[0] > 0
+    assert tot[-1] < tot[0], tot
+
+
 def test_trainer_train_mode_noise_eager_and_graph():
     """model.train(): dropout / LayerDrop / SpecAugment are live (losses differ from eval mode and from step to
     step on a fixed batch with fixed draws), in eager mode and under hipGraph replay; eval mode is unaffected."""

@@ -438,29 +438,29 @@ extern "C" int msmd_lbs_skin_bf16x3(const void* coef_hl, const float* A, const f
 // frame B - 1 (identical bytes), so every wave issues exactly 4 store instructions per tile and the vmcnt arithmetic
 // is uniform.
 template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void vm_wait_n(int n) {   // n = (pieces per load group) a + 4 b, see the kernel
+__device__ __forceinline__ void vm_wait_n(int n) {   // n = (pieces per load group) a + (stores per tile) b, see the kernel
+#define VMW(k) case k: vm_wait<k>(); break;
   switch (n) {
-    case 1: vm_wait<1>(); break;    case 2: vm_wait<2>(); break;    case 3: vm_wait<3>(); break;
-    case 4: vm_wait<4>(); break;    case 5: vm_wait<5>(); break;    case 6: vm_wait<6>(); break;
-    case 7: vm_wait<7>(); break;    case 8: vm_wait<8>(); break;    case 9: vm_wait<9>(); break;
-    case 10: vm_wait<10>(); break;  case 11: vm_wait<11>(); break;  case 12: vm_wait<12>(); break;
-    case 13: vm_wait<13>(); break;  case 14: vm_wait<14>(); break;  case 15: vm_wait<15>(); break;
-    case 16: vm_wait<16>(); break;  case 17: vm_wait<17>(); break;  case 18: vm_wait<18>(); break;
-    case 19: vm_wait<19>(); break;  case 20: vm_wait<20>(); break;  case 21: vm_wait<21>(); break;
-    case 22: vm_wait<22>(); break;
+    VMW(1) VMW(2) VMW(3) VMW(4) VMW(5) VMW(6) VMW(7) VMW(8) VMW(9) VMW(10) VMW(11) VMW(12) VMW(13) VMW(14) VMW(15) VMW(16)
+    VMW(17) VMW(18) VMW(19) VMW(20) VMW(21) VMW(22) VMW(23) VMW(24) VMW(25) VMW(26) VMW(27) VMW(28) VMW(29) VMW(30) VMW(31)
+    VMW(32) VMW(33) VMW(34) VMW(35) VMW(36) VMW(37) VMW(38) VMW(39) VMW(40)
     default: vm_wait<0>(); break;
   }
+#undef VMW
 }
 
 // NWV waves per workgroup (16 vertices each).  ABL (developer ablations, tuning key 8; 0 in the product): 1 = no vertex
 // stores, 2 = no blend MFMAs, 4 = no blendshape MFMAs, 8 = no LDS-DMA after the prologue (stale tiles) -- outputs are
 // then wrong by construction.
-template <int KG, int NS, int NWV, int ABL = 0>
+// WP: also store the un-skinned vertices p = template + coef . dirs (B, V, 3) -- what the backward of the skinning needs
+// (training through the vertex-space loss); 8 instead of 4 store instructions per tile and wave.
+template <int KG, int NS, int NWV, int ABL = 0, bool WP = false>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void lbs_skin_v2_kernel(const bf16_t* __restrict__ coef_hl, const f16_t* __restrict__ at_tiles,
                         const float* __restrict__ tmpl, const bf16_t* __restrict__ dirs_hl,
                         const float* __restrict__ wts, float* __restrict__ verts, int B, int V, int Vp,
-                        int frames_per_block, int vtn) {
+                        int frames_per_block, int vtn, float* __restrict__ vposed = nullptr) {
+  constexpr int SPT = WP ? 8 : 4;   // store instructions per tile and wave
   constexpr int Kp = KG * 32, J = 5, VPB = 16 * NWV;
   constexpr int NCH = 2 * Kp / 8;            // 16-byte chunks per frame of coef_hl (hi then lo)
   constexpr int COEF_BYTES = NCH * 256;      // [chunk][frame] 16 B
@@ -539,7 +539,7 @@ void lbs_skin_v2_kernel(const bf16_t* __restrict__ coef_hl, const f16_t* __restr
   for (int t = 0; t < ntiles; ++t) {
     // ops younger than tile t's loads, in issue order: min(NS-2, ntiles-1-t) load groups (my_np each) and min(NS-1, t)
     // store groups (4 each)
-    vm_wait_n((ABL & 9) ? 0 : my_np * min(NS - 2, ntiles - 1 - t) + 4 * min(NS - 1, t));
+    vm_wait_n((ABL & 9) ? 0 : my_np * min(NS - 2, ntiles - 1 - t) + SPT * min(NS - 1, t));
     __builtin_amdgcn_s_barrier();
     if (t + NS - 1 < ntiles && !(ABL & 8)) issue(t + NS - 1);
     const unsigned char* sc = smem + (t % NS) * STAGE;
@@ -596,13 +596,18 @@ void lbs_skin_v2_kernel(const bf16_t* __restrict__ coef_hl, const f16_t* __restr
       o.x = out[0][e]; o.y = out[1][e]; o.z = out[2][e];
       if constexpr (ABL & 1) asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(f));
       else *(F3*)(verts + ((long)f * V + ve) * 3) = o;   // 16 lanes = 192 contiguous bytes per frame
+      if constexpr (WP) {
+        F3 pp;
+        pp.x = px[e]; pp.y = py[e]; pp.z = pz[e];
+        *(F3*)(vposed + ((long)f * V + ve) * 3) = pp;
+      }
     }
   }
 }
 
-extern "C" int msmd_lbs_skin_v2(const void* coef_hl, const void* at_tiles, const float* v_template, const void* dirs_hl,
-                                const float* lbs_weights, float* verts, int B, int J, int V, int Vp, int Kp,
-                                msmd_stream_t stream) {
+static int lbs_skin_v2_impl(const void* coef_hl, const void* at_tiles, const float* v_template, const void* dirs_hl,
+                            const float* lbs_weights, float* verts, float* vposed, int B, int J, int V, int Vp, int Kp,
+                            msmd_stream_t stream) {
   if (B <= 0 || V <= 0 || Vp < V || J != 5 || Kp != 192 || !at_tiles) return 1;
   // tuning key 9: 1 = two 4-wave workgroups per CU (64 vertices each, 3-stage rings) instead of one 8-wave workgroup
   // (128 vertices, 4-stage ring).  Measured at 25 600 frames: 783 vs 732 us -- the smaller workgroups double the
@@ -620,9 +625,17 @@ extern "C" int msmd_lbs_skin_v2(const void* coef_hl, const void* at_tiles, const
     auto kfn = lbs_skin_v2_kernel<6, NS, NWV, ABL>;                                                                    \
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                       \
     hipLaunchKernelGGL(kfn, grid, dim3(64 * NWV), lds, (hipStream_t)stream, (const bf16_t*)coef_hl,                     \
-                       (const f16_t*)at_tiles, v_template, (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb, vt); \
+                       (const f16_t*)at_tiles, v_template, (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb, vt, \
+                       (float*)nullptr);                                                                              \
   } while (0)
-  if (!big) {
+  if (vposed) {
+    constexpr int lds = 4 * 18 * 1024;
+    auto kfn = lbs_skin_v2_kernel<6, 4, 8, 0, true>;
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int vt8w = (V + 127) / 128;
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, (hipStream_t)stream, (const bf16_t*)coef_hl, (const f16_t*)at_tiles,
+                       v_template, (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb, vt8w, vposed);
+  } else if (!big) {
     LBS_V2_LAUNCH(3, 4, 0);
   } else {
     switch (g_tuning[8]) {
@@ -636,6 +649,127 @@ extern "C" int msmd_lbs_skin_v2(const void* coef_hl, const void* at_tiles, const
     }
   }
 #undef LBS_V2_LAUNCH
+  MSMD_RETURN_LAST();
+}
+
+extern "C" int msmd_lbs_skin_v2(const void* coef_hl, const void* at_tiles, const float* v_template, const void* dirs_hl,
+                                const float* lbs_weights, float* verts, int B, int J, int V, int Vp, int Kp,
+                                msmd_stream_t stream) {
+  return lbs_skin_v2_impl(coef_hl, at_tiles, v_template, dirs_hl, lbs_weights, verts, nullptr, B, J, V, Vp, Kp, stream);
+}
+
+// Training form: the same kernel, additionally writing the un-skinned vertices v_posed (B, V, 3) for msmd_lbs_skin_bwd.
+extern "C" int msmd_lbs_skin_v2_train(const void* coef_hl, const void* at_tiles, const float* v_template,
+                                      const void* dirs_hl, const float* lbs_weights, float* verts, float* v_posed, int B,
+                                      int J, int V, int Vp, int Kp, msmd_stream_t stream) {
+  if (!v_posed || g_tuning[9] == 1) return 1;
+  return lbs_skin_v2_impl(coef_hl, at_tiles, v_template, dirs_hl, lbs_weights, verts, v_posed, B, J, V, Vp, Kp, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// (coef (B, Kp), A (B, 5, 12)) fp32 -> the skinning kernel's operand formats: coef_hl (B, 2, Kp) bf16 hi / lo and the
+// blend rows at_tiles (see lbs_prepare_kernel).  Used where the per-frame kinematics come from somewhere else than
+// msmd_lbs_prepare: the differentiable FLAME pass computes them with autograd on (B, 5, 3, 3)-sized tensors.
+__global__ __launch_bounds__(256) void lbs_pack_kernel(const float* __restrict__ coef, const float* __restrict__ A,
+                                                       bf16_t* __restrict__ coef_hl, f16_t* __restrict__ at_tiles, int B,
+                                                       int Kp) {
+  const int fl = threadIdx.x >> 4, ln = threadIdx.x & 15;
+  const int b = blockIdx.x * 16 + fl;
+  const bool valid = b < B;
+  const int bb = valid ? b : B - 1;
+  if (valid) {
+    for (int k = ln; k < Kp; k += 16) {
+      float v = coef[(long)b * Kp + k];
+      asm volatile("" : "+v"(v));
+      const bf16_t hi = (bf16_t)v;
+      coef_hl[((long)b * 2 + 0) * Kp + k] = hi;
+      coef_hl[((long)b * 2 + 1) * Kp + k] = (bf16_t)(v - (float)hi);
+    }
+  }
+  for (int idx = ln; idx < 12 * 16; idx += 16) {
+    const int m = idx >> 4, slot = idx & 15;
+    float a = slot < 15 ? A[((long)bb * 5 + (slot % 5)) * 12 + m] : 0.f;
+    asm volatile("" : "+v"(a));
+    const f16_t ah = (f16_t)a, al = (f16_t)(a - (float)ah);
+    const f16_t val = slot >= 15 ? (f16_t)0.f : ((slot >= 5 && slot < 10) ? al : ah);
+    at_tiles[((((long)blockIdx.x * 12 + m) * 2 + (slot >> 3)) * 16 + fl) * 8 + (slot & 7)] = val;
+  }
+}
+
+extern "C" int msmd_lbs_pack(const float* coef, const float* A, void* coef_hl, void* at_tiles, int B, int Kp,
+                             msmd_stream_t stream) {
+  if (B <= 0 || Kp <= 0 || !coef || !A || !coef_hl || !at_tiles) return 1;
+  hipLaunchKernelGGL(lbs_pack_kernel, dim3((B + 15) / 16), dim3(256), 0, (hipStream_t)stream, coef, A, (bf16_t*)coef_hl,
+                     (f16_t*)at_tiles, B, Kp);
+  MSMD_RETURN_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Backward of the skinning  v = sum_j w_j (R_j p + t_j),  p = template + coef . dirs  (reference utils/lbs.py:185-221
+// differentiated; the reference gets this from autograd through its materialised (B, V, 4, 4) transforms).  Given
+// g = dL/dv (B, V, 3) and the forward's p (B, V, 3):
+//   dp(b, v)      = (sum_j w_j R_j)^T g                       -> written as coordinate planes (B, 3, Vp) = the A operand of
+//                                                                 the contraction  dcoef = dp . dirs^T  (msmd_gemm)
+//   dA(b, j, r, :) = sum_v w_j(v) g_r(v) [p(v) ; 1]            -> (B, 5, 12), reduced over the vertices in registers
+// One wave per frame: a lane walks vertices lane, lane + 64, ... (768 contiguous bytes per wave-load of g and p), keeps
+// the 60 partial sums of dA in registers and folds them across the wave once at the end.
+__global__ __launch_bounds__(64) void lbs_skin_bwd_kernel(const float* __restrict__ gverts, const float* __restrict__ vposed,
+                                                          const float* __restrict__ A, const float* __restrict__ wts,
+                                                          float* __restrict__ dp, float* __restrict__ dA, int V, int Vp) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  __shared__ float sA[60];
+  if (lane < 60) sA[lane] = A[(long)b * 60 + lane];
+  __syncthreads();
+  float acc[5][12];
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[j][k] = 0.f;
+  float* dpb = dp + (long)b * 3 * Vp;
+  for (int v = lane; v < Vp; v += 64) {
+    float dpx = 0.f, dpy = 0.f, dpz = 0.f;
+    if (v < V) {
+      const float* gp = gverts + ((long)b * V + v) * 3;
+      const float* pp = vposed + ((long)b * V + v) * 3;
+      const float g[3] = {gp[0], gp[1], gp[2]};
+      const float ph[4] = {pp[0], pp[1], pp[2], 1.0f};
+      float R[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R[k] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const float w = wts[(long)j * Vp + v];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) R[r * 3 + c] = fmaf(w, sA[j * 12 + r * 4 + c], R[r * 3 + c]);
+          const float wg = w * g[r];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[j][r * 4 + c] = fmaf(wg, ph[c], acc[j][r * 4 + c]);
+        }
+      }
+      dpx = R[0] * g[0] + R[3] * g[1] + R[6] * g[2];
+      dpy = R[1] * g[0] + R[4] * g[1] + R[7] * g[2];
+      dpz = R[2] * g[0] + R[5] * g[1] + R[8] * g[2];
+    }
+    dpb[v] = dpx;                 // padding vertices: zeros (the contraction runs over Vp)
+    dpb[Vp + v] = dpy;
+    dpb[2 * Vp + v] = dpz;
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const float t = wave_sum(acc[j][k]);
+      if (lane == 0) dA[(long)b * 60 + j * 12 + k] = t;
+    }
+}
+
+extern "C" int msmd_lbs_skin_bwd(const float* grad_verts, const float* v_posed, const float* A, const float* lbs_weights,
+                                 float* dp_planes, float* dA, int B, int J, int V, int Vp, msmd_stream_t stream) {
+  if (B <= 0 || V <= 0 || Vp < V || J != 5 || !grad_verts || !v_posed || !A || !dp_planes || !dA) return 1;
+  hipLaunchKernelGGL(lbs_skin_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, grad_verts, v_posed, A, lbs_weights,
+                     dp_planes, dA, V, Vp);
   MSMD_RETURN_LAST();
 }
 

@@ -78,6 +78,67 @@ extern "C" int msmd_masked_seq_loss(const float* gt, const float* pred, const in
   MSMD_RETURN_LAST();
 }
 
+// Gradient of msmd_masked_seq_loss with respect to `pred`, ADDED into grad_pred (N, T, C; the channels outside
+// [c_lo, c_hi) are untouched):  loss = scale / (cnt nc) sum_{valid rows t} sum_c crit(D gt - D pred)  (mode 1: D gt = 0), D =
+// order-th temporal difference with stencil s = (1), (-1, 1), (1, -2, 1), so
+//   d loss / d pred[n, tau, c] = - scale up / (cnt nc) * sum_k s_k crit'(d[n, tau - k, c])   over the valid rows tau - k.
+// cnt is read from the forward's workspace (acc_ws[1]); `upstream` is the incoming 0-dim gradient on the device.
+__global__ __launch_bounds__(256) void masked_seq_loss_bwd_kernel(const LossArgs p, float* __restrict__ grad,
+                                                                  const float* __restrict__ upstream, float scale) {
+  const int n = blockIdx.y, tau = blockIdx.x;
+  const int nc = p.c_hi - p.c_lo, Td = p.T - p.order;
+  const double cnt = p.acc[1];
+  if (!(cnt > 0.0)) return;
+  const float g0 = -scale * upstream[0] / ((float)cnt * (float)nc);
+  const int pf = p.prefix < 0 ? -p.prefix : p.prefix;
+  const float st[3][3] = {{1.f, 0.f, 0.f}, {-1.f, 1.f, 0.f}, {1.f, -2.f, 1.f}};
+  bool valid[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int t = tau - k;
+    bool v = k <= p.order && t >= 0 && t < Td;
+    if (v) {
+      const int tm = t + p.order;
+      bool ok = p.prefix > 0 && tm < pf;
+      if (!ok && tm >= pf) {
+        const int e = p.end_idx ? p.end_idx[n] : (p.T - pf);
+        ok = (tm - pf) < e;
+      }
+      v = ok;
+    }
+    valid[k] = v;
+  }
+  if (!valid[0] && !valid[1] && !valid[2]) return;
+  for (int c = threadIdx.x; c < nc; c += blockDim.x) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (!valid[k]) continue;
+      const long off = ((long)n * p.T + (tau - k)) * p.C + p.c_lo + c;
+      const float dp = diff_at(p.pred + off, p.C, p.order);
+      const float dg = p.mode == 1 ? 0.f : diff_at(p.gt + off, p.C, p.order);
+      const float d = dg - dp;
+      const float dc = p.criterion == 0 ? 2.0f * d : (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.f));
+      a = fmaf(st[p.order][k], dc, a);
+    }
+    grad[((long)n * p.T + tau) * p.C + p.c_lo + c] += g0 * a;
+  }
+}
+
+extern "C" int msmd_masked_seq_loss_bwd(const float* gt, const float* pred, const int* end_idx, const double* acc_ws,
+                                        const float* upstream, float* grad_pred, int N, int T, int C, int c_lo, int c_hi,
+                                        int order, int prefix, int criterion, int mode, float scale,
+                                        msmd_stream_t stream) {
+  if (N <= 0 || T <= order || C <= 0 || c_lo < 0 || c_hi > C || c_hi <= c_lo || order < 0 || order > 2 || !acc_ws ||
+      !upstream || !grad_pred)
+    return 1;
+  LossArgs p{gt, pred, end_idx, (double*)acc_ws, N, T, C, c_lo, c_hi, order, prefix, criterion, 0, mode};
+  const int threads = (c_hi - c_lo) >= 1024 ? 256 : 64;
+  hipLaunchKernelGGL(masked_seq_loss_bwd_kernel, dim3(T, N), dim3(threads), 0, (hipStream_t)stream, p, grad_pred, upstream,
+                     scale);
+  MSMD_RETURN_LAST();
+}
+
 // KL divergence of the style VAE (reference utils/common.py:443-454): -0.5 * sum(1 + logvar - mu^2 - exp(logvar)).
 __global__ void kl_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, double* acc, long n) {
   __shared__ float red[16];

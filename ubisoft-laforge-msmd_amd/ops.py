@@ -584,6 +584,42 @@ def lbs_skin_v2(coef_hl, at_tiles, v_template_planes, dirs_hl, weight_planes, V)
     return verts
 
 
+def lbs_pack(coef, A):
+    """(coef (B, Kp), A (B, 5, 12)) fp32 -> (coef_hl, at_tiles): the skinning kernel's operand formats."""
+    lib = _lib.load()
+    B, Kp = coef.shape
+    coef_hl = torch.empty(B, 2, Kp, device=coef.device, dtype=torch.bfloat16)
+    at = torch.empty((B + 15) // 16, 12, 2, 16, 8, device=coef.device, dtype=torch.float16)
+    _lib.check(lib.msmd_lbs_pack(_p(coef), _p(A), _p(coef_hl), _p(at), B, Kp, _stream()), "msmd_lbs_pack")
+    return coef_hl, at
+
+
+def lbs_skin_v2_train(coef_hl, at_tiles, v_template_planes, dirs_hl, weight_planes, V):
+    """-> (verts, v_posed): msmd_lbs_skin_v2 that also stores the un-skinned vertices (needed by lbs_skin_bwd)."""
+    lib = _lib.load()
+    B, _, Kp = coef_hl.shape
+    J = weight_planes.shape[0]
+    Vp = dirs_hl.shape[-2]
+    verts = torch.empty(B, V, 3, device=coef_hl.device, dtype=torch.float32)
+    vposed = torch.empty(B, V, 3, device=coef_hl.device, dtype=torch.float32)
+    _lib.check(lib.msmd_lbs_skin_v2_train(_p(coef_hl), _p(at_tiles), _p(v_template_planes), _p(dirs_hl),
+                                          _p(weight_planes), _p(verts), _p(vposed), B, J, V, Vp, Kp, _stream()),
+               "msmd_lbs_skin_v2_train")
+    return verts, vposed
+
+
+def lbs_skin_bwd(grad_verts, vposed, A, weight_planes):
+    """-> (dp planes (B, 3, Vp), dA (B, 5, 12)) of the skinning's backward."""
+    lib = _lib.load()
+    B, V, _ = grad_verts.shape
+    J, Vp = weight_planes.shape
+    dp = torch.empty(B, 3, Vp, device=grad_verts.device, dtype=torch.float32)
+    dA = torch.empty(B, J, 12, device=grad_verts.device, dtype=torch.float32)
+    _lib.check(lib.msmd_lbs_skin_bwd(_p(grad_verts), _p(vposed), _p(A), _p(weight_planes), _p(dp), _p(dA), B, J, V, Vp,
+                                     _stream()), "msmd_lbs_skin_bwd")
+    return dp, dA
+
+
 def landmarks(verts, faces_i32, lmk_faces_idx_i32, bary):
     """lmk_faces_idx: (L,) / (1, L) shared or (B, L) per frame; bary likewise (.., L, 3)."""
     lib = _lib.load()
@@ -629,8 +665,9 @@ def rotation_convert(op, x, in_width, out_shape_tail, x2=None, conv=0):
 
 
 # ----------------------------------------------------------------------------- losses / training pieces
-def masked_seq_loss(gt, pred, end_idx, c_lo, c_hi, order, prefix, criterion=0, mode=0, scale=1.0):
-    """0-dim fp32 tensor = scale * masked mean (see msmd_masked_seq_loss in include/msmd_hip.h)."""
+def masked_seq_loss(gt, pred, end_idx, c_lo, c_hi, order, prefix, criterion=0, mode=0, scale=1.0, return_ws=False):
+    """0-dim fp32 tensor = scale * masked mean (see msmd_masked_seq_loss in include/msmd_hip.h); return_ws also hands
+    back the workspace (valid-row count) that masked_seq_loss_bwd_ needs."""
     lib = _lib.load()
     _need_cuda(gt, pred)
     N, T, C = pred.shape
@@ -638,7 +675,19 @@ def masked_seq_loss(gt, pred, end_idx, c_lo, c_hi, order, prefix, criterion=0, m
     ws = torch.empty(2, device=pred.device, dtype=torch.float64)
     _lib.check(lib.msmd_masked_seq_loss(_p(gt), _p(pred), _p(end_idx), _p(out), _p(ws), N, T, C, c_lo, c_hi, order,
                                         prefix, criterion, mode, float(scale), _stream()), "msmd_masked_seq_loss")
-    return out[0]
+    return (out[0], ws) if return_ws else out[0]
+
+
+def masked_seq_loss_bwd_(grad_pred, gt, pred, end_idx, ws, upstream, c_lo, c_hi, order, prefix, criterion=0, mode=0,
+                         scale=1.0):
+    """grad_pred += d(masked_seq_loss) / d(pred) * upstream (0-dim device tensor)."""
+    lib = _lib.load()
+    N, T, C = pred.shape
+    up = upstream.reshape(1).float().contiguous()
+    _lib.check(lib.msmd_masked_seq_loss_bwd(_p(gt), _p(pred), _p(end_idx), _p(ws), _p(up), _p(grad_pred), N, T, C, c_lo,
+                                            c_hi, order, prefix, criterion, mode, float(scale), _stream()),
+               "msmd_masked_seq_loss_bwd")
+    return grad_pred
 
 
 def kl_loss(mu, logvar):

@@ -388,6 +388,104 @@ def loss_no_vert_train(args, is_starting_sample, motion_coef_gt, target, prev_mo
             loss_head_trans)
 
 
+class VertexSeqLossFn(torch.autograd.Function):
+    """The three vertex-space terms of reference utils/common.py:486-513, 566-574 on (N, T, 15069) vertex sequences:
+    masked means of crit(gt - pred), of crit on first differences, and of crit(second difference of pred) -- each
+    one msmd_masked_seq_loss launch; the backward ADDS the three gradients into ONE (N, T, 15069) buffer
+    (msmd_masked_seq_loss_bwd), instead of autograd's chain of (N, T, 5023, 3) temporaries per term."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, end_idx, prefix, crit, want):
+        pred, gt = pred.float().contiguous(), gt.float().contiguous()
+        C = pred.shape[-1]
+        e32 = end_idx.to(torch.int32).contiguous() if end_idx is not None else None
+        outs, wss = [], []
+        for k, (order, mode) in enumerate(((0, 0), (1, 0), (2, 1))):
+            if want[k]:
+                v, ws = ops.masked_seq_loss(gt, pred, e32, 0, C, order, prefix, crit, mode, return_ws=True)
+            else:
+                v, ws = pred.new_zeros(()), None
+            outs.append(v)
+            wss.append(ws)
+        ctx.save_for_backward(pred, gt)
+        ctx.misc = (e32, prefix, crit, want, wss)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        pred, gt = ctx.saved_tensors
+        e32, prefix, crit, want, wss = ctx.misc
+        C = pred.shape[-1]
+        grad = torch.zeros_like(pred)
+        for k, (order, mode, g) in enumerate(((0, 0, g0), (1, 0, g1), (2, 1, g2))):
+            if want[k] and g is not None:
+                ops.masked_seq_loss_bwd_(grad, gt, pred, e32, wss[k], g, 0, C, order, prefix, crit, mode)
+        return grad, None, None, None, None, None
+
+
+def loss_vert_train(args, is_starting_sample, shape_coef, motion_coef_gt, target, prev_motion_coef, coef_stats, flame,
+                    end_idx=None):
+    """Differentiable restatement of the reference's vertex-space loss (utils/common.py:456-620, target='sample',
+    legacy 54-d motion = 50 expression + 4 pose coefficients): parameter-space noise / head terms with autograd ops on
+    (N, 110, 54) tensors, the vertex / velocity / smoothness terms through FLAME (differentiable pass of
+    utils.flame.FLAME.forward) and VertexSeqLossFn.  Returns the reference's dict."""
+    from .utils.common import get_coef_dict
+    l2 = args.criterion.lower() == "l2"
+    crit = (lambda a, b: (a - b) ** 2) if l2 else (lambda a, b: (a - b).abs())
+    n_prev = args.n_prev_motions
+    if is_starting_sample:
+        target = target[:, n_prev:]
+        prefix = 0
+    else:
+        motion_coef_gt = torch.cat([prev_motion_coef, motion_coef_gt], dim=1)
+        if getattr(args, "no_constrain_prev", False):
+            target = torch.cat([prev_motion_coef, target[:, n_prev:]], dim=1)
+        prefix = n_prev
+    N, T = target.shape[0], target.shape[1]
+    if end_idx is None:
+        mask = torch.ones((N, args.n_motions), dtype=torch.bool, device=target.device)
+    else:
+        mask = torch.arange(args.n_motions, device=target.device).expand(N, -1) < end_idx.unsqueeze(1)
+    if not is_starting_sample:
+        lead = torch.zeros_like if getattr(args, "no_constrain_prev", False) else torch.ones_like
+        mask = torch.cat([lead(mask[:, :n_prev]), mask], dim=1)
+        if getattr(args, "no_constrain_prev", False):
+            prefix = -prefix
+    d1 = lambda x: x[:, 1:] - x[:, :-1]
+    gt, pr = motion_coef_gt.float(), target.float()
+    out = {"noise": _masked_mean(crit(gt, pr), mask) / 2, "vert": 0, "vel": 0, "smooth": 0, "head_angle": 0, "head_vel": 0,
+           "head_smooth": 0, "head_trans": None}
+    if args.l_vert > 0 or args.l_vel > 0:
+        if args.rot_repr != "aa":
+            raise ValueError(f"Unknown rotation representation {args.rot_repr}!")
+        cg = get_coef_dict(gt.detach(), shape_coef, coef_stats, with_global_pose=False, rot_repr=args.rot_repr)
+        cp = get_coef_dict(pr, shape_coef, coef_stats, with_global_pose=False, rot_repr=args.rot_repr)
+        with torch.no_grad():
+            vg = flame(cg["shape"].reshape(-1, 100), cg["exp"].reshape(-1, 50), cg["pose"].reshape(-1, 6),
+                       return_lm2d=False, return_lm3d=False)[0].view(N, T, -1)
+        vp = flame(cp["shape"].reshape(-1, 100), cp["exp"].reshape(-1, 50), cp["pose"].reshape(-1, 6),
+                   return_lm2d=False, return_lm3d=False)[0].view(N, T, -1)
+        lv, lvel, lsm = VertexSeqLossFn.apply(vp, vg, end_idx, prefix, 0 if l2 else 1,
+                                              (args.l_vert > 0, args.l_vel > 0, args.l_smooth > 0))
+        out["vert"], out["vel"], out["smooth"] = lv / 2, lvel / 2, lsm / 2
+    if not args.no_head_pose:
+        hg, hp = gt[:, :, 50:53], pr[:, :, 50:53]
+        if args.l_head_angle > 0:
+            out["head_angle"] = _masked_mean(crit(hg, hp), mask) / 2
+        if args.l_head_vel > 0:
+            out["head_vel"] = _masked_mean(crit(d1(hg), d1(hp)), mask[:, 1:]) / 2
+        if args.l_head_smooth > 0:
+            hv = d1(hp)
+            out["head_smooth"] = _masked_mean(crit(hv[:, 1:], hv[:, :-1]), mask[:, 2:]) / 2
+        if not is_starting_sample and args.l_head_trans > 0:
+            seq = torch.cat([hg[:, n_prev - 3:n_prev], hp[:, n_prev:n_prev + 3]], dim=1)
+            v = d1(seq)
+            a = d1(v)
+            out["head_trans"] = (_masked_mean(crit(v[:, 2:4], v[:, 1:3]), mask[:, n_prev:n_prev + 2])
+                                 + _masked_mean(crit(a[:, 1:], a[:, :-1]), mask[:, n_prev:n_prev + 3]))
+    return out
+
+
 def kl_train(mu, logvar):
     """reference utils/common.py:443-454."""
     return -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp())

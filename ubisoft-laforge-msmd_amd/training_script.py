@@ -147,9 +147,18 @@ def batch_from_loader(item):
 
 
 class Trainer:
-    def __init__(self, args, model, style_enc, process_group=None, bucket_mb=32.0, use_graph=False):
+    def __init__(self, args, model, style_enc, process_group=None, bucket_mb=32.0, use_graph=False, flame=None,
+                 coef_stats=None):
         self.args, self.model, self.style_enc = args, model, style_enc
         self.device = model.device
+        # vertex-space training branch (reference training_script.py:167-170: use_vertex_space on the legacy FLAME
+        # dataset types): the loss runs through FLAME, differentiably (train_graph.loss_vert_train)
+        legacy = args.dataset_type[:9] == "HDTF_TFHP" or args.dataset_type == "flame_mead_ravdess"
+        self.vertex_space = bool(getattr(args, "use_vertex_space", False)) and legacy
+        self.flame = flame
+        self.coef_stats = {k: torch.as_tensor(v).float().to(self.device) for k, v in coef_stats.items()} if coef_stats else None
+        if self.vertex_space and flame is None:
+            raise ValueError("use_vertex_space on a FLAME dataset type needs the FLAME module (Trainer(..., flame=...))")
         # optimizer param groups of the reference: style encoder first, then the model (same lr)
         params = [p for p in style_enc.parameters() if p.requires_grad] + \
                  [p for p in model.parameters() if p.requires_grad]
@@ -316,9 +325,15 @@ class Trainer:
                     else:
                         prev_motion = motion_in[:, -n_prev:].detach()
                         prev_audio = audio_feat[:, -n_prev:]
-                tup = tg.loss_no_vert_train(args, i == 0, motion_in, target, prev_motion if i == 1 else None, end_idx)
-                for key, val in zip(("noise", "vel", "smooth", "head_angle", "head_vel", "head_smooth", "head_trans"), tup):
-                    if val is not None and lw.get(key, 0) > 0:
+                if self.vertex_space:
+                    ld = tg.loss_vert_train(args, i == 0, shape, motion_in, target, prev_motion if i == 1 else None,
+                                            self.coef_stats, self.flame, end_idx)
+                    pairs = ld.items()
+                else:
+                    tup = tg.loss_no_vert_train(args, i == 0, motion_in, target, prev_motion if i == 1 else None, end_idx)
+                    pairs = zip(("noise", "vel", "smooth", "head_angle", "head_vel", "head_smooth", "head_trans"), tup)
+                for key, val in pairs:
+                    if val is not None and torch.is_tensor(val) and lw.get(key, 0) > 0:
                         losses[key] = losses[key] + val
                 losses["kl_div"] = losses["kl_div"] + tg.kl_train(mus[i], logvars[i])
             loss = sum(losses[k] * lw[k] for k in losses if lw[k] > 0)
@@ -611,7 +626,11 @@ def train(args, model, style_enc, train_loader, val_loader, optimizer, save_dir,
     if trainer is None:
         if optimizer is not None:
             args.lr = float(optimizer.param_groups[0]["lr"]) if scheduler is None else float(args.lr)
-        trainer = Trainer(args, model, style_enc, use_graph=use_graph)
+        _ds = getattr(train_loader, "dataset", None)
+        if len(args.dataset_type.split("+")) > 1 and hasattr(_ds, "datasets"):
+            _ds = _ds.datasets[0]
+        trainer = Trainer(args, model, style_enc, use_graph=use_graph, flame=flame,
+                          coef_stats=getattr(_ds, "coef_stats", None))
     save_dir = Path(save_dir)
     if rank == 0:
         save_dir.mkdir(parents=True, exist_ok=True)

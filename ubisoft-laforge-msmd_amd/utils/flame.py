@@ -133,9 +133,16 @@ class FLAME(nn.Module):
             head = pose_params[:, :9] if not ignore_global_rot else self.eye_pose_mat.expand(B, -1)[:, :9]
             full_pose = torch.cat([head, self.neck_pose_mat.expand(B, -1), pose_params[:, 9:], eye_pose_params], dim=1)
         full_pose = full_pose.float().contiguous()
-        vertices, _ = _lbs.lbs(betas, full_pose, self.v_template, self.shapedirs, self.posedirs, self.J_regressor,
-                               self.parents, self.lbs_weights, pose2rot, self.dtype, constants=p["lbs"],
-                               precision=self.lbs_precision)
+        if torch.is_grad_enabled() and (betas.requires_grad or full_pose.requires_grad):
+            # training through the vertex-space loss (reference training_script.py:167-176): differentiable pass --
+            # per-frame kinematics by autograd on tiny tensors, per-vertex skinning forward / backward in HIP
+            if not pose2rot:
+                raise NotImplementedError("the differentiable FLAME pass takes axis-angle poses (pose2rot=True)")
+            vertices = _lbs.lbs_train(betas, full_pose, p["lbs"])
+        else:
+            vertices, _ = _lbs.lbs(betas, full_pose, self.v_template, self.shapedirs, self.posedirs, self.J_regressor,
+                                   self.parents, self.lbs_weights, pose2rot, self.dtype, constants=p["lbs"],
+                                   precision=self.lbs_precision)
         landmarks2d = landmarks3d = None
         if return_lm2d:
             row = ops.dynamic_lmk_row(full_pose, p["chain"], pose_is_matrix=not pose2rot).long()

@@ -52,6 +52,13 @@ class LbsConstants:
         self.parents = par.contiguous()
 
 
+    def dirs_t(self):
+        """(KP, 3 * Vp) fp32: W operand of the backward contraction dcoef = dp . dirs^T (built on first use)."""
+        if getattr(self, "_dirs_t", None) is None:
+            self._dirs_t = self.dirs.permute(1, 0, 2).reshape(KP, 3 * self.Vp).contiguous()
+        return self._dirs_t
+
+
 _CACHE = {}
 
 
@@ -95,6 +102,70 @@ def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_
     else:
         verts = ops.lbs_skin(coef, A, c.template_planes, c.dirs, c.weight_planes, c.V)
     return verts, joints
+
+
+# ----------------------------------------------------------------------------- differentiable pass (training)
+def _rodrigues_torch(r):
+    """reference utils/lbs.py:285-300 on (N, 3), autograd-differentiable (tiny tensors)."""
+    angle = torch.norm(r + 1e-8, dim=1, keepdim=True)
+    d = r / angle
+    cos, sin = torch.cos(angle)[:, None], torch.sin(angle)[:, None]
+    rx, ry, rz = d[:, 0], d[:, 1], d[:, 2]
+    z = torch.zeros_like(rx)
+    K = torch.stack([z, -rz, ry, rz, z, -rx, -ry, rx, z], dim=1).view(-1, 3, 3)
+    return torch.eye(3, device=r.device, dtype=r.dtype)[None] + sin * K + (1 - cos) * torch.bmm(K, K)
+
+
+def kinematics_torch(c: LbsConstants, betas, pose):
+    """What msmd_lbs_prepare computes -- coef (B, KP) = [betas | R[1:] - I | 0] and the relative rigid transforms
+    A (B, J, 12) -- as autograd ops on (B, J, 3, 3)-sized tensors (utils/lbs.py:141-223, 317-371): the per-frame part
+    of the differentiable FLAME pass.  The per-vertex part is SkinFn (HIP forward and backward)."""
+    B, J = betas.shape[0], c.J
+    joints = c.JS[0].view(1, J, 3) + (betas @ c.JS[1:]).view(B, J, 3)
+    R = _rodrigues_torch(pose.reshape(B * J, 3)).view(B, J, 3, 3)
+    eye = torch.eye(3, device=R.device, dtype=R.dtype)
+    coef = torch.cat([betas, (R[:, 1:] - eye).reshape(B, (J - 1) * 9),
+                      betas.new_zeros(B, KP - betas.shape[1] - (J - 1) * 9)], dim=1)
+    par = [int(x) for x in c.parents.tolist()]
+    wR, wt = [R[:, 0]], [joints[:, 0]]
+    for i in range(1, J):
+        pa = par[i]
+        wR.append(torch.bmm(wR[pa], R[:, i]))
+        wt.append(torch.bmm(wR[pa], (joints[:, i] - joints[:, pa]).unsqueeze(-1)).squeeze(-1) + wt[pa])
+    A = []
+    for i in range(J):
+        t = wt[i] - torch.bmm(wR[i], joints[:, i].unsqueeze(-1)).squeeze(-1)
+        A.append(torch.cat([wR[i], t.unsqueeze(-1)], dim=-1).reshape(B, 12))
+    return coef, torch.stack(A, dim=1)
+
+
+class SkinFn(torch.autograd.Function):
+    """verts (B, V, 3) = sum_j w_j A_j [template + coef . dirs ; 1] with the HIP forward (msmd_lbs_skin_v2_train) and
+    backward (msmd_lbs_skin_bwd + one GEMM for dcoef): the reference differentiates utils/lbs.py:185-221 by autograd
+    through its (B, V, 4, 4) intermediates."""
+
+    @staticmethod
+    def forward(ctx, coef, A, c):
+        coef, A = coef.float().contiguous(), A.float().contiguous()
+        coef_hl, at = ops.lbs_pack(coef, A)
+        verts, vposed = ops.lbs_skin_v2_train(coef_hl, at, c.template_planes, c.dirs_hl, c.weight_planes, c.V)
+        ctx.save_for_backward(vposed, A)
+        ctx.c = c
+        return verts
+
+    @staticmethod
+    def backward(ctx, g):
+        vposed, A = ctx.saved_tensors
+        c = ctx.c
+        dp, dA = ops.lbs_skin_bwd(g.float().contiguous(), vposed, A, c.weight_planes)
+        dcoef = ops.gemm(dp.view(dp.shape[0], 3 * c.Vp), c.dirs_t())
+        return dcoef, dA, None
+
+
+def lbs_train(betas, pose, constants: LbsConstants):
+    """Differentiable lbs(): (betas (B, NB), axis-angle pose (B, J*3)) -> verts (B, V, 3) with gradients to both."""
+    coef, A = kinematics_torch(constants, betas.float(), pose.float())
+    return SkinFn.apply(coef, A, constants)
 
 
 def batch_rodrigues(rot_vecs, epsilon=1e-8, dtype=torch.float32):
