@@ -759,18 +759,33 @@ G6_STYLE = ["input_layers.1.weight", "input_layers.5.bias", "encoder.self_attn.i
             "output_layers.7.bias"]
 
 
-def g6_train(M, SE, mc):
+G6_FULL_EXTRA = [
+    "denoising_net.transformer.layers.7.linear1.weight", "denoising_net.transformer.layers.4.multihead_attn.out_proj.weight",
+    "denoising_net.transformer.layers.3.norm2.bias", "audio_encoder.encoder.layers.11.feed_forward.intermediate_dense.weight",
+    "audio_encoder.encoder.layers.6.attention.v_proj.weight", "audio_encoder.encoder.layers.3.final_layer_norm.weight",
+]
+
+
+def g6_train_full(M, SE, mc):
+    """g6_train at FULL depth (12 encoder + 8 decoder layers): for every listed parameter the gradient norm and 64
+    entries sampled across the tensor (element-wise parity, not only norms)."""
+    return g6_train(M, SE, mc, enc_layers=12, dec_layers=8, name="g6_train_full", params=G6_PARAMS + G6_FULL_EXTRA,
+                    sample=64)
+
+
+def g6_train(M, SE, mc, enc_layers=2, dec_layers=2, name="g6_train", params=None, sample=0):
     """Window-0 training forward of the reference in eval mode (no dropout) WITH gradients: fixed t / eps, no CFG
     masking, style from the VAE mean path; loss = weighted parameter-space terms + KL; records losses and the
     gradients' norms and leading entries for parameters spread over every component."""
     from transformers import Wav2Vec2Config
     import utils.wav2vec2 as w2
     from utils import common as C
+    params = params or G6_PARAMS
     w2.Wav2Vec2Model.from_pretrained = classmethod(
-        lambda cls, name, **kw: cls(Wav2Vec2Config(attn_implementation="eager", num_hidden_layers=2)))
+        lambda cls, name, **kw: cls(Wav2Vec2Config(attn_implementation="eager", num_hidden_layers=enc_layers)))
     torch.set_grad_enabled(True)
     try:
-        args = ref_args(n_layers=2)
+        args = ref_args(n_layers=dec_layers)
         model = M.get_diffusion_model(args, device="cpu").eval()
         synth.load_synthetic(model)
         se = SE.get_style_encoder(args, "vae2").eval()
@@ -797,17 +812,22 @@ def g6_train(M, SE, mc):
         out = dict(losses=np.array([float(l) for l in losses[:6]] + [float(kl), float(total)], np.float64),
                    target=target.detach().numpy(), mu=mu.detach().numpy())
         named = dict(model.named_parameters())
-        for k in G6_PARAMS:
+        def pick(gr):
+            flat = gr.reshape(-1)
+            if not sample:
+                return flat[:8].numpy().astype(np.float64)
+            return flat[::max(1, flat.numel() // sample) | 1][:sample].numpy().astype(np.float64)   # odd stride: walks every axis
+        for k in params:
             kk = k.replace("weight_g", "parametrizations.weight.original0").replace("weight_v", "parametrizations.weight.original1")
             gr = named[kk].grad
-            out["gn/" + k] = np.float64(gr.norm())
-            out["g8/" + k] = gr.reshape(-1)[:8].numpy().astype(np.float64)
+            out["gn/" + k] = np.float64(gr.double().norm())
+            out["g8/" + k] = pick(gr)
         snamed = dict(se.named_parameters())
         for k in G6_STYLE:
             gr = snamed[k].grad
-            out["sn/" + k] = np.float64(gr.norm())
-            out["s8/" + k] = gr.reshape(-1)[:8].numpy().astype(np.float64)
-        save("g6_train", **out)
+            out["sn/" + k] = np.float64(gr.double().norm())
+            out["s8/" + k] = pick(gr)
+        save(name, **out)
     finally:
         torch.set_grad_enabled(False)
         w2.Wav2Vec2Model.from_pretrained = classmethod(
@@ -903,7 +923,7 @@ ALL = dict(g1_specaug=g1_specaug, g7_dataset=g7_dataset, g2_lr_schedule=g2_lr_sc
            g3_forward=g3_forward, g3_style=g3_style, g3_sample=g3_sample, g3_infer=g3_infer,
            g4_flame=g4_flame, g4_rotations=g4_rotations, g5_losses=g5_losses, g6_train=g6_train,
            g5_losses_no_constrain_prev=g5_losses_no_constrain_prev, g3_denoiser_options=g3_denoiser_options, g4_lbs_blocks=g4_lbs_blocks,
-           g8_vertex_grad=g8_vertex_grad)
+           g8_vertex_grad=g8_vertex_grad, g6_train_full=g6_train_full)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
