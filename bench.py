@@ -332,10 +332,13 @@ def leg_hubert_large(device, B=32, steps=5):
                 mfma_frac=round(tf / PEAK_MFMA_TFLOPS, 4))
 
 
-def run_legs(device):
+def run_legs(device, which="all"):
+    """`which`: "all" or a comma-separated subset of sampler,lbs,train,hubert (profiling runs time one leg at a time)."""
     legs = {}
     for name, fn in (("sampler_b64_t500", leg_sampler), ("lbs", leg_lbs), ("train_step_b32", leg_train),
                      ("hubert_large_10s_b32", leg_hubert_large)):
+        if which != "all" and not any(name.startswith(w) for w in which.split(",")):
+            continue
         try:
             r = fn(device)
             if name == "lbs":
@@ -417,7 +420,7 @@ def run_forward(a, rank, world, device):
     del model
     torch.cuda.empty_cache()
     if a.legs != "none":
-        out["legs"] = run_legs(device)
+        out["legs"] = run_legs(device, a.legs)
     return out
 
 
@@ -500,7 +503,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32", "f16x2"])
     ap.add_argument("--mode", default="forward", choices=["forward", "train"])
-    ap.add_argument("--legs", default="all", choices=["all", "none"])
+    ap.add_argument("--legs", default="all", help="all | none | comma-separated subset of sampler,lbs,train,hubert")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the f16x2 / fp32 parity-mode timings")
