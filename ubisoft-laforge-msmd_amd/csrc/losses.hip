@@ -72,7 +72,10 @@ extern "C" int msmd_masked_seq_loss(const float* gt, const float* pred, const in
   LossArgs p{gt, pred, end_idx, acc_ws, N, T, C, c_lo, c_hi, order, prefix, criterion, 0, mode};
   const long rows = (long)N * (T - order);
   const int threads = (c_hi - c_lo) >= 1024 ? 256 : 64;
-  dim3 grid((unsigned)min(rows, (long)4096)), block(threads);
+  // every workgroup ends with two double atomics on ONE address pair: size the grid by the work (about 4096 elements
+  // per workgroup), not by the rows -- coefficient-space calls (67 columns) took 75 us with one workgroup per row
+  const long want = rows * (long)(c_hi - c_lo) / 4096;
+  dim3 grid((unsigned)max((long)1, min(rows, min(max(want, (long)64), (long)4096)))), block(threads);
   hipLaunchKernelGGL(masked_seq_loss_kernel, grid, block, 0, st, p);
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, acc_ws, out, scale);
   MSMD_RETURN_LAST();

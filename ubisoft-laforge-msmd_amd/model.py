@@ -255,6 +255,7 @@ class DenoisingNetwork_MSMD(nn.Module):
         P.st2 = (cd(torch.stack([sd[f"static_feature_mapping.{b}.2.weight"] for b in range(nb)], 0)),
                  f32(torch.stack([sd[f"static_feature_mapping.{b}.2.bias"] for b in range(nb)], 0)))
         self._packed, self._packed_dtype = P, (dtype, split)
+        self._pack_gen = getattr(self, "_pack_gen", 0) + 1   # monotonic: captured graphs are keyed on it (ids get reused)
         return P
 
     # ------------------------------------------------------------------ pieces (shared with the sampler)

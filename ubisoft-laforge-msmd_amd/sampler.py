@@ -278,7 +278,7 @@ def _graph_loop(model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, ta
                 mem, kv_list, stat, tok_person, emb_all, scales, coefficients, dyn=None, cross_list=None):
     like = dict(prev_m=prev_m, ind_in=ind_in, mem=mem, kv_list=kv_list, cross_list=cross_list, stat=stat, tok_person=tok_person,
                 emb_all=emb_all, scales=scales)
-    key = (T, N, n_entries, Lp, L, mode, target, dtype, ind_in is not None, id(net._packed), dyn, cross_list is not None)
+    key = (T, N, n_entries, Lp, L, mode, target, dtype, ind_in is not None, getattr(net, "_pack_gen", 0), dyn, cross_list is not None)
     cache = model.__dict__.setdefault("_step_graphs", {})
     g = cache.get(key)
     if g is None:

@@ -201,12 +201,11 @@ def audio_feat_train(model, audio, frame_num, dtype):
 def denoiser_train(net, motion_noisy, audio_feat, person_feat, static_style_feat, prev_motion_feat, prev_audio_feat,
                    step, indicator, dtype):
     """reference model.py:914-996 (differentiable).  Returns (N, Lp + L, dm) fp32."""
-    P = net.pack(dtype)  # constants only (TE table, mask)
     g = lambda n: net.get_parameter(n)
     d, H, nb, dm = net.feature_dim, net.n_heads, net.num_of_basis, net.motion_feat_dim
     N = person_feat.shape[0]
     step = torch.as_tensor(step, device=net.device, dtype=torch.long)
-    te = P.te[step].to(dtype)
+    te = net.TE.pe[0].float()[step].to(dtype)   # the sinusoidal step table is a buffer: no weight pack needed here
     emb = ag.linear(ag.linear(te, g("diff_step_map.0.weight"), g("diff_step_map.0.bias"), act=ops.ACT_GELU),
                     g("diff_step_map.2.weight"), g("diff_step_map.2.bias"))
     person = ag.linear(person_feat.reshape(N, -1).to(dtype), g("person_proj.weight"), g("person_proj.bias")) + emb
@@ -366,18 +365,30 @@ def loss_no_vert_train(args, is_starting_sample, motion_coef_gt, target, prev_mo
         mask = torch.cat([lead(mask[:, :n_prev]), mask], dim=1)
     d1 = lambda x: x[:, 1:] - x[:, :-1]
     gt, pr = motion_coef_gt, target
-    loss_noise = _masked_mean(crit(gt, pr), mask)
-    vg, vp = d1(gt), d1(pr)
-    loss_vel = _masked_mean(crit(vg[..., :-3], vp[..., :-3]).mean(-1) + crit(vg[..., -3:], vp[..., -3:]).mean(-1),
-                            mask[:, 1:])
-    sp = d1(vp)
-    loss_smooth = _masked_mean(crit(sp[..., :-3], 0 * sp[..., :-3]).mean(-1) + crit(sp[..., -3:], 0 * sp[..., -3:]).mean(-1),
-                               mask[:, 2:])
-    hg, hp = gt[..., -3:], pr[..., -3:]
-    loss_head_angle = _masked_mean(crit(hg, hp), mask)
-    loss_head_vel = _masked_mean(crit(d1(hg), d1(hp)).mean(-1), mask[:, 1:])
-    hs = d1(d1(hp))
-    loss_head_smooth = _masked_mean(crit(hs, 0 * hs).mean(-1), mask[:, 2:])
+    C = pr.shape[-1]
+    if pr.is_cuda:
+        # every term is a masked mean of crit(D^k gt, D^k pred) over a column range: six msmd_masked_seq_loss launches
+        # forward, six backward launches adding into ONE gradient buffer (instead of ~400 elementwise launches fwd + bwd)
+        prefix = 0 if is_starting_sample else (-n_prev if getattr(args, "no_constrain_prev", False) else n_prev)
+        specs = ((0, 0, 0, C), (1, 0, 0, C - 3), (1, 0, C - 3, C), (2, 1, 0, C - 3), (2, 1, C - 3, C), (0, 0, C - 3, C))
+        l_noise, vel_a, vel_b, sm_a, sm_b, l_head = SeqLossTermsFn.apply(
+            pr, gt, end_idx, prefix, 0 if args.criterion.lower() == "l2" else 1, specs)
+        loss_noise, loss_vel, loss_smooth = l_noise, vel_a + vel_b, sm_a + sm_b
+        loss_head_angle, loss_head_vel, loss_head_smooth = l_head, vel_b, sm_b
+        hg, hp = gt[..., -3:], pr[..., -3:]
+    else:
+        loss_noise = _masked_mean(crit(gt, pr), mask)
+        vg, vp = d1(gt), d1(pr)
+        loss_vel = _masked_mean(crit(vg[..., :-3], vp[..., :-3]).mean(-1) + crit(vg[..., -3:], vp[..., -3:]).mean(-1),
+                                mask[:, 1:])
+        sp = d1(vp)
+        loss_smooth = _masked_mean(crit(sp[..., :-3], 0 * sp[..., :-3]).mean(-1) + crit(sp[..., -3:], 0 * sp[..., -3:]).mean(-1),
+                                   mask[:, 2:])
+        hg, hp = gt[..., -3:], pr[..., -3:]
+        loss_head_angle = _masked_mean(crit(hg, hp), mask)
+        loss_head_vel = _masked_mean(crit(d1(hg), d1(hp)).mean(-1), mask[:, 1:])
+        hs = d1(d1(hp))
+        loss_head_smooth = _masked_mean(crit(hs, 0 * hs).mean(-1), mask[:, 2:])
     loss_head_trans = None
     if not is_starting_sample and args.l_head_trans > 0:
         seq = torch.cat([hg[:, n_prev - 3:n_prev], hp[:, n_prev:n_prev + 3]], dim=1)
@@ -386,6 +397,36 @@ def loss_no_vert_train(args, is_starting_sample, motion_coef_gt, target, prev_mo
         loss_head_trans = (crit(v[:, 2:4], v[:, 1:3]).mean(-1).mean(-1) + crit(a[:, 1:], a[:, :-1]).mean(-1).mean(-1)).mean()
     return (loss_noise / 2, loss_vel / 2, loss_smooth / 2, loss_head_angle / 2, loss_head_vel / 2, loss_head_smooth / 2,
             loss_head_trans)
+
+
+class SeqLossTermsFn(torch.autograd.Function):
+    """A tuple of masked sequence-loss terms on one (N, T, C) prediction: specs = ((order, mode, c_lo, c_hi), ...), each
+    one msmd_masked_seq_loss launch (mean over valid frames of the mean over columns [c_lo, c_hi) of crit on the
+    order-th temporal difference; mode 1 compares the prediction's difference with 0).  The backward ADDS every term's
+    gradient into one (N, T, C) buffer (msmd_masked_seq_loss_bwd).  Reference: utils/common.py:198-442."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, end_idx, prefix, crit, specs):
+        pred, gt = pred.float().contiguous(), gt.float().contiguous()
+        e32 = end_idx.to(torch.int32).contiguous() if end_idx is not None else None
+        outs, wss = [], []
+        for order, mode, c_lo, c_hi in specs:
+            v, ws = ops.masked_seq_loss(gt, pred, e32, c_lo, c_hi, order, prefix, crit, mode, return_ws=True)
+            outs.append(v)
+            wss.append(ws)
+        ctx.save_for_backward(pred, gt)
+        ctx.misc = (e32, prefix, crit, specs, wss)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        pred, gt = ctx.saved_tensors
+        e32, prefix, crit, specs, wss = ctx.misc
+        grad = torch.zeros_like(pred)
+        for (order, mode, c_lo, c_hi), ws, g in zip(specs, wss, gs):
+            if g is not None:
+                ops.masked_seq_loss_bwd_(grad, gt, pred, e32, ws, g, c_lo, c_hi, order, prefix, crit, mode)
+        return grad, None, None, None, None, None
 
 
 class VertexSeqLossFn(torch.autograd.Function):

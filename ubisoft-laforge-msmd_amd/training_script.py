@@ -217,7 +217,7 @@ class Trainer:
             "optimizer": {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "step": self.opt_step,
                           "layout": [(n, int(p.numel())) for n, p in self._named_trainable()]},
             "scheduler": {"sched_step": self.sched_step, "n_calls": self._lr.calls, "lr": self.current_lr()},
-            "rng": {"numpy": self.rng.get_state(), "noise_state": self.noise_state.cpu()},
+            "rng": {"numpy": self.rng.get_state(), "noise_state": self.noise_state.cpu(), "rank": dp.env_rank()[0]},
         }, path)
 
     def load_checkpoint(self, path_or_dict):
@@ -243,8 +243,17 @@ class Trainer:
                 self._lr.replay(sch["n_calls"])
         rng = ck.get("rng")
         if rng is not None:
-            self.rng.set_state(rng["numpy"])
-            self.noise_state.copy_(rng["noise_state"])
+            rank = dp.env_rank()[0]
+            if rank == int(rng.get("rank", 0)):
+                self.rng.set_state(rng["numpy"])
+                self.noise_state.copy_(rng["noise_state"])
+            else:
+                # the checkpoint holds ONE rank's streams: every other rank re-derives its own from (rank, iteration)
+                # instead of cloning them (identical dropout / SpecAugment / CFG draws on all ranks otherwise)
+                it = int(ck.get("iter", 0))
+                self.rng = np.random.RandomState((1234 + rank + 7919 * (it + 1)) % (2 ** 32))
+                self.noise_state.copy_(torch.tensor([0x5EED0000 + 7919 * rank, int(rng["noise_state"][1])],
+                                                    dtype=torch.int64))
         return int(ck.get("iter", 0))
 
     def _named_trainable(self):
@@ -258,7 +267,10 @@ class Trainer:
         self.model.denoising_net._packed = None
         self.model._afm = None
         self.style_enc._packed = None
-        self.model.audio_encoder._packed = None  # lazily re-packed (bf16 casts of 94 M weights: ~0.1 ms of HBM traffic)
+        enc = self.model.audio_encoder
+        enc._packed = None  # lazily re-packed by the inference paths (the training graph reads parameters directly)
+        if any(p.requires_grad for n, p in enc.named_parameters() if n.startswith("feature_extractor.")):
+            enc._packed_fe = None   # the conv stack's pack survives optimizer steps while it is frozen
 
     # ------------------------------------------------------------------ forward + backward of one iteration
     def _fwd_bwd(self, batch, draws, trunc, cross):

@@ -138,6 +138,8 @@ class Wav2Vec2Model(nn.Module):
             self.add_module(name, m)
         self._packed = None
         self._packed_dtype = None
+        self._packed_fe = None
+        self._packed_fe_dtype = None
         self.split_mode = False   # set by MSMD for compute_dtype "f16x2" (contractions on MSMD_F16X2 split pairs)
 
     @classmethod
@@ -149,25 +151,27 @@ class Wav2Vec2Model(nn.Module):
         return m
 
     def _load_from_state_dict(self, state_dict, prefix, *a, **k):
-        self._packed = None
+        self._packed = self._packed_fe = None
         return super()._load_from_state_dict(state_dict, prefix, *a, **k)
 
     def _apply(self, fn, *a, **k):
-        self._packed = None
+        self._packed = self._packed_fe = None
         return super()._apply(fn, *a, **k)
 
     # ------------------------------------------------------------------ weight packing (load time)
-    def pack(self, dtype):
+    def pack_fe(self, dtype):
+        """The convolutional feature extractor's weights alone (frozen in training, model.py freeze_feature_encoder:
+        the Trainer keeps this pack across optimizer steps instead of re-casting it with the rest)."""
         split = bool(self.split_mode) and dtype == torch.float32
-        if self._packed is not None and self._packed_dtype == (dtype, split):
-            return self._packed
+        if self._packed_fe is not None and self._packed_fe_dtype == (dtype, split):
+            return self._packed_fe
         c = self.config
-        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        fe = "feature_extractor.conv_layers."
+        sd = {k: v.detach() for k, v in self.state_dict().items() if k.startswith(fe)}
         P = SimpleNamespace()
         P.split = split
         f32 = lambda t: t.float().contiguous()
         cd = (lambda t: ops.to_split(t.float().contiguous())) if split else (lambda t: t.to(dtype).contiguous())
-        fe = "feature_extractor.conv_layers."
         P.w0 = f32(sd[fe + "0.conv.weight"].reshape(c.conv_dim, CONV_KERNEL[0]))
         P.gn_g, P.gn_b = f32(sd[fe + "0.layer_norm.weight"]), f32(sd[fe + "0.layer_norm.bias"])
         nconv = len(CONV_KERNEL)
@@ -177,6 +181,18 @@ class Wav2Vec2Model(nn.Module):
         # conv i>=1: (Cout, Cin, k) -> (Cout, k*Cin), K index = kk*Cin + cin (channels-last window)
         P.conv_w = [cd(sd[fe + f"{i}.conv.weight"].permute(0, 2, 1).reshape(c.conv_dim, -1))
                     for i in range(1, len(CONV_KERNEL))]
+        self._packed_fe, self._packed_fe_dtype = P, (dtype, split)
+        return P
+
+    def pack(self, dtype):
+        split = bool(self.split_mode) and dtype == torch.float32
+        if self._packed is not None and self._packed_dtype == (dtype, split):
+            return self._packed
+        c = self.config
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        P = SimpleNamespace(**vars(self.pack_fe(dtype)))
+        f32 = lambda t: t.float().contiguous()
+        cd = (lambda t: ops.to_split(t.float().contiguous())) if split else (lambda t: t.to(dtype).contiguous())
         P.fp_ln = (f32(sd["feature_projection.layer_norm.weight"]), f32(sd["feature_projection.layer_norm.bias"]))
         P.fp_w, P.fp_b = cd(sd["feature_projection.projection.weight"]), f32(sd["feature_projection.projection.bias"])
         # positional conv: fold weight norm (dim=2): w = g * v / ||v||_{dims 0,1}
@@ -211,7 +227,7 @@ class Wav2Vec2Model(nn.Module):
     def feature_extractor_cl(self, audio, dtype, reflect_len=None, replicate_len=None):
         """HF Wav2Vec2FeatureEncoder on UNPADDED audio (B, L) with pad_audio fused into conv0's loads.
         Returns (B, T50, 512) channels-last."""
-        P = self.pack(dtype)
+        P = self.pack_fe(dtype)
         if reflect_len is None:
             reflect_len, replicate_len = 0, 0
         eps = self.config.layer_norm_eps
