@@ -8,7 +8,7 @@ V = int(os.environ.get("VARIANT", "17"))
 lib.msmd_set_tuning(0, V)
 for K in (768, 3072):
     for N in (768,):
-        for mt in (21, 32, 43, 50, 64, 85, 86, 100, 128, 171, 200):
+        for mt in [int(x) for x in os.environ.get("MT", "21,32,43,50,64,85,86,100,128,171,200").split(",")]:
             M = mt * 128
             a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
             w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
@@ -26,4 +26,5 @@ for K in (768, 3072):
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / R * 1e3
             tiles = mt * (N // 128)
-            print(f"K={K} tiles={tiles:5d} ({tiles / 512:.2f} rounds)  {us:7.1f} us  {2.0 * M * N * K / us / 1e6:6.0f} TF", flush=True)
+            chk = (out.float() - torch.nn.functional.gelu(a.float() @ w.float().t() + bias)).abs().max().item() if mt <= 50 else float("nan")
+            print(f"variant {V} K={K} tiles={tiles:5d} ({tiles / 512:.2f} rounds) maxerr {chk:.3f}  {us:7.1f} us  {2.0 * M * N * K / us / 1e6:6.0f} TF", flush=True)

@@ -1004,6 +1004,8 @@ static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
     case 26: return launch_gemm2<TO, 128, 256, 2, 4, 3, true>(p, batch, st);
     case 27: return launch_gemm2<TO, 256, 128, 4, 2, 2, true>(p, batch, st);
     case 28: return launch_gemm2k<TO>(p, batch, st);
+    case 37: return launch_gemm2<TO, 128, 96, 2, 2, 2, true>(p, batch, st);
+    case 38: return launch_gemm2<TO, 128, 96, 2, 2, 3, true>(p, batch, st);
     case 30: return launch_gemm3<TO, bf16_t, 1, 256, 128, 4, 2, 3>(p, batch, st);
     case 31: return launch_gemm3<TO, bf16_t, 1, 256, 256, 2, 4, 2>(p, batch, st);
     case 32: return launch_gemm3<TO, bf16_t, 1, 128, 128, 4, 2, 4>(p, batch, st);
