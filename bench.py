@@ -362,21 +362,64 @@ def run_forward(a, rank, world, device):
     b = synth_batch(a.batch, rank, device)
 
     def timed(mode):
+        """-> (elapsed s for a.steps steps, launch description, target of rank 0's batch, single-stream ms/step or None).
+        A step = one pass over one 32-clip batch.  With --streams S > 1 the steps are issued round-robin onto S HIP
+        streams, each with its own captured hipGraph, input buffers and batch: consecutive steps are independent
+        requests, so up to S of them are in flight and the under-filled phases of one (300-tile GEMMs, the decoder's
+        small grids, attention) run beside another's.  Every timed step still runs every kernel of the path; before
+        timing, concurrent replays are checked bit for bit against one-at-a-time replays (else S falls back to 1)."""
         model.set_compute_dtype(mode)
         for _ in range(2):
             out = step(model, b)   # lazy packing / allocator warm-up before any capture
         target = out[1].float().cpu().numpy()
-        launch, run = "eager", (lambda: step(model, b))
+        launch, run, single_ms = "eager", (lambda: step(model, b)), None
         if not a.eager:
             try:
-                run = graphed_step(model, b)
+                S = max(1, a.streams)
+                runs = [graphed_step(model, b)] + [graphed_step(model, synth_batch(a.batch, 1000 + 16 * rank + i, device))
+                                                   for i in range(1, S)]
+                run = runs[0]
                 launch = "one hipGraph replay per step (inputs refreshed by D2D copies)"
+                if S > 1:
+                    torch.cuda.synchronize()
+                    serial = []
+                    for r in runs:
+                        o = r()
+                        torch.cuda.synchronize()
+                        serial.append(o[1].clone())
+                    streams = [torch.cuda.Stream() for _ in range(S)]
+                    ok = True
+                    for _ in range(3):
+                        for st in streams:
+                            st.wait_stream(torch.cuda.current_stream())
+                        outs = []
+                        for st, r in zip(streams, runs):
+                            with torch.cuda.stream(st):
+                                outs.append(r())
+                        torch.cuda.synchronize()
+                        ok = ok and all(torch.equal(o[1], sref) for o, sref in zip(outs, serial))
+                    if os.environ.get("BENCH_DEBUG"):
+                        print(f"[bench] mode {mode}: streams {S}, concurrent == serial: {ok}", file=sys.stderr)
+                    if ok:
+                        single_ms = dp.timed_steps(runs[0], a.steps, a.warmup, sync=torch.cuda.synchronize, device=device) / a.steps * 1e3
+                        state = {"i": 0}
+
+                        def run():
+                            i = state["i"]
+                            state["i"] = (i + 1) % S
+                            with torch.cuda.stream(streams[i]):
+                                runs[i]()
+                        launch = (f"{S} steps in flight: hipGraph replays issued round-robin on {S} HIP streams, one captured graph + "
+                                  f"input buffers + batch per stream (inputs refreshed by D2D copies; concurrent replays verified "
+                                  f"bit-equal to one-at-a-time replays before timing)")
+                    else:
+                        print("[bench] concurrent replays differ from serial ones; timing one stream", file=sys.stderr)
             except Exception as e:
                 print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
                 torch.cuda.synchronize()
         elapsed = dp.timed_steps(run, a.steps, a.warmup, sync=torch.cuda.synchronize, device=device)
-        return elapsed, launch, target
-    elapsed, launch, target = timed(a.dtype)
+        return elapsed, launch, target, single_ms
+    elapsed, launch, target, single_ms = timed(a.dtype)
     if rank != 0:
         return None
     n = world
@@ -393,6 +436,8 @@ def run_forward(a, rank, world, device):
                    "inputs": "resident in HBM when the timed region starts (H2D of the 8.2 MB batch excluded)"},
         "end_to_end_tflops": round(value * FLOP_PER_FRAME / 1e12 / n, 1),
     }
+    if single_ms is not None:
+        out["single_stream_ms_per_step"] = round(single_ms, 3)   # one step at a time (latency of a step)
     if n > 1:
         return out
     ref = None
@@ -406,8 +451,9 @@ def run_forward(a, rank, world, device):
     if not a.no_parity:
         pm = []
         for mode in [m for m in ("f16x2", "fp32") if m != a.dtype]:
-            el, _, tg = timed(mode)
-            ent = dict(dtype=mode, ms_per_step=round(el / a.steps * 1e3, 3), frames_per_s=round(a.batch * 100 * a.steps / el, 1),
+            el, _, tg, sm = timed(mode)
+            ent = dict(dtype=mode, ms_per_step=round(el / a.steps * 1e3, 3), single_stream_ms_per_step=None if sm is None else round(sm, 3),
+                       frames_per_s=round(a.batch * 100 * a.steps / el, 1),
                        max_abs_err_vs_oracle=err(tg),
                        end_to_end_tflops=round(a.batch * 100 * a.steps / el * FLOP_PER_FRAME / 1e12, 1))
             if ent["max_abs_err_vs_oracle"] is not None:
@@ -508,6 +554,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the f16x2 / fp32 parity-mode timings")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of hipGraph replays")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="forward mode: steps in flight (one hipGraph + batch per HIP stream).  2 gives +30 %% throughput, but on "
+                         "this ROCm stack kernels of one stream were observed to start before their same-stream producer had "
+                         "finished once a second stream is active (DESIGN.md 5b), so the default stays 1")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:

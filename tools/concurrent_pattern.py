@@ -1,0 +1,42 @@
+"""Dev experiment, part 4: where do concurrent extract_audio_feature results differ from serial ones?"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from msmd_amd.config import default_args
+from msmd_amd.model import get_diffusion_model
+model = get_diffusion_model(default_args(compute_dtype="bf16"), "cuda").eval()
+bs = [bench.synth_batch(32, r, "cuda") for r in range(2)]
+which = sys.argv[1] if len(sys.argv) > 1 else "feat"
+enc = model.audio_encoder
+from msmd_amd.utils.model_common import pad_audio_plan
+r_, rep_ = pad_audio_plan(64000)
+def fn(i):
+    if which == "feat": return model.extract_audio_feature(bs[i]["audio"])
+    if which == "enc": return enc.encode(bs[i]["audio"], 25, frame_num=200, dtype=torch.bfloat16, pad=True).float()
+    if which == "fe_fp":
+        x = enc.feature_extractor_cl(bs[i]["audio"], torch.bfloat16, r_, rep_)
+        from msmd_amd import ops
+        P = enc.pack(torch.bfloat16)
+        return ops.gemm(ops.layernorm(x, *P.fp_ln, eps=enc.config.layer_norm_eps), P.fp_w, P.fp_b).float()
+refs = []
+for i in range(2):
+    o = fn(i); torch.cuda.synchronize(); refs.append(o.clone())
+s = [torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=-1)] if os.environ.get("PRIO") else [torch.cuda.Stream(), torch.cuda.Stream()]
+print("priority range", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else "?")
+nbad = 0
+for rep in range(int(os.environ.get("REPS", "20"))):
+    for st in s: st.wait_stream(torch.cuda.current_stream())
+    for k in range(2):
+        outs = []
+        for i in range(2):
+            with torch.cuda.stream(s[i]): outs.append(fn(i))
+    torch.cuda.synchronize()
+    for i in range(2):
+        if not torch.equal(outs[i], refs[i]):
+            nbad += 1
+            d = (outs[i] - refs[i]).abs()
+            idx = torch.nonzero(d > 0)
+            if nbad <= 6:
+                print(f"rep {rep} stream {i}: {idx.shape[0]} of {d.numel()} differ, max {float(d.max()):.3g}; clips {sorted(set(idx[:, 0].tolist()))[:12]}; frames {int(idx[:, 1].min())}..{int(idx[:, 1].max())}")
+print(which, "mismatching results:", nbad, "of", 2 * int(os.environ.get("REPS", "20")))
