@@ -352,9 +352,58 @@ def run_legs(device, which="all"):
     return legs
 
 
+def multi_stream_forward(model, a, rank, device, S):
+    """S independent 32-clip steps in flight: one captured hipGraph + input buffers + batch per HIP stream, replays issued
+    round-robin.  Every step's output (warm-up and timed) is compared ON THE DEVICE, bit for bit, with that batch's
+    one-at-a-time result (three small kernels per step on the step's own stream, inside the timed region).  The bf16 /
+    fp16 GEMM runs its non-pipelined 128x128 schedule (tuning key 0 = 13) here: the pipelined one gave results that
+    differ from serial ones in ~10 % of two-stream runs, this one in 0 of 1 800.
+    -> dict(ms_per_step, frames_per_s, steps, mismatching_streams) or None when capture fails."""
+    from msmd_amd import dp, ops
+    ops.set_tuning(0, 13)
+    try:
+        b0 = synth_batch(a.batch, rank, device)
+        for _ in range(2):
+            step(model, b0)
+        runs = [graphed_step(model, b0)] + [graphed_step(model, synth_batch(a.batch, 1000 + 16 * rank + i, device)) for i in range(1, S)]
+        torch.cuda.synchronize()
+        serial = []
+        for r in runs:
+            o = r()
+            torch.cuda.synchronize()
+            serial.append(o[1].clone())
+        streams = [torch.cuda.Stream() for _ in range(S)]
+        flags = [torch.zeros((), dtype=torch.bool, device=device) for _ in range(S)]
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+        state = {"i": 0}
+
+        def run():
+            i = state["i"]
+            state["i"] = (i + 1) % S
+            with torch.cuda.stream(streams[i]):
+                o = runs[i]()
+                flags[i].logical_or_(torch.ne(o[1], serial[i]).any())
+        elapsed = dp.timed_steps(run, a.steps, a.warmup, sync=torch.cuda.synchronize, device=device)
+        bad = [i for i in range(S) if bool(flags[i].item())]
+        return dict(streams=S, ms_per_step=round(elapsed / a.steps * 1e3, 3), frames_per_s=round(a.batch * 100 * a.steps / elapsed, 1),
+                    steps_verified_bit_equal_to_serial=(a.steps + a.warmup) if not bad else 0, mismatching_streams=bad,
+                    gemm="gemm2_kernel<bf16,128,128,4,2,2> (non-pipelined fragment reads)",
+                    launch=f"{S} steps in flight: hipGraph replays round-robin on {S} HIP streams, one graph + input buffers + batch "
+                           f"per stream; every step's output compared on the device with its one-at-a-time result inside the timed region")
+    except Exception as e:
+        print(f"[bench] multi-stream leg unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+        torch.cuda.synchronize()
+        return None
+    finally:
+        ops.set_tuning(0, 0)
+
+
 # ----------------------------------------------------------------------------------------------- modes
 def run_forward(a, rank, world, device):
-    from msmd_amd import dp
+    from msmd_amd import dp, ops
+    for kv in [x for x in a.tune.split(",") if x]:
+        ops.set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
     from msmd_amd.config import default_args
     from msmd_amd.model import get_diffusion_model
     args = default_args(compute_dtype=a.dtype)
@@ -463,6 +512,11 @@ def run_forward(a, rank, world, device):
             pm.append(ent)
         out["parity_mode"] = pm
         model.set_compute_dtype(a.dtype)
+    if a.two_streams_leg and not a.eager and a.streams == 1:
+        model.set_compute_dtype(a.dtype)
+        ms2 = multi_stream_forward(model, a, rank, device, 2)
+        if ms2 is not None:
+            out["forward_two_streams"] = ms2
     del model
     torch.cuda.empty_cache()
     if a.legs != "none":
@@ -554,6 +608,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the f16x2 / fp32 parity-mode timings")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of hipGraph replays")
+    ap.add_argument("--no-two-streams-leg", dest="two_streams_leg", action="store_false",
+                    help="skip the extra leg that times two steps in flight (verified per step)")
+    ap.add_argument("--tune", default="", help="developer: comma-separated key=value pairs for msmd_set_tuning")
     ap.add_argument("--streams", type=int, default=1,
                     help="forward mode: steps in flight (one hipGraph + batch per HIP stream).  2 gives +30 %% throughput, but on "
                          "this ROCm stack kernels of one stream were observed to start before their same-stream producer had "

@@ -5,15 +5,20 @@ import torch
 import bench
 from msmd_amd.config import default_args
 from msmd_amd.model import get_diffusion_model
-model = get_diffusion_model(default_args(compute_dtype="bf16"), "cuda").eval()
+DT = os.environ.get("DT", "bf16")
+TD = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32, "f16x2": torch.float32}[DT]
+model = get_diffusion_model(default_args(compute_dtype=DT), "cuda").eval()
 bs = [bench.synth_batch(32, r, "cuda") for r in range(2)]
+from msmd_amd import ops as _ops
+for kv in os.environ.get("TUNE", "").split(","):
+    if kv: _ops.set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
 which = sys.argv[1] if len(sys.argv) > 1 else "feat"
 enc = model.audio_encoder
 from msmd_amd.utils.model_common import pad_audio_plan
 r_, rep_ = pad_audio_plan(64000)
 def fn(i):
     if which == "feat": return model.extract_audio_feature(bs[i]["audio"])
-    if which == "enc": return enc.encode(bs[i]["audio"], 25, frame_num=200, dtype=torch.bfloat16, pad=True).float()
+    if which == "enc": return enc.encode(bs[i]["audio"], 25, frame_num=200, dtype=TD, pad=True).float()
     if which == "fe_fp":
         x = enc.feature_extractor_cl(bs[i]["audio"], torch.bfloat16, r_, rep_)
         from msmd_amd import ops
