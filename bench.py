@@ -517,6 +517,13 @@ def run_forward(a, rank, world, device):
         ms2 = multi_stream_forward(model, a, rank, device, 2)
         if ms2 is not None:
             out["forward_two_streams"] = ms2
+        if not a.no_parity and a.dtype != "f16x2":   # the parity-grade mode the same way (its GEMM has one schedule only)
+            model.set_compute_dtype("f16x2")
+            ms2 = multi_stream_forward(model, a, rank, device, 2)
+            if ms2 is not None:
+                ms2["gemm"] = "gemm2s_kernel<128,128,4,2,2>"
+                out["forward_two_streams_f16x2"] = ms2
+            model.set_compute_dtype(a.dtype)
     del model
     torch.cuda.empty_cache()
     if a.legs != "none":
