@@ -318,6 +318,16 @@ def leg_hubert_large(device, B=32, steps=5):
     ts = [(37 * i + 11) % 500 + 1 for i in range(B)]
     shape, ind = torch.zeros(B, 100, device=device), torch.ones(B, 250, device=device)
     run = lambda: model(motion, audio, shape, style, time_step=ts, indicator=ind, train_with_CFG=False, eps=eps)
+    launch = "eager"
+    for _ in range(2):
+        run()
+    try:
+        tsd = torch.tensor(ts, device=device, dtype=torch.long)
+        cap = model.capture_forward(motion, audio, shape, style, tsd, ind, eps)
+        run, launch = (lambda: cap.graph.replay()), "one hipGraph replay per step"
+    except Exception as e:
+        print(f"[bench] hubert-large leg: hipGraph capture unavailable ({type(e).__name__}: {e}); eager", file=sys.stderr)
+        torch.cuda.synchronize()
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -327,7 +337,7 @@ def leg_hubert_large(device, B=32, steps=5):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     tf = B * HUBERT_LARGE_FLOP_PER_CLIP / dt / 1e12
-    return dict(config=f"configs[3]: HuBERT-large encoder (24 layers, 1024 wide), B={B} x 10 s clips, bf16, MSMD.forward, eager",
+    return dict(config=f"configs[3]: HuBERT-large encoder (24 layers, 1024 wide), B={B} x 10 s clips, bf16, MSMD.forward, {launch}",
                 ms_per_step=round(dt * 1e3, 2), frames_per_s=round(B * 250 / dt), encoder_tflops=round(tf, 1),
                 mfma_frac=round(tf / PEAK_MFMA_TFLOPS, 4))
 
