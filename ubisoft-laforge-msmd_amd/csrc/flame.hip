@@ -567,8 +567,9 @@ void lbs_skin_v2_kernel(const bf16_t* __restrict__ coef_hl, const f16_t* __restr
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int m = 4 * c + k;
-        u32x4 fa = u32x4{0, 0, 0, 0};          // K slots 16 .. 31 are zero on both sides
-        if (q < 2) fa = *(const u32x4*)(sat + ((m * 2 + q) * 16 + i) * 16);
+        // K slots 16 .. 31 are zero on the vertex side (wB), so lanes q >= 2 may feed any finite values: they re-read
+        // octet q & 1 (no divergent branch, no select)
+        const u32x4 fa = *(const u32x4*)(sat + ((m * 2 + (q & 1)) * 16 + i) * 16);
         if constexpr (ABL & 2) {
           T[k] = __builtin_bit_cast(f32x4, fa);
           asm volatile("" :: "v"(wB));
