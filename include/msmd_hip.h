@@ -290,6 +290,8 @@ int msmd_cfg_ddpm_step_dev(float* x, const float* res, const float* z, const flo
  * msmd_lbs_prepare: per frame, coef (B, Kp) = [betas | pose_feature = (R[1:] - I) | 0], the relative rigid
  *   transforms A (B, J, 12) (3x4 row-major) and optionally the posed joints (B, J, 3).
  *   pose: (B, J*3) axis-angle, or (B, J*9) rotation matrices when pose_is_matrix != 0.
+ *   coef_hl (B, 2, Kp) bf16 (msmd_lbs_skin_bf16x3's operand) and at_tiles (msmd_lbs_skin_v2's skin_tiles records,
+ *   J = 5 and Kp = 192 only) are optional outputs (NULL = skip).
  * msmd_lbs_skin: verts (B, V, 3) = sum_j w[v][j] A[b][j] . [v_template + coef . dirs ; 1].
  */
 int msmd_lbs_prepare(const float* betas, const float* pose, const float* JS, const int* parents,
@@ -309,23 +311,31 @@ int msmd_lbs_skin_bf16x3(const void* coef_hl, const float* A, const float* v_tem
 /* msmd_lbs_skin_bf16x3 with the per-(vertex, frame) joint blend T = sum_j w_j A_j on the matrix pipe as well: for each
  * of the 12 components of the 3x4 transforms ONE v_mfma_f32_16x16x32_f16 contracts the five joints (both sides split
  * into fp16 hi + lo: 15 of the 32 K slots), its accumulator landing where the blendshape product puts p(vertex,
- * frame).  at_tiles (ceil(B / 16), 12, 2, 16, 8) fp16 = the frame-side rows, written by msmd_lbs_prepare.  128 vertices
- * per workgroup (8 waves), 16-frame tiles through a 3-deep LDS-DMA ring; Vp = padded vertex count of the constant
- * planes (any value >= V).  HBM-bound target: 60 936 algorithmic bytes per frame.  Same reference lines. */
-int msmd_lbs_skin_v2(const void* coef_hl, const void* at_tiles, const float* v_template, const void* dirs_hl,
-                     const float* lbs_weights, float* verts, int B, int J, int V, int Vp, int Kp, msmd_stream_t stream);
+ * frame).
+ * skin_tiles: ceil(B / 16) records of 18 432 bytes, one per 16 frames, written by msmd_lbs_prepare (its at_tiles
+ *   argument) or msmd_lbs_pack and read by 18 contiguous one-KiB LDS-DMA pieces:
+ *     [0, 12 288)       coefficients as bf16 hi then lo, [chunk = (hi|lo) * 24 + k / 8][frame % 16][k % 8]
+ *     [12 288, 18 432)  blend rows, fp16, [component m of the 3x4][slot / 8][frame % 16][slot % 8] with the 16 K slots
+ *                       [Ah_0..4 | Al_0..4 | Ah_0..4 | 0];
+ *   frames beyond B - 1 of the last record repeat frame B - 1.
+ * 128 vertices per workgroup (8 waves), 16-frame tiles through a 4-deep LDS-DMA ring, one workgroup barrier per two
+ * tiles; Vp = padded vertex count of the constant planes (any value >= V).  HBM-bound target: 60 936 algorithmic bytes
+ * per frame.  Reference: utils/lbs.py:141-223. */
+int msmd_lbs_skin_v2(const void* skin_tiles, const float* v_template, const void* dirs_hl, const float* lbs_weights,
+                     float* verts, int B, int J, int V, int Vp, int Kp, msmd_stream_t stream);
 
 /* Training through FLAME (the reference's use_vertex_space branch: training_script.py:167-176 -> utils/common.py:486-513
  * -> utils/lbs.py:141-223, differentiated by autograd there).
  * msmd_lbs_skin_v2_train: msmd_lbs_skin_v2 that also stores the un-skinned vertices v_posed = template + coef . dirs.
- * msmd_lbs_pack: (coef (B, Kp), A (B, 5, 12)) fp32 -> coef_hl / at_tiles, for per-frame kinematics computed elsewhere
- *   (the differentiable pass builds them with autograd on (B, 5, 3, 3)-sized tensors).
+ * msmd_lbs_pack: (coef (B, Kp), A (B, 5, 12)) fp32 -> skin_tiles (and coef_hl (B, 2, Kp) bf16 when not NULL), for
+ *   per-frame kinematics computed elsewhere (the differentiable pass builds them with autograd on (B, 5, 3, 3)-sized
+ *   tensors).  Kp = 192.
  * msmd_lbs_skin_bwd: given grad_verts (B, V, 3) and v_posed: dp_planes (B, 3, Vp) = (sum_j w_j R_j)^T g (the A operand
  *   of dcoef = dp . dirs^T, an msmd_gemm) and dA (B, 5, 12) = sum_v w_j(v) g(v) [v_posed(v) ; 1]^T. */
-int msmd_lbs_skin_v2_train(const void* coef_hl, const void* at_tiles, const float* v_template, const void* dirs_hl,
+int msmd_lbs_skin_v2_train(const void* skin_tiles, const float* v_template, const void* dirs_hl,
                            const float* lbs_weights, float* verts, float* v_posed, int B, int J, int V, int Vp, int Kp,
                            msmd_stream_t stream);
-int msmd_lbs_pack(const float* coef, const float* A, void* coef_hl, void* at_tiles, int B, int Kp, msmd_stream_t stream);
+int msmd_lbs_pack(const float* coef, const float* A, void* coef_hl, void* skin_tiles, int B, int Kp, msmd_stream_t stream);
 int msmd_lbs_skin_bwd(const float* grad_verts, const float* v_posed, const float* A, const float* lbs_weights,
                       float* dp_planes, float* dA, int B, int J, int V, int Vp, msmd_stream_t stream);
 

@@ -253,7 +253,7 @@ def test_flame_skinning_kernels_agree_over_many_launches():
         coef, coef_hl, A, joints, at = o.lbs_prepare(betas, pose, c.JS, c.parents, 192, want_split=True,
                                                      want_blend_tiles=True)
         ref = o.lbs_skin_bf16x3(coef_hl, A, c.template_planes, c.dirs_hl, c.weight_planes, c.V)
-        out = o.lbs_skin_v2(coef_hl, at, c.template_planes, c.dirs_hl, c.weight_planes, c.V)
+        out = o.lbs_skin_v2(at, B, c.template_planes, c.dirs_hl, c.weight_planes, c.V)
         assert float((out - ref).abs().max()) < 2e-6, (it, B)
 
 

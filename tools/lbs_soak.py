@@ -20,7 +20,7 @@ for it in range(N):
     pose = 0.3 * torch.randn(B, 15, device="cuda", generator=g)
     coef, coef_hl, A, joints, at = ops.lbs_prepare(betas, pose, c.JS, c.parents, 192, want_split=True, want_blend_tiles=True)
     ref = ops.lbs_skin_bf16x3(coef_hl, A, c.template_planes, c.dirs_hl, c.weight_planes, c.V)
-    out = ops.lbs_skin_v2(coef_hl, at, c.template_planes, c.dirs_hl, c.weight_planes, c.V)
+    out = ops.lbs_skin_v2(at, B, c.template_planes, c.dirs_hl, c.weight_planes, c.V)
     d = (out - ref).abs().max().item()
     if not d < 1e-5:
         bad_runs += 1

@@ -54,6 +54,8 @@ extern "C" int msmd_batch_rodrigues(const float* rot_vecs, float* R, int N, msmd
 // the kinematic chain runs joint by joint (parents[i] < i) with 12 lanes computing the 3x4 entries of a transform.
 #define LBS_MAXJ 8
 #define LBS_FPB 16
+#define LBS_TILE_COEF_BYTES 12288   // 2 (hi, lo) x 192 K x 16 frames x 2 B
+#define LBS_TILE_BYTES 18432        // + 12 components x 16 slots x 16 frames x 2 B of blend rows
 __global__ __launch_bounds__(256) void lbs_prepare_kernel(const float* __restrict__ betas,
                                                           const float* __restrict__ pose,
                                                           const float* __restrict__ JS,
@@ -131,7 +133,13 @@ __global__ __launch_bounds__(256) void lbs_prepare_kernel(const float* __restric
     }
   }
   // coefficient row = [betas | pose_feature = (R[1:] - I) | 0 pad]
-  if (valid) {
+  // Skin tiles (msmd_lbs_skin_v2's input, one 18 KB record per 16 frames, read by contiguous LDS-DMA):
+  //   bytes [0, 12288): coefficients, bf16 hi then lo, chunk-major [chunk = (hi|lo) * Kp/8 + k/8][frame % 16][k % 8]
+  //   bytes [12288, 18432): blend rows, see below.
+  // Frames beyond B - 1 of the last tile carry frame B - 1's values (the kernel clamps them to that frame and stores
+  // identical bytes).
+  unsigned char* tile = at_tiles ? (unsigned char*)at_tiles + (long)blockIdx.x * LBS_TILE_BYTES : nullptr;
+  {
     float* crow = coef + (long)b * Kp;
     for (int k = ln; k < Kp; k += 16) {
       float v = 0.f;
@@ -140,29 +148,36 @@ __global__ __launch_bounds__(256) void lbs_prepare_kernel(const float* __restric
         const int pf = k - NB, jj = 1 + pf / 9, rc = pf % 9;
         v = sR[fl][jj * 9 + rc] - ((rc == 0 || rc == 4 || rc == 8) ? 1.0f : 0.0f);
       }
-      crow[k] = v;
-      if (coef_hl) {  // bf16 hi/lo split for the 3-product MFMA form: v ~= hi + lo with 16 significant bits
+      if (valid) crow[k] = v;
+      if (coef_hl || tile) {  // bf16 hi/lo split for the 3-product MFMA form: v ~= hi + lo with 16 significant bits
         asm volatile("" : "+v"(v));
-        const bf16_t hi = (bf16_t)v;
-        coef_hl[((long)b * 2 + 0) * Kp + k] = hi;
-        coef_hl[((long)b * 2 + 1) * Kp + k] = (bf16_t)(v - (float)hi);
+        const bf16_t hi = (bf16_t)v, lo = (bf16_t)(v - (float)hi);
+        if (coef_hl && valid) {
+          coef_hl[((long)b * 2 + 0) * Kp + k] = hi;
+          coef_hl[((long)b * 2 + 1) * Kp + k] = lo;
+        }
+        if (tile) {
+          bf16_t* tc = (bf16_t*)tile;
+          tc[((k >> 3) * 16 + fl) * 8 + (k & 7)] = hi;
+          tc[((Kp / 8 + (k >> 3)) * 16 + fl) * 8 + (k & 7)] = lo;
+        }
       }
     }
   }
-  if (at_tiles) {
+  if (tile) {
     // Frame-side operand of the skinning kernel's blend MFMA (msmd_lbs_skin_v2): for component m of the 3x4 transforms,
     // 16 fp16 K slots per frame = [Ah_0..4 | Al_0..4 | Ah_0..4 | 0] (A = Ah + Al, unscaled: |A| = O(1), so the lo
-    // halves keep 2^-25 absolute).  Tile layout [frame / 16][m][slot / 8][frame % 16][slot % 8]: one 16-byte chunk per
-    // (m, slot octet, frame), frames of a tile contiguous -> conflict-free ds_read_b128.  Frames beyond B - 1 of the
-    // last tile carry frame B - 1's rows (the kernel clamps them to that frame and stores identical values).
+    // halves keep 2^-25 absolute).  Layout [m][slot / 8][frame % 16][slot % 8]: one 16-byte chunk per
+    // (m, slot octet, frame), frames of a tile contiguous -> conflict-free ds_read_b128.
     __syncthreads();
+    f16_t* ta = (f16_t*)(tile + LBS_TILE_COEF_BYTES);
     for (int idx = ln; idx < 12 * 16; idx += 16) {
       const int m = idx >> 4, slot = idx & 15;
       float a = slot < 15 ? sAo[fl][(slot % 5) * 12 + m] : 0.f;
       asm volatile("" : "+v"(a));
       const f16_t ah = (f16_t)a, al = (f16_t)(a - (float)ah);
       const f16_t val = slot >= 15 ? (f16_t)0.f : ((slot >= 5 && slot < 10) ? al : ah);
-      at_tiles[((((long)blockIdx.x * 12 + m) * 2 + (slot >> 3)) * 16 + fl) * 8 + (slot & 7)] = val;
+      ta[((m * 2 + (slot >> 3)) * 16 + fl) * 8 + (slot & 7)] = val;
     }
   }
 }
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(256) void lbs_prepare_kernel(const float* __restric
 extern "C" int msmd_lbs_prepare(const float* betas, const float* pose, const float* JS, const int* parents,
                                 float* coef, void* coef_hl, float* A, float* joints, void* at_tiles, int B, int NB, int J,
                                 int Kp, int pose_is_matrix, msmd_stream_t stream) {
-  if (B <= 0 || NB <= 0 || NB > 256 || J <= 0 || J > 5 || Kp < NB + (J - 1) * 9 || (at_tiles && J != 5)) return 1;
+  if (B <= 0 || NB <= 0 || NB > 256 || J <= 0 || J > 5 || Kp < NB + (J - 1) * 9 || (at_tiles && (J != 5 || Kp != 192))) return 1;
   hipLaunchKernelGGL(lbs_prepare_kernel, dim3((B + LBS_FPB - 1) / LBS_FPB), dim3(256), 0, (hipStream_t)stream, betas, pose,
                      JS, parents, coef, (bf16_t*)coef_hl, A, joints, NB, J, Kp, pose_is_matrix, (f16_t*)at_tiles, B);
   MSMD_RETURN_LAST();
@@ -456,7 +471,7 @@ __device__ __forceinline__ void vm_wait_n(int n) {   // n = (pieces per load gro
 // (training through the vertex-space loss); 8 instead of 4 store instructions per tile and wave.
 template <int KG, int NS, int NWV, int ABL = 0, bool WP = false, int RB = 0>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void lbs_skin_v2_kernel(const bf16_t* __restrict__ coef_hl, const f16_t* __restrict__ at_tiles,
+void lbs_skin_v2_kernel(const unsigned char* __restrict__ tiles,
                         const float* __restrict__ tmpl, const bf16_t* __restrict__ dirs_hl,
                         const float* __restrict__ wts, float* __restrict__ verts, int B, int V, int Vp,
                         int frames_per_block, int vtn, float* __restrict__ vposed = nullptr) {
@@ -516,20 +531,13 @@ void lbs_skin_v2_kernel(const bf16_t* __restrict__ coef_hl, const f16_t* __restr
   typedef __attribute__((address_space(1))) const void gbl_t;
   // piece k of a tile -> wave k % NWV; a wave stages pieces wid, wid + NWV, ... (my_np of them: the vmcnt unit)
   const int my_np = (NP - wid + NWV - 1) / NWV;
-  auto issue = [&](int t) {
+  auto issue = [&](int t) {   // one 18 KB tile record = 18 contiguous one-KiB LDS-DMA pieces
     unsigned char* base = smem + (t % NS) * STAGE;
-    const int f0 = f_begin + 16 * t;
+    const unsigned char* src = tiles + (long)((f_begin >> 4) + t) * STAGE + lane * 16;
 #pragma unroll
     for (int r = 0; r < (NP + NWV - 1) / NWV; ++r) {
       const int k = wid + NWV * r;
-      if (k < 12) {          // coefficient piece: LDS slot p = chunk * 16 + frame
-        const int p = k * 64 + lane;
-        const int fr = min(f0 + (p & 15), B - 1), ch = p >> 4;
-        __builtin_amdgcn_global_load_lds((gbl_t*)(coef_hl + (long)fr * 2 * Kp + ch * 8), (lds_t*)(base + k * 1024), 16, 0, 0);
-      } else if (k < NP) {   // blend rows: contiguous
-        __builtin_amdgcn_global_load_lds((gbl_t*)(at_tiles + (long)(f0 >> 4) * (AT_BYTES / 2) + (k - 12) * 512 + lane * 8),
-                                         (lds_t*)(base + k * 1024), 16, 0, 0);
-      }
+      if (k < NP) __builtin_amdgcn_global_load_lds((gbl_t*)(src + k * 1024), (lds_t*)(base + k * 1024), 16, 0, 0);
     }
   };
 
@@ -638,10 +646,10 @@ void lbs_skin_v2_kernel(const bf16_t* __restrict__ coef_hl, const f16_t* __restr
   }
 }
 
-static int lbs_skin_v2_impl(const void* coef_hl, const void* at_tiles, const float* v_template, const void* dirs_hl,
+static int lbs_skin_v2_impl(const void* skin_tiles, const float* v_template, const void* dirs_hl,
                             const float* lbs_weights, float* verts, float* vposed, int B, int J, int V, int Vp, int Kp,
                             msmd_stream_t stream) {
-  if (B <= 0 || V <= 0 || Vp < V || J != 5 || Kp != 192 || !at_tiles) return 1;
+  if (B <= 0 || V <= 0 || Vp < V || J != 5 || Kp != 192 || !skin_tiles) return 1;
   // tuning key 9: 1 = two 4-wave workgroups per CU (64 vertices each, 3-stage rings) instead of one 8-wave workgroup
   // (128 vertices, 4-stage ring).  Measured at 25 600 frames: 783 vs 732 us -- the smaller workgroups double the
   // staged bytes per vertex and their phase drift buys less than that costs.
@@ -657,8 +665,8 @@ static int lbs_skin_v2_impl(const void* coef_hl, const void* at_tiles, const flo
     constexpr int lds = NS * 18 * 1024;                                                                                \
     auto kfn = lbs_skin_v2_kernel<6, NS, NWV, ABL, false, ##__VA_ARGS__>;                                                                 \
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                       \
-    hipLaunchKernelGGL(kfn, grid, dim3(64 * NWV), lds, (hipStream_t)stream, (const bf16_t*)coef_hl,                     \
-                       (const f16_t*)at_tiles, v_template, (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb, vt, \
+    hipLaunchKernelGGL(kfn, grid, dim3(64 * NWV), lds, (hipStream_t)stream, (const unsigned char*)skin_tiles,           \
+                       v_template, (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb, vt, \
                        (float*)nullptr);                                                                              \
   } while (0)
   if (vposed) {
@@ -666,7 +674,7 @@ static int lbs_skin_v2_impl(const void* coef_hl, const void* at_tiles, const flo
     auto kfn = lbs_skin_v2_kernel<6, 4, 8, 0, true>;
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int vt8w = (V + 127) / 128;
-    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, (hipStream_t)stream, (const bf16_t*)coef_hl, (const f16_t*)at_tiles,
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, (hipStream_t)stream, (const unsigned char*)skin_tiles,
                        v_template, (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb, vt8w, vposed);
   } else if (!big) {
     LBS_V2_LAUNCH(3, 4, 0);
@@ -686,18 +694,18 @@ static int lbs_skin_v2_impl(const void* coef_hl, const void* at_tiles, const flo
   MSMD_RETURN_LAST();
 }
 
-extern "C" int msmd_lbs_skin_v2(const void* coef_hl, const void* at_tiles, const float* v_template, const void* dirs_hl,
+extern "C" int msmd_lbs_skin_v2(const void* skin_tiles, const float* v_template, const void* dirs_hl,
                                 const float* lbs_weights, float* verts, int B, int J, int V, int Vp, int Kp,
                                 msmd_stream_t stream) {
-  return lbs_skin_v2_impl(coef_hl, at_tiles, v_template, dirs_hl, lbs_weights, verts, nullptr, B, J, V, Vp, Kp, stream);
+  return lbs_skin_v2_impl(skin_tiles, v_template, dirs_hl, lbs_weights, verts, nullptr, B, J, V, Vp, Kp, stream);
 }
 
 // Training form: the same kernel, additionally writing the un-skinned vertices v_posed (B, V, 3) for msmd_lbs_skin_bwd.
-extern "C" int msmd_lbs_skin_v2_train(const void* coef_hl, const void* at_tiles, const float* v_template,
+extern "C" int msmd_lbs_skin_v2_train(const void* skin_tiles, const float* v_template,
                                       const void* dirs_hl, const float* lbs_weights, float* verts, float* v_posed, int B,
                                       int J, int V, int Vp, int Kp, msmd_stream_t stream) {
   if (!v_posed || g_tuning[9] == 1) return 1;
-  return lbs_skin_v2_impl(coef_hl, at_tiles, v_template, dirs_hl, lbs_weights, verts, v_posed, B, J, V, Vp, Kp, stream);
+  return lbs_skin_v2_impl(skin_tiles, v_template, dirs_hl, lbs_weights, verts, v_posed, B, J, V, Vp, Kp, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -705,36 +713,41 @@ extern "C" int msmd_lbs_skin_v2_train(const void* coef_hl, const void* at_tiles,
 // blend rows at_tiles (see lbs_prepare_kernel).  Used where the per-frame kinematics come from somewhere else than
 // msmd_lbs_prepare: the differentiable FLAME pass computes them with autograd on (B, 5, 3, 3)-sized tensors.
 __global__ __launch_bounds__(256) void lbs_pack_kernel(const float* __restrict__ coef, const float* __restrict__ A,
-                                                       bf16_t* __restrict__ coef_hl, f16_t* __restrict__ at_tiles, int B,
-                                                       int Kp) {
+                                                       bf16_t* __restrict__ coef_hl, unsigned char* __restrict__ tiles,
+                                                       int B, int Kp) {
   const int fl = threadIdx.x >> 4, ln = threadIdx.x & 15;
   const int b = blockIdx.x * 16 + fl;
   const bool valid = b < B;
   const int bb = valid ? b : B - 1;
-  if (valid) {
-    for (int k = ln; k < Kp; k += 16) {
-      float v = coef[(long)b * Kp + k];
-      asm volatile("" : "+v"(v));
-      const bf16_t hi = (bf16_t)v;
+  unsigned char* tile = tiles + (long)blockIdx.x * LBS_TILE_BYTES;
+  bf16_t* tc = (bf16_t*)tile;
+  for (int k = ln; k < Kp; k += 16) {
+    float v = coef[(long)bb * Kp + k];
+    asm volatile("" : "+v"(v));
+    const bf16_t hi = (bf16_t)v, lo = (bf16_t)(v - (float)hi);
+    if (valid && coef_hl) {
       coef_hl[((long)b * 2 + 0) * Kp + k] = hi;
-      coef_hl[((long)b * 2 + 1) * Kp + k] = (bf16_t)(v - (float)hi);
+      coef_hl[((long)b * 2 + 1) * Kp + k] = lo;
     }
+    tc[((k >> 3) * 16 + fl) * 8 + (k & 7)] = hi;
+    tc[((Kp / 8 + (k >> 3)) * 16 + fl) * 8 + (k & 7)] = lo;
   }
+  f16_t* ta = (f16_t*)(tile + LBS_TILE_COEF_BYTES);
   for (int idx = ln; idx < 12 * 16; idx += 16) {
     const int m = idx >> 4, slot = idx & 15;
     float a = slot < 15 ? A[((long)bb * 5 + (slot % 5)) * 12 + m] : 0.f;
     asm volatile("" : "+v"(a));
     const f16_t ah = (f16_t)a, al = (f16_t)(a - (float)ah);
     const f16_t val = slot >= 15 ? (f16_t)0.f : ((slot >= 5 && slot < 10) ? al : ah);
-    at_tiles[((((long)blockIdx.x * 12 + m) * 2 + (slot >> 3)) * 16 + fl) * 8 + (slot & 7)] = val;
+    ta[((m * 2 + (slot >> 3)) * 16 + fl) * 8 + (slot & 7)] = val;
   }
 }
 
 extern "C" int msmd_lbs_pack(const float* coef, const float* A, void* coef_hl, void* at_tiles, int B, int Kp,
                              msmd_stream_t stream) {
-  if (B <= 0 || Kp <= 0 || !coef || !A || !coef_hl || !at_tiles) return 1;
+  if (B <= 0 || Kp != 192 || !coef || !A || !at_tiles) return 1;
   hipLaunchKernelGGL(lbs_pack_kernel, dim3((B + 15) / 16), dim3(256), 0, (hipStream_t)stream, coef, A, (bf16_t*)coef_hl,
-                     (f16_t*)at_tiles, B, Kp);
+                     (unsigned char*)at_tiles, B, Kp);
   MSMD_RETURN_LAST();
 }
 

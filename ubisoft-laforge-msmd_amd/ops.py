@@ -535,9 +535,13 @@ def mean_time(x):
 
 
 # ----------------------------------------------------------------------------- FLAME
+SKIN_TILE_BYTES = 18432   # msmd_lbs_skin_v2's input record per 16 frames (include/msmd_hip.h)
+
+
 def lbs_prepare(betas, pose, JS, parents, Kp=192, pose_is_matrix=False, want_joints=True, want_split=False,
                 want_blend_tiles=False):
-    """-> coef, coef_hl, A, joints[, at_tiles]: want_blend_tiles adds the fp16 frame-side rows of msmd_lbs_skin_v2."""
+    """-> coef, coef_hl, A, joints[, skin_tiles]: want_blend_tiles adds msmd_lbs_skin_v2's 18 KB-per-16-frames records
+    (coefficients as bf16 hi / lo + fp16 blend rows); want_split the row-major coef_hl of msmd_lbs_skin_bf16x3."""
     lib = _lib.load()
     B, NB = betas.shape
     J = parents.shape[0]
@@ -545,7 +549,7 @@ def lbs_prepare(betas, pose, JS, parents, Kp=192, pose_is_matrix=False, want_joi
     coef_hl = torch.empty(B, 2, Kp, device=betas.device, dtype=torch.bfloat16) if want_split else None
     A = torch.empty(B, J, 12, device=betas.device, dtype=torch.float32)
     joints = torch.empty(B, J, 3, device=betas.device, dtype=torch.float32) if want_joints else None
-    at = torch.empty((B + 15) // 16, 12, 2, 16, 8, device=betas.device, dtype=torch.float16) if want_blend_tiles else None
+    at = torch.empty((B + 15) // 16, SKIN_TILE_BYTES // 2, device=betas.device, dtype=torch.float16) if want_blend_tiles else None
     _lib.check(lib.msmd_lbs_prepare(_p(betas), _p(pose), _p(JS), _p(parents), _p(coef), _p(coef_hl), _p(A), _p(joints),
                                     _p(at), B, NB, J, Kp, int(pose_is_matrix), _stream()), "msmd_lbs_prepare")
     return (coef, coef_hl, A, joints, at) if want_blend_tiles else (coef, coef_hl, A, joints)
@@ -573,36 +577,36 @@ def lbs_skin_bf16x3(coef_hl, A, v_template_planes, dirs_hl, weight_planes, V):
     return verts
 
 
-def lbs_skin_v2(coef_hl, at_tiles, v_template_planes, dirs_hl, weight_planes, V):
+def lbs_skin_v2(skin_tiles, B, v_template_planes, dirs_hl, weight_planes, V, Kp=192):
     lib = _lib.load()
-    B, _, Kp = coef_hl.shape
+    assert skin_tiles.numel() * skin_tiles.element_size() == ((B + 15) // 16) * SKIN_TILE_BYTES
     J = weight_planes.shape[0]
     Vp = dirs_hl.shape[-2]
-    verts = torch.empty(B, V, 3, device=coef_hl.device, dtype=torch.float32)
-    _lib.check(lib.msmd_lbs_skin_v2(_p(coef_hl), _p(at_tiles), _p(v_template_planes), _p(dirs_hl), _p(weight_planes),
+    verts = torch.empty(B, V, 3, device=skin_tiles.device, dtype=torch.float32)
+    _lib.check(lib.msmd_lbs_skin_v2(_p(skin_tiles), _p(v_template_planes), _p(dirs_hl), _p(weight_planes),
                                     _p(verts), B, J, V, Vp, Kp, _stream()), "msmd_lbs_skin_v2")
     return verts
 
 
-def lbs_pack(coef, A):
-    """(coef (B, Kp), A (B, 5, 12)) fp32 -> (coef_hl, at_tiles): the skinning kernel's operand formats."""
+def lbs_pack(coef, A, want_split=False):
+    """(coef (B, Kp), A (B, 5, 12)) fp32 -> skin_tiles (, coef_hl): the skinning kernels' operand formats."""
     lib = _lib.load()
     B, Kp = coef.shape
-    coef_hl = torch.empty(B, 2, Kp, device=coef.device, dtype=torch.bfloat16)
-    at = torch.empty((B + 15) // 16, 12, 2, 16, 8, device=coef.device, dtype=torch.float16)
+    coef_hl = torch.empty(B, 2, Kp, device=coef.device, dtype=torch.bfloat16) if want_split else None
+    at = torch.empty((B + 15) // 16, SKIN_TILE_BYTES // 2, device=coef.device, dtype=torch.float16)
     _lib.check(lib.msmd_lbs_pack(_p(coef), _p(A), _p(coef_hl), _p(at), B, Kp, _stream()), "msmd_lbs_pack")
-    return coef_hl, at
+    return (at, coef_hl) if want_split else at
 
 
-def lbs_skin_v2_train(coef_hl, at_tiles, v_template_planes, dirs_hl, weight_planes, V):
+def lbs_skin_v2_train(skin_tiles, B, v_template_planes, dirs_hl, weight_planes, V, Kp=192):
     """-> (verts, v_posed): msmd_lbs_skin_v2 that also stores the un-skinned vertices (needed by lbs_skin_bwd)."""
     lib = _lib.load()
-    B, _, Kp = coef_hl.shape
+    assert skin_tiles.numel() * skin_tiles.element_size() == ((B + 15) // 16) * SKIN_TILE_BYTES
     J = weight_planes.shape[0]
     Vp = dirs_hl.shape[-2]
-    verts = torch.empty(B, V, 3, device=coef_hl.device, dtype=torch.float32)
-    vposed = torch.empty(B, V, 3, device=coef_hl.device, dtype=torch.float32)
-    _lib.check(lib.msmd_lbs_skin_v2_train(_p(coef_hl), _p(at_tiles), _p(v_template_planes), _p(dirs_hl),
+    verts = torch.empty(B, V, 3, device=skin_tiles.device, dtype=torch.float32)
+    vposed = torch.empty(B, V, 3, device=skin_tiles.device, dtype=torch.float32)
+    _lib.check(lib.msmd_lbs_skin_v2_train(_p(skin_tiles), _p(v_template_planes), _p(dirs_hl),
                                           _p(weight_planes), _p(verts), _p(vposed), B, J, V, Vp, Kp, _stream()),
                "msmd_lbs_skin_v2_train")
     return verts, vposed

@@ -90,13 +90,13 @@ def lbs(betas, pose, v_template, shapedirs, posedirs, J_regressor, parents, lbs_
     precision = precision or DEFAULT_PRECISION
     if precision not in ("bf16x3", "bf16x3_valu", "fp32"):
         raise ValueError(f"Unknown LBS precision {precision}!")
-    split = precision != "fp32"
     v2 = precision == "bf16x3" and c.J == 5
+    split = precision != "fp32" and not v2
     res = ops.lbs_prepare(betas, pose, c.JS, c.parents, KP, pose_is_matrix=not pose2rot, want_split=split,
                           want_blend_tiles=v2)
     coef, coef_hl, A, joints = res[:4]
     if v2:
-        verts = ops.lbs_skin_v2(coef_hl, res[4], c.template_planes, c.dirs_hl, c.weight_planes, c.V)
+        verts = ops.lbs_skin_v2(res[4], B, c.template_planes, c.dirs_hl, c.weight_planes, c.V)
     elif split:
         verts = ops.lbs_skin_bf16x3(coef_hl, A, c.template_planes, c.dirs_hl, c.weight_planes, c.V)
     else:
@@ -147,8 +147,8 @@ class SkinFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, coef, A, c):
         coef, A = coef.float().contiguous(), A.float().contiguous()
-        coef_hl, at = ops.lbs_pack(coef, A)
-        verts, vposed = ops.lbs_skin_v2_train(coef_hl, at, c.template_planes, c.dirs_hl, c.weight_planes, c.V)
+        tiles = ops.lbs_pack(coef, A)
+        verts, vposed = ops.lbs_skin_v2_train(tiles, coef.shape[0], c.template_planes, c.dirs_hl, c.weight_planes, c.V)
         ctx.save_for_backward(vposed, A)
         ctx.c = c
         return verts
