@@ -35,3 +35,9 @@ ops.set_tuning(9, 1)
 t = timeit(lambda: ops.lbs_skin_v2(at, B, c.template_planes, c.dirs_hl, c.weight_planes, c.V))
 print(f"  skin_v2 [4-wave workgroups, 3 stages] {t*1e3:7.1f} us   {B * 60276 / t / 1e6:7.0f} GB/s written")
 ops.set_tuning(9, 0)
+ops.set_tuning(8, 0)
+for xm in (0, 1, 0, 1):
+    ops.set_tuning(10, xm)
+    t = timeit(lambda: ops.lbs_skin_v2(at, B, c.template_planes, c.dirs_hl, c.weight_planes, c.V))
+    print(f"  skin_v2 [xcd map {'slices dealt one by one' if xm else 'adjacent slices per XCD (default)'}] {t*1e3:7.1f} us")
+ops.set_tuning(10, 0)
