@@ -297,6 +297,13 @@ int msmd_cfg_ddpm_step_dev(float* x, const float* res, const float* z, const flo
 int msmd_lbs_prepare(const float* betas, const float* pose, const float* JS, const int* parents,
                      float* coef, void* coef_hl, float* A, float* joints, void* at_tiles, int B, int NB, int J, int Kp,
                      int pose_is_matrix, msmd_stream_t stream);
+/* FLAME.forward's inputs (utils/flame.py:180-212) straight into msmd_lbs_skin_v2's tile records: coefficient row =
+ * [shape (B, NS) | expr (B, NE)], pose6 (B, 6) = [global | jaw] axis-angle with the identity neck, eye (B, 6) or NULL
+ * (identity), global rotation dropped when ignore_global_rot != 0 -- no concatenated betas / full_pose tensors.
+ * coef (B, 192), A (B, 5, 12), joints (B, 5, 3): optional outputs (NULL = skip).  J = 5, Kp = 192. */
+int msmd_flame_prepare(const float* shape, const float* expr, const float* pose6, const float* eye, const float* JS,
+                       const int* parents, float* coef, float* A, float* joints, void* skin_tiles, int B, int NS, int NE,
+                       int ignore_global_rot, msmd_stream_t stream);
 int msmd_lbs_skin(const float* coef, const float* A, const float* v_template, const float* dirs,
                   const float* lbs_weights, float* verts, int B, int J, int V, int Vp, int Kp,
                   msmd_stream_t stream);

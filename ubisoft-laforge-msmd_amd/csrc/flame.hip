@@ -62,7 +62,12 @@ __global__ __launch_bounds__(256) void lbs_prepare_kernel(const float* __restric
                                                           const int* __restrict__ parents, float* __restrict__ coef,
                                                           bf16_t* __restrict__ coef_hl, float* __restrict__ A,
                                                           float* __restrict__ joints_out, int NB, int J, int Kp,
-                                                          int pose_is_matrix, f16_t* __restrict__ at_tiles, int B) {
+                                                          int pose_is_matrix, f16_t* __restrict__ at_tiles, int B,
+                                                          const float* __restrict__ betas2 = nullptr, int NB1 = 0,
+                                                          const float* __restrict__ eye = nullptr, int pose_mode = 0) {
+  // betas2 != NULL: the coefficient row is [betas (B, NB1) | betas2 (B, NB - NB1)] (FLAME's shape | expression, no
+  // concatenated copy).  pose_mode 1 / 2: `pose` is FLAME's (B, 6) [global | jaw] axis-angle input, the neck is the
+  // identity, `eye` (B, 6) or NULL = identity; 2 also ignores the global rotation (utils/flame.py:199-207).
   __shared__ float sJS[257 * 15];
   __shared__ float sB[LBS_FPB][260];
   __shared__ float sJ[LBS_FPB][16];
@@ -75,11 +80,25 @@ __global__ __launch_bounds__(256) void lbs_prepare_kernel(const float* __restric
   const int bb = valid ? b : B - 1;
   const int J3 = J * 3;
   for (int k = tid; k < (NB + 1) * J3; k += 256) sJS[k] = JS[k];
-  const float* be = betas + (long)bb * NB;
-  for (int k = ln; k < NB; k += 16) sB[fl][k] = be[k];
+  if (betas2) {
+    const float* b1 = betas + (long)bb * NB1;
+    const float* b2 = betas2 + (long)bb * (NB - NB1);
+    for (int k = ln; k < NB; k += 16) sB[fl][k] = k < NB1 ? b1[k] : b2[k - NB1];
+  } else {
+    const float* be = betas + (long)bb * NB;
+    for (int k = ln; k < NB; k += 16) sB[fl][k] = be[k];
+  }
   if (ln < J) {
     float R[9];
-    if (pose_is_matrix) {
+    if (pose_mode) {
+      float r[3] = {0.f, 0.f, 0.f};
+      const float* src = nullptr;
+      if (ln == 0 && pose_mode == 1) src = pose + (long)bb * 6;
+      else if (ln == 2) src = pose + (long)bb * 6 + 3;
+      else if (ln >= 3 && eye) src = eye + (long)bb * 6 + (ln - 3) * 3;
+      if (src) { r[0] = src[0]; r[1] = src[1]; r[2] = src[2]; }
+      rodrigues(r, R);
+    } else if (pose_is_matrix) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) R[k] = pose[((long)bb * J + ln) * 9 + k];
     } else {
@@ -128,7 +147,7 @@ __global__ __launch_bounds__(256) void lbs_prepare_kernel(const float* __restric
     if (c == 3) v -= Tr[0] * sJ[fl][i * 3] + Tr[1] * sJ[fl][i * 3 + 1] + Tr[2] * sJ[fl][i * 3 + 2];
     sAo[fl][e] = v;
     if (valid) {
-      A[(long)b * J * 12 + e] = v;
+      if (A) A[(long)b * J * 12 + e] = v;
       if (joints_out && c == 3) joints_out[((long)b * J + i) * 3 + r] = Tr[3];
     }
   }
@@ -148,7 +167,7 @@ __global__ __launch_bounds__(256) void lbs_prepare_kernel(const float* __restric
         const int pf = k - NB, jj = 1 + pf / 9, rc = pf % 9;
         v = sR[fl][jj * 9 + rc] - ((rc == 0 || rc == 4 || rc == 8) ? 1.0f : 0.0f);
       }
-      if (valid) crow[k] = v;
+      if (valid && coef) crow[k] = v;
       if (coef_hl || tile) {  // bf16 hi/lo split for the 3-product MFMA form: v ~= hi + lo with 16 significant bits
         asm volatile("" : "+v"(v));
         const bf16_t hi = (bf16_t)v, lo = (bf16_t)(v - (float)hi);
@@ -268,6 +287,20 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__
       }
     }
   }
+}
+
+// FLAME.forward's inputs straight into the skinning kernel's tile records: shape (B, NS) | expression (B, NE) as the
+// coefficient row, pose6 (B, 6) = [global | jaw] axis-angle with the identity neck, eye (B, 6) or NULL (identity eyes):
+// no concatenated betas / full_pose tensors.  coef / A / joints are optional outputs.
+extern "C" int msmd_flame_prepare(const float* shape, const float* expr, const float* pose6, const float* eye,
+                                  const float* JS, const int* parents, float* coef, float* A, float* joints,
+                                  void* skin_tiles, int B, int NS, int NE, int ignore_global_rot, msmd_stream_t stream) {
+  const int NB = NS + NE, J = 5, Kp = 192;
+  if (B <= 0 || NS <= 0 || NE <= 0 || NB > 256 || Kp < NB + (J - 1) * 9 || !shape || !expr || !pose6 || !skin_tiles) return 1;
+  hipLaunchKernelGGL(lbs_prepare_kernel, dim3((B + LBS_FPB - 1) / LBS_FPB), dim3(256), 0, (hipStream_t)stream, shape, pose6,
+                     JS, parents, coef, (bf16_t*)nullptr, A, joints, NB, J, Kp, 0, (f16_t*)skin_tiles, B, expr, NS, eye,
+                     ignore_global_rot ? 2 : 1);
+  MSMD_RETURN_LAST();
 }
 
 extern "C" int msmd_lbs_skin(const float* coef, const float* A, const float* v_template, const float* dirs,

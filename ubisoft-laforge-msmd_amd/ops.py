@@ -555,6 +555,19 @@ def lbs_prepare(betas, pose, JS, parents, Kp=192, pose_is_matrix=False, want_joi
     return (coef, coef_hl, A, joints, at) if want_blend_tiles else (coef, coef_hl, A, joints)
 
 
+def flame_prepare(shape, expr, pose6, eye, JS, parents, ignore_global_rot=False):
+    """FLAME.forward's (B, NS) shape, (B, NE) expression, (B, 6) [global | jaw] pose (+ optional (B, 6) eye pose) ->
+    msmd_lbs_skin_v2's tile records, without the concatenated betas / full_pose tensors."""
+    lib = _lib.load()
+    _need_cuda(shape, expr, pose6)
+    B = shape.shape[0]
+    tiles = torch.empty((B + 15) // 16, SKIN_TILE_BYTES // 2, device=shape.device, dtype=torch.float16)
+    _lib.check(lib.msmd_flame_prepare(_p(shape), _p(expr), _p(pose6), _p(eye), _p(JS), _p(parents), None, None, None,
+                                      _p(tiles), B, shape.shape[1], expr.shape[1], int(ignore_global_rot), _stream()),
+               "msmd_flame_prepare")
+    return tiles
+
+
 def lbs_skin(coef, A, v_template_planes, dirs, weight_planes, V):
     lib = _lib.load()
     B, Kp = coef.shape

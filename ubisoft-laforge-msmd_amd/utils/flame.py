@@ -117,6 +117,20 @@ class FLAME(nn.Module):
         """reference utils/flame.py:180-244."""
         p = self._pack()
         B = shape_params.shape[0]
+        c = p["lbs"]
+        needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in
+                                                     (shape_params, expression_params, pose_params, eye_pose_params))
+        if (pose2rot and not return_lm2d and pose_params is not None and not needs_grad
+                and (self.lbs_precision or _lbs.DEFAULT_PRECISION) == "bf16x3" and c.J == 5 and pose_params.shape[1] == 6 and shape_params.shape[1] + expression_params.shape[1] + 36 <= 192
+                and shape_params.is_cuda and shape_params.shape[0] == expression_params.shape[0] == pose_params.shape[0]):
+            # inference fast path: the kinematics kernel reads shape / expression / pose where they are (no concatenated
+            # betas / full_pose copies) and writes the skinning kernel's tile records directly
+            f32c = lambda t: None if t is None else t.float().contiguous()
+            tiles = ops.flame_prepare(f32c(shape_params), f32c(expression_params), f32c(pose_params), f32c(eye_pose_params),
+                                      c.JS, c.parents, ignore_global_rot)
+            vertices = ops.lbs_skin_v2(tiles, B, c.template_planes, c.dirs_hl, c.weight_planes, c.V)
+            landmarks3d = ops.landmarks(vertices, p["faces"], p["full_idx"], self.full_lmk_bary_coords) if return_lm3d else None
+            return vertices, None, landmarks3d
         betas = torch.cat([shape_params, expression_params], dim=1).float().contiguous()
         if pose2rot:
             if pose_params is None:
