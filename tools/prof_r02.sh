@@ -3,7 +3,7 @@
 # gpurun_out/<tag>_kernel_stats.csv, to be copied into profiles/.   Usage: bash tools/prof_r02.sh <tag-prefix>
 P=${1:-r02}
 D=$(dirname "$0")
-C="--steps 20 --warmup 3 --no-cpu-baseline --no-parity"
+C="--steps 20 --warmup 3 --no-cpu-baseline --no-parity --no-two-streams-leg"
 bash $D/prof_bench.sh ${P}_bench_b32_bf16 $C --legs none | tail -3
 bash $D/prof_bench.sh ${P}_bench_b32_f16x2 $C --legs none --dtype f16x2 | tail -3
 bash $D/prof_bench.sh ${P}_bench_b32_fp32 $C --legs none --dtype fp32 --steps 5 | tail -3
