@@ -300,10 +300,15 @@ int msmd_lbs_prepare(const float* betas, const float* pose, const float* JS, con
 /* FLAME.forward's inputs (utils/flame.py:180-212) straight into msmd_lbs_skin_v2's tile records: coefficient row =
  * [shape (B, NS) | expr (B, NE)], pose6 (B, 6) = [global | jaw] axis-angle with the identity neck, eye (B, 6) or NULL
  * (identity), global rotation dropped when ignore_global_rot != 0 -- no concatenated betas / full_pose tensors.
- * coef (B, 192), A (B, 5, 12), joints (B, 5, 3): optional outputs (NULL = skip).  J = 5, Kp = 192. */
+ * coef (B, 192), A (B, 5, 12), joints (B, 5, 3): optional outputs (NULL = skip).  J = 5, Kp = 192.
+ * One subject, many frames: with shape_varies (1 int) and v_template_folded (3, Vp) given (plus dirs (3, 192, Vp) and
+ * v_template (3, Vp) to build it from), the call also writes  v_template_folded = v_template + sum_{k < 96} shape[0][k]
+ * dirs[k]  and sets *shape_varies to whether any frame's first 96 shape coefficients differ from frame 0's -- on the
+ * device, nothing reads back.  msmd_lbs_skin_v2 handed both skips those K groups when *shape_varies == 0. */
 int msmd_flame_prepare(const float* shape, const float* expr, const float* pose6, const float* eye, const float* JS,
                        const int* parents, float* coef, float* A, float* joints, void* skin_tiles, int B, int NS, int NE,
-                       int ignore_global_rot, msmd_stream_t stream);
+                       int ignore_global_rot, int* shape_varies, float* v_template_folded, const float* dirs,
+                       const float* v_template, int Vp, msmd_stream_t stream);
 int msmd_lbs_skin(const float* coef, const float* A, const float* v_template, const float* dirs,
                   const float* lbs_weights, float* verts, int B, int J, int V, int Vp, int Kp,
                   msmd_stream_t stream);
@@ -327,9 +332,11 @@ int msmd_lbs_skin_bf16x3(const void* coef_hl, const float* A, const float* v_tem
  *   frames beyond B - 1 of the last record repeat frame B - 1.
  * 128 vertices per workgroup (8 waves), 16-frame tiles through a 4-deep LDS-DMA ring, one workgroup barrier per two
  * tiles; Vp = padded vertex count of the constant planes (any value >= V).  HBM-bound target: 60 936 algorithmic bytes
- * per frame.  Reference: utils/lbs.py:141-223. */
+ * per frame.  shape_varies / v_template_folded: NULL, or msmd_flame_prepare's outputs (see there).
+ * Reference: utils/lbs.py:141-223. */
 int msmd_lbs_skin_v2(const void* skin_tiles, const float* v_template, const void* dirs_hl, const float* lbs_weights,
-                     float* verts, int B, int J, int V, int Vp, int Kp, msmd_stream_t stream);
+                     float* verts, int B, int J, int V, int Vp, int Kp, const int* shape_varies,
+                     const float* v_template_folded, msmd_stream_t stream);
 
 /* Training through FLAME (the reference's use_vertex_space branch: training_script.py:167-176 -> utils/common.py:486-513
  * -> utils/lbs.py:141-223, differentiated by autograd there).

@@ -228,6 +228,16 @@ def test_flame_lbs_matches_oracle_and_golden(precision):
         vi, _, _ = fl(dev(xi["shape"]), dev(xi["exp"]), dev(xi["pose"]), return_lm2d=False, return_lm3d=False)
         vr, _, _ = orc.forward(xi["shape"], xi["exp"], xi["pose"], return_lm2d=False, return_lm3d=False)
         assert maxabs(vi.cpu().numpy(), vr) <= 5e-6, B
+    # one subject, many frames: every frame carries the same shape row -> folded template, shape K groups skipped on the
+    # device's own decision (msmd_flame_prepare); one differing frame must send the call back to the general path
+    for B, poke in ((100, False), (37, False), (100, True)):
+        xi = flame_inputs(B, tag=f"flame_uni{B}")
+        shp = np.repeat(xi["shape"][:1], B, 0).copy()
+        if poke:
+            shp[B // 2, 5] += 0.5
+        vi, _, _ = fl(dev(shp), dev(xi["exp"]), dev(xi["pose"]), return_lm2d=False, return_lm3d=False)
+        vr, _, _ = orc.forward(shp, xi["exp"], xi["pose"], return_lm2d=False, return_lm3d=False)
+        assert maxabs(vi.cpu().numpy(), vr) <= 5e-6, (B, poke)
 
 
 def test_flame_skinning_kernels_agree_over_many_launches():

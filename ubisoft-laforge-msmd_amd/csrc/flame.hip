@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void lbs_prepare_kernel(const float* __restric
                                                           float* __restrict__ joints_out, int NB, int J, int Kp,
                                                           int pose_is_matrix, f16_t* __restrict__ at_tiles, int B,
                                                           const float* __restrict__ betas2 = nullptr, int NB1 = 0,
-                                                          const float* __restrict__ eye = nullptr, int pose_mode = 0) {
+                                                          const float* __restrict__ eye = nullptr, int pose_mode = 0,
+                                                          int* __restrict__ shape_varies = nullptr, int kfold = 0) {
   // betas2 != NULL: the coefficient row is [betas (B, NB1) | betas2 (B, NB - NB1)] (FLAME's shape | expression, no
   // concatenated copy).  pose_mode 1 / 2: `pose` is FLAME's (B, 6) [global | jaw] axis-angle input, the neck is the
   // identity, `eye` (B, 6) or NULL = identity; 2 also ignores the global rotation (utils/flame.py:199-207).
@@ -84,6 +85,11 @@ __global__ __launch_bounds__(256) void lbs_prepare_kernel(const float* __restric
     const float* b1 = betas + (long)bb * NB1;
     const float* b2 = betas2 + (long)bb * (NB - NB1);
     for (int k = ln; k < NB; k += 16) sB[fl][k] = k < NB1 ? b1[k] : b2[k - NB1];
+    if (shape_varies) {   // do the first kfold shape coefficients of this frame differ from frame 0's?  (see lbs_shape_fold)
+      bool diff = false;
+      for (int k = ln; k < kfold; k += 16) diff |= b1[k] != betas[k];
+      if (diff) atomicOr(shape_varies, 1);
+    }
   } else {
     const float* be = betas + (long)bb * NB;
     for (int k = ln; k < NB; k += 16) sB[fl][k] = be[k];
@@ -292,14 +298,45 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__
 // FLAME.forward's inputs straight into the skinning kernel's tile records: shape (B, NS) | expression (B, NE) as the
 // coefficient row, pose6 (B, 6) = [global | jaw] axis-angle with the identity neck, eye (B, 6) or NULL (identity eyes):
 // no concatenated betas / full_pose tensors.  coef / A / joints are optional outputs.
+// One subject, many frames (the usual call: every frame carries the same shape row, or zeros): the first LBS_KFOLD shape
+// directions can be added to the template ONCE, v_folded = template + sum_{k < LBS_KFOLD} shape_0[k] dirs[k], and the
+// skinning kernel then skips those K groups (27 of its 54 blendshape MFMAs per tile).  Whether the frames really share
+// the row is decided on the device (shape_varies, set by the kinematics kernel), so nothing reads back to the host and
+// the general path stays one uniform branch away.
+#define LBS_KFOLD 96
+__global__ __launch_bounds__(256) void lbs_shape_fold_kernel(const float* __restrict__ shape0, const float* __restrict__ dirs,
+                                                             const float* __restrict__ tmpl, float* __restrict__ out,
+                                                             int Vp, int Kp, int kfold) {
+  const int v = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+  if (v >= Vp) return;
+  float a0 = tmpl[(long)c * Vp + v], a1 = 0.f;
+  const float* d = dirs + (long)c * Kp * Vp + v;
+  for (int k = 0; k + 1 < kfold; k += 2) {
+    a0 = fmaf(shape0[k], d[(long)k * Vp], a0);
+    a1 = fmaf(shape0[k + 1], d[(long)(k + 1) * Vp], a1);
+  }
+  out[(long)c * Vp + v] = a0 + a1;
+}
+
 extern "C" int msmd_flame_prepare(const float* shape, const float* expr, const float* pose6, const float* eye,
                                   const float* JS, const int* parents, float* coef, float* A, float* joints,
-                                  void* skin_tiles, int B, int NS, int NE, int ignore_global_rot, msmd_stream_t stream) {
+                                  void* skin_tiles, int B, int NS, int NE, int ignore_global_rot, int* shape_varies,
+                                  float* v_template_folded, const float* dirs, const float* v_template, int Vp,
+                                  msmd_stream_t stream) {
   const int NB = NS + NE, J = 5, Kp = 192;
   if (B <= 0 || NS <= 0 || NE <= 0 || NB > 256 || Kp < NB + (J - 1) * 9 || !shape || !expr || !pose6 || !skin_tiles) return 1;
-  hipLaunchKernelGGL(lbs_prepare_kernel, dim3((B + LBS_FPB - 1) / LBS_FPB), dim3(256), 0, (hipStream_t)stream, shape, pose6,
+  hipStream_t st = (hipStream_t)stream;
+  const bool fold = shape_varies && v_template_folded && dirs && v_template && NS >= LBS_KFOLD;
+  if (fold) {
+    hipError_t e = hipMemsetAsync(shape_varies, 0, sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(lbs_prepare_kernel, dim3((B + LBS_FPB - 1) / LBS_FPB), dim3(256), 0, st, shape, pose6,
                      JS, parents, coef, (bf16_t*)nullptr, A, joints, NB, J, Kp, 0, (f16_t*)skin_tiles, B, expr, NS, eye,
-                     ignore_global_rot ? 2 : 1);
+                     ignore_global_rot ? 2 : 1, fold ? shape_varies : (int*)nullptr, LBS_KFOLD);
+  if (fold)
+    hipLaunchKernelGGL(lbs_shape_fold_kernel, dim3((Vp + 255) / 256, 3), dim3(256), 0, st, shape, dirs, v_template,
+                       v_template_folded, Vp, Kp, LBS_KFOLD);
   MSMD_RETURN_LAST();
 }
 
@@ -507,8 +544,13 @@ __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2))
 void lbs_skin_v2_kernel(const unsigned char* __restrict__ tiles,
                         const float* __restrict__ tmpl, const bf16_t* __restrict__ dirs_hl,
                         const float* __restrict__ wts, float* __restrict__ verts, int B, int V, int Vp,
-                        int frames_per_block, int vtn, float* __restrict__ vposed = nullptr, int xcd_adj = 0) {
+                        int frames_per_block, int vtn, float* __restrict__ vposed = nullptr, int xcd_adj = 0,
+                        const int* __restrict__ shape_varies = nullptr, const float* __restrict__ tmpl_folded = nullptr) {
   constexpr int SPT = WP ? 8 : 4;   // store instructions per tile and wave
+  // all frames share their first LBS_KFOLD shape coefficients (msmd_flame_prepare): folded template, skip those K groups
+  const bool uni = shape_varies != nullptr && tmpl_folded != nullptr && *shape_varies == 0;
+  const int g_first = uni ? LBS_KFOLD / 32 : 0;
+  if (uni) tmpl = tmpl_folded;
   constexpr int Kp = KG * 32, J = 5, VPB = 16 * NWV;
   constexpr int NCH = 2 * Kp / 8;            // 16-byte chunks per frame of coef_hl (hi then lo)
   constexpr int COEF_BYTES = NCH * 256;      // [chunk][frame] 16 B
@@ -587,6 +629,7 @@ void lbs_skin_v2_kernel(const unsigned char* __restrict__ tiles,
     for (int c = 0; c < 3; ++c) accp[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
+      if (g < g_first) continue;   // wave-uniform
       const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4*)(sc + ((4 * g + q) * 16 + i) * 16));
       const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4*)(sc + ((Kp / 8 + 4 * g + q) * 16 + i) * 16));
 #pragma unroll
@@ -684,7 +727,7 @@ void lbs_skin_v2_kernel(const unsigned char* __restrict__ tiles,
 
 static int lbs_skin_v2_impl(const void* skin_tiles, const float* v_template, const void* dirs_hl,
                             const float* lbs_weights, float* verts, float* vposed, int B, int J, int V, int Vp, int Kp,
-                            msmd_stream_t stream) {
+                            msmd_stream_t stream, const int* shape_varies = nullptr, const float* tmpl_folded = nullptr) {
   if (B <= 0 || V <= 0 || Vp < V || J != 5 || Kp != 192 || !skin_tiles) return 1;
   // tuning key 9: 1 = two 4-wave workgroups per CU (64 vertices each, 3-stage rings) instead of one 8-wave workgroup
   // (128 vertices, 4-stage ring).  Measured at 25 600 frames: 783 vs 732 us -- the smaller workgroups double the
@@ -704,7 +747,7 @@ static int lbs_skin_v2_impl(const void* skin_tiles, const float* v_template, con
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                       \
     hipLaunchKernelGGL(kfn, grid, dim3(64 * NWV), lds, (hipStream_t)stream, (const unsigned char*)skin_tiles,           \
                        v_template, (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb, vt, \
-                       (float*)nullptr, xcd_adj);                                                                              \
+                       (float*)nullptr, xcd_adj, shape_varies, tmpl_folded);                                                                              \
   } while (0)
   if (vposed) {
     constexpr int lds = 4 * 18 * 1024;
@@ -712,7 +755,7 @@ static int lbs_skin_v2_impl(const void* skin_tiles, const float* v_template, con
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int vt8w = (V + 127) / 128;
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, (hipStream_t)stream, (const unsigned char*)skin_tiles,
-                       v_template, (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb, vt8w, vposed, xcd_adj);
+                       v_template, (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb, vt8w, vposed, xcd_adj, (const int*)nullptr, (const float*)nullptr);
   } else if (!big) {
     LBS_V2_LAUNCH(3, 4, 0);
   } else {
@@ -733,8 +776,9 @@ static int lbs_skin_v2_impl(const void* skin_tiles, const float* v_template, con
 
 extern "C" int msmd_lbs_skin_v2(const void* skin_tiles, const float* v_template, const void* dirs_hl,
                                 const float* lbs_weights, float* verts, int B, int J, int V, int Vp, int Kp,
-                                msmd_stream_t stream) {
-  return lbs_skin_v2_impl(skin_tiles, v_template, dirs_hl, lbs_weights, verts, nullptr, B, J, V, Vp, Kp, stream);
+                                const int* shape_varies, const float* v_template_folded, msmd_stream_t stream) {
+  return lbs_skin_v2_impl(skin_tiles, v_template, dirs_hl, lbs_weights, verts, nullptr, B, J, V, Vp, Kp, stream,
+                          shape_varies, v_template_folded);
 }
 
 // Training form: the same kernel, additionally writing the un-skinned vertices v_posed (B, V, 3) for msmd_lbs_skin_bwd.

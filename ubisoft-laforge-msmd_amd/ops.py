@@ -555,17 +555,24 @@ def lbs_prepare(betas, pose, JS, parents, Kp=192, pose_is_matrix=False, want_joi
     return (coef, coef_hl, A, joints, at) if want_blend_tiles else (coef, coef_hl, A, joints)
 
 
-def flame_prepare(shape, expr, pose6, eye, JS, parents, ignore_global_rot=False):
+def flame_prepare(shape, expr, pose6, eye, JS, parents, ignore_global_rot=False, dirs=None, v_template_planes=None):
     """FLAME.forward's (B, NS) shape, (B, NE) expression, (B, 6) [global | jaw] pose (+ optional (B, 6) eye pose) ->
-    msmd_lbs_skin_v2's tile records, without the concatenated betas / full_pose tensors."""
+    msmd_lbs_skin_v2's tile records, without the concatenated betas / full_pose tensors.  With `dirs` (3, 192, Vp) and the
+    template planes also -> (shape_varies flag, folded template) for the one-subject fast path of lbs_skin_v2."""
     lib = _lib.load()
     _need_cuda(shape, expr, pose6)
     B = shape.shape[0]
     tiles = torch.empty((B + 15) // 16, SKIN_TILE_BYTES // 2, device=shape.device, dtype=torch.float16)
+    flag = folded = None
+    Vp = 0
+    if dirs is not None and v_template_planes is not None:
+        Vp = dirs.shape[-1]
+        flag = torch.empty(1, device=shape.device, dtype=torch.int32)
+        folded = torch.empty(3, Vp, device=shape.device, dtype=torch.float32)
     _lib.check(lib.msmd_flame_prepare(_p(shape), _p(expr), _p(pose6), _p(eye), _p(JS), _p(parents), None, None, None,
-                                      _p(tiles), B, shape.shape[1], expr.shape[1], int(ignore_global_rot), _stream()),
-               "msmd_flame_prepare")
-    return tiles
+                                      _p(tiles), B, shape.shape[1], expr.shape[1], int(ignore_global_rot), _p(flag),
+                                      _p(folded), _p(dirs), _p(v_template_planes), Vp, _stream()), "msmd_flame_prepare")
+    return tiles, flag, folded
 
 
 def lbs_skin(coef, A, v_template_planes, dirs, weight_planes, V):
@@ -590,14 +597,15 @@ def lbs_skin_bf16x3(coef_hl, A, v_template_planes, dirs_hl, weight_planes, V):
     return verts
 
 
-def lbs_skin_v2(skin_tiles, B, v_template_planes, dirs_hl, weight_planes, V, Kp=192):
+def lbs_skin_v2(skin_tiles, B, v_template_planes, dirs_hl, weight_planes, V, Kp=192, shape_varies=None, folded=None):
     lib = _lib.load()
     assert skin_tiles.numel() * skin_tiles.element_size() == ((B + 15) // 16) * SKIN_TILE_BYTES
     J = weight_planes.shape[0]
     Vp = dirs_hl.shape[-2]
     verts = torch.empty(B, V, 3, device=skin_tiles.device, dtype=torch.float32)
     _lib.check(lib.msmd_lbs_skin_v2(_p(skin_tiles), _p(v_template_planes), _p(dirs_hl), _p(weight_planes),
-                                    _p(verts), B, J, V, Vp, Kp, _stream()), "msmd_lbs_skin_v2")
+                                    _p(verts), B, J, V, Vp, Kp, _p(shape_varies), _p(folded), _stream()),
+               "msmd_lbs_skin_v2")
     return verts
 
 

@@ -126,9 +126,11 @@ class FLAME(nn.Module):
             # inference fast path: the kinematics kernel reads shape / expression / pose where they are (no concatenated
             # betas / full_pose copies) and writes the skinning kernel's tile records directly
             f32c = lambda t: None if t is None else t.float().contiguous()
-            tiles = ops.flame_prepare(f32c(shape_params), f32c(expression_params), f32c(pose_params), f32c(eye_pose_params),
-                                      c.JS, c.parents, ignore_global_rot)
-            vertices = ops.lbs_skin_v2(tiles, B, c.template_planes, c.dirs_hl, c.weight_planes, c.V)
+            tiles, varies, folded = ops.flame_prepare(f32c(shape_params), f32c(expression_params), f32c(pose_params),
+                                                      f32c(eye_pose_params), c.JS, c.parents, ignore_global_rot, c.dirs,
+                                                      c.template_planes)
+            vertices = ops.lbs_skin_v2(tiles, B, c.template_planes, c.dirs_hl, c.weight_planes, c.V, shape_varies=varies,
+                                       folded=folded)
             landmarks3d = ops.landmarks(vertices, p["faces"], p["full_idx"], self.full_lmk_bary_coords) if return_lm3d else None
             return vertices, None, landmarks3d
         betas = torch.cat([shape_params, expression_params], dim=1).float().contiguous()
