@@ -307,15 +307,20 @@ __global__ __launch_bounds__(256) void lbs_skin_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void lbs_shape_fold_kernel(const float* __restrict__ shape0, const float* __restrict__ dirs,
                                                              const float* __restrict__ tmpl, float* __restrict__ out,
                                                              int Vp, int Kp, int kfold) {
-  const int v = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
-  if (v >= Vp) return;
-  float a0 = tmpl[(long)c * Vp + v], a1 = 0.f;
-  const float* d = dirs + (long)c * Kp * Vp + v;
-  for (int k = 0; k + 1 < kfold; k += 2) {
-    a0 = fmaf(shape0[k], d[(long)k * Vp], a0);
-    a1 = fmaf(shape0[k + 1], d[(long)(k + 1) * Vp], a1);
+  // 64 vertices x 4 K slices per workgroup (the first version walked all 96 directions serially in 60 workgroups: 24 us)
+  __shared__ float part[4][64];
+  const int vl = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const int v = blockIdx.x * 64 + vl, c = blockIdx.y;
+  const int kn = kfold / 4, k0 = ks * kn;
+  float a = 0.f;
+  if (v < Vp) {
+    const float* d = dirs + ((long)c * Kp + k0) * Vp + v;
+#pragma unroll 8
+    for (int k = 0; k < kn; ++k) a = fmaf(shape0[k0 + k], d[(long)k * Vp], a);
   }
-  out[(long)c * Vp + v] = a0 + a1;
+  part[ks][vl] = a;
+  __syncthreads();
+  if (ks == 0 && v < Vp) out[(long)c * Vp + v] = tmpl[(long)c * Vp + v] + ((part[0][vl] + part[1][vl]) + (part[2][vl] + part[3][vl]));
 }
 
 extern "C" int msmd_flame_prepare(const float* shape, const float* expr, const float* pose6, const float* eye,
@@ -335,7 +340,7 @@ extern "C" int msmd_flame_prepare(const float* shape, const float* expr, const f
                      JS, parents, coef, (bf16_t*)nullptr, A, joints, NB, J, Kp, 0, (f16_t*)skin_tiles, B, expr, NS, eye,
                      ignore_global_rot ? 2 : 1, fold ? shape_varies : (int*)nullptr, LBS_KFOLD);
   if (fold)
-    hipLaunchKernelGGL(lbs_shape_fold_kernel, dim3((Vp + 255) / 256, 3), dim3(256), 0, st, shape, dirs, v_template,
+    hipLaunchKernelGGL(lbs_shape_fold_kernel, dim3((Vp + 63) / 64, 3), dim3(256), 0, st, shape, dirs, v_template,
                        v_template_folded, Vp, Kp, LBS_KFOLD);
   MSMD_RETURN_LAST();
 }
