@@ -238,6 +238,16 @@ def test_flame_lbs_matches_oracle_and_golden(precision):
         vi, _, _ = fl(dev(shp), dev(xi["exp"]), dev(xi["pose"]), return_lm2d=False, return_lm3d=False)
         vr, _, _ = orc.forward(shp, xi["exp"], xi["pose"], return_lm2d=False, return_lm3d=False)
         assert maxabs(vi.cpu().numpy(), vr) <= 5e-6, (B, poke)
+    # explicit eye poses (utils/flame.py:196-203): the in-place kinematics path (msmd_flame_prepare), the general path
+    # (concatenated full pose) and the oracle's lbs() on the same 15-d pose
+    xi = flame_inputs(33, tag="flame_eye")
+    eye = (0.3 * synth.normalish("flame_eye/eye", (33, 6))).astype(np.float32)
+    v_fast = fl(dev(xi["shape"]), dev(xi["exp"]), dev(xi["pose"]), dev(eye), return_lm2d=False, return_lm3d=False)[0]
+    v_gen = fl(dev(xi["shape"]), dev(xi["exp"]), dev(xi["pose"]), dev(eye), return_lm2d=True, return_lm3d=False)[0]
+    fp = np.concatenate([xi["pose"][:, :3], np.zeros((33, 3), np.float32), xi["pose"][:, 3:], eye], 1)
+    vr, _ = ofl.lbs(np.concatenate([xi["shape"], xi["exp"]], 1), fp, orc.v_template, orc.shapedirs, orc.posedirs,
+                    orc.J_regressor, orc.parents, orc.lbs_weights)
+    assert maxabs(v_fast.cpu().numpy(), vr) <= 5e-6 and maxabs(v_gen.cpu().numpy(), vr) <= 5e-6
 
 
 def test_flame_skinning_kernels_agree_over_many_launches():
