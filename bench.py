@@ -370,7 +370,8 @@ def multi_stream_forward(model, a, rank, device, S):
     differ from serial ones in ~10 % of two-stream runs, this one in 0 of 1 800.
     -> dict(ms_per_step, frames_per_s, steps, mismatching_streams) or None when capture fails."""
     from msmd_amd import dp, ops
-    ops.set_tuning(0, 13)
+    scope = ops.gemm_defaults(variant=13)   # per-call hint, baked into the graphs captured below; restored on exit
+    scope.__enter__()
     try:
         b0 = synth_batch(a.batch, rank, device)
         for _ in range(2):
@@ -406,14 +407,14 @@ def multi_stream_forward(model, a, rank, device, S):
         torch.cuda.synchronize()
         return None
     finally:
-        ops.set_tuning(0, 0)
+        scope.__exit__(None, None, None)
 
 
 # ----------------------------------------------------------------------------------------------- modes
 def run_forward(a, rank, world, device):
     from msmd_amd import dp, ops
-    for kv in [x for x in a.tune.split(",") if x]:
-        ops.set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
+    for kv in [x for x in a.tune.split(",") if x]:   # developer library only (MSMD_LIB=.../libmsmd_hip_exp.so)
+        ops.exp_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
     from msmd_amd.config import default_args
     from msmd_amd.model import get_diffusion_model
     args = default_args(compute_dtype=a.dtype)
@@ -627,7 +628,7 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of hipGraph replays")
     ap.add_argument("--no-two-streams-leg", dest="two_streams_leg", action="store_false",
                     help="skip the extra leg that times two steps in flight (verified per step)")
-    ap.add_argument("--tune", default="", help="developer: comma-separated key=value pairs for msmd_set_tuning")
+    ap.add_argument("--tune", default="", help="developer (experimental library only): comma-separated key=value pairs for msmd_exp_set_tuning")
     ap.add_argument("--streams", type=int, default=1,
                     help="forward mode: steps in flight (one hipGraph + batch per HIP stream).  2 gives +30 %% throughput, but on "
                          "this ROCm stack kernels of one stream were observed to start before their same-stream producer had "
@@ -647,10 +648,14 @@ def main():
     if world > 1:
         import torch.distributed as td
         world = td.get_world_size()    # what RCCL actually sees
-    if os.environ.get("MSMD_TUNE"):   # developer A/B knob, e.g. MSMD_TUNE="7=1" (msmd_set_tuning key=value pairs)
+    if os.environ.get("MSMD_TUNE"):   # developer A/B knob of the experimental library, e.g. MSMD_TUNE="7=1"
         from msmd_amd import ops as _ops
         for kv in os.environ["MSMD_TUNE"].split(","):
-            _ops.set_tuning(*(int(v) for v in kv.split("=")))
+            _ops.exp_set_tuning(*(int(v) for v in kv.split("=")))
+    if os.environ.get("MSMD_GEMM_FLAGS") or os.environ.get("MSMD_GEMM_VARIANT"):   # per-call knobs of the product library
+        from msmd_amd import ops as _ops
+        _ops._GEMM_DEFAULT.update(flags=int(os.environ.get("MSMD_GEMM_FLAGS", "0")) << 16,
+                                  variant=int(os.environ.get("MSMD_GEMM_VARIANT", "0")))
     out = run_train(a, rank, world, device) if a.mode == "train" else run_forward(a, rank, world, device)
     if rank == 0 and out is not None:
         print(json.dumps(out), flush=True)

@@ -42,12 +42,13 @@ typedef void* msmd_stream_t; /* hipStream_t */
 
 /* Library / device probe: returns the ABI version; safe to call without a GPU. */
 int msmd_abi_version(void);
-/* Developer knobs for A/B measurements (tools/ab_graph.py, tools/bench_gemm.py); not part of the drop-in surface.
- * key 0: force a bf16 GEMM kernel variant (0 = built-in heuristic, -1 = register-staged v1 kernels only);
- * key 1: msmd_gemm_tn work items in plain launch order (1) instead of XCD-contiguous eighths; key 2: its split count;
- * key 4: 13 instead of 17 for the 128x128 tile; keys 5 / 6: variant for M >= 20000 / the other 128x128 problems;
- * key 7: XCDs along N for the GEMM tile map (1, 2, 4; 0 = chosen per problem from the operand sizes). */
-int msmd_set_tuning(int key, int value);
+/* The library keeps NO process-global state: every entry point is re-entrant per stream.  What used to be developer
+ * knobs travels per call -- the GEMM kernel variant and epilogue flags in `act` (msmd_gemm below), the contraction
+ * split count of msmd_gemm_tn in its `accumulate` argument.  The experimental kernel families of DESIGN.md section 5 /
+ * 5b and their A/B switch exist only in the developer build (`make -C csrc EXP=1` -> libmsmd_hip_exp.so). */
+#define MSMD_GEMM_VARIANT(v) ((v) << 8)   /* bits 8-15 of `act`: 0 = shape heuristic, 9 / 12 / 13 / 17 (bf16, fp16), 1 / 5 (f16x2) */
+#define MSMD_GEMM_WRITE_THROUGH (1 << 16) /* output stores carry `sc1`: the bytes leave the XCD's L2 as they are stored */
+#define MSMD_GEMM_PAIRED_STORES (1 << 17) /* 16-bit outputs: lane pairs swap a fragment row, one 16-byte store each */
 
 /* Measurement aid: one wavefront that spins for `us` microseconds of the 100 MHz constant clock (s_memrealtime) and
  * optionally stores the ticks it actually spun.  bench.py times it at two lengths to calibrate the overhead of a HIP
@@ -66,8 +67,9 @@ int msmd_spin_us(float us, long* ticks_out, msmd_stream_t stream);
  *   out_dtype MSMD_F32 or MSMD_F16X2; K, lda, ldw, a_batch_stride and the A / W strides must be multiples of 32, and
  *   for split output also N % 4 == 0 and ldc / ldr / strideC / strideR multiples of 32.
  *   batch > 1 launches independent problems with the given element strides (grouped conv).
- *   act: MSMD_ACT_* in bits 0-7; bits 8-15 may carry a kernel-variant hint chosen by a host-side autotuner (0 = the
- *   library's own shape heuristic; every variant computes bit-identical results).
+ *   act: MSMD_ACT_* in bits 0-7; bits 8-15 may carry a kernel-variant hint (MSMD_GEMM_VARIANT; 0 = the library's own
+ *   shape heuristic; every variant computes bit-identical results); bits 16-23 epilogue flags (MSMD_GEMM_WRITE_THROUGH,
+ *   MSMD_GEMM_PAIRED_STORES: how the output is stored, never what is stored).
  *   Requirements: K % (16 / sizeof(in)) == 0, lda/ldw/a_batch_stride/strideA/strideW multiples of the same.
  * Replaces: nn.Linear / nn.Conv1d / nn.MultiheadAttention projections at reference model.py:115,856-906,
  *   style_encoder.py:135-175, utils/wav2vec2.py:79,95,111 (HF conv stack, projection, pos-conv, encoder FFN).
@@ -101,7 +103,8 @@ int msmd_gemm_batched2(const void* A, const void* W, void* C, int M, int N, int 
  * multiples of 8; pointers 16-byte aligned.  colsum (N) fp32 or NULL: fused bias gradient sum_m A[m][n]
  * (batch must be 1).  B may be a windowed view (row r at (r / b_rows_per_window) * b_window_stride +
  * (r % b_rows_per_window) * ldb; 0 = plain) so a Conv1d weight gradient needs no unfolded copy.
- * C / colsum are fully overwritten, or added to when `accumulate` (gradient accumulation in place).  ws / ws_bytes: optional device workspace for
+ * C / colsum are fully overwritten, or added to when bit 0 of `accumulate` is set (gradient accumulation in place);
+ * bits 8-15 of `accumulate` force the contraction split count (0 = chosen from the shape).  ws / ws_bytes: optional device workspace for
  * split-contraction partial products (msmd_gemm_tn_workspace() bytes fill the chip; NULL = unsplit).  Replaces what autograd computes for nn.Linear in the
  * reference's loss.backward() (training_script.py:196). */
 int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsum, int M, int N, int K, long lda, long ldb,

@@ -345,13 +345,11 @@ def test_gemm_tn_weight_gradient_product(M, N, K):
     ref = a.double().t() @ b.double()
     cs_ref = a.double().sum(0)
     for splits in (0, 1, 3):
-        o.set_tuning(2, splits)
-        c, cs = o.gemm_tn(a, b, want_colsum=True)
+        c, cs = o.gemm_tn(a, b, want_colsum=True, splits=splits)
         torch.cuda.synchronize()
         tol = 2e-3 * float(ref.abs().max()) + 1e-3
         assert float((c.double() - ref).abs().max()) < tol, (splits, float((c.double() - ref).abs().max()))
         assert float((cs.double() - cs_ref).abs().max()) < 2e-3 * float(cs_ref.abs().max()) + 1e-3
-    o.set_tuning(2, 0)
     # batched, strided views
     a3 = (torch.randn(3, 120, 64, generator=g)).to(torch.bfloat16).to(DEV)
     b3 = (torch.randn(3, 120, 40, generator=g)).to(torch.bfloat16).to(DEV)

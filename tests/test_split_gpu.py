@@ -64,12 +64,8 @@ def test_split_gemm_matches_float64(M, N, K):
     r = synth.normalish(f"sgemm/r/{M}x{N}", (M, N))
     ref = a.astype(np.float64) @ w.astype(np.float64).T + b
     ws = o.to_split(dev(w))
-    for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
-        o.set_tuning(3, variant)
-        try:
-            c = o.gemm(o.to_split(dev(a)), ws, dev(b)).cpu().numpy()
-        finally:
-            o.set_tuning(3, 0)
+    for variant in (0, 1, 5):   # heuristic, 128 x 128, 64 x 64: per-call hint (MSMD_GEMM_VARIANT), no library state
+        c = o.gemm(o.to_split(dev(a)), ws, dev(b), variant=variant).cpu().numpy()
         assert maxabs(c, ref) < 4e-6, (variant, maxabs(c, ref))
     c32 = o.gemm(dev(a), dev(w), dev(b)).cpu().numpy()
     c = o.gemm(dev(a), ws, dev(b)).cpu().numpy()          # fp32 activations are converted on the way in

@@ -10,8 +10,8 @@ TD = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32, "f16
 model = get_diffusion_model(default_args(compute_dtype=DT), "cuda").eval()
 bs = [bench.synth_batch(32, r, "cuda") for r in range(2)]
 from msmd_amd import ops as _ops
-for kv in os.environ.get("TUNE", "").split(","):
-    if kv: _ops.set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
+# per-call GEMM knobs of the product library: VARIANT (0 = heuristic: 17), FLAGS (1 = write-through, 2 = paired stores)
+_ops._GEMM_DEFAULT.update(variant=int(os.environ.get("VARIANT", "0")), flags=int(os.environ.get("FLAGS", "0")) << 16)
 which = sys.argv[1] if len(sys.argv) > 1 else "feat"
 enc = model.audio_encoder
 from msmd_amd.utils.model_common import pad_audio_plan
@@ -44,4 +44,4 @@ for rep in range(int(os.environ.get("REPS", "20"))):
             idx = torch.nonzero(d > 0)
             if nbad <= 6:
                 print(f"rep {rep} stream {i}: {idx.shape[0]} of {d.numel()} differ, max {float(d.max()):.3g}; clips {sorted(set(idx[:, 0].tolist()))[:12]}; frames {int(idx[:, 1].min())}..{int(idx[:, 1].max())}")
-print(which, "mismatching results:", nbad, "of", 2 * int(os.environ.get("REPS", "20")))
+print(f"RESULT {which} dtype={DT} variant={os.environ.get('VARIANT', '0')} flags={os.environ.get('FLAGS', '0')}: mismatching results", nbad, "of", 2 * int(os.environ.get("REPS", "20")))

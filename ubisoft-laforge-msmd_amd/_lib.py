@@ -14,7 +14,8 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, "include", "msmd_hip.h")
-LIB_PATH = os.path.join(_HERE, "csrc", "libmsmd_hip.so")
+# MSMD_LIB selects another build of the SAME C ABI (developers: the experimental library, make -C csrc EXP=1)
+LIB_PATH = os.environ.get("MSMD_LIB") or os.path.join(_HERE, "csrc", "libmsmd_hip.so")
 
 _CTYPE = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,

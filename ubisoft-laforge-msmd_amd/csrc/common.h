@@ -44,7 +44,14 @@ __device__ __forceinline__ Philox4 dropout_bits(const unsigned long* __restrict_
 // keep iff uniform [0,1) >= p  <=>  bits >= p * 2^32
 __device__ __forceinline__ unsigned dropout_threshold(float p) { return (unsigned)fminf(p * 4294967296.0f, 4294967295.0f); }
 
-extern int g_tuning[16];  // msmd_set_tuning knobs (gemm.hip)
+// Developer knobs: only the experimental build (make EXP=1, -DMSMD_EXPERIMENTAL) has them; in the product library every
+// MSMD_TUNE(k) is the constant 0 and the code it guards folds away (no process-global state: re-entrant per stream).
+#ifdef MSMD_EXPERIMENTAL
+extern int g_tuning[16];
+#define MSMD_TUNE(k) (g_tuning[k])
+#else
+#define MSMD_TUNE(k) 0
+#endif
 #define MSMD_RETURN_LAST() return (int)hipGetLastError()
 
 __device__ __forceinline__ float to_f32(float x) { return x; }

@@ -737,14 +737,14 @@ static int lbs_skin_v2_impl(const void* skin_tiles, const float* v_template, con
   // tuning key 9: 1 = two 4-wave workgroups per CU (64 vertices each, 3-stage rings) instead of one 8-wave workgroup
   // (128 vertices, 4-stage ring).  Measured at 25 600 frames: 783 vs 732 us -- the smaller workgroups double the
   // staged bytes per vertex and their phase drift buys less than that costs.
-  const bool big = g_tuning[9] != 1;
+  const bool big = MSMD_TUNE(9) != 1;
   const int vpb = big ? 128 : 64;
   const int vt = (V + vpb - 1) / vpb;
   int splits = max(1, min((B + 63) / 64, ((big ? 1024 : 2048) + vt - 1) / vt));   // >= 64 frames per workgroup amortise the dirs load
   int fpb = (((B + splits - 1) / splits) + 15) / 16 * 16;
   splits = (B + fpb - 1) / fpb;
   dim3 grid(((vt + 7) / 8) * 8 * splits);
-  const int xcd_adj = g_tuning[10] != 1;   // key 10 = 1: the round-1 dealing
+  const int xcd_adj = MSMD_TUNE(10) != 1;   // key 10 = 1: the round-1 dealing
 #define LBS_V2_LAUNCH(NS, NWV, ABL, ...)                                                                                    \
   do {                                                                                                                 \
     constexpr int lds = NS * 18 * 1024;                                                                                \
@@ -761,19 +761,22 @@ static int lbs_skin_v2_impl(const void* skin_tiles, const float* v_template, con
     const int vt8w = (V + 127) / 128;
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, (hipStream_t)stream, (const unsigned char*)skin_tiles,
                        v_template, (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb, vt8w, vposed, xcd_adj, (const int*)nullptr, (const float*)nullptr);
+#ifdef MSMD_EXPERIMENTAL
   } else if (!big) {
     LBS_V2_LAUNCH(3, 4, 0);
-  } else {
-    switch (g_tuning[8]) {
+  } else if (MSMD_TUNE(8)) {
+    switch (MSMD_TUNE(8)) {   // ablation builds (tools/lbs_ablate.py)
       case 1: LBS_V2_LAUNCH(4, 8, 1); break;
       case 2: LBS_V2_LAUNCH(4, 8, 2); break;
       case 4: LBS_V2_LAUNCH(4, 8, 4); break;
       case 8: LBS_V2_LAUNCH(4, 8, 8); break;
       case 7: LBS_V2_LAUNCH(4, 8, 7); break;
       case 15: LBS_V2_LAUNCH(4, 8, 15); break;
-      case 100: LBS_V2_LAUNCH(4, 8, 0); break;        // one barrier per tile (the round-2a schedule)
-      default: LBS_V2_LAUNCH(4, 8, 0, 2); break;      // one barrier per two tiles + wave priorities
+      default: LBS_V2_LAUNCH(4, 8, 0); break;         // 100: one barrier per tile (the round-2a schedule)
     }
+#endif
+  } else {
+    LBS_V2_LAUNCH(4, 8, 0, 2);                        // one barrier per two tiles + wave priorities
   }
 #undef LBS_V2_LAUNCH
   MSMD_RETURN_LAST();
@@ -790,7 +793,7 @@ extern "C" int msmd_lbs_skin_v2(const void* skin_tiles, const float* v_template,
 extern "C" int msmd_lbs_skin_v2_train(const void* skin_tiles, const float* v_template,
                                       const void* dirs_hl, const float* lbs_weights, float* verts, float* v_posed, int B,
                                       int J, int V, int Vp, int Kp, msmd_stream_t stream) {
-  if (!v_posed || g_tuning[9] == 1) return 1;
+  if (!v_posed || MSMD_TUNE(9) == 1) return 1;
   return lbs_skin_v2_impl(skin_tiles, v_template, dirs_hl, lbs_weights, verts, v_posed, B, J, V, Vp, Kp, stream);
 }
 

@@ -28,6 +28,7 @@ struct GemmArgs {
   // residual add; the keep mask is Philox(rng, site, (m * N + n) / 4), i.e. msmd_dropout's on a contiguous (M, N) C
   void* Z; float p_drop; const unsigned long* rng; unsigned site;
   int xn;  // XCDs along N (1, 2 or 4): the 8 XCDs form an (8 / xn) x xn grid over (M tiles, N tiles)
+  int flags;  // MSMD_GEMM_* bits 16.. of `act`, shifted down: 1 = write-through (sc1) output stores, 2 = paired 16-B stores
 };
 
 template <typename T> struct Mfma;
@@ -76,6 +77,27 @@ template <typename TO> __device__ __forceinline__ float act_out(float x, int act
   return x;
 }
 
+// Output stores.  wt = write-through (`sc1`): the bytes leave the XCD's L2 for memory as they are stored instead of
+// waiting dirty for the end-of-kernel write-back (MI355X_MICROARCH.md, "stores of each flavour"), so a consumer kernel
+// on another XCD never depends on that write-back having completed.
+__device__ __forceinline__ void store16_wt(void* p, const u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store8_wt(void* p, const u32x2 v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+template <typename TO> __device__ __forceinline__ void store4_out(TO* p, const float* v, bool wt) {
+  if constexpr (sizeof(TO) == 4) {
+    const f32x4 o = f32x4{v[0], v[1], v[2], v[3]};
+    if (wt) store16_wt(p, __builtin_bit_cast(u32x4, o));
+    else *(f32x4*)p = o;
+  } else {
+    const typename Vec4T<TO>::type o = pack4<TO>(v[0], v[1], v[2], v[3]);
+    if (wt) store8_wt(p, __builtin_bit_cast(u32x2, o));
+    else *(typename Vec4T<TO>::type*)p = o;
+  }
+}
+
 // Interior tiles (fully inside M x N, vector-aligned): straight-line code, no per-element bounds checks.
 template <typename TO, int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int z, int m_base,
@@ -84,48 +106,76 @@ __device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const 
                        (long)(m_base + fr) * p.ldc + n_base + fq * 4;
   const TO* __restrict__ R = p.R ? (const TO*)p.R + z * p.strideR + (long)(m_base + fr) * p.ldr + n_base + fq * 4 : nullptr;
   const float* __restrict__ bias = p.bias ? p.bias + z * p.strideBias + n_base + fq * 4 : nullptr;
+  const bool wt = p.flags & 1;
   f32x4 bv[FN];
 #pragma unroll
   for (int i = 0; i < FN; ++i) bv[i] = bias ? *(const f32x4*)(bias + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < FM; ++j) {
+  // the finished 4 values of fragment (i, j): bias, optional pre-activation copy, activation, dropout, residual
+  auto finish = [&](int i, int j, float (&v)[4]) {
     TO* crow = C + (long)j * 16 * p.ldc;
     const TO* rrow = R ? R + (long)j * 16 * p.ldr : nullptr;
 #pragma unroll
-    for (int i = 0; i < FN; ++i) {
-      float v[4];
+    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[i][e];
+    if (p.Z) store4_out<TO>((TO*)p.Z + (crow + i * 16 - (TO*)p.C), v, wt);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[i][e];
-      if (p.Z) {
-        TO* zp = (TO*)p.Z + (crow + i * 16 - (TO*)p.C);
-        if constexpr (sizeof(TO) == 4) *(f32x4*)zp = f32x4{v[0], v[1], v[2], v[3]};
-        else *(typename Vec4T<TO>::type*)zp = pack4<TO>(v[0], v[1], v[2], v[3]);
+    for (int e = 0; e < 4; ++e) v[e] = act_out<TO>(v[e], p.act);
+    if (p.p_drop > 0.f) {
+      const long idx = (long)(m_base + j * 16 + fr) * p.N + (n_base + i * 16 + fq * 4);
+      const Philox4 rb = dropout_bits(p.rng, p.site, (unsigned long)(idx >> 2));
+      const unsigned thr = dropout_threshold(p.p_drop);
+      const float c = 1.0f / (1.0f - p.p_drop);
+      v[0] = rb.x >= thr ? v[0] * c : 0.f;
+      v[1] = rb.y >= thr ? v[1] * c : 0.f;
+      v[2] = rb.z >= thr ? v[2] * c : 0.f;
+      v[3] = rb.w >= thr ? v[3] * c : 0.f;
+    }
+    if (rrow) {
+      if constexpr (sizeof(TO) == 4) {
+        const f32x4 r = *(const f32x4*)(rrow + i * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
+      } else {
+        const typename Vec4T<TO>::type r = *(const typename Vec4T<TO>::type*)(rrow + i * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
       }
+    }
+  };
+  if constexpr (sizeof(TO) == 2 && FM % 2 == 0) {
+    if (p.flags & 2) {
+      // Paired 16-byte stores: lanes l and l ^ 16 hold columns 4 fq .. 4 fq + 3 and the next four of the same rows.
+      // They swap one fragment row each (even fq keeps row j0 and takes the partner's half of it, odd fq keeps row
+      // j0 + 1), so every lane issues ONE 16-byte store per fragment-row pair instead of two 8-byte ones.
+      const bool odd = fq & 1;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = act_out<TO>(v[e], p.act);
-      if (p.p_drop > 0.f) {
-        const long idx = (long)(m_base + j * 16 + fr) * p.N + (n_base + i * 16 + fq * 4);
-        const Philox4 rb = dropout_bits(p.rng, p.site, (unsigned long)(idx >> 2));
-        const unsigned thr = dropout_threshold(p.p_drop);
-        const float c = 1.0f / (1.0f - p.p_drop);
-        v[0] = rb.x >= thr ? v[0] * c : 0.f;
-        v[1] = rb.y >= thr ? v[1] * c : 0.f;
-        v[2] = rb.z >= thr ? v[2] * c : 0.f;
-        v[3] = rb.w >= thr ? v[3] * c : 0.f;
-      }
-      if (rrow) {
-        if constexpr (sizeof(TO) == 4) {
-          const f32x4 r = *(const f32x4*)(rrow + i * 16);
+      for (int jp = 0; jp < FM / 2; ++jp) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += r[e];
-        } else {
-          const typename Vec4T<TO>::type r = *(const typename Vec4T<TO>::type*)(rrow + i * 16);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+        for (int i = 0; i < FN; ++i) {
+          float v0[4], v1[4];
+          finish(i, 2 * jp, v0);
+          finish(i, 2 * jp + 1, v1);
+          const u32x2 a = __builtin_bit_cast(u32x2, pack4<TO>(v0[0], v0[1], v0[2], v0[3]));
+          const u32x2 b = __builtin_bit_cast(u32x2, pack4<TO>(v1[0], v1[1], v1[2], v1[3]));
+          const u32x2 send = odd ? a : b;
+          u32x2 recv;
+          recv[0] = __shfl_xor(send[0], 16, 64);
+          recv[1] = __shfl_xor(send[1], 16, 64);
+          const u32x4 o = odd ? u32x4{recv[0], recv[1], b[0], b[1]} : u32x4{a[0], a[1], recv[0], recv[1]};
+          TO* dst = C + (long)(2 * jp + (odd ? 1 : 0)) * 16 * p.ldc + i * 16 - (odd ? 4 : 0);
+          if (wt) store16_wt(dst, o);
+          else *(u32x4*)dst = o;
         }
       }
-      if constexpr (sizeof(TO) == 4) *(f32x4*)(crow + i * 16) = f32x4{v[0], v[1], v[2], v[3]};
-      else *(typename Vec4T<TO>::type*)(crow + i * 16) = pack4<TO>(v[0], v[1], v[2], v[3]);
+      return;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      float v[4];
+      finish(i, j, v);
+      store4_out<TO>(C + (long)j * 16 * p.ldc + i * 16, v, wt);
     }
   }
 }
@@ -187,11 +237,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
             for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
           }
         }
-        if constexpr (sizeof(TO) == 4) {
-          *(f32x4*)cp = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-          *(typename Vec4T<TO>::type*)cp = pack4<TO>(v[0], v[1], v[2], v[3]);
-        }
+        store4_out<TO>(cp, v, p.flags & 1);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -417,115 +463,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K-split wave layout of the same 128x128 / 8-wave / 2-stage tile: the default kernel above is LDS-bandwidth bound
-// (per K tile a workgroup reads 96 KB of fragments + 32 KB of LDS-DMA writes = 1024 clk at 128 B/clk against 512 clk
-// of MFMA issue per SIMD; tools/gemm_big.py).  Here the 8 waves are 2 x 2 spatial x 2 along K: a wave owns a 64 x 64
-// output block and ONE 32-deep half of every K tile, i.e. 8 fragment reads per 16 MFMAs instead of 12 (64 KB per K
-// tile).  The two K halves meet once per tile: each wave parks the 32 rows its partner finishes in the (then idle)
-// stage buffers, adds the partner's half to the rows it keeps, and runs the usual 32 x 64 epilogue.
-template <typename TO, typename TI = bf16_t>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm2k_kernel(const GemmArgs p) {
-  constexpr int BM = 128, BN = 128, NW = 8, NT = 512;
-  constexpr int STAGE = (BM + BN) * 128;
-  constexpr int LPT = (BM + BN) * 8 / NT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int pid = blockIdx.x;
-  const int xcd = pid & 7, slot = pid >> 3;
-  const int m_tile = (slot / p.nt) * 8 + xcd, n_tile = slot % p.nt;
-  if (m_tile >= p.mt) return;
-  const int z = blockIdx.z;
-  const int zo = z / p.batch_inner, zi = z % p.batch_inner;
-  const bf16_t* __restrict__ A = (const bf16_t*)p.A + zo * p.strideA + zi * p.strideA2;
-  const bf16_t* __restrict__ W = (const bf16_t*)p.W + zo * p.strideW + zi * p.strideW2;
-  const int m0 = m_tile * BM, n0 = n_tile * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-
-  const bf16_t* src[LPT];
-#pragma unroll
-  for (int i = 0; i < LPT; ++i) {
-    const int id = (i * NW + wid) * 64 + lane;
-    const int row = id >> 3, phys = id & 7;
-    const int c = phys ^ ((row >> 1) & 7);
-    if (row < BM) src[i] = A + a_row_offset(p, min(m0 + row, p.M - 1)) + c * 8;
-    else src[i] = W + (long)min(n0 + row - BM, p.N - 1) * p.ldw + c * 8;
-  }
-  auto issue = [&](int kt, int stage) {
-#pragma unroll
-    for (int i = 0; i < LPT; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[i] + kt * 64),
-                                       (lds_void_t*)(smem + stage * STAGE + (i * NW + wid) * 1024), 16, 0, 0);
-  };
-
-  const int wk = wid & 1, wn = ((wid >> 1) & 1) * 64, wm = (wid >> 2) * 64;
-  const int fr = lane & 15, fq = lane >> 4;
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.K / 64;
-  issue(0, 0);
-  int stage = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nk) issue(kt + 1, stage ^ 1);
-    const unsigned char* sa = smem + stage * STAGE;
-    const unsigned char* sw = sa + BM * 128;
-    u32x4 fx[4], fw[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fx[j] = *(const u32x4*)(sa + lds_off(wm + j * 16 + fr, wk * 4 + fq));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fw[i] = *(const u32x4*)(sw + lds_off(wn + i * 16 + fr, wk * 4 + fq));
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) Mfma<TI>::run(fw[i], fx[j], acc[i][j]);
-    __builtin_amdgcn_sched_barrier(0);
-    stage ^= 1;
-  }
-  // meet the partner's K half: wave wk finishes rows [wk*32, wk*32+32) of the pair's 64 x 64 block.  The selects work
-  // on laundered VALUES: left alone, hipcc folds "wk ? acc[a] : acc[b]" into a dynamically indexed stack array.
-  __syncthreads();
-  f32x4* park = (f32x4*)smem + (wid ^ 1) * (8 * 64) + lane;    // read back by the partner as ITS region
-  const f32x4* mine = (const f32x4*)smem + wid * (8 * 64) + lane;
-  f32x4 fin[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      f32x4 lo = acc[i][jj], hi = acc[i][2 + jj];
-      asm volatile("" : "+v"(lo), "+v"(hi));
-      park[(i * 2 + jj) * 64] = wk ? lo : hi;
-      fin[i][jj] = wk ? hi : lo;
-    }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) fin[i][jj] += mine[(i * 2 + jj) * 64];
-  gemm_epilogue<TO, 2, 4>(p, fin, z, m0 + wm + wk * 32, n0 + wn, fr, fq);
-}
-
-template <typename TO, typename TI = bf16_t>
-static int launch_gemm2k(GemmArgs& p, int batch, hipStream_t st) {
-  constexpr int lds = 2 * 256 * 128;
-  static bool attr_done = false;
-  auto kfn = gemm2k_kernel<TO, TI>;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
-  }
-  p.mt = (p.M + 127) / 128; p.nt = (p.N + 127) / 128;
-  dim3 grid(((p.mt + 7) / 8) * 8 * p.nt, 1, batch);
-  hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, p);
-  MSMD_RETURN_LAST();
-}
-
-// ---------------------------------------------------------------------------------------------------
 // MSMD_F16X2 ("split pair", common.h) kernel: the parity-grade speed mode.  Operands are rows of 2K fp16 numbers in
 // 32-element blocks [hi x 32 | lo x 32], so ONE 128-byte line = one 32-deep k-step of both planes and the LDS-DMA
 // ring, LDS image, swizzle and fragment reads are those of gemm2_kernel (chunks 0-3 of a row = hi, 4-7 = lo).  Per
@@ -651,245 +588,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2s_kernel(const GemmArgs p) 
   else gemm_epilogue_split<FM, FN>(p, acc0, z, m0 + wm, n0 + wn, fr, fq);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// gemm3: ONE workgroup per CU (8 waves, 2 per SIMD, up to 256 VGPRs), large tiles, fragment reads software-pipelined
-// ACROSS ring stages.  Why: the 128x128 kernels above stage 32 KB per 2.1 MFLOP (bf16) -- at 2 workgroups per CU the
-// MFMA rate would need 64 B/clk/CU of L2 -> LDS traffic (34 TB/s chip-wide), and they top out where the LDS-DMA stream
-// does (10-12 TB/s measured: 700-850 TF).  A 256x128 tile needs 2/3 of those bytes per FLOP, 256x256 half.  With one
-// workgroup per CU nothing else covers a wave's read -> wait -> multiply chain, so the chain is broken here instead:
-// the work is a sequence of UNITS (one 32-deep k-step; bf16: two per 128-byte stage row, split pairs: one), and while
-// the MFMAs of unit u issue from one register set, the fragments of unit u+1 are already being read into the other --
-// also when u+1 lives in the NEXT ring stage (its DMA was retired by the counted vmcnt + barrier at the stage entry,
-// where the stage just drained is immediately refilled NB stages ahead).  One barrier per stage, none per unit.
-//   NPL = 1: bf16 / f16 operands (MFMA per fragment pair and unit: 1); NPL = 2: MSMD_F16X2 split pairs (3, two accumulators).
-// Fragment reads as inline asm: through plain loads hipcc waits lgkmcnt(0) in front of the MFMAs of unit u for the
-// reads of unit u + 1 it has just issued (the loop-carried register sets defeat its counted waits), which is exactly
-// the serialisation this kernel exists to remove.  The counted wait is placed by hand (wait_units) and tied to the
-// registers it guards so no consumer can be scheduled above it (cdna_hip_programming.md 5.7 items 1 and 3).
-template <int OFF>
-__device__ __forceinline__ u32x4 lds_read128(unsigned addr) {
-  u32x4 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-  return v;
-}
-template <int BASE, int C, int NPL, int... Rs>
-__device__ __forceinline__ void lds_read_rows(u32x4 (&dst)[sizeof...(Rs)][NPL], unsigned addr,
-                                              std::integer_sequence<int, Rs...>) {
-  ((dst[Rs][C] = lds_read128<BASE + Rs * 2048>(addr)), ...);
-}
-template <int N>
-__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void pin(u32x4& v) { asm volatile("" : "+v"(v)); }
-
-//   NL = 0: every wave stages its share of each ring stage itself.  NL = 4: four extra LOADER waves (one per SIMD) issue
-//   all LDS-DMA; the eight consumer waves only read fragments and multiply.  An LDS-DMA wave-instruction costs the wave
-//   that issues it on the order of 100+ cycles (MI355X_MICROARCH.md cycle constants) during which it cannot issue MFMAs:
-//   at 48-64 pieces per stage that is more than the stage's MFMA time, so it is moved off the multiplying waves.
-template <typename TO, typename TI, int NPL, int BM, int BN, int WM, int WN, int NB, int NL = 0>
-__global__ __launch_bounds__(512 + 64 * NL) __attribute__((amdgpu_waves_per_eu(NL ? 3 : 2, NL ? 3 : 2))) void gemm3_kernel(const GemmArgs p) {
-  static_assert(WM * WN == 8, "8 waves");
-  constexpr int NW = NL ? NL : 8, NT = NW * 64;   // waves / threads that stage
-  constexpr int STAGE = (BM + BN) * 128;
-  constexpr int LPT = (BM + BN) * 8 / NT;
-  static_assert((BM + BN) * 8 % NT == 0, "stage chunks must divide over the staging threads");
-  constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
-  constexpr int UPS = NPL == 1 ? 2 : 1;   // units per stage
-  constexpr int NACC = NPL;               // accumulator sets
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int pid = blockIdx.x;
-  const int xcd = pid & 7, slot = pid >> 3;
-  const int xm_n = 8 / p.xn, ntx = (p.nt + p.xn - 1) / p.xn;
-  const int m_tile = (slot / ntx) * xm_n + (xcd % xm_n), n_tile = (slot % ntx) * p.xn + xcd / xm_n;
-  if (m_tile >= p.mt || n_tile >= p.nt) return;
-  const int z = blockIdx.z;
-  const int zo = z / p.batch_inner, zi = z % p.batch_inner;
-  const uint16_t* __restrict__ A = (const uint16_t*)p.A + zo * p.strideA + zi * p.strideA2;
-  const uint16_t* __restrict__ W = (const uint16_t*)p.W + zo * p.strideW + zi * p.strideW2;
-  const int m0 = m_tile * BM, n0 = n_tile * BN;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = NL > 0 && wid_all >= 8;
-  const int wid = NL > 0 ? (loader ? wid_all - 8 : wid_all) : wid_all;   // index among the stagers / among the consumers
-  const int nk = NPL == 1 ? p.K / 64 : p.K / 32;   // ring stages
-
-  const uint16_t* src[LPT];
-#pragma unroll
-  for (int i = 0; i < LPT; ++i) {
-    const int id = (i * NW + (NL > 0 && !loader ? 0 : wid)) * 64 + lane;
-    const int row = id >> 3, phys = id & 7;
-    const int c = phys ^ ((row >> 1) & 7);
-    if (row < BM) src[i] = A + a_row_offset(p, min(m0 + row, p.M - 1)) + c * 8;
-    else src[i] = W + (long)min(n0 + row - BM, p.N - 1) * p.ldw + c * 8;
-  }
-  auto issue = [&](int st) {   // stage st -> ring slot st % NB
-    unsigned char* dst = smem + (st % NB) * STAGE + wid * 1024;
-#pragma unroll
-    for (int i = 0; i < LPT; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[i] + st * 64), (lds_void_t*)(dst + i * NW * 1024), 16, 0, 0);
-  };
-
-  if constexpr (NL > 0) {
-    if (loader) {   // same barrier cadence as the consumers' enter_stage(S), S = 0 .. nk - 1
-#pragma unroll
-      for (int s = 0; s < NB; ++s)
-        if (s < nk) issue(s);
-      for (int S = 0; S < nk; ++S) {
-        if (S + NB - 2 < nk && S >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * LPT) : "memory");
-        else if (S == 0 && NB - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 1) * LPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (S >= 1 && S - 1 + NB < nk) issue(S - 1 + NB);
-      }
-      return;
-    }
-  }
-  const int wm = (wid / WN) * (BM / WM), wn = (wid % WN) * (BN / WN);
-  const int fr = lane & 15, fq = lane >> 4;
-  const int sw = (fr >> 1) & 7;
-  // fragment row r of the X (activation) block sits at byte (wm + 16 r + fr) * 128, of the W block BM * 128 further
-  const int xrow = (wm + fr) * 128, wrow = (BM + wn + fr) * 128;
-  const int ch0 = (fq ^ sw) << 4, ch1 = ((4 + fq) ^ sw) << 4;
-
-  f32x4 acc[NACC][FN][FM];
-#pragma unroll
-  for (int a = 0; a < NACC; ++a)
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-      for (int j = 0; j < FM; ++j) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nu = nk * UPS;
-
-  struct Frags { u32x4 x[FM][NPL]; u32x4 w[FN][NPL]; };
-  constexpr int RPU = (FM + FN) * NPL;   // ds_read_b128 per unit and wave
-  static_assert(RPU <= 15, "lgkmcnt counts to 15");
-  auto read_unit = [&](int u, Frags& f) {
-    const unsigned sb = (unsigned)(((u / UPS) % NB) * STAGE);
-    if constexpr (NPL == 1) {
-      const unsigned ch = sb + ((u & 1) ? ch1 : ch0);
-      lds_read_rows<0, 0, NPL>(f.x, ch + xrow, std::make_integer_sequence<int, FM>{});
-      lds_read_rows<0, 0, NPL>(f.w, ch + wrow, std::make_integer_sequence<int, FN>{});
-    } else {
-      lds_read_rows<0, 0, NPL>(f.x, sb + xrow + ch0, std::make_integer_sequence<int, FM>{});
-      lds_read_rows<0, 1, NPL>(f.x, sb + xrow + ch1, std::make_integer_sequence<int, FM>{});
-      lds_read_rows<0, 0, NPL>(f.w, sb + wrow + ch0, std::make_integer_sequence<int, FN>{});
-      lds_read_rows<0, 1, NPL>(f.w, sb + wrow + ch1, std::make_integer_sequence<int, FN>{});
-    }
-  };
-  auto pin_unit = [&](Frags& f) {   // after a counted wait: the fragments are (re)defined HERE for the scheduler
-#pragma unroll
-    for (int j = 0; j < FM; ++j)
-#pragma unroll
-      for (int c = 0; c < NPL; ++c) pin(f.x[j][c]);
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-      for (int c = 0; c < NPL; ++c) pin(f.w[i][c]);
-  };
-  auto mfma_unit = [&](const Frags& f) {
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        if constexpr (NPL == 1) {
-          Mfma<TI>::run(f.w[i][0], f.x[j][0], acc[0][i][j]);
-        } else {
-          Mfma<f16_t>::run(f.w[i][0], f.x[j][0], acc[0][i][j]);
-          Mfma<f16_t>::run(f.w[i][0], f.x[j][1], acc[1][i][j]);
-          Mfma<f16_t>::run(f.w[i][1], f.x[j][0], acc[1][i][j]);
-        }
-      }
-  };
-  // entering ring stage S (its first unit's fragments are about to be read): retire its DMA, make sure every wave has
-  // finished READING stage S - 1 (its fragments are in registers), then refill that slot with stage S - 1 + NB
-  auto enter_stage = [&](int S) {
-    if constexpr (NL == 0) {
-      if (S + NB - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * LPT) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    lds_wait<0>();
-    __builtin_amdgcn_s_barrier();
-    if constexpr (NL == 0) {
-      if (S >= 1 && S - 1 + NB < nk) issue(S - 1 + NB);
-    }
-  };
-  auto step = [&](int u, Frags& cur, Frags& nxt) {
-    if (u + 1 < nu) {
-      if ((u + 1) % UPS == 0) enter_stage((u + 1) / UPS);
-      read_unit(u + 1, nxt);
-      lds_wait<RPU>();        // everything but the reads just issued: unit u's fragments have landed
-    } else {
-      lds_wait<0>();
-    }
-    pin_unit(cur);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    mfma_unit(cur);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  if constexpr (NL == 0) {
-#pragma unroll
-    for (int s = 0; s < NB; ++s)
-      if (s < nk) issue(s);
-  }
-  Frags fa, fb;
-  enter_stage(0);
-  read_unit(0, fa);
-  for (int u = 0; u < nu; u += 2) {
-    step(u, fa, fb);
-    if (u + 1 < nu) step(u + 1, fb, fa);
-  }
-
-  if constexpr (NPL == 2) {
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-      for (int j = 0; j < FM; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[0][i][j][e] = fmaf(acc[1][i][j][e], MSMD_SPLIT_INV, acc[0][i][j][e]);
-  }
-  if constexpr (NPL == 2 && sizeof(TO) == 2) gemm_epilogue_split<FM, FN>(p, acc[0], z, m0 + wm, n0 + wn, fr, fq);
-  else gemm_epilogue<TO, FM, FN>(p, acc[0], z, m0 + wm, n0 + wn, fr, fq);
-}
-
-template <typename TO, typename TI, int NPL, int BM, int BN, int WM, int WN, int NB, int NL = 0>
-static int launch_gemm3(GemmArgs& p, int batch, hipStream_t st) {
-  constexpr int lds = NB * (BM + BN) * 128;
-  static_assert(lds <= 160 * 1024, "ring does not fit the CU's LDS");
-  static bool attr_done = false;
-  auto kfn = gemm3_kernel<TO, TI, NPL, BM, BN, WM, WN, NB, NL>;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
-  }
-  p.mt = (p.M + BM - 1) / BM; p.nt = (p.N + BN - 1) / BN;
-  int want_xn = 1;
-  if (g_tuning[7] == 1 || g_tuning[7] == 2 || g_tuning[7] == 4) {
-    want_xn = g_tuning[7];
-  } else {
-    const double a_bytes = 2.0 * p.M * (double)(p.rows_per_batch < p.M ? p.lda : p.K * NPL), w_bytes = 2.0 * NPL * p.N * (double)p.K;
-    double best = 1e30;
-    for (int xn = 1; xn <= 4; xn *= 2) {
-      const double c = 0.7 * xn * a_bytes + (8.0 / xn) * w_bytes;
-      if (c < best && p.nt >= xn) { best = c; want_xn = xn; }
-    }
-  }
-  p.xn = p.nt >= want_xn ? want_xn : 1;
-  const int xm_n = 8 / p.xn;
-  dim3 grid(((p.mt + xm_n - 1) / xm_n) * ((p.nt + p.xn - 1) / p.xn) * 8, 1, batch);
-  hipLaunchKernelGGL(kfn, grid, dim3(512 + 64 * NL), lds, st, p);
-  MSMD_RETURN_LAST();
-}
-
-int g_tuning[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // shared with gemm_tn.hip (key 2 = forced contraction splits)
-extern "C" int msmd_set_tuning(int key, int value) {
+#ifdef MSMD_EXPERIMENTAL
+// Developer knobs exist ONLY in the experimental build (make EXP=1 -> libmsmd_hip_exp.so): the product library has no
+// process-global state -- kernel variant and epilogue flags travel per call in `act` (include/msmd_hip.h).
+int g_tuning[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" int msmd_exp_set_tuning(int key, int value) {
   if (key < 0 || key >= 16) return 1;
   g_tuning[key] = value;
   return 0;
 }
+#include "exp/gemm_variants.inc"
+#endif
 
 template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t>
 static int launch_gemm2(GemmArgs& p, int batch, hipStream_t st) {
@@ -907,8 +616,8 @@ static int launch_gemm2(GemmArgs& p, int batch, hipStream_t st) {
   // (the 0.7 fitted on the qkv shape, where 2 x 4 ties with 8 x 1 and both trail 4 x 2).  Forward step, same-graph A/B
   // in both orders: 8 x 1 4.96 ms, 4 x 2 everywhere 4.89, this rule 4.88.  tuning key 7 forces xn = 1 / 2 / 4.
   int want_xn = 1;
-  if (g_tuning[7] == 1 || g_tuning[7] == 2 || g_tuning[7] == 4) {
-    want_xn = g_tuning[7];
+  if (MSMD_TUNE(7) == 1 || MSMD_TUNE(7) == 2 || MSMD_TUNE(7) == 4) {
+    want_xn = MSMD_TUNE(7);
   } else {
     const double a_bytes = 2.0 * p.M * (double)(p.rows_per_batch < p.M ? p.lda : p.K), w_bytes = 2.0 * p.N * (double)p.K;
     double best = 1e30;
@@ -935,8 +644,8 @@ static int launch_gemm2s(GemmArgs& p, int batch, hipStream_t st) {
   }
   p.mt = (p.M + BM - 1) / BM; p.nt = (p.N + BN - 1) / BN;
   int want_xn = 1;
-  if (g_tuning[7] == 1 || g_tuning[7] == 2 || g_tuning[7] == 4) {
-    want_xn = g_tuning[7];
+  if (MSMD_TUNE(7) == 1 || MSMD_TUNE(7) == 2 || MSMD_TUNE(7) == 4) {
+    want_xn = MSMD_TUNE(7);
   } else {   // same cost model as launch_gemm2 (bytes are 4 per logical element here; the ratio is what matters)
     const double a_bytes = 4.0 * p.M * (double)(p.rows_per_batch < p.M ? p.lda / 2 : p.K), w_bytes = 4.0 * p.N * (double)p.K;
     double best = 1e30;
@@ -955,11 +664,12 @@ static int launch_gemm2s(GemmArgs& p, int batch, hipStream_t st) {
 template <typename TO>
 static int dispatch_gemm2s(GemmArgs& p, int batch, hipStream_t st, int variant) {
   switch (variant) {
-    case 1: return launch_gemm2s<TO, 128, 128, 4, 2, 2>(p, batch, st);   // 64 KB
+    case 1: return launch_gemm2s<TO, 128, 128, 4, 2, 2>(p, batch, st);   // 64 KB, 2 workgroups / CU (default)
+    case 5: return launch_gemm2s<TO, 64, 64, 2, 2, 4>(p, batch, st);     // small grids
+#ifdef MSMD_EXPERIMENTAL
     case 2: return launch_gemm2s<TO, 128, 128, 4, 2, 4>(p, batch, st);   // 128 KB, deep ring
     case 3: return launch_gemm2s<TO, 128, 128, 2, 2, 2>(p, batch, st);   // 4 waves of 64 x 64
     case 4: return launch_gemm2s<TO, 256, 128, 4, 2, 3>(p, batch, st);   // 144 KB, 64 x 64 wave tiles
-    case 5: return launch_gemm2s<TO, 64, 64, 2, 2, 4>(p, batch, st);
     case 6: return launch_gemm2s<TO, 128, 64, 2, 2, 3>(p, batch, st);
     case 7: return launch_gemm2s<TO, 64, 128, 2, 2, 3>(p, batch, st);
     case 8: return launch_gemm2s<TO, 128, 128, 2, 2, 4>(p, batch, st);
@@ -969,13 +679,23 @@ static int dispatch_gemm2s(GemmArgs& p, int batch, hipStream_t st, int variant) 
     case 12: return launch_gemm3<TO, f16_t, 2, 128, 128, 4, 2, 3>(p, batch, st);
     case 13: return launch_gemm3<TO, f16_t, 2, 128, 128, 2, 4, 4>(p, batch, st);
     case 14: return launch_gemm3<TO, f16_t, 2, 128, 128, 4, 2, 4, 4>(p, batch, st);   // + 4 loader waves
+#endif
     default: return -1;
   }
 }
 
+// Product variants: 17 = 128 x 128, 8 waves (4 x 2), 2-stage ring, fragment reads of both k-steps issued first (default
+// once the grid fills the chip); 13 = the same tile with the compiler's own read / multiply interleave; 9 / 12 = 64 x 64
+// tiles with a 4- / 2-stage ring for grids that would not fill the chip.  Every other family that was built and measured
+//  lives in exp/gemm_variants.inc and is compiled only with -DMSMD_EXPERIMENTAL.
 template <typename TO>
 static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
   switch (variant) {
+    case 9: return launch_gemm2<TO, 64, 64, 2, 2, 4>(p, batch, st);
+    case 12: return launch_gemm2<TO, 64, 64, 2, 2, 2>(p, batch, st);
+    case 13: return launch_gemm2<TO, 128, 128, 4, 2, 2>(p, batch, st);
+    case 17: return launch_gemm2<TO, 128, 128, 4, 2, 2, true>(p, batch, st);
+#ifdef MSMD_EXPERIMENTAL
     case 1: return launch_gemm2<TO, 128, 128, 2, 2, 2>(p, batch, st);
     case 2: return launch_gemm2<TO, 128, 128, 2, 2, 3>(p, batch, st);
     case 3: return launch_gemm2<TO, 128, 128, 2, 2, 4>(p, batch, st);
@@ -984,15 +704,11 @@ static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
     case 6: return launch_gemm2<TO, 128, 256, 2, 4, 3>(p, batch, st);
     case 7: return launch_gemm2<TO, 64, 128, 1, 4, 4>(p, batch, st);
     case 8: return launch_gemm2<TO, 128, 64, 4, 1, 4>(p, batch, st);
-    case 9: return launch_gemm2<TO, 64, 64, 2, 2, 4>(p, batch, st);
     case 10: return launch_gemm2<TO, 128, 64, 2, 2, 3>(p, batch, st);
     case 11: return launch_gemm2<TO, 64, 128, 2, 2, 3>(p, batch, st);
-    case 12: return launch_gemm2<TO, 64, 64, 2, 2, 2>(p, batch, st);
-    case 13: return launch_gemm2<TO, 128, 128, 4, 2, 2>(p, batch, st);
     case 14: return launch_gemm2<TO, 128, 64, 2, 2, 2>(p, batch, st);
     case 15: return launch_gemm2<TO, 64, 128, 2, 2, 2>(p, batch, st);
     case 16: return launch_gemm2<TO, 128, 128, 2, 4, 2>(p, batch, st);
-    case 17: return launch_gemm2<TO, 128, 128, 4, 2, 2, true>(p, batch, st);
     case 18: return launch_gemm2<TO, 128, 128, 2, 4, 2, true>(p, batch, st);
     case 19: return launch_gemm2<TO, 64, 64, 2, 2, 2, true>(p, batch, st);
     case 20: return launch_gemm2<TO, 64, 64, 2, 2, 4, true>(p, batch, st);
@@ -1013,6 +729,7 @@ static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
     case 34: return launch_gemm3<TO, bf16_t, 1, 256, 128, 4, 2, 3, 4>(p, batch, st);   // + 4 loader waves
     case 35: return launch_gemm3<TO, bf16_t, 1, 128, 128, 4, 2, 4, 4>(p, batch, st);
     case 36: return launch_gemm3<TO, bf16_t, 1, 128, 256, 2, 4, 3, 4>(p, batch, st);
+#endif
     default: return -1;
   }
 }
@@ -1050,6 +767,7 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
                      void* z_out = nullptr, float p_drop = 0.f, const unsigned long* rng = nullptr, unsigned site = 0) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch_inner <= 0 || !A || !W || !C) return 1;
   const int hint = (act >> 8) & 0xff;  // caller-chosen kernel variant (host-side autotune), 0 = heuristic below
+  const int flags = (act >> 16) & 0xff;  // MSMD_GEMM_WRITE_THROUGH / MSMD_GEMM_PAIRED_STORES (include/msmd_hip.h)
   act &= 0xff;
   if (in_dtype == MSMD_F16X2) {
     // split-pair operands: logical sizes in, fp16 strides (x 2) into the kernel; 32-element blocks must stay whole
@@ -1067,7 +785,7 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
     p.inv_rpb = 1.0f / (float)rows_per_batch;
     p.strideA = 2 * strideA; p.strideW = 2 * strideW; p.strideC = strideC; p.strideBias = strideBias; p.strideR = strideR;
     p.batch_inner = batch_inner; p.strideA2 = 2 * strideA2; p.strideW2 = 2 * strideW2; p.strideC2 = strideC2;
-    p.Z = nullptr; p.p_drop = 0.f; p.rng = nullptr; p.site = 0; p.xn = 1;
+    p.Z = nullptr; p.p_drop = 0.f; p.rng = nullptr; p.site = 0; p.xn = 1; p.flags = flags & 1;
     if (out_dtype == MSMD_F16X2) {
       if ((N & 3) || ldc % 32 || strideC % 32 || strideC2 % 32 || (residual && (ldr % 32 || strideR % 32))) return 1;
       if (bias && (((uintptr_t)bias & 15) || (strideBias & 3))) return 1;
@@ -1078,7 +796,7 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
     }
     hipStream_t st = (hipStream_t)stream;
     const int nz = batch * batch_inner;
-    int variant = g_tuning[3] > 0 ? g_tuning[3] : hint;
+    int variant = MSMD_TUNE(3) > 0 ? MSMD_TUNE(3) : hint;
     if (variant == 0) {
       const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nz;
       variant = (N > 64 && tiles128 >= 192) ? 1 : 5;
@@ -1100,25 +818,27 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
   p.inv_rpb = 1.0f / (float)rows_per_batch;
   p.strideA = strideA; p.strideW = strideW; p.strideC = strideC; p.strideBias = strideBias; p.strideR = strideR;
   p.batch_inner = batch_inner; p.strideA2 = strideA2; p.strideW2 = strideW2; p.strideC2 = strideC2;
-  p.Z = z_out; p.p_drop = p_drop; p.rng = rng; p.site = site; p.xn = 1;
+  p.Z = z_out; p.p_drop = p_drop; p.rng = rng; p.site = site; p.xn = 1; p.flags = flags;
   if (p_drop != 0.f && (!(p_drop > 0.f && p_drop < 1.f) || !rng || (N & 3) || ldc != N || batch != 1 || batch_inner != 1))
     return 1;  // the mask index assumes one contiguous (M, N) output
   const int osz = out_dtype == MSMD_F32 ? 4 : 2;
   p.vec_ok = (ldc % 4 == 0) && (strideC % 4 == 0) && (strideC2 % 4 == 0) && (((uintptr_t)C % (4 * osz)) == 0) &&
              (!residual || ((ldr % 4 == 0) && (strideR % 4 == 0) && (((uintptr_t)residual % (4 * osz)) == 0)));
+  if ((p.flags & 2) && (osz != 2 || (ldc % 8) || (strideC % 8) || (strideC2 % 8) || ((uintptr_t)C % 16) || !p.vec_ok))
+    p.flags &= ~2;   // paired stores need 16-byte aligned row pairs
   hipStream_t st = (hipStream_t)stream;
   const int nz = batch * batch_inner;
-  if (in_dtype == MSMD_BF16 && (K % 64) == 0 && g_tuning[0] >= 0) {
+  if (in_dtype == MSMD_BF16 && (K % 64) == 0 && MSMD_TUNE(0) >= 0) {
     // Measured on MI355X (tools/bench_gemm.py): the 128x128 LDS-DMA kernel wins once the grid fills the
     // chip at 2 workgroups per CU; below that, 64x64 tiles (deep ring for long K) keep more CUs busy.
-    int variant = g_tuning[0] ? g_tuning[0] : hint;
+    int variant = MSMD_TUNE(0) ? MSMD_TUNE(0) : hint;
     if (variant == 0) {
       const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nz;
       if (N > 64 && tiles128 >= 192) {
-        variant = g_tuning[4] ? 13 : 17;  // 128x128, 8 waves (4x2), 2-stage ring, 2 workgroups/CU, fragment reads pipelined
+        variant = MSMD_TUNE(4) ? 13 : 17;  // 128x128, 8 waves (4x2), 2-stage ring, 2 workgroups/CU, fragment reads pipelined
         // experiment knobs (tools/ab_graph.py): 5 = variant for M >= 20000 (conv stack), 6 = variant for the rest
-        if (M >= 20000 && g_tuning[5] > 0) variant = g_tuning[5];
-        if (M < 20000 && g_tuning[6] > 0) variant = g_tuning[6];
+        if (M >= 20000 && MSMD_TUNE(5) > 0) variant = MSMD_TUNE(5);
+        if (M < 20000 && MSMD_TUNE(6) > 0) variant = MSMD_TUNE(6);
       }
       else variant = (K >= 1024) ? 9 : 12;
     }
@@ -1126,7 +846,7 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
                                          : dispatch_gemm2<float>(p, nz, st, variant);
     if (r >= 0) return r;
   }
-  if (in_dtype == MSMD_F16 && (out_dtype == MSMD_F16 || out_dtype == MSMD_F32) && (K % 64) == 0 && g_tuning[0] >= 0) {
+  if (in_dtype == MSMD_F16 && (out_dtype == MSMD_F16 || out_dtype == MSMD_F32) && (K % 64) == 0 && MSMD_TUNE(0) >= 0) {
     // fp16 storage: same LDS-DMA kernels with v_mfma_f32_16x16x32_f16 (the heuristic's variants only)
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nz;
     const int variant = (N > 64 && tiles128 >= 192) ? 17 : ((K >= 1024) ? 9 : 12);

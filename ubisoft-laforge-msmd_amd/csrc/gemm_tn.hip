@@ -316,7 +316,10 @@ extern "C" int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsu
   const long tiles = (long)p.nt_n * p.nt_k * batch;
   const int nk = (M + 63) / 64;
   long splits = tn_auto_splits(tiles, (long)N * K);
-  if (g_tuning[2] > 0) splits = g_tuning[2];
+  const int forced = (accumulate >> 8) & 0xff;   // per-call override of the contraction split count (tests, tuning)
+  accumulate &= 1;
+  if (forced > 0) splits = forced;
+  if (MSMD_TUNE(2) > 0) splits = MSMD_TUNE(2);
   splits = max(1L, min(splits, (long)max(1, nk / 4)));
   const long slab = (long)batch * N * K;
   if (!ws) splits = 1;
@@ -329,7 +332,7 @@ extern "C" int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsu
   p.b_wstride = b_window_stride; p.inv_rpw = p.b_rpw ? 1.0f / (float)p.b_rpw : 0.f;
   if (p.b_rpw && ((b_window_stride & 7) || M >= (1 << 24))) return 1;
   p.accumulate = accumulate ? 1 : 0;
-  p.plain_order = g_tuning[1] == 1;
+  p.plain_order = MSMD_TUNE(1) == 1;
   if (p.splits > 1 && colsum && !accumulate) {
     hipError_t e = hipMemsetAsync(colsum, 0, sizeof(float) * N, st);
     if (e != hipSuccess) return (int)e;

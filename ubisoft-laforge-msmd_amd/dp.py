@@ -127,6 +127,11 @@ class GradBucketReducer:
         self.works = []
         self.enabled = True  # set False on gradient-accumulation micro-steps (reference training_script.py:199)
         self.mute = False    # measurement switch (bench.py --mode train): run the step with NO exchange at all
+        # One-GPU rehearsal of the overlapped exchange (tests/test_train_gpu.py, tools/dp_sidestream_check.py): with
+        # world_size 1 there is nothing to reduce, so `standin(view)` -- any in-place, value-preserving device work on the
+        # bucket -- is run on the side stream exactly where the all-reduce would be: same events, same second queue
+        # active under the rest of backward.  None (default) = world 1 launches nothing.
+        self.standin = None
         # Completion tracking that does not depend on autograd hooks alone: every gradient WRITE of a parameter -- an
         # autograd accumulation (hook below) or a kernel that adds straight into the arena view (autograd.GRAD_WRITTEN)
         # -- is noted in order.  `trace_begin()` / `trace_end()` record one backward's write sequence; afterwards
@@ -214,11 +219,11 @@ class GradBucketReducer:
             if w is not None:
                 w.wait()   # NCCL: the CURRENT STREAM waits for the collective (no host block); gloo: host wait
         self.works = []
-        if self.cuda and self.world > 1:
+        if self.cuda and (self.world > 1 or self.standin is not None):
             torch.cuda.current_stream().wait_stream(self.side)
 
     def _launch(self, b):
-        if self.launched[b] or self.world == 1 or self.mute:
+        if self.launched[b] or self.mute or (self.world == 1 and self.standin is None):
             self.launched[b] = True
             return
         self.launched[b] = True
@@ -229,7 +234,10 @@ class GradBucketReducer:
             ev.record(torch.cuda.current_stream())
             self.side.wait_event(ev)
             with torch.cuda.stream(self.side):
-                self.works.append(self.td.all_reduce(view, op=self.td.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.world == 1:
+                    self.standin(view)
+                else:
+                    self.works.append(self.td.all_reduce(view, op=self.td.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self.works.append(self.td.all_reduce(view, op=self.td.ReduceOp.SUM, group=self.group, async_op=True))
 

@@ -159,8 +159,31 @@ def _need_cuda(*ts):
 # bench workload the library's shape heuristic is within run-to-run noise of the tuned choice (5.20 vs 5.22 ms/step).
 GEMM_AUTOTUNE = os.environ.get("MSMD_GEMM_AUTOTUNE", "0") == "1"
 _TUNE_MIN_FLOP = 1.0e9
-_TUNE_CANDIDATES = (13, 16, 15, 14, 9, 12)
+_TUNE_CANDIDATES = (17, 13, 9, 12)
 _TUNED = {}
+# Per-call GEMM knobs (include/msmd_hip.h: MSMD_GEMM_VARIANT / _WRITE_THROUGH / _PAIRED_STORES).  The C library has no
+# global state; these module-level defaults are what `gemm()` passes when the caller gives none (`gemm_defaults`
+# scopes a change, e.g. while a hipGraph is captured -- the choice is then baked into that graph).
+GEMM_WRITE_THROUGH, GEMM_PAIRED_STORES = 1 << 16, 1 << 17
+_GEMM_DEFAULT = {"variant": 0, "flags": 0, "split_variant": 0}
+
+
+class gemm_defaults:
+    """with ops.gemm_defaults(variant=13, flags=ops.GEMM_WRITE_THROUGH): ...   (None = leave as is)"""
+
+    def __init__(self, variant=None, flags=None, split_variant=None):
+        self.new = {k: v for k, v in (("variant", variant), ("flags", flags), ("split_variant", split_variant))
+                    if v is not None}
+
+    def __enter__(self):
+        self.old = dict(_GEMM_DEFAULT)
+        _GEMM_DEFAULT.update(self.new)
+        return self
+
+    def __exit__(self, *exc):
+        _GEMM_DEFAULT.clear()
+        _GEMM_DEFAULT.update(self.old)
+        return False
 
 
 def _autotune_gemm(lib, args, key, out, residual):
@@ -188,7 +211,7 @@ def _autotune_gemm(lib, args, key, out, residual):
 
 def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None, *, M=None, K=None, lda=None,
          rows_per_batch=0, a_batch_stride=0, batch=1, strideA=0, strideW=0, strideC=0, strideBias=0, strideR=0,
-         N=None, ldw=None, ldc=None, z_out=None, p_drop=0.0, rng_state=None, site=0):
+         N=None, ldw=None, ldc=None, z_out=None, p_drop=0.0, rng_state=None, site=0, variant=None, flags=None):
     """C = dropout_p(act(A @ W^T + bias)) + residual (p_drop = 0: no dropout); z_out (like C) receives the
     pre-activation A @ W^T + bias when given (training epilogue, msmd_gemm_ex).  a: (..., K) contiguous unless M/K/lda describe a windowed view;
     w: (N, K) (or (batch, N, K) with strideW).  Returns C with a's leading dims + (N,)."""
@@ -226,9 +249,14 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
     if GEMM_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    if variant is None:
+        variant = _GEMM_DEFAULT["split_variant"] if isinstance(a, Split) else _GEMM_DEFAULT["variant"]
+    flags = _GEMM_DEFAULT["flags"] if flags is None else flags
+    act = act | (variant << 8) | flags
     args = [_p(a), _p(w), _p(bias), _p(residual), _p(out), M, N, K, _dt(a), _dt(out), lda, rows_per_batch,
             a_batch_stride, ldw, ldc, ldr, act, batch, strideA, strideW, strideC, strideBias, strideR, _stream()]
-    if GEMM_AUTOTUNE and a.dtype == torch.bfloat16 and K % 64 == 0 and 2.0 * M * N * K * batch >= _TUNE_MIN_FLOP:
+    if (GEMM_AUTOTUNE and variant == 0 and a.dtype == torch.bfloat16 and K % 64 == 0
+            and 2.0 * M * N * K * batch >= _TUNE_MIN_FLOP):
         key = (M, N, K, batch, out.dtype, act, bias is not None, residual is not None, rows_per_batch > 0, lda, ldc)
         v = _TUNED.get(key)
         if v is None:
@@ -245,16 +273,21 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
     return out
 
 
-def set_tuning(key, value):
-    """msmd_set_tuning: 0 = forced GEMM variant (-1: v1 kernel), 2 = forced contraction splits of gemm_tn (0 = auto)."""
-    _lib.check(_lib.load().msmd_set_tuning(int(key), int(value)), "msmd_set_tuning")
+def exp_set_tuning(key, value):
+    """Developer builds only (make -C csrc EXP=1; MSMD_LIB=.../libmsmd_hip_exp.so): msmd_exp_set_tuning(key, value).
+    The product library has no such switch -- use the per-call `variant` / `flags` / `splits` arguments."""
+    lib = _lib.load()
+    fn = getattr(lib, "msmd_exp_set_tuning", None)
+    if fn is None:
+        raise _lib.MsmdLibraryError("msmd_exp_set_tuning needs the experimental library (make -C csrc EXP=1, MSMD_LIB=...)")
+    _lib.check(fn(int(key), int(value)), "msmd_exp_set_tuning")
 
 
 g_tn_split = True
 
 
 def gemm_tn(a, b, want_colsum=False, *, M=None, N=None, K=None, lda=None, ldb=None, batch=1, strideA=0, strideB=0,
-            b_rows_per_window=0, b_window_stride=0, out=None, colsum_out=None, accumulate=False):
+            b_rows_per_window=0, b_window_stride=0, out=None, colsum_out=None, accumulate=False, splits=0):
     """C (N, K) fp32 = a^T @ b for bf16 a (M, N), b (M, K) (contraction over rows: the weight-gradient product, no
     transposes).  Returns C, or (C, colsum) with colsum[n] = sum_m a[m, n] (the bias gradient) when asked."""
     _need_cuda(a, b)
@@ -275,7 +308,7 @@ def gemm_tn(a, b, want_colsum=False, *, M=None, N=None, K=None, lda=None, ldb=No
     nws = lib.msmd_gemm_tn_workspace(M, N, K, batch) if g_tn_split else 0
     ws = torch.empty(nws, device=a.device, dtype=torch.uint8) if nws > 0 else None
     _lib.check(lib.msmd_gemm_tn(_p(a), _p(b), _p(out), _p(cs), M, N, K, lda, ldb, K, batch, strideA, strideB, N * K,
-                                b_rows_per_window, b_window_stride, int(bool(accumulate)), _p(ws), nws,
+                                b_rows_per_window, b_window_stride, int(bool(accumulate)) | (int(splits) << 8), _p(ws), nws,
                                 _stream()), "msmd_gemm_tn")
     return (out, cs) if (want_colsum or colsum_out is not None) else out
 

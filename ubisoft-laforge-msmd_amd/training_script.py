@@ -550,9 +550,10 @@ class Trainer:
                         gr.capture_begin(pool=self._graph_pool)
 
                 def cut(bucket):
-                    cur[1].append(bucket)
                     if getattr(red, "_last_cut_count", None) == red.write_count:
-                        return                   # several buckets final at the same write: one cut
+                        segs[-1][1].append(bucket)   # several buckets final at the same write: one cut, and they all
+                        return                       # belong to the segment that just closed
+                    cur[1].append(bucket)
                     red._last_cut_count = red.write_count
                     cur[0].capture_end()
                     if self._graph_pool is None:
@@ -574,11 +575,6 @@ class Trainer:
                     red.on_bucket_final, red.final_pos = None, None
                     ag.GRAD_WRITTEN = None
                 torch.cuda.current_stream().wait_stream(cs)
-                # buckets whose cut coincided share the segment that ended there
-                merged = []
-                for gseg, bks in segs:
-                    merged.append((gseg, list(bks)))
-                segs = merged
         ag.TrainNoise.spec_masks = None
         self._invalidate_caches()             # cached casts now live in the graph's pool: eager code must re-make them
         self.reducer.arena.copy_(saved)
