@@ -270,3 +270,29 @@ def test_vertex_space_training_loss_gradients_match_reference_autograd():
             assert np.allclose(got[ok], want[ok], rtol=2e-4, atol=1e-8), (key, got, want)
             err, scale = maxabs(tgd.grad.cpu().numpy(), g["grad_" + key]), np.abs(g["grad_" + key]).max()
             assert err <= 2e-4 * scale, (key, err, scale)
+
+
+def test_training_losses_when_every_sample_is_truncated_to_one_frame():
+    """A starting window whose samples are ALL truncated at end_idx == 1 has no valid row for the velocity / smoothness
+    differences: the reference maps the empty selections to None -> 0 (utils/common.py:389-397), so the accumulated
+    training loss stays finite.  The HIP loss kernels must give 0 for those terms (not NaN), the plain term its usual
+    masked mean, and the backward a finite gradient -- compared with the same function's torch-op branch on CPU."""
+    from msmd_amd import train_graph as tg
+    args = default_args()
+    N = 4
+    gt = synth.normalish("loss1/gt", (N, 100, 67))
+    target = synth.normalish("loss1/target", (N, 110, 67))
+    end_idx = np.ones(N, np.int64)
+    res = {}
+    for where in ("cpu", DEV):
+        t = torch.from_numpy(target).to(where).requires_grad_(True)
+        tup = tg.loss_no_vert_train(args, True, torch.from_numpy(gt).to(where), t, None, torch.from_numpy(end_idx).to(where))
+        total = sum(v for v in tup if v is not None and torch.is_tensor(v))
+        total.backward()
+        res[where] = ([None if v is None else float(v) for v in tup], t.grad.detach().cpu().numpy())
+    (lc, gc), (lg, gg) = res["cpu"], res[DEV]
+    assert all(v is None or np.isfinite(v) for v in lg), lg
+    assert lg[1] == 0.0 and lg[2] == 0.0, lg                   # vel, smooth: empty -> 0
+    for a, b in zip(lc, lg):
+        assert (a is None) == (b is None) and (a is None or abs(a - b) < 2e-6 * max(1.0, abs(a))), (lc, lg)
+    assert np.isfinite(gg).all() and maxabs(gg, gc) < 1e-6

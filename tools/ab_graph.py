@@ -1,4 +1,4 @@
-"""Dev tool: A/B msmd_set_tuning settings on the forward bench step, each captured as its own hipGraph (replay timing
+"""Dev tool: A/B msmd_exp_set_tuning settings on the forward bench step, each captured as its own hipGraph (replay timing
 is stable to ~0.5 %, unlike eager launches)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,14 +14,14 @@ b["time_step"] = torch.tensor(b["time_step"], device="cuda", dtype=torch.long)
 for _ in range(3): bench.step(model, b)
 graphs = {}
 for v in vals:
-    ops.set_tuning(key, v)
+    ops.exp_set_tuning(key, v)
     s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s): bench.step(model, b)
     torch.cuda.current_stream().wait_stream(s); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g): bench.step(model, b)
     graphs[v] = g
-ops.set_tuning(key, 0)
+ops.exp_set_tuning(key, 0)
 res = {v: [] for v in vals}
 for rep in range(5):
     for v in vals:

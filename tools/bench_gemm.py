@@ -31,7 +31,7 @@ for (M, N, K, lda, rpb, abs_, name) in shapes:
     bias = torch.randn(N, device="cuda")
     ref = None
     for v in variants:
-        lib.msmd_set_tuning(0, v)
+        lib.msmd_exp_set_tuning(0, v)
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         kw = dict(M=M, K=K, lda=lda, rows_per_batch=rpb, a_batch_stride=abs_) if rpb else {}
         for _ in range(3):
@@ -54,4 +54,4 @@ for (M, N, K, lda, rpb, abs_, name) in shapes:
         res[(name, v)] = (us, tf, err)
     print(f"{name:8s} M={M:6d} N={N:4d} K={K:4d} | " + " | ".join(
         f"v{v}:{res[(name, v)][1]:6.0f}TF{'' if res[(name, v)][2] < 0.05 else ' ERR%.2g' % res[(name, v)][2]}" for v in variants), flush=True)
-lib.msmd_set_tuning(0, 0)
+lib.msmd_exp_set_tuning(0, 0)

@@ -2,10 +2,10 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-if os.environ.get("TUNE"):   # e.g. TUNE="7=1,6=28": msmd_set_tuning knobs for A/B runs
+if os.environ.get("TUNE"):   # e.g. TUNE="7=1,6=28": msmd_exp_set_tuning knobs for A/B runs
     from msmd_amd import ops as _ops
     for kv in os.environ["TUNE"].split(","):
-        _ops.set_tuning(*(int(v) for v in kv.split("=")))
+        _ops.exp_set_tuning(*(int(v) for v in kv.split("=")))
 from msmd_amd.config import default_args
 from msmd_amd.model import get_diffusion_model
 model = get_diffusion_model(default_args(compute_dtype=os.environ.get("DTYPE", "bf16")), "cuda").eval()

@@ -19,11 +19,26 @@ r_, rep_ = pad_audio_plan(64000)
 def fn(i):
     if which == "feat": return model.extract_audio_feature(bs[i]["audio"])
     if which == "enc": return enc.encode(bs[i]["audio"], 25, frame_num=200, dtype=TD, pad=True).float()
+    if which == "conv0":      # conv0 moments (2 launches) -> stats -> conv0 + GroupNorm + GELU: a 4-kernel chain
+        from msmd_amd import ops
+        return ops.conv0_gn_gelu(bs[i]["audio"], FE["w0"], FE["g"], FE["b"], r_, rep_, torch.bfloat16).float()
+    if which == "stats":
+        from msmd_amd import ops
+        B, L = bs[i]["audio"].shape
+        st = torch.empty(B, 512, 2, device="cuda"); ws = torch.empty(B, ops.CONV0_SPLITS, 66, device="cuda")
+        from msmd_amd import _lib
+        _lib.check(_lib.load().msmd_conv0_stats(bs[i]["audio"].data_ptr(), FE["w0"].data_ptr(), st.data_ptr(), ws.data_ptr(), B, L, r_, rep_, 512, 1e-5,
+                                                torch.cuda.current_stream().cuda_stream), "stats")
+        return st
     if which == "fe_fp":
         x = enc.feature_extractor_cl(bs[i]["audio"], torch.bfloat16, r_, rep_)
         from msmd_amd import ops
         P = enc.pack(torch.bfloat16)
         return ops.gemm(ops.layernorm(x, *P.fp_ln, eps=enc.config.layer_norm_eps), P.fp_w, P.fp_b).float()
+FE = None
+if which in ("conv0", "stats"):
+    _P = enc.pack_fe(torch.bfloat16)
+    FE = dict(w0=_P.w0, g=_P.gn_g, b=_P.gn_b)
 refs = []
 for i in range(2):
     o = fn(i); torch.cuda.synchronize(); refs.append(o.clone())

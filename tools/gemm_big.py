@@ -11,7 +11,7 @@ for (M, N, K) in [(16384, 4096, 3072), (16384, 4096, 768), (32768, 2048, 1024)]:
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     line = []
     for v in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "17,13,21,22,24,25,26,27").split(",")]:
-        lib.msmd_set_tuning(0, v)
+        lib.msmd_exp_set_tuning(0, v)
         for _ in range(3):
             ops.gemm(a, w, bias, None, 1, out=out)
         torch.cuda.synchronize()
@@ -24,4 +24,4 @@ for (M, N, K) in [(16384, 4096, 3072), (16384, 4096, 768), (32768, 2048, 1024)]:
         us = e0.elapsed_time(e1) / 20 * 1e3
         line.append(f"v{v}:{2.0 * M * N * K / us / 1e6:5.0f}TF")
     print(M, N, K, " ".join(line), flush=True)
-lib.msmd_set_tuning(0, 0)
+lib.msmd_exp_set_tuning(0, 0)

@@ -5,7 +5,7 @@ import torch
 from msmd_amd import ops, _lib
 lib = _lib.load()
 V = int(os.environ.get("VARIANT", "17"))
-lib.msmd_set_tuning(0, V)
+lib.msmd_exp_set_tuning(0, V)
 for K in (768, 3072):
     for N in (768,):
         for mt in [int(x) for x in os.environ.get("MT", "21,32,43,50,64,85,86,100,128,171,200").split(",")]:

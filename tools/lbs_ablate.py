@@ -27,17 +27,17 @@ tp = timeit(lambda: ops.lbs_prepare(betas, full_pose, c.JS, c.parents, 192, want
 coef, coef_hl, A, joints, at = ops.lbs_prepare(betas, full_pose, c.JS, c.parents, 192, want_split=True, want_blend_tiles=True)
 print(f"B={B}: prepare {tp*1e3:.1f} us")
 for abl, name in ((0, "full (barrier per 2 tiles)"), (100, "barrier per tile"), (0, "full again"), (100, "per tile again"), (1, "no stores"), (2, "no blend MFMA"), (4, "no blendshape MFMA"), (8, "no DMA"), (7, "no stores/MFMAs"), (15, "nothing")):
-    ops.set_tuning(8, abl)
+    ops.exp_set_tuning(8, abl)
     t = timeit(lambda: ops.lbs_skin_v2(at, B, c.template_planes, c.dirs_hl, c.weight_planes, c.V))
     print(f"  skin_v2 [{name:20s}] {t*1e3:7.1f} us   {B * 60276 / t / 1e6:7.0f} GB/s written")
-ops.set_tuning(8, 0)
-ops.set_tuning(9, 1)
+ops.exp_set_tuning(8, 0)
+ops.exp_set_tuning(9, 1)
 t = timeit(lambda: ops.lbs_skin_v2(at, B, c.template_planes, c.dirs_hl, c.weight_planes, c.V))
 print(f"  skin_v2 [4-wave workgroups, 3 stages] {t*1e3:7.1f} us   {B * 60276 / t / 1e6:7.0f} GB/s written")
-ops.set_tuning(9, 0)
-ops.set_tuning(8, 0)
+ops.exp_set_tuning(9, 0)
+ops.exp_set_tuning(8, 0)
 for xm in (0, 1, 0, 1):
-    ops.set_tuning(10, xm)
+    ops.exp_set_tuning(10, xm)
     t = timeit(lambda: ops.lbs_skin_v2(at, B, c.template_planes, c.dirs_hl, c.weight_planes, c.V))
     print(f"  skin_v2 [xcd map {'slices dealt one by one' if xm else 'adjacent slices per XCD (default)'}] {t*1e3:7.1f} us")
-ops.set_tuning(10, 0)
+ops.exp_set_tuning(10, 0)

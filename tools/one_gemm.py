@@ -5,7 +5,7 @@ import torch
 from msmd_amd import ops, _lib
 lib = _lib.load()
 v, M, N, K, act = (int(x) for x in sys.argv[1:6])
-lib.msmd_set_tuning(0, v)
+lib.msmd_exp_set_tuning(0, v)
 a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
 w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
 bias = torch.randn(N, device="cuda")

@@ -57,8 +57,11 @@ __global__ __launch_bounds__(256) void masked_seq_loss_kernel(const LossArgs p) 
   }
 }
 
-__global__ void loss_finish_kernel(const double* acc, float* out, float scale) {
-  out[0] = acc[1] > 0.0 ? (float)(acc[0] / acc[1] * (double)scale) : nanf("");
+// No valid row: the plain term is the mean of an empty selection (NaN, as torch's); the velocity / smoothness terms are
+// None -> 0 in the reference when every sample is too short for a difference (utils/common.py:571-583), e.g. a window
+// whose samples are all truncated at end_idx == 1.
+__global__ void loss_finish_kernel(const double* acc, float* out, float scale, int empty_is_zero) {
+  out[0] = acc[1] > 0.0 ? (float)(acc[0] / acc[1] * (double)scale) : (empty_is_zero ? 0.f : nanf(""));
 }
 
 extern "C" int msmd_masked_seq_loss(const float* gt, const float* pred, const int* end_idx, float* out, double* acc_ws,
@@ -77,7 +80,7 @@ extern "C" int msmd_masked_seq_loss(const float* gt, const float* pred, const in
   const long want = rows * (long)(c_hi - c_lo) / 4096;
   dim3 grid((unsigned)max((long)1, min(rows, min(max(want, (long)64), (long)4096)))), block(threads);
   hipLaunchKernelGGL(masked_seq_loss_kernel, grid, block, 0, st, p);
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, acc_ws, out, scale);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1), 0, st, acc_ws, out, scale, order > 0 ? 1 : 0);
   MSMD_RETURN_LAST();
 }
 

@@ -50,7 +50,9 @@ class LbsConstants:
         par = parents.to(torch.int32).clone()
         par[0] = -1
         self.parents = par.contiguous()
-
+        # host copy for the python loops of the differentiable pass: reading the device tensor there would be a D2H
+        # sync on every call, and a sync inside a stream capture (Trainer(use_graph=True) + use_vertex_space) kills it
+        self.parents_host = [int(x) for x in par.cpu().tolist()]
 
     def dirs_t(self):
         """(KP, 3 * Vp) fp32: W operand of the backward contraction dcoef = dp . dirs^T (built on first use)."""
@@ -126,7 +128,7 @@ def kinematics_torch(c: LbsConstants, betas, pose):
     eye = torch.eye(3, device=R.device, dtype=R.dtype)
     coef = torch.cat([betas, (R[:, 1:] - eye).reshape(B, (J - 1) * 9),
                       betas.new_zeros(B, KP - betas.shape[1] - (J - 1) * 9)], dim=1)
-    par = [int(x) for x in c.parents.tolist()]
+    par = c.parents_host
     wR, wt = [R[:, 0]], [joints[:, 0]]
     for i in range(1, J):
         pa = par[i]
