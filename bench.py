@@ -365,13 +365,12 @@ def run_legs(device, which="all"):
 def multi_stream_forward(model, a, rank, device, S):
     """S independent 32-clip steps in flight: one captured hipGraph + input buffers + batch per HIP stream, replays issued
     round-robin.  Every step's output (warm-up and timed) is compared ON THE DEVICE, bit for bit, with that batch's
-    one-at-a-time result (three small kernels per step on the step's own stream, inside the timed region).  The bf16 /
-    fp16 GEMM runs its non-pipelined 128x128 schedule (tuning key 0 = 13) here: the pipelined one gave results that
-    differ from serial ones in ~10 % of two-stream runs, this one in 0 of 1 800.
+    one-at-a-time result (three small kernels per step on the step's own stream, inside the timed region).  Round 2 saw
+    10-40 % of two-stream passes differ from serial ones; round 3 traced that to packed-fp32 VALU math (first wrong op: the
+    conv0 + GroupNorm + GELU kernel, low halves of v_pk_* results in lanes 48-63) and the library is now built without it
+    (csrc/Makefile) -- this leg keeps verifying every step.
     -> dict(ms_per_step, frames_per_s, steps, mismatching_streams) or None when capture fails."""
-    from msmd_amd import dp, ops
-    scope = ops.gemm_defaults(variant=13)   # per-call hint, baked into the graphs captured below; restored on exit
-    scope.__enter__()
+    from msmd_amd import dp
     try:
         b0 = synth_batch(a.batch, rank, device)
         for _ in range(2):
@@ -399,15 +398,13 @@ def multi_stream_forward(model, a, rank, device, S):
         bad = [i for i in range(S) if bool(flags[i].item())]
         return dict(streams=S, ms_per_step=round(elapsed / a.steps * 1e3, 3), frames_per_s=round(a.batch * 100 * a.steps / elapsed, 1),
                     steps_verified_bit_equal_to_serial=(a.steps + a.warmup) if not bad else 0, mismatching_streams=bad,
-                    gemm="gemm2_kernel<bf16,128,128,4,2,2> (non-pipelined fragment reads)",
+                    gemm="the single-stream kernels (no special schedule)",
                     launch=f"{S} steps in flight: hipGraph replays round-robin on {S} HIP streams, one graph + input buffers + batch "
                            f"per stream; every step's output compared on the device with its one-at-a-time result inside the timed region")
     except Exception as e:
         print(f"[bench] multi-stream leg unavailable ({type(e).__name__}: {e})", file=sys.stderr)
         torch.cuda.synchronize()
         return None
-    finally:
-        scope.__exit__(None, None, None)
 
 
 # ----------------------------------------------------------------------------------------------- modes

@@ -25,6 +25,39 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert _lib.load().msmd_abi_version() == 1  # host-only call, no GPU needed
 
 
+def test_library_is_stateless_and_has_no_packed_fp32_math(tmp_path):
+    """Two properties of the SHIPPED code object, read from the built library itself:
+    * no process-global tuning switch is exported (the library is re-entrant per stream; kernel variant / epilogue flags
+      travel per call in `act`, include/msmd_hip.h);
+    * no gfx950 kernel contains packed-fp32 VALU math (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): kernels built with
+      it returned wrong low-half results in lanes 48-63 once a second HIP stream was busy (csrc/Makefile).
+    Every code object of the .hip_fatbin section is unbundled and disassembled with the ROCm LLVM tools."""
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    assert not hasattr(lib, "msmd_set_tuning") and not hasattr(lib, "msmd_exp_set_tuning")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(f"{llvm}/llvm-objdump"):
+        pytest.skip("ROCm LLVM tools not present")
+    fat = tmp_path / "fat.bin"
+    subprocess.run([f"{llvm}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", _lib.LIB_PATH, str(tmp_path / "copy.so")], check=True)
+    blob = fat.read_bytes()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [i for i in range(len(blob)) if blob.startswith(magic, i)]
+    assert len(starts) >= 10, "one bundle per csrc/*.hip translation unit expected"
+    n_kernels = n_inst = 0
+    for k, a in enumerate(starts):
+        piece = tmp_path / f"b{k}.bin"
+        piece.write_bytes(blob[a:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+        co = tmp_path / f"b{k}.co"
+        subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        f"--input={piece}", f"--output={co}"], check=True)
+        dis = subprocess.run([f"{llvm}/llvm-objdump", "-d", str(co)], check=True, stdout=subprocess.PIPE, text=True).stdout
+        n_kernels += dis.count(">:\n")
+        n_inst += dis.count("v_mfma_f32")
+        for bad in ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"):
+            assert bad not in dis, f"{bad} in code object {k}: build csrc with the Makefile's NOPK flags"
+    assert n_kernels > 50 and n_inst > 1000      # the disassembly really is the kernels (MFMA GEMMs and all)
+
+
 def test_product_path_fails_loudly_without_gpu_or_library(tmp_path):
     from msmd_amd import ops
     with pytest.raises(RuntimeError, match="no CPU path"):

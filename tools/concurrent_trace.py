@@ -102,6 +102,19 @@ for rep in range(reps):
             print(f"rep {rep} stream {i}: FIRST differing op #{j} {n} shape {tuple(t.shape)} {t.dtype}: {int((d > 0).sum())} elements, "
                   f"max |d| {float(d.max()):.4g} (max |ref| {float(r.float().abs().max()):.3g}); rows {len(rl)} in {len(runs)} runs "
                   f"{runs[:6]}{'...' if len(runs) > 6 else ''}; cols {int(cols.min())}..{int(cols.max())} ({cols.numel()} distinct)", flush=True)
+            if t.dim() == 3:        # detail of the first bad row: which columns, what values, a neighbouring frame's?
+                idx = torch.nonzero(d > 0)
+                b0, t0 = int(idx[0, 0]), int(idx[0, 1])
+                cs = sorted(set(idx[(idx[:, 0] == b0) & (idx[:, 1] == t0)][:, 2].tolist()))
+                print(f"    first bad row (clip {b0}, frame {t0}): columns {cs}")
+                print(f"      got {[round(float(t[b0, t0, x]), 4) for x in cs[:16]]}")
+                print(f"      ref {[round(float(r[b0, t0, x]), 4) for x in cs[:16]]}")
+                for dt in range(-8, 9):
+                    if dt and 0 <= t0 + dt < t.shape[1] and all(float(t[b0, t0, x]) == float(r[b0, t0 + dt, x]) for x in cs):
+                        print(f"      = the reference values of frame {t0 + dt}")
+                per_row = torch.bincount((idx[:, 0] * t.shape[1] + idx[:, 1]) - int((idx[:, 0] * t.shape[1] + idx[:, 1]).min()))
+                per_row = per_row[per_row > 0]
+                print(f"      bad elements per bad row: min {int(per_row.min())} max {int(per_row.max())}; frames mod 64 of bad rows: {sorted(set((idx[:, 1] % 64).tolist()))[:20]}; mod 4: {sorted(set((idx[:, 1] % 4).tolist()))}")
             # how many later ops differ
             later = sum(not torch.equal(t2, r2) for (_, t2), (_, r2) in zip(recs[i][j + 1:], ref_rec[i][j + 1:]))
             print(f"    previous op #{j - 1} {recs[i][j - 1][0] if j else '-'} equal; {later} of {len(recs[i]) - j - 1} later ops differ")
