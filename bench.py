@@ -102,16 +102,18 @@ def event_pair_overhead_us():
     return over[len(over) // 2]
 
 
-def roofline_leg(model, b, mode, steps=3):
+def roofline_leg(model, b, mode, steps=3, run_step=None):
     """Per-launch HIP-event timing of every msmd_gemm launch of `steps` eager steps; the dominant kernel is the
-    128x128-tile kernel of the mode (bf16: gemm2_kernel, f16x2: gemm2s_kernel; fp32: gemm_kernel<float>)."""
+    128x128-tile kernel of the mode (bf16: gemm2_kernel, f16x2: gemm2s_kernel; fp32: gemm_kernel<float>).
+    `run_step` (default: the forward step on batch b) is what gets traced: --mode train passes its eager iteration."""
     from msmd_amd import ops
-    step(model, b)
+    step_fn = run_step or (lambda: step(model, b))
+    step_fn()
     torch.cuda.synchronize()
     overhead = event_pair_overhead_us() * 1e-3   # ms
     ops.GEMM_TRACE = []
     for _ in range(steps):
-        step(model, b)
+        step_fn()
     torch.cuda.synchronize()
     trace, ops.GEMM_TRACE = ops.GEMM_TRACE, None
     flops = ms = big_f = big_ms = 0.0
@@ -198,7 +200,7 @@ def cpu_baseline_leg(B, want_lbs=True):
     # torch's intra-op pool does not scale to every core of a 2-socket host on this path (128 threads ran SLOWER than 16
     # on the EPYC 9575F box): scan thread counts on an 8-clip slice and time the batch at the best one
     scan = {}
-    for thr in [c for c in (8, 16, 32, 64, 128, 256) if c <= ncpu] or [ncpu]:
+    for thr in [c for c in (8, 16, 32, 64) if c <= ncpu] or [ncpu]:   # wider pools only ever ran slower (and cost minutes)
         torch.set_num_threads(thr)
         sl = slice(0, min(8, B))
         scan[thr], _ = med(lambda: tc.msmd_forward(sd, sched, motion[sl], audio[sl], shape[sl], style[sl], ts[:sl.stop],
@@ -225,27 +227,110 @@ def cpu_baseline_leg(B, want_lbs=True):
     return out, target.numpy()
 
 
+def cpu_train_baseline(n=2):
+    """Training-step baseline on the host: forward + backward of BOTH windows of `n` samples through oracle/torch_cpu.py
+    (the torch-CPU fp32 restatement of the reference modules, autograd by torch) with a plain MSE on the predicted
+    sample; the frozen conv feature extractor gets no gradient, as in the reference (model.py:97).  The style encoder,
+    the loss terms and Adam (< 2 % of the step's FLOPs) are left out, which flatters the CPU."""
+    from msmd_amd import shapes, synth
+    from msmd_amd.config import default_args
+    from oracle import diffusion as od, torch_cpu as tc
+    ncpu = os.cpu_count() or 1
+    threads = min(64, ncpu)
+    torch.set_num_threads(threads)
+    args = default_args()
+    sd = tc.to_torch(synth.fill_state_dict(shapes.msmd_shapes(args)))
+    for k, v in sd.items():
+        if v.is_floating_point() and "feature_extractor" not in k:
+            v.requires_grad_(True)
+    sched = od.diffusion_schedule(500, "cosine")
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).float()
+    audio = [t(synth.audio_clips(n, 64000, tag=f"train_r0_it0_a{i}")) for i in range(2)]
+    motion = [t(synth.motion_clips(n, tag=f"train_r0_it0_m{i}")) for i in range(2)]
+    style, eps = t(synth.normalish("bench_style_r0", (n, 256))), t(synth.normalish("bench_eps_r0", (n, 100, 67)))
+    ts = [(37 * i + 11) % 500 + 1 for i in range(n)]
+    shape, ind = torch.zeros(n, 100), torch.ones(n, 100)
+
+    fwd = getattr(tc.msmd_forward, "__wrapped__", tc.msmd_forward)   # the oracle's forward without its no_grad wrapper
+
+    def it():
+        for v in sd.values():
+            v.grad = None
+        loss = 0.0
+        for w in range(2):
+            _, target, _ = fwd(sd, sched, motion[w], audio[w], shape, style, ts, eps, ind)
+            loss = loss + ((target[:, -100:] - motion[w]) ** 2).mean()
+        loss.backward()
+    it()
+    tt = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        it()
+        tt.append(time.perf_counter() - t0)
+    dt = sorted(tt)[1]
+    return dict(value=round(n * 200 / dt, 1), unit="frames/s", cores=int(threads), kind="port",
+                sample=f"oracle/torch_cpu.py forward + torch-autograd backward of both windows of {n} samples (conv feature "
+                       f"extractor frozen; no style encoder / loss terms / Adam: < 2 % of the FLOPs): median of 3 = {dt:.2f} s; "
+                       f"host {ncpu} logical CPUs, {threads} torch threads")
+
+
 # ----------------------------------------------------------------------------------------------- legs (other configs)
-def leg_sampler(device, B=64, T=500, dtype="fp16"):
-    from msmd_amd import synth
+class _LazyNoise:
+    """noise[t] for the sampler's injected-noise path: the SAME pseudo-random tensor for a given (seed, t) whoever asks."""
+
+    def __init__(self, shape, device, seed):
+        self.shape, self.device, self.seed = shape, device, seed
+
+    def __getitem__(self, t):
+        g = torch.Generator(device=self.device).manual_seed(self.seed * 1000003 + int(t))
+        return torch.randn(self.shape, generator=g, device=self.device)
+
+
+def leg_sampler(device, B=64, T=500):
+    """configs[4]: sample() B=64, T=500, 3 CFG entries.  Timed in fp16 storage (the config's dtype) AND in the parity-grade
+    f16x2 mode, each as hipGraph replays; `mfma_frac` divides the reference-NOMINAL FLOPs (3 x 7.886 GFLOP per sequence and
+    step) by the time, `mfma_frac_executed` the FLOPs of the GEMMs the loop actually launches (the diagonal
+    cross-attention fast path and the hoisted step-invariant work remove ~30 % of the nominal ones); `fp16_vs_f16x2` is the
+    drift of the fp16 sampler against the f16x2 one over all 500 steps under IDENTICAL injected noise (eager loops)."""
+    from msmd_amd import ops, synth
     from msmd_amd.config import default_args
     from msmd_amd.model import get_diffusion_model
-    model = get_diffusion_model(default_args(compute_dtype=dtype), device).eval()
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
     af, style = t(synth.normalish("leg_samp_af", (B, 100, 512))), t(synth.normalish("leg_samp_style", (B, 256)))
     shape, ind = torch.zeros(B, 100, device=device), torch.ones(B, 100, device=device)
-    model.sample(af, shape, style, indicator=ind, cfg_scale=1.15)      # warm-up: packs, captures the step graph
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    x0, _, _ = model.sample(af, shape, style, indicator=ind, cfg_scale=1.15)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tf = B * 3 * DENOISER_FLOP * T / dt / 1e12
-    out = dict(config=f"configs[4]: sample() B={B}, T={T} DDPM steps x 3 CFG entries, {dtype}, one hipGraph replay per step",
-               ms_per_step=round(dt / T * 1e3, 3), frames_per_s=round(B * 100 / dt, 1), tflops=round(tf, 1),
-               mfma_frac=round(tf / PEAK_MFMA_TFLOPS, 4), finite=bool(torch.isfinite(x0).all()))
-    del model
-    return out
+    xT = t(synth.normalish("leg_samp_xT", (B, 100, 67)))
+    noise = _LazyNoise((B, 100, 67), device, 77)
+    out, x0 = {}, {}
+    for dtype in ("fp16", "f16x2"):
+        model = get_diffusion_model(default_args(compute_dtype=dtype), device).eval()
+        model.sample(af, shape, style, indicator=ind, cfg_scale=1.15)      # warm-up: packs, captures the step graph
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x, _, _ = model.sample(af, shape, style, indicator=ind, cfg_scale=1.15)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ops.GEMM_FLOPS = [0.0]
+        xe, _, _ = model.sample(af, shape, style, motion_at_T=xT, indicator=ind, cfg_scale=1.15, noise=noise)   # eager, injected noise
+        torch.cuda.synchronize()
+        executed, ops.GEMM_FLOPS = ops.GEMM_FLOPS[0], None
+        x0[dtype] = xe.float()
+        tf = B * 3 * DENOISER_FLOP * T / dt / 1e12
+        out[dtype] = dict(config=f"configs[4]: sample() B={B}, T={T} DDPM steps x 3 CFG entries, {dtype}, one hipGraph replay per step",
+                          ms_per_step=round(dt / T * 1e3, 3), frames_per_s=round(B * 100 / dt, 1), tflops_nominal=round(tf, 1),
+                          mfma_frac=round(tf / PEAK_MFMA_TFLOPS, 4),
+                          gemm_tflop_executed_per_call=round(executed / 1e12, 2),
+                          mfma_frac_executed=round(executed / dt / 1e12 / PEAK_MFMA_TFLOPS, 4),
+                          finite=bool(torch.isfinite(x).all() and torch.isfinite(xe).all()))
+        del model
+        torch.cuda.empty_cache()
+    r = out["fp16"]
+    r["f16x2"] = {k: out["f16x2"][k] for k in ("ms_per_step", "frames_per_s", "mfma_frac", "mfma_frac_executed", "finite")}
+    r["f16x2"]["note"] = "parity-grade mode (fp32-grade contractions: three f16 MFMAs per product); mfma_frac counts algorithmic FLOPs"
+    r["fp16_vs_f16x2"] = dict(max_abs_x0=float((x0["fp16"] - x0["f16x2"]).abs().max()),
+                              rms_x0=float((x0["fp16"] - x0["f16x2"]).pow(2).mean().sqrt()),
+                              max_abs_ref=float(x0["f16x2"].abs().max()),
+                              sample=f"x_0 after all {T} steps, same x_T and the same injected noise at every step, all {B} sequences")
+    return r
 
 
 def leg_lbs(device, frames_list=(6400, 25600)):
@@ -276,7 +361,28 @@ def leg_lbs(device, frames_list=(6400, 25600)):
         gbs = n * LBS_BYTES_PER_FRAME / ms / 1e6
         out[f"lbs_{n}"] = dict(ms=round(ms, 4), frames_per_s=round(n / ms * 1e3), gb_per_s=round(gbs, 1),
                                hbm_frac=round(gbs / PEAK_HBM_GBS, 4), precision=fl.lbs_precision or "bf16x3 (split-bf16 MFMA, fp32 accumulate)",
-                               bytes_per_frame=LBS_BYTES_PER_FRAME)
+                               bytes_per_frame=LBS_BYTES_PER_FRAME,
+                               inputs="shape = 0 for every frame (SURVEY 8d): the one-subject fold of msmd_flame_prepare")
+    # the general path the reference's lbs() computes (utils/lbs.py:185): a different shape vector per frame
+    n = frames_list[-1]
+    g = torch.Generator(device="cpu").manual_seed(n + 1)
+    exp = (0.5 * torch.randn(n, 50, generator=g)).to(device)
+    pose = (0.2 * torch.randn(n, 6, generator=g)).to(device)
+    shape = (0.3 * torch.randn(n, 100, generator=g)).to(device)
+    for _ in range(3):
+        fl(shape, exp, pose, return_lm2d=False, return_lm3d=False)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        fl(shape, exp, pose, return_lm2d=False, return_lm3d=False)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    gbs = n * (LBS_BYTES_PER_FRAME + 400) / ms / 1e6
+    out[f"lbs_{n}_per_frame_shape"] = dict(ms=round(ms, 4), frames_per_s=round(n / ms * 1e3), gb_per_s=round(gbs, 1),
+                                           hbm_frac=round(gbs / PEAK_HBM_GBS, 4), bytes_per_frame=LBS_BYTES_PER_FRAME + 400,
+                                           inputs="a different 100-d shape vector per frame: all 66 MFMAs per tile (no fold)")
     return out
 
 
@@ -475,7 +581,13 @@ def run_forward(a, rank, world, device):
                 print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
                 torch.cuda.synchronize()
         elapsed = dp.timed_steps(run, a.steps, a.warmup, sync=torch.cuda.synchronize, device=device)
+        if launch != "eager" and max(1, a.streams) == 1:
+            # the object that was TIMED (the hipGraph replay), not only the eager step before it, goes to the checker
+            o = run()
+            torch.cuda.synchronize()
+            replay_target[mode] = o[1].float().cpu().numpy()
         return elapsed, launch, target, single_ms
+    replay_target = {}
     elapsed, launch, target, single_ms = timed(a.dtype)
     if rank != 0:
         return None
@@ -502,6 +614,10 @@ def run_forward(a, rank, world, device):
         out["cpu_baseline"], ref = cpu_baseline_leg(a.batch)
     err = lambda t: None if ref is None else float(np.abs(t - ref).max())
     out["max_abs_err_vs_oracle"] = err(target)
+    if a.dtype in replay_target:
+        out["replay_checked_vs_oracle"] = dict(max_abs_err=err(replay_target[a.dtype]),
+                                               equals_eager_step_bitwise=bool(np.array_equal(replay_target[a.dtype], target)),
+                                               what="output of one more replay of the TIMED hipGraph, after the timed region")
     out["tolerance"] = "reference parity bound: 1e-4 max-abs on the motion coefficients (north_star); see parity_mode"
     if not a.no_roofline:
         out["roofline"] = roofline_leg(model, b, a.dtype)
@@ -515,6 +631,8 @@ def run_forward(a, rank, world, device):
                        end_to_end_tflops=round(a.batch * 100 * a.steps / el * FLOP_PER_FRAME / 1e12, 1))
             if ent["max_abs_err_vs_oracle"] is not None:
                 ent["meets_1e-4"] = bool(ent["max_abs_err_vs_oracle"] < 1e-4)
+            if mode in replay_target:
+                ent["replay_max_abs_err_vs_oracle"] = err(replay_target[mode])
             if not a.no_roofline:
                 ent["roofline"] = roofline_leg(model, b, mode)
             pm.append(ent)
@@ -568,6 +686,16 @@ def run_train(a, rank, world, device):
         extra = dict(allreduce_ms=round(ar * 1e3, 3), step_without_exchange_ms=round(solo * 1e3, 3),
                      overlap_frac=round(max(0.0, min(1.0, 1.0 - exposed / ar)), 3) if ar > 0 else None,
                      gradient_bytes=int(tr.reducer.arena.numel() * 4), buckets=len(tr.reducer.buckets))
+    roof = None
+    if not a.no_roofline:
+        # dominant kernel of the iteration (the 128 x 128 forward / data-gradient GEMM: ~27 % of the step's GPU time),
+        # per-launch HIP events on an EAGER iteration of the same trainer (the timed one replays hipGraphs)
+        was = (tr.use_graph, tr.direct_grad)
+        tr.use_graph, tr.direct_grad = False, tr.reducer.world == 1
+        try:
+            roof = roofline_leg(None, None, "bf16", steps=1, run_step=lambda: tr.step(batch, it=1))
+        finally:
+            tr.use_graph, tr.direct_grad = was
     if rank != 0:
         return None
     value = a.batch * 200 * a.steps * world / elapsed
@@ -583,7 +711,19 @@ def run_train(a, rank, world, device):
         "end_to_end_tflops": round(value / 200 * TRAIN_FLOP_PER_SAMPLE / 1e12 / world, 1),
     }
     out.update(extra)
+    if roof is not None:
+        roof["note"] = ("dominant kernel of the training iteration = the forward / data-gradient GEMM (msmd_gemm; the weight-gradient "
+                        "product is msmd_gemm_tn); launches traced on one eager iteration. " + roof["note"])
+        out["roofline"] = roof
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_train_baseline()
     return out
+
+
+def spawn_command(a, argv, port):
+    """The launcher line of `--gpus N` (exactly what the driver would run itself)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr",
+            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def spawn(a, argv):
@@ -595,9 +735,7 @@ def spawn(a, argv):
     s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    p = subprocess.run(spawn_command(a, argv, port), env=env, stdout=subprocess.PIPE, text=True)
     line = None
     for ln in p.stdout.splitlines():
         if ln.startswith("{") and '"metric"' in ln:

@@ -37,14 +37,21 @@ def _interp(x, out_len):
     return (1.0 - w1) * x[:, torch.from_numpy(i0)] + w1 * x[:, torch.from_numpy(i1)]
 
 
-def audio_encoder(sd, audio_padded, output_fps=25, frame_num=None, n_heads=12, prefix="audio_encoder."):
-    """oracle.audio_encoder.audio_encoder (post-LN base encoders) on torch ops; activations (B, C, T) inside the conv
-    stack as the reference's HF modules keep them, (B, T, C) afterwards."""
+def audio_encoder(sd, audio_padded, output_fps=25, frame_num=None, n_heads=12, prefix="audio_encoder.",
+                  stable_layer_norm=False):
+    """oracle.audio_encoder.audio_encoder on torch ops; activations (B, C, T) inside the conv stack as the reference's HF
+    modules keep them, (B, T, C) afterwards.  Base checkpoints: GroupNorm conv stack + post-LN layers; large ones
+    (read off the state dict / `stable_layer_norm`): conv bias + LayerNorm over channels after every conv, pre-LN layers
+    and ONE LayerNorm after the last (HubertEncoderStableLayerNorm; reference utils/hubert.py:13-51)."""
     fe = f"{prefix}feature_extractor.conv_layers."
+    layer_mode = (fe + "1.layer_norm.weight") in sd
     x = audio_padded[:, None, :]
     for i, (k, s) in enumerate(zip(CONV_KERNEL, CONV_STRIDE)):
         x = F.conv1d(x, sd[f"{fe}{i}.conv.weight"], sd.get(f"{fe}{i}.conv.bias"), stride=s)
-        if i == 0:
+        if layer_mode:
+            x = F.layer_norm(x.transpose(1, 2), (x.shape[1],), sd[f"{fe}{i}.layer_norm.weight"],
+                             sd[f"{fe}{i}.layer_norm.bias"], 1e-5).transpose(1, 2)
+        elif i == 0:
             x = F.group_norm(x, x.shape[1], sd[f"{fe}0.layer_norm.weight"], sd[f"{fe}0.layer_norm.bias"], 1e-5)
         x = F.gelu(x)
     x = x.transpose(1, 2)
@@ -66,24 +73,34 @@ def audio_encoder(sd, audio_padded, output_fps=25, frame_num=None, n_heads=12, p
     pos = F.conv1d(x.transpose(1, 2), w, sd[base + "bias"], padding=64, groups=16)[:, :, :x.shape[1]].transpose(1, 2)
     x = x + F.gelu(pos)
     d = x.shape[-1]
-    x = F.layer_norm(x, (d,), sd[f"{prefix}encoder.layer_norm.weight"], sd[f"{prefix}encoder.layer_norm.bias"], 1e-5)
     B, T, _ = x.shape
     hd = d // n_heads
+
+    def attn(p, h):
+        q = F.linear(h, sd[p + "attention.q_proj.weight"], sd[p + "attention.q_proj.bias"]).view(B, T, n_heads, hd).transpose(1, 2)
+        k = F.linear(h, sd[p + "attention.k_proj.weight"], sd[p + "attention.k_proj.bias"]).view(B, T, n_heads, hd).transpose(1, 2)
+        v = F.linear(h, sd[p + "attention.v_proj.weight"], sd[p + "attention.v_proj.bias"]).view(B, T, n_heads, hd).transpose(1, 2)
+        a = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, T, d)
+        return F.linear(a, sd[p + "attention.out_proj.weight"], sd[p + "attention.out_proj.bias"])
+
+    def ffn(p, h):
+        return F.linear(F.gelu(F.linear(h, sd[p + "feed_forward.intermediate_dense.weight"],
+                                        sd[p + "feed_forward.intermediate_dense.bias"])),
+                        sd[p + "feed_forward.output_dense.weight"], sd[p + "feed_forward.output_dense.bias"])
+    ln = lambda h, key: F.layer_norm(h, (d,), sd[key + ".weight"], sd[key + ".bias"], 1e-5)
+    if not stable_layer_norm:
+        x = ln(x, f"{prefix}encoder.layer_norm")
     i = 0
     while f"{prefix}encoder.layers.{i}.attention.q_proj.weight" in sd:
         p = f"{prefix}encoder.layers.{i}."
-        q = F.linear(x, sd[p + "attention.q_proj.weight"], sd[p + "attention.q_proj.bias"]).view(B, T, n_heads, hd).transpose(1, 2)
-        k = F.linear(x, sd[p + "attention.k_proj.weight"], sd[p + "attention.k_proj.bias"]).view(B, T, n_heads, hd).transpose(1, 2)
-        v = F.linear(x, sd[p + "attention.v_proj.weight"], sd[p + "attention.v_proj.bias"]).view(B, T, n_heads, hd).transpose(1, 2)
-        a = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, T, d)
-        a = F.linear(a, sd[p + "attention.out_proj.weight"], sd[p + "attention.out_proj.bias"])
-        x = F.layer_norm(x + a, (d,), sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"], 1e-5)
-        f = F.linear(F.gelu(F.linear(x, sd[p + "feed_forward.intermediate_dense.weight"],
-                                     sd[p + "feed_forward.intermediate_dense.bias"])),
-                     sd[p + "feed_forward.output_dense.weight"], sd[p + "feed_forward.output_dense.bias"])
-        x = F.layer_norm(x + f, (d,), sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"], 1e-5)
+        if stable_layer_norm:      # pre-LN (HubertEncoderLayerStableLayerNorm)
+            x = x + attn(p, ln(x, p + "layer_norm"))
+            x = x + ffn(p, ln(x, p + "final_layer_norm"))
+        else:                      # post-LN
+            x = ln(x + attn(p, x), p + "layer_norm")
+            x = ln(x + ffn(p, x), p + "final_layer_norm")
         i += 1
-    return x
+    return ln(x, f"{prefix}encoder.layer_norm") if stable_layer_norm else x
 
 
 def extract_audio_feature(sd, audio, fps=25, frame_num=100):
@@ -174,6 +191,32 @@ def denoise_step(sd, x, audio_feat, shape_feat, style_feat, t, indicator, n_entr
     rep = lambda v: torch.cat([v] * n_entries, 0)
     return denoising_net(sd, rep(x), audio_in, person_in, rep(style_feat), rep(sd["start_motion_feat"].expand(B, -1, -1)),
                          rep(sd["start_audio_feat"].expand(B, -1, -1)), torch.full((B * n_entries,), int(t)), rep(indicator))
+
+
+@torch.no_grad()
+def sample(sd, sched, audio_feat, shape_feat, style_feat, motion_at_T, z_list, indicator, cfg_scale=1.15, n_motions=100):
+    """oracle.diffusion.sample for the reference's default inference configuration (model.py:283-440: incremental CFG
+    over [audio, style] -> entries [null, audio, audio + style], target = 'sample', start tokens as the previous window,
+    flexibility 0) on torch ops; `z_list[t]` is the draw used at step t (t = T .. 2; step 1 uses zeros).  The head of
+    entry 0 is accumulated in place as in the reference (model.py:407-415); in incremental mode entry 0 is only read
+    before its first update, so this equals the textbook sum."""
+    T = sched["betas"].shape[0] - 1
+    x = motion_at_T.clone()
+    f32 = lambda v: torch.tensor(float(v), dtype=torch.float32)
+    scales = [cfg_scale, cfg_scale] if not isinstance(cfg_scale, (list, tuple)) else list(cfg_scale)
+    for t in range(T, 0, -1):
+        z = z_list[t].float() if t > 1 else torch.zeros_like(x)
+        alpha, ab, abp = f32(sched["alphas"][t]), f32(sched["alpha_bars"][t]), f32(sched["alpha_bars"][t - 1])
+        sigma = f32(sched["sigmas_inflex"][t])
+        res = denoise_step(sd, x, audio_feat, shape_feat, style_feat, t, indicator, n_entries=3)
+        e = [r.clone() for r in res.chunk(3, dim=0)]
+        theta = e[0][:, -n_motions:]                      # a VIEW of entry 0, accumulated in place
+        theta += f32(scales[0]) * (e[1][:, -n_motions:] - e[0][:, -n_motions:])
+        theta += f32(scales[1]) * (e[2][:, -n_motions:] - e[1][:, -n_motions:])
+        c0 = (1 - abp) * torch.sqrt(alpha) / (1 - ab)
+        c1 = (1 - alpha) * torch.sqrt(abp) / (1 - ab)
+        x = c0 * x + c1 * theta + sigma * z
+    return x
 
 
 class FlameTorch:

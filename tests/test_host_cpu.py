@@ -396,3 +396,37 @@ def test_window_plan_edge_lengths():
         n_pad = 64000 * n_sub - S
         got = window_plan(S, 25, 100, 640.0)
         assert (got[0], got[2], got[3], got[4]) == (clip_len, n_sub, n_pad, math.ceil(n_pad / 640.0)), S
+
+
+def test_bench_spawn_builds_the_launcher_line_and_relays_rank0(monkeypatch, capsys):
+    """`python bench.py --gpus N` without WORLD_SIZE starts the ranks itself, from a process that has not touched the GPU:
+    the command is the driver's own launcher line (torch.distributed.run, 127.0.0.1, one rank per GPU, this file + the
+    original arguments), HSA_ENABLE_IPC_MODE_LEGACY=0 is kept in the environment, rank 0's JSON line is relayed on stdout
+    and everything else goes to stderr."""
+    import argparse
+    import bench
+    seen = {}
+
+    class P:
+        returncode = 0
+        stdout = 'warming up\n{"metric": "FLAME frames/sec", "value": 1.0, "n_gpus": 4}\nbye\n'
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return P()
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    argv = ["--gpus", "4", "--mode", "train", "--steps", "7"]
+    rc = bench.spawn(argparse.Namespace(gpus=4), argv)
+    cmd = seen["cmd"]
+    assert rc == 0 and cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == argv
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    out, err = capsys.readouterr()
+    assert out.strip() == '{"metric": "FLAME frames/sec", "value": 1.0, "n_gpus": 4}'
+    assert "warming up" in err and "bye" in err
+    cmd2 = bench.spawn_command(argparse.Namespace(gpus=2), ["--gpus", "2"], 29511)
+    assert cmd2[3:7] == ["--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1"]

@@ -552,3 +552,58 @@ def test_two_streams_in_one_process_reproduce_the_serial_result_bit_for_bit(dtyp
         torch.cuda.synchronize()
         bad += [(rep, i, int((outs[i] != refs[i]).sum())) for i in range(2) if not torch.equal(outs[i], refs[i])]
     assert not bad, bad[:6]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "f16x2"])
+def test_hubert_large_full_depth_10s_against_torch_cpu_restatement(dtype):
+    """BASELINE configs[3] at FULL size: all 24 layers of the HuBERT-large architecture (1024 wide, 16 heads, LayerNorm
+    conv stack), B = 2 x 10 s clips, in both parity-grade modes against oracle/torch_cpu.py (the torch-CPU restatement
+    pinned to the reference wrapper's 2-layer golden by tests/test_oracle_vs_golden.py) on one clip: < 1e-4 on the final
+    LayerNorm-ed hidden states of all 500 frames; the second clip is checked for batch-independence."""
+    from oracle import torch_cpu as tc
+    from oracle import audio_encoder as oae
+    model, args = get_model("hubert_large", dtype, n_motions=250)
+    enc = model.audio_encoder
+    assert enc.config.num_hidden_layers == 24
+    audio = synth.audio_clips(2, 160000, tag="hl_full")
+    h = enc.encode(dev(audio), 25, frame_num=500, dtype=torch.float32, pad=True)
+    h1 = enc.encode(dev(audio[1:]), 25, frame_num=500, dtype=torch.float32, pad=True)
+    torch.cuda.synchronize()
+    assert h.shape == (2, 500, 1024)
+    sd = {"audio_encoder." + k: v.detach().float().cpu() for k, v in enc.state_dict().items()}
+    torch.set_num_threads(min(32, torch.get_num_threads() or 8))
+    ref = tc.audio_encoder(sd, torch.from_numpy(oae.pad_audio(audio[:1])), 25, frame_num=500, n_heads=16,
+                           stable_layer_norm=True).numpy()
+    err = maxabs(h[:1].float().cpu().numpy(), ref)
+    print(f"hubert-large 24 layers, {dtype}: max-abs-err vs torch-CPU {err:.3g}")
+    assert err < 1e-4
+    assert maxabs(h[1:].float().cpu().numpy(), h1.float().cpu().numpy()) < 2e-5      # rows do not depend on their batch
+
+
+def test_sampler_b64_t20_f16x2_against_torch_cpu_sampler():
+    """BASELINE configs[4]'s batch (B = 64, 3 CFG entries = 192 sequences per step) through sample() in the parity-grade
+    f16x2 mode, T = 20 steps, x_T and the noise of every step injected, against oracle/torch_cpu.sample (pinned to the
+    numpy sampler / g3_sample) run on rows 0 and 63 of the SAME inputs: < 1e-4 on x_0.  Then the hipGraph loop (device
+    noise) on the same batch: finite, and its first-row statistics stay in the range of the injected-noise run."""
+    from oracle import diffusion as od, torch_cpu as tc
+    B, T = 64, 20
+    model, args = get_model("wav2vec2", "f16x2", n_diff_steps=T)
+    af = synth.normalish("s64/af", (B, 100, 512))
+    style, xT = synth.normalish("s64/style", (B, 256)), synth.normalish("s64/xT", (B, 100, 67))
+    shape, ind = np.zeros((B, 100), np.float32), np.ones((B, 100), np.float32)
+    zs = {t: synth.normalish(f"s64/z{t}", (B, 100, 67)) for t in range(2, T + 1)}
+    x0, _, _ = model.sample(dev(af), dev(shape), dev(style), motion_at_T=dev(xT), indicator=dev(ind), cfg_scale=1.15,
+                            noise={t: dev(z) for t, z in zs.items()})
+    torch.cuda.synchronize()
+    rows = [0, 63]
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()
+    ref = tc.sample(sd, od.diffusion_schedule(T, "cosine"), t(af[rows]), t(shape[rows]), t(style[rows]), t(xT[rows]),
+                    {k: t(v[rows]) for k, v in zs.items()}, t(ind[rows]), cfg_scale=1.15).numpy()
+    err = maxabs(x0[rows].float().cpu().numpy(), ref)
+    print(f"sample() B=64 T=20 f16x2: max-abs-err vs torch-CPU sampler on rows {rows}: {err:.3g} (|x0| max {np.abs(ref).max():.3g})")
+    assert err < 1e-4
+    xg, _, _ = model.sample(dev(af), dev(shape), dev(style), motion_at_T=dev(xT), indicator=dev(ind), cfg_scale=1.15)
+    torch.cuda.synchronize()
+    assert xg.shape == (B, 100, 67) and bool(torch.isfinite(xg).all())
+    assert float(xg.abs().max()) < 4 * float(x0.abs().max()) + 1.0

@@ -344,6 +344,22 @@ def test_torch_cpu_restatement_matches_reference_goldens():
                             rep(np.broadcast_to(sd["start_audio_feat"], (B, 10, 512))), np.full(3 * B, 250),
                             rep(x["indicator"]))
     assert maxabs(got, want) <= 1e-4
+    # the whole sampler loop (default inference configuration) vs the numpy oracle's, which test_sampler pins to g3_sample
+    T = 4
+    sch = od.diffusion_schedule(T, "cosine")
+    xT = synth.normalish("tc/xT", (B, 100, 67))
+    zs = {tt: synth.normalish(f"tc/z{tt}", (B, 100, 67)) for tt in range(2, T + 1)}
+    want = od.sample(sd, sch, x["audio_feat"], x["shape"], x["style"], xT, zs, indicator=x["indicator"], cfg_scale=1.15)
+    got = tc.sample(tsd, sch, t(x["audio_feat"]), t(x["shape"]), t(x["style"]), t(xT), {k: t(v) for k, v in zs.items()},
+                    t(x["indicator"]), cfg_scale=1.15).numpy()
+    assert maxabs(got, want) <= 1e-4
+    # HuBERT-large architecture (LayerNorm conv stack, pre-LN layers) through the torch restatement vs the reference golden
+    from helpers import hubert_large_state_dict
+    gl = load_golden("g3_audio_hubert_large")
+    hsd = hubert_large_state_dict()
+    a10 = synth.audio_clips(1, 160000, tag="audio10s")
+    h = tc.audio_encoder(tc.to_torch(hsd), t(oa.pad_audio(a10)), 25, frame_num=500, n_heads=16, stable_layer_norm=True).numpy()
+    assert h.shape == (1, 500, 1024) and maxabs(h[:, ::2, ::3], gl["hidden_10s"]) <= 1e-4
     # FLAME vertices
     gf = load_golden("g4_flame")
     fo = ofl.FlameOracle(synth.flame_asset())

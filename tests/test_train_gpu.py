@@ -468,7 +468,7 @@ def test_backward_with_the_side_stream_busy_equals_backward_alone(use_graph, mon
     from msmd_amd.style_encoder import get_style_encoder
     from msmd_amd.training_script import Trainer, synthetic_batch
     monkeypatch.setenv("MSMD_SEGMENT_GRAPHS", "1")
-    args = default_args(compute_dtype="bf16", encoder_layers=3, n_layers=2, lr=1e-4, warm_iter=0,
+    args = default_args(compute_dtype="bf16", encoder_layers=3, n_layers=2, lr=2e-5, warm_iter=0,
                         gradient_accumulation_steps=1)
     B, steps = 8, (200 if use_graph else 24)
     torch.manual_seed(0)
@@ -515,7 +515,8 @@ def test_backward_with_the_side_stream_busy_equals_backward_alone(use_graph, mon
         n0 = len(launched)
         o2 = fwd_bwd(batch, draws)
         assert len(launched) - n0 == len(red.buckets)            # every bucket went through the side stream once
-        assert abs(float(o1["loss"]) - float(o2["loss"])) <= 1e-6 * max(1.0, abs(float(o1["loss"])))
+        l1, l2 = float(o1["loss"]), float(o2["loss"])
+        assert np.isfinite(l1) and abs(l1 - l2) <= 1e-6 * max(1.0, abs(l1)), (it, l1, l2)
         for (s, e, _m) in red.buckets:
             rel = float((g1[s:e] - red.arena[s:e]).abs().max() / g1[s:e].abs().max().clamp_min(1e-30))
             worst = max(worst, rel)

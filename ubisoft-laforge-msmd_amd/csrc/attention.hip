@@ -117,38 +117,69 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const AttnArgs p) {
       }
     }
 
-    // ---- scale, mask, online softmax (query = lane & 15; keys 16 f + 4 fq + e)
-    float mx = -INFINITY;
+    // ---- mask, online softmax (query = lane & 15; keys 16 f + 4 fq + e).  Keys are only tested where a test can fail:
+    // in the last, ragged tile and under an explicit mask (both wave-uniform conditions).
+    if (kv0 + 64 > p.Tk || p.mask) {
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+      for (int f = 0; f < 4; ++f)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int key = kv0 + 16 * f + 4 * fq + e;
-        float v = s[f][e] * p.scale;
-        bool dead = key >= p.Tk;
-        if (p.mask && !dead) dead = p.mask[(long)qrow * p.Tk + key] != 0;
-        v = dead ? -INFINITY : v;
-        s[f][e] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = (m_run == -INFINITY) ? 0.f : (BF ? __expf(m_run - m_use) : expf(m_run - m_use));
-    float ps = 0.f;
+        for (int e = 0; e < 4; ++e) {
+          const int key = kv0 + 16 * f + 4 * fq + e;
+          bool dead = key >= p.Tk;
+          if (p.mask && !dead) dead = p.mask[(long)qrow * p.Tk + key] != 0;
+          if (dead) s[f][e] = -INFINITY;
+        }
+    }
+    float mx = -INFINITY, ps = 0.f, alpha;
+    if constexpr (BF) {
+      // 16-bit storage mode: p = exp2(s c - m c) with c = scale log2(e) > 0 -- ONE fma + ONE v_exp_f32 per score (was
+      // scale, subtract, scale, exp) and the running maximum taken on the raw scores (the kernel is bound by these
+      // vector instructions, not by its 16 MFMAs per tile: DESIGN.md 5b)
+      const float c = p.scale * 1.4426950408889634f;
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+      for (int f = 0; f < 4; ++f)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float pv = BF ? __expf(s[f][e] - m_use) : expf(s[f][e] - m_use);
-        s[f][e] = pv;
-        ps += pv;
-      }
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[f][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float mc = (m_new == -INFINITY) ? 0.f : m_new * c;
+      alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(s[f][e], c, -mc));
+          s[f][e] = pv;
+          ps += pv;
+        }
+      m_run = m_new;
+    } else {
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[f][e] *= p.scale;                  // -inf stays -inf
+          mx = fmaxf(mx, s[f][e]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_use);
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pv = expf(s[f][e] - m_use);
+          s[f][e] = pv;
+          ps += pv;
+        }
+      m_run = m_new;
+    }
     ps += __shfl_xor(ps, 16, 64);
     ps += __shfl_xor(ps, 32, 64);
     l_run = l_run * alpha + ps;
-    m_run = m_new;
     if (p.p_drop > 0.f) {  // drop probabilities AFTER the softmax denominator; the 1/(1-p) factor is applied to O
       const unsigned thr = dropout_threshold(p.p_drop);
       const unsigned long rowbase = ((unsigned long)(b * p.H + h) * p.Tq + qrow) * 128ul;
@@ -161,10 +192,12 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const AttnArgs p) {
         s[f][3] = r.w >= thr ? s[f][3] : 0.f;
       }
     }
+    if (!__all(alpha == 1.0f)) {   // the running maximum moved for some query of this wave: rescale the accumulators
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+      for (int d = 0; d < 4; ++d)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc_o[d][e] *= alpha;
+        for (int e = 0; e < 4; ++e) acc_o[d][e] *= alpha;
+    }
 
     // ---- O^T += V^T . P^T
     if constexpr (BF) {
@@ -394,7 +427,7 @@ static int attention_impl(const void* Q, const void* K, const void* V, void* O, 
                           long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
                           float p_drop, const unsigned long* rng_state, unsigned site, int dtype,
                           msmd_stream_t stream) {
-  if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || !Q || !K || !V || !O) return 1;
+  if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || !Q || !K || !V || !O || !(scale > 0.f)) return 1;
   if (!(p_drop >= 0.f && p_drop < 1.f) || (p_drop > 0.f && (!rng_state || Tk > 512))) return 1;
   const int E = dtype == MSMD_F32 ? 4 : 8;
   if (q_tstride % E || k_tstride % E || v_tstride % E || o_tstride % 4 || q_bstride % E || k_bstride % E ||

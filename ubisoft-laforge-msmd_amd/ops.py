@@ -123,6 +123,8 @@ CONV0_SPLITS = 16
 # Optional per-launch timing of the dominant kernel (bench.py roofline leg): when a list is installed
 # here, every msmd_gemm launch is bracketed by HIP events recorded on the launch stream.
 GEMM_TRACE = None
+# Optional FLOP counter (bench.py sampler leg): a one-element list that every msmd_gemm call adds 2 M N K batch to.
+GEMM_FLOPS = None
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -246,6 +248,8 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
     ldr = residual.stride(-2) if residual is not None and residual.dim() >= 2 else N
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("bias must be fp32")
+    if GEMM_FLOPS is not None:
+        GEMM_FLOPS[0] += 2.0 * M * N * K * batch
     if GEMM_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
