@@ -430,8 +430,11 @@ int msmd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * base + zo * stride + zi * stride_i (elements). */
 int msmd_transpose(const void* x, void* y, int rows, int cols, long ldx, long ldy, int batch, long stride_x,
                    long stride_y, int batch_inner, long stride_x_i, long stride_y_i, int dtype, msmd_stream_t stream);
-/* out[c] (+)= sum_r x[r][c] in fp32 (bias gradient). */
-int msmd_colsum(const void* x, float* out, long rows, int cols, long ld, int accumulate, int dtype,
+/* out[c] (+)= sum_r x[r][c] in fp32 (bias gradient, weight-norm reductions).  With a workspace of
+ * msmd_colsum_workspace(rows, cols) bytes the sum is deterministic (per-row-block partial sums added in block order by a
+ * second launch); ws = NULL: the row blocks meet through float atomics. */
+long msmd_colsum_workspace(long rows, int cols);
+int msmd_colsum(const void* x, float* out, long rows, int cols, long ld, int accumulate, int dtype, void* ws, long ws_bytes,
                 msmd_stream_t stream);
 /* y = act(z);  dz = dy * act'(z)  (exact erf GELU / ELU derivatives). */
 int msmd_act_fwd(const void* z, void* y, long n, int act, int dtype, msmd_stream_t stream);

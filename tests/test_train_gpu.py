@@ -290,8 +290,8 @@ def test_trainer_segmented_hipgraph_matches_single_graph(monkeypatch):
         res.append((outs, tr.flat_param.clone(), tr, list(launched)))
     (o1, p1, tr1, _), (o2, p2, tr2, l2) = res
     for a, b in zip(o1, o2):
-        for k in a:
-            assert float(a[k]) == float(b[k]), k
+        for k in a:     # float atomics (column sums of the weight-norm fold, bias gradients) order differently: last bits
+            assert abs(float(a[k]) - float(b[k])) <= 2e-4 * max(1.0, abs(float(a[k]))), k
     d = (p1 - p2).abs()          # split-contraction wgrad kernels reduce through workspaces: last-bit differences only
     assert float(d.max()) < 2e-5 and float((d > 1e-6).float().mean()) < 1e-3, (float(d.max()), float((d > 1e-6).float().mean()))
     (segs,) = [ent[3] for ent in tr2._graphs.values()]

@@ -1,0 +1,40 @@
+"""Per-call GEMM variant A/B on the path's shapes (product library: variant is an argument, no global switch).
+  python tools/bench_gemm_variants.py 17,40 [reps]   -> TFLOP/s per shape and variant (hot caches, back-to-back launches),
+  plus a bit-equality check of every variant against the first."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from msmd_amd import ops
+
+variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "17,40").split(",")]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+shapes = [("conv1", 205024, 512, 1536), ("conv3", 51232, 512, 1536), ("conv5", 12800, 512, 1024), ("qkv", 6400, 2304, 768),
+          ("ffn1", 6400, 3072, 768), ("ffn2", 6400, 768, 3072), ("out", 6400, 768, 768), ("dec_qkv", 21120, 1536, 512),
+          ("dec_ffn1", 21120, 2048, 512), ("big", 16384, 4096, 3072)]
+g = torch.Generator(device="cuda").manual_seed(0)
+for name, M, N, K in shapes:
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g)
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    base, line = None, []
+    for v in variants:
+        ops.gemm(a, w, b, None, ops.ACT_GELU, out=out, variant=v)
+        torch.cuda.synchronize()
+        if base is None:
+            base = out.clone()
+        same = torch.equal(out, base)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e9
+        for _ in range(3):
+            e0.record()
+            for _ in range(reps):
+                ops.gemm(a, w, b, None, ops.ACT_GELU, out=out, variant=v)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / reps)
+        line.append(f"v{v}: {best * 1e3:7.1f} us {2.0 * M * N * K / best / 1e9:7.1f} TF{'' if same else ' MISMATCH'}")
+    print(f"{name:9s} {M:6d}x{N:4d}x{K:4d}  " + "   ".join(line), flush=True)

@@ -88,7 +88,7 @@ def fwd_bwd(batch, draws):
 
 
 quiet_twice = os.environ.get("QUIET_TWICE", "0") == "1"
-exact = bad = 0
+exact = bad = nonfinite = 0
 worst = 0.0
 t0 = time.time()
 for it in range(1, steps + 1):
@@ -104,6 +104,9 @@ for it in range(1, steps + 1):
     red.standin = None if quiet_twice else busy
     o2 = fwd_bwd(batch, draws)
     g2 = red.arena
+    if not (np.isfinite(float(o1["loss"])) and np.isfinite(float(o2["loss"])) and bool(torch.isfinite(g1).all())):
+        print(f"it {it}: NON-FINITE loss / gradients ({float(o1['loss'])}, {float(o2['loss'])})", flush=True)
+        nonfinite += 1
     same = torch.equal(g1, g2)
     exact += int(same)
     if not same:
@@ -125,5 +128,5 @@ for it in range(1, steps + 1):
 print(f"{mode} mode, B={B}, layers {enc_l}+{dec_l}, train_mode={int(train_mode)}, gemm variant {ops._GEMM_DEFAULT['variant']} "
       f"flags {ops._GEMM_DEFAULT['flags'] >> 16}, side work: {'none (idle vs idle)' if quiet_twice else f'{passes} x mul_(1.0) per bucket' + (' + GEMM' if side_w is not None else '')}; "
       f"{len(red.buckets)} buckets, segments {[len(e[3]) for e in tr._graphs.values()] if tr.use_graph else '-'}")
-print(f"RESULT steps={steps} bit_equal={exact} gross_mismatch(>1e-3)={bad} worst_rel={worst:.3e} "
+print(f"RESULT steps={steps} non_finite={nonfinite} bit_equal={exact} gross_mismatch(>1e-3)={bad} worst_rel={worst:.3e} "
       f"({(time.time() - t0) / steps * 1e3:.0f} ms per double step)")

@@ -44,32 +44,49 @@ extern "C" int msmd_transpose(const void* x, void* y, int rows, int cols, long l
 }
 
 // ---------------------------------------------------------------------------------------------------
-// out[c] (+)= sum_r x[r][c]   (bias gradients; fp32 accumulation, atomics across row blocks)
+// out[c] (+)= sum_r x[r][c]   (bias gradients, weight-norm reductions; fp32 accumulation).  With a workspace the sum is
+// DETERMINISTIC: row blocks write partial sums (no atomics), a second launch adds them in block order; without one the
+// row blocks meet through float atomics (order-dependent last bits).
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long rows,
-                                                     int cols, long ld, int rows_per_block) {
+                                                     int cols, long ld, int rows_per_block, float* __restrict__ partial) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= cols) return;
   const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
   float s = 0.f;
   for (long r = r0; r < r1; ++r) s += to_f32(x[r * ld + c]);
-  atomicAdd(&out[c], s);
+  if (partial) partial[(long)blockIdx.y * cols + c] = s;
+  else atomicAdd(&out[c], s);
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                            int nblocks, int cols, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = accumulate ? out[c] : 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * cols + c];
+  out[c] = s;
 }
 
+extern "C" long msmd_colsum_workspace(long rows, int cols) { return ((rows + 127) / 128) * (long)cols * (long)sizeof(float); }
+
 extern "C" int msmd_colsum(const void* x, float* out, long rows, int cols, long ld, int accumulate, int dtype,
-                           msmd_stream_t stream) {
+                           void* ws, long ws_bytes, msmd_stream_t stream) {
   if (rows <= 0 || cols <= 0) return 1;
   hipStream_t st = (hipStream_t)stream;
-  if (!accumulate) {
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), st);
+  const int rpb = 128;
+  const int nblocks = (int)((rows + rpb - 1) / rpb);
+  float* partial = (ws && ws_bytes >= msmd_colsum_workspace(rows, cols)) ? (float*)ws : nullptr;
+  if (!accumulate && !partial) {
+    hipError_t e = msmd_zero_async(out, (size_t)cols * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
   }
-  const int rpb = 128;
-  dim3 grid((cols + 255) / 256, (unsigned)((rows + rpb - 1) / rpb)), block(256);
+  dim3 grid((cols + 255) / 256, (unsigned)nblocks), block(256);
   if (dtype == MSMD_F32)
-    hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, (const float*)x, out, rows, cols, ld, rpb);
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, st, (const float*)x, out, rows, cols, ld, rpb, partial);
   else
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, out, rows, cols, ld, rpb);
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, out, rows, cols, ld, rpb, partial);
+  if (partial)
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, partial, out, nblocks, cols, accumulate ? 1 : 0);
   MSMD_RETURN_LAST();
 }
 

@@ -54,6 +54,20 @@ extern int g_tuning[16];
 #endif
 #define MSMD_RETURN_LAST() return (int)hipGetLastError()
 
+// Zero a small device workspace with a kernel launch instead of hipMemsetAsync: every node of a captured hipGraph is then
+// a kernel node (memset nodes were one suspect while hunting the second-replay NaN of the segmented training graphs,
+// DESIGN.md 5c -- the cause turned out to be the host library's multi-block reduction; this stays because it costs nothing).
+static __global__ void msmd_zero_kernel(unsigned* __restrict__ p, long n_words) {
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i < n_words) p[i] = 0u;
+}
+static inline hipError_t msmd_zero_async(void* p, size_t bytes, hipStream_t st) {   // bytes % 4 == 0
+  const long n = (long)(bytes / 4);
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(msmd_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned*)p, n);
+  return hipGetLastError();
+}
+
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
 __device__ __forceinline__ float to_f32(f16_t x) { return (float)x; }

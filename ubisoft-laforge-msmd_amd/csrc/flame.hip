@@ -333,7 +333,7 @@ extern "C" int msmd_flame_prepare(const float* shape, const float* expr, const f
   hipStream_t st = (hipStream_t)stream;
   const bool fold = shape_varies && v_template_folded && dirs && v_template && NS >= LBS_KFOLD;
   if (fold) {
-    hipError_t e = hipMemsetAsync(shape_varies, 0, sizeof(int), st);
+    hipError_t e = msmd_zero_async(shape_varies, sizeof(int), st);
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(lbs_prepare_kernel, dim3((B + LBS_FPB - 1) / LBS_FPB), dim3(256), 0, st, shape, pose6,

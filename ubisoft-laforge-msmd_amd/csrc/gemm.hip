@@ -696,6 +696,7 @@ static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
     case 13: return launch_gemm2<TO, 128, 128, 4, 2, 2>(p, batch, st);
     case 17: return launch_gemm2<TO, 128, 128, 4, 2, 2, true>(p, batch, st);
 #ifdef MSMD_EXPERIMENTAL
+    case 40: return launch_gemm8p<TO>(p, batch, st);   // 256 x 256, 8-phase schedule, one workgroup per CU (round 3: slower, see exp/)
     case 1: return launch_gemm2<TO, 128, 128, 2, 2, 2>(p, batch, st);
     case 2: return launch_gemm2<TO, 128, 128, 2, 2, 3>(p, batch, st);
     case 3: return launch_gemm2<TO, 128, 128, 2, 2, 4>(p, batch, st);

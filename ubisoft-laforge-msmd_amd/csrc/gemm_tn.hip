@@ -334,7 +334,7 @@ extern "C" int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsu
   p.accumulate = accumulate ? 1 : 0;
   p.plain_order = MSMD_TUNE(1) == 1;
   if (p.splits > 1 && colsum && !accumulate) {
-    hipError_t e = hipMemsetAsync(colsum, 0, sizeof(float) * N, st);
+    hipError_t e = msmd_zero_async(colsum, sizeof(float) * N, st);
     if (e != hipSuccess) return (int)e;
   }
   // 2-stage ring = 64 KB of LDS = TWO workgroups per CU: a K tile costs a workgroup ~0.7 us whatever the ring depth

@@ -70,7 +70,7 @@ extern "C" int msmd_masked_seq_loss(const float* gt, const float* pred, const in
   if (N <= 0 || T <= order || C <= 0 || c_lo < 0 || c_hi > C || c_hi <= c_lo || order < 0 || order > 2 || !acc_ws)
     return 1;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(acc_ws, 0, 2 * sizeof(double), st);
+  hipError_t e = msmd_zero_async(acc_ws, 2 * sizeof(double), st);
   if (e != hipSuccess) return (int)e;
   LossArgs p{gt, pred, end_idx, acc_ws, N, T, C, c_lo, c_hi, order, prefix, criterion, 0, mode};
   const long rows = (long)N * (T - order);
@@ -160,7 +160,7 @@ extern "C" int msmd_kl_loss(const float* mu, const float* logvar, float* out, do
                             msmd_stream_t stream) {
   if (n <= 0 || !acc_ws) return 1;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(acc_ws, 0, 2 * sizeof(double), st);
+  hipError_t e = msmd_zero_async(acc_ws, 2 * sizeof(double), st);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kl_kernel, dim3((unsigned)min((n + 255) / 256, (long)256)), dim3(256), 0, st, mu, logvar, acc_ws, n);
   hipLaunchKernelGGL(kl_finish_kernel, dim3(1), dim3(1), 0, st, acc_ws, out);

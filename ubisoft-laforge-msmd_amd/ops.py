@@ -803,13 +803,26 @@ def transpose2d(x, pad_to=8):
 
 
 def colsum(x2d, out=None, accumulate=False):
+    """out[c] (+)= sum_r x2d[r, c] in fp32, deterministic (per-row-block partial sums added in block order)."""
     lib = _lib.load()
     rows, cols = x2d.shape
     if out is None:
         out = torch.empty(cols, device=x2d.device, dtype=torch.float32)
-    _lib.check(lib.msmd_colsum(_p(x2d), _p(out), rows, cols, x2d.stride(0), int(accumulate), _dt(x2d), _stream()),
+    nws = lib.msmd_colsum_workspace(rows, cols)
+    ws = torch.empty(nws, device=x2d.device, dtype=torch.uint8)
+    _lib.check(lib.msmd_colsum(_p(x2d), _p(out), rows, cols, x2d.stride(0), int(accumulate), _dt(x2d), _p(ws), nws, _stream()),
                "msmd_colsum")
     return out
+
+
+def fold_weight_norm(g, v):
+    """weight_norm(dim=2) of the positional conv, no autograd: w[o, i, k] = g[k] v[o, i, k] / ||v[:, :, k]||.  The norm
+    is a column sum by msmd_colsum: the host library's multi-block reduction returned NaN from the second replay on when it
+    sat inside a segmented hipGraph, so no pack / training graph uses it."""
+    O, I, K = v.shape
+    v2 = v.detach().reshape(O * I, K).float()
+    s = g.detach().reshape(K).float() * torch.rsqrt(colsum((v2 * v2).contiguous()))
+    return v.detach().float() * s.view(1, 1, K)
 
 
 def act_fwd(z, act):

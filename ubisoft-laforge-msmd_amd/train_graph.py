@@ -92,9 +92,41 @@ class PosConvFn(torch.autograd.Function):
         return dh, dw, db
 
 
+class FoldWeightNormFn(torch.autograd.Function):
+    """weight_norm(dim=2) of the positional conv: w[o, i, k] = g[k] v[o, i, k] / n[k],  n[k] = ||v[:, :, k]|| over (o, i).
+    Forward and backward use elementwise tensor ops and msmd_colsum for the two reductions over the 36 864 (o, i)
+    pairs.  (It used to be `v * (g / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())` on the host library's reduction:
+    inside a SEGMENTED hipGraph -- the data-parallel mode -- that multi-block reduction returned NaN for window 0 on every
+    second replay (params finite, window 1 fine; tools/dp_sidestream_check.py now fails on non-finite losses), so the
+    training graph keeps no multi-block host-library reduction.)
+      d g[k] = sum_{o,i} dw v / n,      d v = (g / n) dw - v (g / n^3) sum_{o,i} dw v"""
+
+    @staticmethod
+    def forward(ctx, g, v):
+        O, I, K = v.shape
+        v2 = v.detach().reshape(O * I, K).float()
+        inv = torch.rsqrt(ops.colsum((v2 * v2).contiguous()))          # 1 / n  (K)
+        s = g.detach().reshape(K).float() * inv                         # g / n
+        ctx.save_for_backward(v, s, inv)
+        ctx.g_shape = g.shape
+        return (v.detach().float() * s.view(1, 1, K)).to(v.dtype)
+
+    @staticmethod
+    def backward(ctx, dw):
+        v, s, inv = ctx.saved_tensors
+        O, I, K = v.shape
+        vf, dwf = v.detach().float(), dw.float()
+        dwv = ops.colsum((dwf * vf).reshape(O * I, K).contiguous())     # sum_{o,i} dw v  (K)
+        dg = (dwv * inv).reshape(ctx.g_shape)
+        dv = dwf * s.view(1, 1, K) - vf * (s * dwv * inv * inv).view(1, 1, K)
+        return dg.to(v.dtype), dv.to(v.dtype)
+
+
 def _fold_weight_norm(g, v):
-    """weight_norm(dim=2): w = g * v / ||v||_{dims 0,1} as torch autograd ops on the (768, 48, 128) parameter."""
-    return v * (g / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+    """weight_norm(dim=2): w = g * v / ||v||_{dims 0,1} on the (768, 48, 128) parameter (CPU tensors: plain autograd ops)."""
+    if not v.is_cuda:
+        return v * (g / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+    return FoldWeightNormFn.apply(g, v)
 
 
 # ----------------------------------------------------------------------------- audio encoder

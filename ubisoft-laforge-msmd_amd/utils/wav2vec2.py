@@ -197,7 +197,7 @@ class Wav2Vec2Model(nn.Module):
         P.fp_w, P.fp_b = cd(sd["feature_projection.projection.weight"]), f32(sd["feature_projection.projection.bias"])
         # positional conv: fold weight norm (dim=2): w = g * v / ||v||_{dims 0,1}
         g, v = sd["encoder.pos_conv_embed.conv.weight_g"].float(), sd["encoder.pos_conv_embed.conv.weight_v"].float()
-        w = v * (g / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+        w = ops.fold_weight_norm(g, v) if v.is_cuda else v * (g / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
         G = c.num_conv_pos_embedding_groups
         cg = c.hidden_size // G
         kpos = c.num_conv_pos_embeddings
