@@ -342,7 +342,10 @@ def leg_lbs(device, frames_list=(6400, 25600)):
     cfg.asset = synth.flame_asset()
     fl = FLAME(cfg).to(device)
     out = {}
-    for n in frames_list:
+    only = os.environ.get("MSMD_BENCH_LBS")      # profiling runs: "6400" | "25600" | "shape" = one workload per process
+    if only in ("6400", "25600"):
+        frames_list = (int(only),)
+    for n in (() if only == "shape" else frames_list):
         g = torch.Generator(device="cpu").manual_seed(n)
         exp = (0.5 * torch.randn(n, 50, generator=g)).to(device)
         pose = (0.2 * torch.randn(n, 6, generator=g)).to(device)
@@ -363,6 +366,8 @@ def leg_lbs(device, frames_list=(6400, 25600)):
                                hbm_frac=round(gbs / PEAK_HBM_GBS, 4), precision=fl.lbs_precision or "bf16x3 (split-bf16 MFMA, fp32 accumulate)",
                                bytes_per_frame=LBS_BYTES_PER_FRAME,
                                inputs="shape = 0 for every frame (SURVEY 8d): the one-subject fold of msmd_flame_prepare")
+    if only in ("6400", "25600"):
+        return out
     # the general path the reference's lbs() computes (utils/lbs.py:185): a different shape vector per frame
     n = frames_list[-1]
     g = torch.Generator(device="cpu").manual_seed(n + 1)

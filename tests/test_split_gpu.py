@@ -137,14 +137,17 @@ def test_split_layernorm_and_conv0_outputs():
     assert maxabs(ys.float().cpu().numpy(), want) < 3e-6
     only = o.layernorm(dev(x), dev(g), dev(b), residual=dev(r), split="only")
     assert torch.equal(only.t, ys.t)
-    # conv0 + GroupNorm + GELU written in split storage == the fp32 kernel's output to 2^-22 relative
+    # conv0 + GroupNorm + GELU written in split storage == the fp32 kernel's output up to the split rounding (2^-22
+    # relative) and the GELU's erf (split / 16-bit outputs use the A&S 7.1.26 form, |abs err| <= 1.5e-7 on erf, i.e.
+    # <= 0.5 |x| 1.5e-7 on the output; the fp32 kernel calls libm's erff)
     audio = dev(synth.audio_clips(2, 6400, tag="sconv0"))
     w0 = dev(synth.uniform("sconv0/w", (512, 10), -0.5, 0.5))
     gg, bb = dev(synth.uniform("sconv0/g", (512,), 0.5, 1.5)), dev(synth.uniform("sconv0/b", (512,), -0.2, 0.2))
     f = o.conv0_gn_gelu(audio, w0, gg, bb, 20, 0, torch.float32)
     s = o.conv0_gn_gelu(audio, w0, gg, bb, 20, 0, o.SPLIT)
     assert isinstance(s, o.Split) and s.shape == f.shape
-    assert torch.all((s.float() - f).abs() <= f.abs() * 2.0 ** -21 + 2.0 ** -34)   # + the lo plane's subnormal floor
+    xin = f.abs() + 1.0     # |GELU(x)| <= |x|; the erf error scales with |x| <= |out| + 1
+    assert torch.all((s.float() - f).abs() <= f.abs() * 2.0 ** -21 + 2.0 ** -34 + 2.0e-7 * xin)
 
 
 @pytest.mark.parametrize("B,H,Tq,Tk,masked", [(2, 12, 200, 200, False), (3, 8, 111, 111, False), (3, 8, 111, 110, True),

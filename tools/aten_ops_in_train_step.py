@@ -1,0 +1,55 @@
+"""Which host-library (ATen) ops does ONE eager training iteration issue, by op and shape?  (The HIP kernels are called
+through ctypes and do not show up here: this lists exactly the glue that is NOT ours.)  python tools/aten_ops_in_train_step.py"""
+import collections
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+from msmd_amd.config import default_args
+from msmd_amd.model import get_diffusion_model
+from msmd_amd.style_encoder import get_style_encoder
+from msmd_amd.training_script import Trainer, synthetic_batch
+
+B = int(os.environ.get("B", "32"))
+args = default_args(compute_dtype="bf16", lr=2e-5, warm_iter=5000)
+model = get_diffusion_model(args, "cuda").train()
+se = get_style_encoder(args, "vae2").to("cuda").train()
+tr = Trainer(args, model, se, use_graph=False)
+batch = synthetic_batch(B, 0, "cuda")
+tr.step(batch, it=1)
+torch.cuda.synchronize()
+counts = collections.Counter()
+bytes_ = collections.Counter()
+
+
+class Count(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        name = str(func).replace("aten.", "")
+        if name.split(".")[0] in ("view", "_unsafe_view", "reshape", "detach", "alias", "t", "transpose", "permute", "expand", "slice",
+                                  "select", "unsqueeze", "squeeze", "as_strided", "split", "unbind", "chunk", "_reshape_alias", "empty",
+                                  "empty_like", "empty_strided", "new_empty", "is_same_size", "sym_size", "stride", "storage_offset", "numel"):
+            return out
+        shp = next((tuple(a.shape) for a in args if torch.is_tensor(a)), ())
+        t = out if torch.is_tensor(out) else None
+        counts[(name, shp)] += 1
+        if t is not None:
+            bytes_[(name, shp)] += t.numel() * t.element_size()
+        return out
+
+
+with Count():
+    tr.step(batch, it=1)
+torch.cuda.synchronize()
+tot = sum(counts.values())
+print(f"{tot} data-moving ATen ops in one eager iteration (B = {B})")
+by_name = collections.Counter()
+for (n, s), c in counts.items():
+    by_name[n] += c
+print("by op:", by_name.most_common(25))
+print("largest by bytes written:")
+for (n, s), b in bytes_.most_common(40):
+    print(f"  {n:28s} {str(s):28s} x{counts[(n, s)]:4d}  {b / 1e6:9.1f} MB")

@@ -94,11 +94,14 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const AttnArgs p) {
     __syncthreads();
     if (kv0 + 64 < p.Tk) prefetch(kv0 + 64);
 
-    // ---- S^T tile: 4 fragments of 16 keys x 16 queries
+    // ---- S^T tile: 4 fragments of 16 keys x 16 queries; the last, ragged tile only touches the nf fragments that
+    // hold keys (T = 200: one of four -- 19 % of the kernel's products and softmax work were on padding)
+    const int nf = min(4, (p.Tk - kv0 + 15) >> 4);
     f32x4 s[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       s[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (f >= nf) continue;
       const int row = 16 * f + fr;
       if constexpr (BF) {
 #pragma unroll
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const AttnArgs p) {
           const int key = kv0 + 16 * f + 4 * fq + e;
           bool dead = key >= p.Tk;
           if (p.mask && !dead) dead = p.mask[(long)qrow * p.Tk + key] != 0;
-          if (dead) s[f][e] = -INFINITY;
+          if (dead) s[f][e] = -INFINITY;    // (fragments f >= nf are all dead: their exp below is skipped, p = 0)
         }
     }
     float mx = -INFINITY, ps = 0.f, alpha;
@@ -139,20 +142,22 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const AttnArgs p) {
 #pragma unroll
       for (int f = 0; f < 4; ++f)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[f][e]);
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[f][e]);      // -inf for dead keys
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
       const float mc = (m_new == -INFINITY) ? 0.f : m_new * c;
       alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(fmaf(m_run, c, -mc));
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
+      for (int f = 0; f < 4; ++f) {
+        if (f >= nf) { s[f] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float pv = __builtin_amdgcn_exp2f(fmaf(s[f][e], c, -mc));
           s[f][e] = pv;
           ps += pv;
         }
+      }
       m_run = m_new;
     } else {
 #pragma unroll
@@ -204,6 +209,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const AttnArgs p) {
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
         const int f0 = 2 * pr, f1 = 2 * pr + 1;
+        if (f0 >= nf) continue;      // this pair of key fragments is padding
         typedef typename Vec8T<T>::type V8;
         const V8 pbv = V8{(T)s[f0][0], (T)s[f0][1], (T)s[f0][2], (T)s[f0][3],
                           (T)s[f1][0], (T)s[f1][1], (T)s[f1][2], (T)s[f1][3]};
@@ -319,10 +325,13 @@ __global__ __launch_bounds__(64 * NW) void attn_split_kernel(const AttnArgs p) {
     __syncthreads();
     if (kv0 + 64 < p.Tk) prefetch(kv0 + 64);
 
+    const int nf = min(4, (p.Tk - kv0 + 15) >> 4);   // key fragments of this tile that hold keys (ragged last tile)
     f32x4 s[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+      s[f] = s0;
+      if (f >= nf) continue;
       const int row = 16 * f + fr;
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
@@ -333,22 +342,26 @@ __global__ __launch_bounds__(64 * NW) void attn_split_kernel(const AttnArgs p) {
         s1 = mfma16<f16_t>(kl, qh[g], s1);
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s[f][e] = fmaf(s1[e], MSMD_SPLIT_INV, s0[e]);
+      for (int e = 0; e < 4; ++e) s[f][e] = fmaf(s1[e], MSMD_SPLIT_INV, s0[e]) * p.scale;
     }
 
+    // keys are only tested where a test can fail: the ragged last tile and an explicit mask (wave-uniform conditions)
+    if (kv0 + 64 > p.Tk || p.mask) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int key = kv0 + 16 * f + 4 * fq + e;
+          bool dead = key >= p.Tk;
+          if (p.mask && !dead) dead = p.mask[(long)qrow * p.Tk + key] != 0;
+          if (dead) s[f][e] = -INFINITY;
+        }
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int key = kv0 + 16 * f + 4 * fq + e;
-        float v = s[f][e] * p.scale;
-        bool dead = key >= p.Tk;
-        if (p.mask && !dead) dead = p.mask[(long)qrow * p.Tk + key] != 0;
-        v = dead ? -INFINITY : v;
-        s[f][e] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[f][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
@@ -356,26 +369,31 @@ __global__ __launch_bounds__(64 * NW) void attn_split_kernel(const AttnArgs p) {
     const float alpha = (m_run == -INFINITY) ? 0.f : exp_neg_accurate(m_run - m_use);
     float ps = 0.f;
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < 4; ++f) {
+      if (f >= nf) { s[f] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float pe = exp_neg_accurate(s[f][e] - m_use);
         s[f][e] = pe;
         ps += pe;
       }
+    }
     ps += __shfl_xor(ps, 16, 64);
     ps += __shfl_xor(ps, 32, 64);
     l_run = l_run * alpha + ps;
     m_run = m_new;
+    if (!__all(alpha == 1.0f)) {
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+      for (int d = 0; d < 4; ++d)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { o0[d][e] *= alpha; o1[d][e] *= alpha; }
+        for (int e = 0; e < 4; ++e) { o0[d][e] *= alpha; o1[d][e] *= alpha; }
+    }
 
     const int qp = fr >> 2, pp = fr & 3;
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
       const int f0 = 2 * pr, f1 = 2 * pr + 1;
+      if (f0 >= nf) continue;        // padding
       f16x8 phv, plv;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -422,6 +440,23 @@ __global__ __launch_bounds__(64 * NW) void attn_split_kernel(const AttnArgs p) {
   }
 }
 
+// Waves per workgroup (16 queries each; a workgroup shares every staged K / V tile): the candidate that gives the most
+// loaded CU the fewest wave-tiles -- ceil(workgroups / 256 CUs) x waves -- ties to the larger workgroup (K / V read once
+// per more queries).  T = 200, 12 heads, B = 32: 13 waves = 384 workgroups = two per CU on half of the chip (26); 7 waves
+// = 768 workgroups = three per CU everywhere (21).
+static int attn_waves(int Tq, int H, int B) {
+  const int cand[4] = {16, 13, 7, 4};
+  int best = 4;
+  long best_cost = 1L << 60;
+  for (int i = 0; i < 4; ++i) {
+    const int nw = cand[i];
+    const long blocks = (long)((Tq + 16 * nw - 1) / (16 * nw)) * H * B;
+    const long cost = ((blocks + 255) / 256) * nw;
+    if (cost < best_cost) { best_cost = cost; best = nw; }
+  }
+  return best;
+}
+
 static int attention_impl(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
                           long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
                           long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
@@ -436,8 +471,7 @@ static int attention_impl(const void* Q, const void* K, const void* V, void* O, 
   if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)V & 15) || ((uintptr_t)O & 15)) return 1;
   AttnArgs p{Q, K, V, O, B, H, Tq, Tk, q_bstride, q_tstride, k_bstride, k_tstride, v_bstride, v_tstride,
              o_bstride, o_tstride, scale, mask, p_drop, rng_state, site};
-  const int need = (Tq + 15) / 16;   // waves that cover all queries of one (batch, head)
-  const int nw = need <= 4 ? 4 : (need <= 7 ? 7 : (need <= 13 ? 13 : 16));
+  const int nw = attn_waves(Tq, H, B);
   dim3 grid((Tq + 16 * nw - 1) / (16 * nw), H, B), block(64 * nw);
   hipStream_t st = (hipStream_t)stream;
 #define MSMD_ATTN(T)                                                                                   \
@@ -487,8 +521,7 @@ extern "C" int msmd_attention_f16x2(const void* Q, const void* K, const void* V,
   if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)V & 15) || ((uintptr_t)O & 15)) return 1;
   AttnArgs p{Q, K, V, O, B, H, Tq, Tk, q_bstride, q_tstride, k_bstride, k_tstride, v_bstride, v_tstride,
              o_bstride, o_tstride, scale, mask, 0.f, nullptr, 0u};
-  const int need = (Tq + 15) / 16;
-  const int nw = need <= 4 ? 4 : (need <= 7 ? 7 : (need <= 13 ? 13 : 16));
+  const int nw = attn_waves(Tq, H, B);
   dim3 grid((Tq + 16 * nw - 1) / (16 * nw), H, B), block(64 * nw);
   hipStream_t st = (hipStream_t)stream;
 #define MSMD_ATTN_S(TO)                                                                                \

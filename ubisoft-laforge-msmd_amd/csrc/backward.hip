@@ -58,13 +58,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
   if (partial) partial[(long)blockIdx.y * cols + c] = s;
   else atomicAdd(&out[c], s);
 }
+// 64 columns x 4 interleaved groups of partial rows per workgroup, the four group sums added in a fixed order
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                             int nblocks, int cols, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
-  float s = accumulate ? out[c] : 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * cols + c];
-  out[c] = s;
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  float s = 0.f;
+  if (c < cols)
+    for (int b = g; b < nblocks; b += 4) s += partial[(long)b * cols + c];
+  red[g][cx] = s;
+  __syncthreads();
+  if (g == 0 && c < cols) out[c] = (accumulate ? out[c] : 0.f) + ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
 }
 
 extern "C" long msmd_colsum_workspace(long rows, int cols) { return ((rows + 127) / 128) * (long)cols * (long)sizeof(float); }
@@ -86,7 +91,7 @@ extern "C" int msmd_colsum(const void* x, float* out, long rows, int cols, long 
   else
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, out, rows, cols, ld, rpb, partial);
   if (partial)
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, partial, out, nblocks, cols, accumulate ? 1 : 0);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, partial, out, nblocks, cols, accumulate ? 1 : 0);
   MSMD_RETURN_LAST();
 }
 

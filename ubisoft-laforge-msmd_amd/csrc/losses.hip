@@ -191,25 +191,42 @@ extern "C" int msmd_truncate_rows(float* x, const int* end_idx, int N, int L, in
 
 // Fused multi-tensor Adam step on a flat parameter / gradient / moment arena (torch.optim.Adam semantics,
 // reference training_script.py:548-551: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float bc1, float bc2,
-                            float grad_scale) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float gi = g[i] * grad_scale;
-    const float mi = b1 * m[i] + (1.0f - b1) * gi;
-    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-    p[i] -= (lr / bc1) * (mi / denom);
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps,
+                                         float bc1, float bc2, float grad_scale) {
+  const float gi = g * grad_scale;
+  const float mi = b1 * m + (1.0f - b1) * gi;
+  const float vi = b2 * v + (1.0f - b2) * gi * gi;
+  m = mi;
+  v = vi;
+  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+  p -= (lr / bc1) * (mi / denom);
+}
+// 16 bytes per lane and stream (7 streams: read p, g, m, v; write p, m, v = 28 B per parameter): HBM-bound
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                   float bc1, float bc2, float grad_scale) {
+  const long n4 = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 pp = ((f32x4*)p)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+    const f32x4 gg = ((const f32x4*)g)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float pe = pp[e], me = mm[e], ve = vv[e];
+      adam_one(pe, gg[e], me, ve, lr, b1, b2, eps, bc1, bc2, grad_scale);
+      pp[e] = pe; mm[e] = me; vv[e] = ve;
+    }
+    ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
   }
+  for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    adam_one(p[i], g[i], m[i], v[i], lr, b1, b2, eps, bc1, bc2, grad_scale);
 }
 
 extern "C" int msmd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
                               float beta1, float beta2, float eps, int step, float grad_scale, msmd_stream_t stream) {
   if (n <= 0 || step <= 0) return 1;
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
-  dim3 grid((unsigned)min((n + 255) / 256, (long)4096)), block(256);
+  if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return 1;
+  dim3 grid((unsigned)min((n / 4 + 255) / 256 + 1, (long)8192)), block(256);
   hipLaunchKernelGGL(adam_kernel, grid, block, 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
                      beta2, eps, bc1, bc2, grad_scale);
   MSMD_RETURN_LAST();

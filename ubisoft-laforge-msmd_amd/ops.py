@@ -167,7 +167,7 @@ _TUNED = {}
 # global state; these module-level defaults are what `gemm()` passes when the caller gives none (`gemm_defaults`
 # scopes a change, e.g. while a hipGraph is captured -- the choice is then baked into that graph).
 GEMM_WRITE_THROUGH, GEMM_PAIRED_STORES = 1 << 16, 1 << 17
-_GEMM_DEFAULT = {"variant": 0, "flags": 0, "split_variant": 0}
+_GEMM_DEFAULT = {"variant": 0, "flags": GEMM_PAIRED_STORES, "split_variant": 0}   # paired 16-byte stores: -1 % on the forward step
 
 
 class gemm_defaults:
