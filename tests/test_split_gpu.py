@@ -146,8 +146,7 @@ def test_split_layernorm_and_conv0_outputs():
     f = o.conv0_gn_gelu(audio, w0, gg, bb, 20, 0, torch.float32)
     s = o.conv0_gn_gelu(audio, w0, gg, bb, 20, 0, o.SPLIT)
     assert isinstance(s, o.Split) and s.shape == f.shape
-    xin = f.abs() + 1.0     # |GELU(x)| <= |x|; the erf error scales with |x| <= |out| + 1
-    assert torch.all((s.float() - f).abs() <= f.abs() * 2.0 ** -21 + 2.0 ** -34 + 2.0e-7 * xin)
+    assert torch.all((s.float() - f).abs() <= f.abs() * 2.0 ** -21 + 1.0e-6)   # 0.5 |x| 1.5e-7 with |x| up to ~6 here
 
 
 @pytest.mark.parametrize("B,H,Tq,Tk,masked", [(2, 12, 200, 200, False), (3, 8, 111, 111, False), (3, 8, 111, 110, True),
