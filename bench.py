@@ -154,7 +154,7 @@ def pmc_traffic(mode):
     """HBM bytes per launch of the dominant kernel from this round's committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE in SEPARATE runs; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC counters
     cannot be read from inside this process: the figure is a constant from profiles/ (null when absent), not this run."""
-    for name in ("r02_pmc_hbm_fetch_write_per_kernel.json", "r01e_pmc_hbm_fetch_write_per_kernel.json"):
+    for name in ("r03_pmc_hbm_fetch_write_per_kernel.json", "r02_pmc_hbm_fetch_write_per_kernel.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
