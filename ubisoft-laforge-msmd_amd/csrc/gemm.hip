@@ -359,8 +359,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t>
-__global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const GemmArgs p) {
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t, bool STAG = false>
+__global__ __launch_bounds__(WM * WN * 64, STAG ? 4 : 1) void gemm2_kernel(const GemmArgs p) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int LPT = (BM + BN) * 8 / NT;  // LDS-DMA instructions per thread per K tile
@@ -415,6 +415,56 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2_kernel(const GemmArgs p) {
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s, s);
   int stage = 0;
+  if constexpr (STAG) {
+    // Staggered halves (MI355X_MICROARCH.md, "Two waves per SIMD", item 9): the eight waves run the same program with one
+    // barrier per K tile, so SIMD partners reach their fragment reads, their MFMAs and the barrier together.  Waves 4-7
+    // (the younger wave of every SIMD) multiply tile k AFTER the barrier of tile k + 1, from fragments they read one
+    // iteration earlier: while waves 0-3 read the new tile, waves 4-7 keep the matrix pipe busy, and vice versa.  Same
+    // products in the same order per output element: results are bit-identical to the unstaggered kernel.
+    // MEASURED (round 3): 25-30 % SLOWER on every shape and 4.76 -> 5.64 ms on the forward step -- with two workgroups per CU
+    // the co-resident workgroup already fills the other's read phase, and the late half lengthens every tile's critical
+    // path.  Experimental build only (variant 41).
+    static_assert(NSTAGE == 2 && NW == 8, "stagger is written for the 2-stage, 8-wave kernel");
+    const bool late = __builtin_amdgcn_readfirstlane(wid) >= 4;
+    u32x4 fx[2][FM], fw[2][FN];
+    auto read_frags = [&](int st) {
+      const unsigned char* sa = smem + st * STAGE;
+      const unsigned char* sw = sa + BM * 128;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int j = 0; j < FM; ++j) fx[g][j] = *(const u32x4*)(sa + lds_off(wm + j * 16 + fr, g * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < FN; ++i) fw[g][i] = *(const u32x4*)(sw + lds_off(wn + i * 16 + fr, g * 4 + fq));
+      }
+    };
+    auto multiply = [&]() {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+          for (int j = 0; j < FM; ++j) Mfma<TI>::run(fw[g][i], fx[g][j], acc[i][j]);
+    };
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) issue(kt + 1, stage ^ 1);
+      if (late && kt > 0) multiply();           // waves 4-7: tile kt - 1, from the fragments read before this barrier
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(stage);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!late) multiply();                     // waves 0-3: this tile
+      // waves 4-7: the reads must have RETURNED before the wave arrives at the next barrier (after it any wave may re-stage
+      // this buffer); waves 0-3 have consumed theirs in the MFMAs above
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      stage ^= 1;
+    }
+    if (late) multiply();
+    gemm_epilogue<TO, FM, FN>(p, acc, z, m0 + wm, n0 + wn, fr, fq);
+    return;
+  }
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + NSTAGE - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LPT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -600,11 +650,11 @@ extern "C" int msmd_exp_set_tuning(int key, int value) {
 #include "exp/gemm_variants.inc"
 #endif
 
-template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t>
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t, bool STAG = false>
 static int launch_gemm2(GemmArgs& p, int batch, hipStream_t st) {
   constexpr int lds = NSTAGE * (BM + BN) * 128;
   static bool attr_done = false;
-  auto kfn = gemm2_kernel<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI>;
+  auto kfn = gemm2_kernel<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, STAG>;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
@@ -696,6 +746,7 @@ static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
     case 13: return launch_gemm2<TO, 128, 128, 4, 2, 2>(p, batch, st);
     case 17: return launch_gemm2<TO, 128, 128, 4, 2, 2, true>(p, batch, st);
 #ifdef MSMD_EXPERIMENTAL
+    case 41: return launch_gemm2<TO, 128, 128, 4, 2, 2, true, bf16_t, true>(p, batch, st);   // 17 with waves 4-7 staggered: -25 % (5c)
     case 40: return launch_gemm8p<TO>(p, batch, st);   // 256 x 256, 8-phase schedule, one workgroup per CU (round 3: slower, see exp/)
     case 1: return launch_gemm2<TO, 128, 128, 2, 2, 2>(p, batch, st);
     case 2: return launch_gemm2<TO, 128, 128, 2, 2, 3>(p, batch, st);

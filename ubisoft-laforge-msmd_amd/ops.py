@@ -167,6 +167,7 @@ _TUNED = {}
 # global state; these module-level defaults are what `gemm()` passes when the caller gives none (`gemm_defaults`
 # scopes a change, e.g. while a hipGraph is captured -- the choice is then baked into that graph).
 GEMM_WRITE_THROUGH, GEMM_PAIRED_STORES = 1 << 16, 1 << 17
+GEMM_ROUTER = None   # developer hook (tools/ab_forward.py): callable (M, N, K, batch) -> variant or None, consulted per call
 _GEMM_DEFAULT = {"variant": 0, "flags": GEMM_PAIRED_STORES, "split_variant": 0}   # paired 16-byte stores: -1 % on the forward step
 
 
@@ -255,6 +256,8 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
         e0.record()
     if variant is None:
         variant = _GEMM_DEFAULT["split_variant"] if isinstance(a, Split) else _GEMM_DEFAULT["variant"]
+        if GEMM_ROUTER is not None and not isinstance(a, Split):
+            variant = GEMM_ROUTER(M, N, K, batch) or variant
     flags = _GEMM_DEFAULT["flags"] if flags is None else flags
     act = act | (variant << 8) | flags
     args = [_p(a), _p(w), _p(bias), _p(residual), _p(out), M, N, K, _dt(a), _dt(out), lda, rows_per_batch,
