@@ -502,3 +502,79 @@ def test_lbs_building_blocks_match_reference():
     a = _compute_mask_indices((3, 199), 0.05, 10, None, 2)
     np.random.seed(4)
     assert np.array_equal(a, compute_mask_indices((3, 199), 0.05, 10, 2))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_store_flags_and_variants_are_bit_identical(dtype):
+    """Per-call knobs (include/msmd_hip.h MSMD_GEMM_VARIANT / _WRITE_THROUGH / _PAIRED_STORES) change tile shape and
+    store instructions only: same K order inside a tile => every combination must give the SAME bits (interior tiles
+    and ragged edges, with bias + GELU + residual)."""
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    M, N, K = 1000, 776, 512            # ragged M, N % 8 == 0 but not a tile multiple
+    a = torch.randn(M, K, generator=g).to(DEV, dtype)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV, dtype)
+    b = torch.randn(N, generator=g).to(DEV)
+    r = torch.randn(M, N, generator=g).to(DEV, dtype)
+    ref = o.gemm(a, w, b, r, act=o.ACT_GELU, variant=17, flags=0)
+    variants = (0, 9, 12, 17) + ((13,) if dtype == torch.bfloat16 else ())
+    for v in variants:
+        for fl in (0, o.GEMM_WRITE_THROUGH, o.GEMM_PAIRED_STORES, o.GEMM_WRITE_THROUGH | o.GEMM_PAIRED_STORES):
+            c = o.gemm(a, w, b, r, act=o.ACT_GELU, variant=v, flags=fl)
+            assert torch.equal(c, ref), (v, fl, float((c.float() - ref.float()).abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_ln_folds_layernorm_into_producer_and_consumer(dtype):
+    """msmd_gemm_ln: Linear -> +residual -> LayerNorm -> Linear as two launches.  Producer: C1 = A W1^T + b1 + LN_R(r)
+    (r un-normalised, its row statistics given) and the row statistics of the stored C1; consumer: LN(C1) W2^T + b2
+    through gamma-folded weights.  Reference: the same chain in fp64 from the SAME rounded operands; tolerance = the
+    16-bit output rounding of O(1) values plus the statistics being exact sums of the stored values (5e-3 * scale for
+    bf16, 1e-3 for fp16: the plain chain layernorm kernel + gemm kernel has the same error against fp64)."""
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M, D, F = 1000, 768, 3072
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    u0 = (torch.randn(M, D, generator=g) * 2 + 0.3).to(dtype)          # un-normalised residual rows
+    a = torch.randn(M, D, generator=g).to(dtype)
+    w1 = (torch.randn(D, D, generator=g) / math.sqrt(D)).to(dtype)
+    b1 = torch.randn(D, generator=g)
+    g0, be0 = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.1
+    g1, be1 = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.1
+    w2 = torch.randn(F, D, generator=g) / math.sqrt(D)
+    b2 = torch.randn(F, generator=g)
+
+    def stats(x):      # (M, cols / 64, 2) partial sums of the stored values
+        x = x.double().reshape(x.shape[0], -1, 64)
+        return torch.stack([x.sum(-1), (x * x).sum(-1)], -1).float().contiguous()
+
+    def ln(x, gm, bt):
+        x = x.double()
+        mu = x.mean(-1, keepdim=True)
+        var = (x * x).mean(-1, keepdim=True) - mu * mu
+        return (x - mu) / torch.sqrt(var + 1e-5) * gm.double() + bt.double()
+
+    # producer
+    c1, st1 = o.gemm_ln(a.to(DEV), w1.to(DEV), b1.to(DEV), u0.to(DEV), r_stats=stats(u0).to(DEV), r_gamma=g0.to(DEV),
+                        r_beta=be0.to(DEV), stats_out=True)
+    ref1 = a.double() @ w1.double().T + b1.double() + ln(u0, g0, be0)
+    assert c1.dtype == dtype
+    assert maxabs(c1.double().cpu().numpy(), ref1.numpy()) < tol * 4      # O(4) values
+    # the statistics are those of the STORED rows (what the consumer will multiply), fp32 sums of 64 values
+    assert maxabs(st1.cpu().numpy(), stats(c1.cpu()).numpy()) < 2e-3
+    # consumer: GELU(LN(c1) W2^T + b2)
+    wf, cs, bf = o.fold_layernorm(w2.to(DEV), b2.to(DEV), g1.to(DEV), be1.to(DEV), dtype)
+    c2 = o.gemm_ln(c1, wf, bf, act=o.ACT_GELU, a_stats=st1, w_colsum=cs)
+    z = ln(c1.cpu(), g1, be1) @ w2.double().T + b2.double()
+    ref2 = 0.5 * z * (1 + torch.erf(z / math.sqrt(2)))
+    assert maxabs(c2.double().cpu().numpy(), ref2.numpy()) < tol * 4
+    # and against the unfused chain of the library itself (LayerNorm kernel -> 16-bit rows -> GEMM): same error class
+    h = o.layernorm(c1, g1.to(DEV), be1.to(DEV))
+    c2u = o.gemm(h, w2.to(DEV, dtype), b2.to(DEV), act=o.ACT_GELU)
+    e_f, e_u = maxabs(c2.double().cpu().numpy(), ref2.numpy()), maxabs(c2u.double().cpu().numpy(), ref2.numpy())
+    assert e_f < 2.0 * e_u + 1e-3, (e_f, e_u)
+    # rejected shapes: N not a multiple of 128, fp32 operands
+    with pytest.raises(Exception):
+        o.gemm_ln(a.to(DEV), w1[:700].to(DEV).contiguous(), None)
+    with pytest.raises(Exception):
+        o.gemm_ln(a.to(DEV).float(), w1.to(DEV).float(), None)

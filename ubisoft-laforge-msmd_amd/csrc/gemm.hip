@@ -29,6 +29,14 @@ struct GemmArgs {
   void* Z; float p_drop; const unsigned long* rng; unsigned site;
   int xn;  // XCDs along N (1, 2 or 4): the 8 XCDs form an (8 / xn) x xn grid over (M tiles, N tiles)
   int flags;  // MSMD_GEMM_* bits 16.. of `act`, shifted down: 1 = write-through (sc1) output stores, 2 = paired 16-B stores
+  // LayerNorm folded into the GEMMs around it (msmd_gemm_ln; all NULL for plain calls):
+  //   a_stats (M, a_nt, 2): A holds UN-normalised rows u, the partial (sum, sum of squares) of each row over 64-column
+  //     slabs; W carries gamma folded in, w_colsum[n] = sum_k W'[n][k], bias carries beta . W:  y = rstd (acc - mu s[n]) + c[n]
+  //   r_stats (M, r_nt, 2) + r_gamma / r_beta (N): the residual operand holds un-normalised rows: R <- LN(R) on the fly
+  //   stats_out (M, N / 64, 2): partial (sum, sum of squares) of the STORED (rounded) output rows, per 64-column slab
+  const float* a_stats = nullptr; int a_nt = 0; const float* w_colsum = nullptr;
+  const float* r_stats = nullptr; int r_nt = 0; const float* r_gamma = nullptr; const float* r_beta = nullptr;
+  float* stats_out = nullptr; float ln_eps = 1e-5f;
 };
 
 template <typename T> struct Mfma;
@@ -110,10 +118,24 @@ __device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const 
   f32x4 bv[FN];
 #pragma unroll
   for (int i = 0; i < FN; ++i) bv[i] = bias ? *(const f32x4*)(bias + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+  // every residual fragment is requested BEFORE the first output store: loads issued between the stores are serialised
+  // into one L2 round trip per fragment (load, wait, store, load, ...), 8 of them on a 128 x 128 tile
+  // (fp32 outputs: one fragment row at a time -- all of them would take the 128 x 128 kernel past 128 registers)
+  typedef typename Vec4T<TO>::type V4;
+  constexpr int RJ = sizeof(TO) == 2 ? FM : 1;
+  V4 rr[RJ][FN];
+  auto load_residual = [&](int j0) {
+    if (R) {
+#pragma unroll
+      for (int j = 0; j < RJ; ++j)
+#pragma unroll
+        for (int i = 0; i < FN; ++i) rr[j][i] = *(const V4*)(R + (long)(j0 + j) * 16 * p.ldr + i * 16);
+    }
+  };
+  if constexpr (RJ == FM) load_residual(0);
   // the finished 4 values of fragment (i, j): bias, optional pre-activation copy, activation, dropout, residual
   auto finish = [&](int i, int j, float (&v)[4]) {
     TO* crow = C + (long)j * 16 * p.ldc;
-    const TO* rrow = R ? R + (long)j * 16 * p.ldr : nullptr;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[i][e];
     if (p.Z) store4_out<TO>((TO*)p.Z + (crow + i * 16 - (TO*)p.C), v, wt);
@@ -129,16 +151,9 @@ __device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const 
       v[2] = rb.z >= thr ? v[2] * c : 0.f;
       v[3] = rb.w >= thr ? v[3] * c : 0.f;
     }
-    if (rrow) {
-      if constexpr (sizeof(TO) == 4) {
-        const f32x4 r = *(const f32x4*)(rrow + i * 16);
+    if (R) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += r[e];
-      } else {
-        const typename Vec4T<TO>::type r = *(const typename Vec4T<TO>::type*)(rrow + i * 16);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-      }
+      for (int e = 0; e < 4; ++e) v[e] += (float)rr[j % RJ][i][e];
     }
   };
   if constexpr (sizeof(TO) == 2 && FM % 2 == 0) {
@@ -171,6 +186,7 @@ __device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const 
   }
 #pragma unroll
   for (int j = 0; j < FM; ++j) {
+    if constexpr (RJ != FM) load_residual(j);
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
       float v[4];
@@ -247,6 +263,138 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
             cp[e] = from_f32<TO>(o);
           }
         }
+      }
+    }
+  }
+}
+
+// LayerNorm folded into the GEMM (see GemmArgs).  Statistics travel as per-row partial (sum, sum of squares) over
+// 64-column slabs = what ONE wave of a 128 x 128 tile (4 x 2 waves) holds of a row, so writing them needs no LDS and no
+// barrier.  Reading them is latency, not bandwidth: the producer ran on other XCDs, so the first touch of a row's partials
+// misses this XCD's L2.  Measured on the encoder's FFN1 (49 us): a loop over the slabs in the epilogue +5.5 us (serialised
+// round trips), all slabs loaded and reduced before the K loop +8.5 us (every workgroup stalls on the miss before its first
+// tile).  So: ln_issue only ISSUES the loads before the K loop -- lane (fr, fq) takes slabs fq, fq + 4, ... of the FM rows
+// it owns, 16 registers -- and ln_finish reduces them (two cross-lane adds) in the epilogue, a whole K loop later.
+template <int FM>
+__device__ __forceinline__ void ln_issue(const float* stats, int nt, int M, int m_base, int fr, int fq, f32x2 (&raw)[FM][4]) {
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const f32x2* sp = (const f32x2*)stats + (long)min(m_base + j * 16 + fr, M - 1) * nt;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) raw[j][q] = fq + 4 * q < nt ? sp[fq + 4 * q] : f32x2{0.f, 0.f};
+  }
+}
+
+template <int FM>
+__device__ __forceinline__ void ln_finish(const float* stats, int nt, int M, int m_base, int fr, int fq, const f32x2 (&raw)[FM][4],
+                                          float inv_cols, float eps, float (&mu)[FM], float (&rs)[FM]) {
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    float S = (raw[j][0][0] + raw[j][1][0]) + (raw[j][2][0] + raw[j][3][0]);
+    float Q = (raw[j][0][1] + raw[j][1][1]) + (raw[j][2][1] + raw[j][3][1]);
+    if (nt > 16) {     // rows wider than 1024 columns: the rest, serially
+      const f32x2* sp = (const f32x2*)stats + (long)min(m_base + j * 16 + fr, M - 1) * nt;
+      for (int t = 16 + fq; t < nt; t += 4) { const f32x2 w = sp[t]; S += w[0]; Q += w[1]; }
+    }
+    S += __shfl_xor(S, 16, 64); S += __shfl_xor(S, 32, 64);
+    Q += __shfl_xor(Q, 16, 64); Q += __shfl_xor(Q, 32, 64);
+    mu[j] = S * inv_cols;
+    rs[j] = rsqrtf(fmaxf(Q * inv_cols - mu[j] * mu[j], 0.f) + eps);
+  }
+}
+
+// Epilogue of a wave whose FN fragments span exactly one 64-column slab (FN == 4).  MODE 1: the operand was LayerNorm'ed
+// (folded weights; no residual).  MODE 2: residual add, the residual LayerNorm'ed on the fly when r_stats is given, and
+// the statistics of the stored rows written when stats_out is given.  Every load of the epilogue (bias, column sums or
+// gamma / beta, the residual fragments) is issued up front, unconditionally: with run-time "is this pointer set" tests
+// inside the fragment loops the compiler serialises them into one L2 round trip per fragment column (+4 us per launch).
+template <typename TO, int FM, int FN, int MODE>
+__device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int m_base, int n_base,
+                                                 int fr, int fq, const f32x2 (&raw)[FM][4]) {
+  static_assert(FN == 4 && FM == 2, "one wave = one 64-column statistics slab, two fragment rows");
+  typedef typename Vec4T<TO>::type V4;
+  const int n = n_base + fq * 4;
+  f32x4 bv[FN], xv[FN], yv[FN];
+  V4 rr[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FN; ++i) bv[i] = *(const f32x4*)(p.bias + n + i * 16);
+  if constexpr (MODE == 1) {
+#pragma unroll
+    for (int i = 0; i < FN; ++i) xv[i] = *(const f32x4*)(p.w_colsum + n + i * 16);
+  } else {
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const TO* rp = (const TO*)p.R + (long)min(m_base + j * 16 + fr, p.M - 1) * p.ldr + n;
+#pragma unroll
+      for (int i = 0; i < FN; ++i) rr[j][i] = *(const V4*)(rp + i * 16);
+    }
+    if (p.r_stats) {
+#pragma unroll
+      for (int i = 0; i < FN; ++i) { xv[i] = *(const f32x4*)(p.r_gamma + n + i * 16); yv[i] = *(const f32x4*)(p.r_beta + n + i * 16); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < FN; ++i) { xv[i] = f32x4{1.f, 1.f, 1.f, 1.f}; yv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+  }
+  float mu[FM], rs[FM];
+#pragma unroll
+  for (int j = 0; j < FM; ++j) { mu[j] = 0.f; rs[j] = 1.f; }      // (r - 0) * 1 * 1 + 0 == r exactly: the plain residual
+  if constexpr (MODE == 1) ln_finish<FM>(p.a_stats, p.a_nt, p.M, m_base, fr, fq, raw, 1.0f / (float)p.K, p.ln_eps, mu, rs);
+  else if (p.r_stats) ln_finish<FM>(p.r_stats, p.r_nt, p.M, m_base, fr, fq, raw, 1.0f / (float)p.N, p.ln_eps, mu, rs);
+
+  float rowS[FM], rowQ[FM];
+#pragma unroll
+  for (int j = 0; j < FM; ++j) rowS[j] = rowQ[j] = 0.f;
+  const bool odd = fq & 1;
+  const bool pair = sizeof(TO) == 2 && (p.flags & 2);
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+    V4 o[FM];
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = acc[i][j][e];
+        if constexpr (MODE == 1) x = rs[j] * (x - mu[j] * xv[i][e]);
+        v[e] = act_out<TO>(x + bv[i][e], p.act);
+        if constexpr (MODE == 2) v[e] += fmaf(((float)rr[j][i][e] - mu[j]) * rs[j], xv[i][e], yv[i][e]);
+      }
+      if constexpr (sizeof(TO) == 4) o[j] = V4{v[0], v[1], v[2], v[3]};
+      else o[j] = pack4<TO>(v[0], v[1], v[2], v[3]);
+      if constexpr (MODE == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float w = (float)o[j][e]; rowS[j] += w; rowQ[j] = fmaf(w, w, rowQ[j]); }   // of what the consumer will read
+      }
+    }
+    if constexpr (sizeof(TO) == 2) {
+      if (pair) {     // lanes l and l ^ 16 swap one fragment row: one 16-byte store each (see gemm_epilogue_interior)
+        const u32x2 a = __builtin_bit_cast(u32x2, o[0]), b = __builtin_bit_cast(u32x2, o[1]);
+        const u32x2 send = odd ? a : b;
+        u32x2 recv;
+        recv[0] = __shfl_xor(send[0], 16, 64);
+        recv[1] = __shfl_xor(send[1], 16, 64);
+        const u32x4 w = odd ? u32x4{recv[0], recv[1], b[0], b[1]} : u32x4{a[0], a[1], recv[0], recv[1]};
+        const int m = m_base + (odd ? 16 : 0) + fr;
+        if (m < p.M) *(u32x4*)((TO*)p.C + (long)m * p.ldc + n + i * 16 - (odd ? 4 : 0)) = w;
+        continue;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int m = m_base + j * 16 + fr;
+      if (m < p.M) *(V4*)((TO*)p.C + (long)m * p.ldc + n + i * 16) = o[j];
+    }
+  }
+  if constexpr (MODE == 2) {
+    if (p.stats_out) {
+      // row sums over this wave's 64 columns: the 4 lane groups (fq) hold 4 columns of every fragment each
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        rowS[j] += __shfl_xor(rowS[j], 16, 64); rowS[j] += __shfl_xor(rowS[j], 32, 64);
+        rowQ[j] += __shfl_xor(rowQ[j], 16, 64); rowQ[j] += __shfl_xor(rowQ[j], 32, 64);
+        const int m = m_base + j * 16 + fr;
+        if (fq == 0 && m < p.M) *(f32x2*)(p.stats_out + ((long)m * (p.N / 64) + n_base / 64) * 2) = f32x2{rowS[j], rowQ[j]};
       }
     }
   }
@@ -414,6 +562,13 @@ __global__ __launch_bounds__(WM * WN * 64, STAG ? 4 : 1) void gemm2_kernel(const
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s, s);
+  // LayerNorm-folding mode (msmd_gemm_ln; the 4 x 2-wave 128 x 128 tile only): the row statistics' loads go out now, consumed in the epilogue
+  constexpr bool LNK = BN == 128 && WN == 2 && !STAG && sizeof(TO) == 2;
+  f32x2 lnraw[LNK ? FM : 1][4];
+  if constexpr (LNK) {
+    if (p.a_stats) ln_issue<FM>(p.a_stats, p.a_nt, p.M, m0 + wm, fr, fq, lnraw);
+    else if (p.r_stats) ln_issue<FM>(p.r_stats, p.r_nt, p.M, m0 + wm, fr, fq, lnraw);
+  }
   int stage = 0;
   if constexpr (STAG) {
     // Staggered halves (MI355X_MICROARCH.md, "Two waves per SIMD", item 9): the eight waves run the same program with one
@@ -508,6 +663,10 @@ __global__ __launch_bounds__(WM * WN * 64, STAG ? 4 : 1) void gemm2_kernel(const
       }
     }
     stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
+  }
+  if constexpr (LNK) {
+    if (p.a_stats) { gemm_epilogue_ln<TO, FM, FN, 1>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
+    if (p.r_stats || p.stats_out) { gemm_epilogue_ln<TO, FM, FN, 2>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
   }
   gemm_epilogue<TO, FM, FN>(p, acc, z, m0 + wm, n0 + wn, fr, fq);
 }
@@ -922,6 +1081,42 @@ extern "C" int msmd_gemm(const void* A, const void* W, const float* bias, const 
                          long strideW, long strideC, long strideBias, long strideR, msmd_stream_t stream) {
   return gemm_impl(A, W, bias, residual, C, M, N, K, in_dtype, out_dtype, lda, rows_per_batch, a_batch_stride, ldw, ldc,
                    ldr, act, batch, strideA, strideW, strideC, strideBias, strideR, 1, 0, 0, 0, stream);
+}
+
+// C = act(LN_A(A) . W^T + bias) + LN_R(residual), with both LayerNorms folded into this GEMM's epilogue and (optionally)
+// the row statistics of C written for the next consumer: see GemmArgs.  Plain row-major operands, no batch; 16-bit
+// operands (bf16 / fp16), K % 64 == 0, N % 128 == 0; always the 128 x 128 kernel.
+extern "C" int msmd_gemm_ln(const void* A, const void* W, const float* bias, const void* residual, void* C, int M, int N,
+                            int K, int in_dtype, int out_dtype, long lda, long ldw, long ldc, long ldr, int act,
+                            const float* a_stats, const float* w_colsum, const float* r_stats, const float* r_gamma,
+                            const float* r_beta, float* stats_out, float eps, msmd_stream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !C || (K % 64) || (N % 128)) return 1;
+  if ((in_dtype != MSMD_BF16 && in_dtype != MSMD_F16) || out_dtype != in_dtype) return 1;   // 16-bit rows in and out
+  if ((lda % 8) || (ldw % 8) || (ldc % 4) || (residual && (ldr % 4))) return 1;
+  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 15) || ((uintptr_t)residual & 7) || ((uintptr_t)bias & 15)) return 1;
+  if ((a_stats != nullptr) != (w_colsum != nullptr)) return 1;
+  if (!bias || (a_stats && (residual || stats_out)) || (!a_stats && !residual)) return 1;   // the two epilogue modes
+  if (r_stats && (!residual || !r_gamma || !r_beta || a_stats)) return 1;   // one side per call
+  if (((uintptr_t)w_colsum & 15) || ((uintptr_t)r_gamma & 15) || ((uintptr_t)r_beta & 15) || ((uintptr_t)a_stats & 7) ||
+      ((uintptr_t)r_stats & 7) || ((uintptr_t)stats_out & 7))
+    return 1;
+  GemmArgs p;
+  p.A = A; p.W = W; p.bias = bias; p.R = residual; p.C = C;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.rows_per_batch = M; p.a_batch_stride = 0; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.act = act & 0xff;
+  p.inv_rpb = 1.0f / (float)M; p.vec_ok = 1;
+  p.strideA = p.strideW = p.strideC = p.strideBias = p.strideR = 0;
+  p.batch_inner = 1; p.strideA2 = p.strideW2 = p.strideC2 = 0;
+  p.Z = nullptr; p.p_drop = 0.f; p.rng = nullptr; p.site = 0; p.xn = 1;
+  p.flags = (ldc % 8) == 0 ? 2 : 0;   // paired 16-byte stores
+  p.a_stats = a_stats; p.a_nt = K / 64; p.w_colsum = w_colsum;
+  p.r_stats = r_stats; p.r_nt = N / 64; p.r_gamma = r_gamma; p.r_beta = r_beta;
+  p.stats_out = stats_out; p.ln_eps = eps;
+  hipStream_t st = (hipStream_t)stream;
+  int r;
+  if (in_dtype == MSMD_BF16) r = dispatch_gemm2<bf16_t>(p, 1, st, 17);
+  else r = dispatch_gemm2_f16<f16_t>(p, 1, st, 17);
+  return r >= 0 ? r : 1;
 }
 
 extern "C" int msmd_gemm_ex(const void* A, const void* W, const float* bias, const void* residual, void* C, int M,

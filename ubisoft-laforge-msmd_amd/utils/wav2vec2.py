@@ -220,6 +220,21 @@ class Wav2Vec2Model(nn.Module):
             L.w2, L.b2 = cd(sd[p + "feed_forward.output_dense.weight"]), f32(sd[p + "feed_forward.output_dense.bias"])
             L.ln2 = (f32(sd[p + "final_layer_norm.weight"]), f32(sd[p + "final_layer_norm.bias"]))
             P.layers.append(L)
+        # LayerNorm folded into the GEMMs around it (ops.gemm_ln): the Linear that consumes LN(u) carries gamma in its
+        # weights, beta in its bias and the row sums of the folded weights for the mean correction
+        P.fold = (not split and dtype in (torch.bfloat16, torch.float16) and c.hidden_size % 128 == 0
+                  and c.intermediate_size % 128 == 0 and sd["encoder.layer_norm.weight"].is_cuda)
+        if P.fold:
+            for n, L in enumerate(P.layers):
+                p = f"encoder.layers.{n}."
+                wqkv = torch.cat([sd[p + f"attention.{x}_proj.weight"] for x in ("q", "k", "v")], 0)
+                w1 = sd[p + "feed_forward.intermediate_dense.weight"]
+                if c.do_stable_layer_norm:      # pre-LN block: LN1 feeds QKV, LN2 feeds the FFN
+                    L.f_qkv = ops.fold_layernorm(wqkv, L.bqkv, *L.ln1, dtype)
+                    L.f_w1 = ops.fold_layernorm(w1, L.b1, *L.ln2, dtype)
+                else:                           # post-LN block: the PREVIOUS layer's LN2 feeds QKV, this layer's LN1 the FFN
+                    L.f_qkv = ops.fold_layernorm(wqkv, L.bqkv, *P.layers[n - 1].ln2, dtype) if n else None
+                    L.f_w1 = ops.fold_layernorm(w1, L.b1, *L.ln1, dtype)
         self._packed, self._packed_dtype = P, (dtype, split)
         return P
 
@@ -275,6 +290,21 @@ class Wav2Vec2Model(nn.Module):
         ops.gemm(xp, P.pos_w, P.pos_b, h, ops.ACT_GELU, out=y, M=B * T, N=cg, K=kpos * cgp, lda=cgp, rows_per_batch=T,
                  a_batch_stride=G * Tp * cgp, ldw=kpos * cgp, ldc=d, batch=G, strideA=Tp * cgp, strideW=cg * kpos * cgp,
                  strideC=cg, strideBias=cg, strideR=cg)
+        scale, eps = (d // H) ** -0.5, c.layer_norm_eps
+        if P.fold and ops.FOLD_LN and c.do_stable_layer_norm:
+            # pre-LN blocks without LayerNorm launches: every residual GEMM also writes the row statistics of what it
+            # stored, the GEMM that consumes LN(h) applies them in its epilogue (include/msmd_hip.h msmd_gemm_ln)
+            h, st = y, None                     # y comes from the grouped positional conv: no statistics yet
+            for L in P.layers:
+                if st is None:
+                    qkv = ops.gemm(ops.layernorm(h, *L.ln1, eps=eps), L.wqkv, L.bqkv)
+                else:
+                    qkv = ops.gemm_ln(h, L.f_qkv[0], L.f_qkv[2], a_stats=st, w_colsum=L.f_qkv[1], eps=eps)
+                a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale)
+                h, st = ops.gemm_ln(a, L.wo, L.bo, h, stats_out=True)
+                f = ops.gemm_ln(h, L.f_w1[0], L.f_w1[2], act=ops.ACT_GELU, a_stats=st, w_colsum=L.f_w1[1], eps=eps)
+                h, st = ops.gemm_ln(f, L.w2, L.b2, h, stats_out=True)
+            return ops.layernorm(h, *P.enc_ln, eps=eps)
         if c.do_stable_layer_norm:
             # HubertEncoderStableLayerNorm: pre-LN blocks, ONE LayerNorm after the last layer
             h = y
@@ -286,6 +316,25 @@ class Wav2Vec2Model(nn.Module):
                 h = ops.gemm(f, L.w2, L.b2, residual=h)
             return ops.layernorm(h, *P.enc_ln, eps=c.layer_norm_eps)
         h = ops.layernorm(y, *P.enc_ln, eps=c.layer_norm_eps)
+        if P.fold and ops.FOLD_LN:
+            # post-LN blocks without LayerNorm launches: u = the un-normalised rows a residual GEMM stored (+ their row
+            # statistics); LN(u) is applied on the fly where it is the next GEMM's operand (folded weights) and where it
+            # is the next residual (r_stats).  Only the last layer's LN2 is a kernel of its own.
+            u = st = ln = None
+            for n, L in enumerate(P.layers):
+                if n == 0:
+                    qkv = ops.gemm(h, L.wqkv, L.bqkv)
+                else:
+                    qkv = ops.gemm_ln(u, L.f_qkv[0], L.f_qkv[2], a_stats=st, w_colsum=L.f_qkv[1], eps=eps)
+                a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale)
+                if n == 0:
+                    u1, st1 = ops.gemm_ln(a, L.wo, L.bo, h, stats_out=True)
+                else:
+                    u1, st1 = ops.gemm_ln(a, L.wo, L.bo, u, r_stats=st, r_gamma=ln[0], r_beta=ln[1], stats_out=True, eps=eps)
+                f = ops.gemm_ln(u1, L.f_w1[0], L.f_w1[2], act=ops.ACT_GELU, a_stats=st1, w_colsum=L.f_w1[1], eps=eps)
+                u, st = ops.gemm_ln(f, L.w2, L.b2, u1, r_stats=st1, r_gamma=L.ln1[0], r_beta=L.ln1[1], stats_out=True, eps=eps)
+                ln = L.ln2
+            return ops.layernorm(u, *ln, eps=eps)
         for L in P.layers:
             qkv = ops.gemm(h, L.wqkv, L.bqkv)
             a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, (d // H) ** -0.5)
