@@ -87,23 +87,26 @@ int msmd_gemm(const void* A, const void* W, const float* bias, const void* resid
  * ldc == N, batch == 1.  Replaces nn.Linear -> activation -> nn.Dropout (-> residual add) chains of the HF encoder
  * layers, nn.TransformerDecoderLayer / EncoderLayer and the style encoder in train() mode. */
 /* LayerNorm folded into the GEMMs around it (post-LN / pre-LN transformer blocks without LayerNorm launches and without
- * materialising the normalised rows; 16-bit operands and output of one dtype, K % 64 == 0, N % 128 == 0, no batch).
+ * materialising the normalised rows; 16-bit operands and output of one dtype, K % 64 == 0, N % 64 == 0, no batch).
  *   C = act(LN_A(A) . W^T + bias) + LN_R(residual)       bias required; two forms, anything else returns 1:
  *     operand form:  a_stats + w_colsum, no residual, no stats_out;
  *     residual form: residual required, r_stats (+ r_gamma, r_beta) and stats_out each optional.
- *   a_stats (M, K / 64, 2) + w_colsum (N): A holds UN-normalised rows u; a_stats = per-row partial (sum, sum of squares)
- *     over 64-column slabs (what a producer's stats_out wrote); W must carry the LayerNorm weight folded in
+ *   Row statistics travel as per-row partial (sum, sum of squares) over column slabs, fp32, slab-major: (cols / slab, rows, 2).  The slab
+ *   is what one wave of the producing kernel holds of a row: slab_out = 64 selects the 128 x 128 tile (N % 128 == 0),
+ *   slab_out = 32 the 64 x 64 tile (for grids that would not fill the chip otherwise); slab_in is the slab the producer
+ *   of a_stats / r_stats used.
+ *   a_stats (K / slab_in, M, 2) + w_colsum (N): A holds UN-normalised rows u; W must carry the LayerNorm weight folded in
  *     (W'[n][k] = gamma[k] W[n][k]), w_colsum[n] = sum_k W'[n][k] (of the ROUNDED W'), bias[n] = b[n] + sum_k beta[k] W[n][k]:
  *     the epilogue applies  rstd (acc - mu w_colsum[n]) + bias[n].
- *   r_stats (M, N / 64, 2) + r_gamma / r_beta (N): the residual operand holds un-normalised rows; LN is applied on the fly.
- *   stats_out (M, N / 64, 2): partial (sum, sum of squares) of the stored (rounded) rows of C per 64-column slab.
+ *   r_stats (N / slab_in, M, 2) + r_gamma / r_beta (N): the residual operand holds un-normalised rows; LN is applied on the fly.
+ *   stats_out (N / slab_out, M, 2): statistics of the stored (rounded) rows of C.
  * Replaces the LayerNorm modules between the Linear layers of HF Wav2Vec2EncoderLayer / HubertEncoderLayer(StableLayerNorm)
  *  and nn.TransformerDecoderLayer (reference model.py:874-878): the sequence Linear -> +residual -> LayerNorm ->
  * Linear becomes two launches. */
 int msmd_gemm_ln(const void* A, const void* W, const float* bias, const void* residual, void* C, int M, int N, int K,
                  int in_dtype, int out_dtype, long lda, long ldw, long ldc, long ldr, int act, const float* a_stats,
                  const float* w_colsum, const float* r_stats, const float* r_gamma, const float* r_beta,
-                 float* stats_out, float eps, msmd_stream_t stream);
+                 float* stats_out, int slab_in, int slab_out, float eps, msmd_stream_t stream);
 
 int msmd_gemm_ex(const void* A, const void* W, const float* bias, const void* residual, void* C, int M, int N, int K,
                  int in_dtype, int out_dtype, long lda, int rows_per_batch, long a_batch_stride, long ldw, long ldc,

@@ -524,8 +524,9 @@ def test_gemm_store_flags_and_variants_are_bit_identical(dtype):
             assert torch.equal(c, ref), (v, fl, float((c.float() - ref.float()).abs().max()))
 
 
+@pytest.mark.parametrize("M", [1000, 6500])     # 64 x 64 tiles / 32-column slabs; 128 x 128 tiles / 64-column slabs (ragged M)
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_gemm_ln_folds_layernorm_into_producer_and_consumer(dtype):
+def test_gemm_ln_folds_layernorm_into_producer_and_consumer(dtype, M):
     """msmd_gemm_ln: Linear -> +residual -> LayerNorm -> Linear as two launches.  Producer: C1 = A W1^T + b1 + LN_R(r)
     (r un-normalised, its row statistics given) and the row statistics of the stored C1; consumer: LN(C1) W2^T + b2
     through gamma-folded weights.  Reference: the same chain in fp64 from the SAME rounded operands; tolerance = the
@@ -533,7 +534,7 @@ def test_gemm_ln_folds_layernorm_into_producer_and_consumer(dtype):
     bf16, 1e-3 for fp16: the plain chain layernorm kernel + gemm kernel has the same error against fp64)."""
     o = ops()
     g = torch.Generator(device="cpu").manual_seed(11)
-    M, D, F = 1000, 768, 3072
+    D, F = 768, 3072
     tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
     u0 = (torch.randn(M, D, generator=g) * 2 + 0.3).to(dtype)          # un-normalised residual rows
     a = torch.randn(M, D, generator=g).to(dtype)
@@ -544,9 +545,9 @@ def test_gemm_ln_folds_layernorm_into_producer_and_consumer(dtype):
     w2 = torch.randn(F, D, generator=g) / math.sqrt(D)
     b2 = torch.randn(F, generator=g)
 
-    def stats(x):      # (M, cols / 64, 2) partial sums of the stored values
-        x = x.double().reshape(x.shape[0], -1, 64)
-        return torch.stack([x.sum(-1), (x * x).sum(-1)], -1).float().contiguous()
+    def stats(x, slab):      # (cols / slab, M, 2) partial sums of the stored values
+        x = x.double().reshape(x.shape[0], -1, slab)
+        return torch.stack([x.sum(-1), (x * x).sum(-1)], -1).transpose(0, 1).float().contiguous()
 
     def ln(x, gm, bt):
         x = x.double()
@@ -555,13 +556,15 @@ def test_gemm_ln_folds_layernorm_into_producer_and_consumer(dtype):
         return (x - mu) / torch.sqrt(var + 1e-5) * gm.double() + bt.double()
 
     # producer
-    c1, st1 = o.gemm_ln(a.to(DEV), w1.to(DEV), b1.to(DEV), u0.to(DEV), r_stats=stats(u0).to(DEV), r_gamma=g0.to(DEV),
+    c1, st1 = o.gemm_ln(a.to(DEV), w1.to(DEV), b1.to(DEV), u0.to(DEV), r_stats=stats(u0, 32 if M == 6500 else 64).to(DEV), r_gamma=g0.to(DEV),
                         r_beta=be0.to(DEV), stats_out=True)
     ref1 = a.double() @ w1.double().T + b1.double() + ln(u0, g0, be0)
     assert c1.dtype == dtype
     assert maxabs(c1.double().cpu().numpy(), ref1.numpy()) < tol * 4      # O(4) values
-    # the statistics are those of the STORED rows (what the consumer will multiply), fp32 sums of 64 values
-    assert maxabs(st1.cpu().numpy(), stats(c1.cpu()).numpy()) < 2e-3
+    # the statistics are those of the STORED rows (what the consumer will multiply), fp32 sums of a slab's values
+    slab = D // st1.shape[0]
+    assert slab == (64 if M == 6500 else 32)
+    assert maxabs(st1.cpu().numpy(), stats(c1.cpu(), slab).numpy()) < 2e-3
     # consumer: GELU(LN(c1) W2^T + b2)
     wf, cs, bf = o.fold_layernorm(w2.to(DEV), b2.to(DEV), g1.to(DEV), be1.to(DEV), dtype)
     c2 = o.gemm_ln(c1, wf, bf, act=o.ACT_GELU, a_stats=st1, w_colsum=cs)

@@ -607,3 +607,73 @@ def test_sampler_b64_t20_f16x2_against_torch_cpu_sampler():
     torch.cuda.synchronize()
     assert xg.shape == (B, 100, 67) and bool(torch.isfinite(xg).all())
     assert float(xg.abs().max()) < 4 * float(x0.abs().max()) + 1.0
+
+
+@pytest.mark.parametrize("am,kw", [("wav2vec2", {}), ("hubert_large", dict(encoder_layers=4, n_motions=100))])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_layernorm_folded_into_gemms_keeps_the_16_bit_modes_error(am, kw, dtype):
+    """ops.FOLD_LN (msmd_gemm_ln: no LayerNorm launches inside the encoder blocks, post-LN and pre-LN forms) against the
+    LayerNorm-kernel path of the same mode, both measured against the fp32 path on the same weights and audio: the
+    folded path rounds the gamma-folded weights instead of the normalised rows -- its error must stay in the same class
+    (<= 1.5 x the unfused error + 0.01 on O(1) features)."""
+    from msmd_amd import ops
+    audio = dev(synth.audio_clips(3, 64000, tag="fold"))
+    ref = get_model(am, "fp32", **kw)[0].extract_audio_feature(audio).float().cpu().numpy()
+    model, _ = get_model(am, dtype, **kw)
+    assert model.audio_encoder.pack({"bf16": torch.bfloat16, "fp16": torch.float16}[dtype]).fold
+    with mock.patch.object(ops, "FOLD_LN", True):
+        with mock.patch.object(ops, "layernorm", wraps=ops.layernorm) as ln:
+            folded = model.extract_audio_feature(audio).float().cpu().numpy()
+            n_fold = ln.call_count
+    with mock.patch.object(ops, "FOLD_LN", False):
+        with mock.patch.object(ops, "layernorm", wraps=ops.layernorm) as ln:
+            plain = model.extract_audio_feature(audio).float().cpu().numpy()
+            n_plain = ln.call_count
+    layers = model.audio_encoder.config.num_hidden_layers
+    assert n_plain - n_fold == 2 * layers - (1 if am == "wav2vec2" else 1), (n_plain, n_fold)
+    e_f, e_p = maxabs(folded, ref), maxabs(plain, ref)
+    print(f"{am} {dtype}: folded err {e_f:.4f}, LayerNorm-kernel err {e_p:.4f}")
+    assert e_f <= 1.5 * e_p + 0.01
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_layernorm_fold_in_the_denoiser_trunk_and_sampler(dtype):
+    """The decoder layers' three LayerNorms folded into their GEMMs (general masked path: all but the last norm3; diagonal
+    sampler path: norm3 only) against the LayerNorm-kernel path of the same 16-bit mode, both against the fp32 path:
+    the error must stay in the same class (<= 1.5 x + 0.01).  The 500-step sampler is compared in fp16 only (bf16's own
+    drift over 500 steps is larger than any difference between the two paths)."""
+    from msmd_amd import ops
+    args = default_args()
+    x = denoiser_inputs(4, args, tag="foldd")
+    xs = denoiser_inputs(2, args, tag="folds")
+    audio = dev(synth.audio_clips(4, 64000, tag="foldd_audio"))
+    eps = torch.randn(x["motion"].shape, generator=torch.Generator().manual_seed(3)).to(DEV)
+
+    def fwd(model):
+        return model(dev(x["motion"]), audio, dev(x["shape"]), dev(x["style"]), time_step=[3, 499, 100, 250],
+                     indicator=dev(x["indicator"]), train_with_CFG=False, eps=eps)[1].float().cpu().numpy()
+
+    def smp(model):
+        torch.manual_seed(7)
+        return model.sample(dev(xs["audio_feat"]), dev(xs["shape"]), dev(xs["style"]),
+                            indicator=dev(xs["indicator"]))[0].float().cpu().numpy()
+
+    m32 = get_model("wav2vec2", "fp32")[0]
+    ref, ref_s = fwd(m32), (smp(m32) if dtype == "fp16" else None)
+    model, _ = get_model("wav2vec2", dtype)
+    res = {}
+    for on in (True, False):
+        with mock.patch.object(ops, "FOLD_LN", on):
+            with mock.patch.object(ops, "layernorm", wraps=ops.layernorm) as ln:
+                res[on] = fwd(model)
+                res[on, "n"] = ln.call_count
+            if dtype == "fp16":
+                res[on, "s"] = smp(model)
+    e_f, e_p = maxabs(res[True], ref), maxabs(res[False], ref)
+    print(f"forward {dtype}: folded err {e_f:.4f} ({res[True, 'n']} LayerNorm launches), LayerNorm kernels err {e_p:.4f} ({res[False, 'n']})")
+    assert res[False, "n"] - res[True, "n"] == 23 + 23      # encoder 2 x 12 - 1, denoiser 3 x 8 - 1
+    assert e_f <= 1.5 * e_p + 0.01
+    if dtype == "fp16":
+        s_f, s_p = maxabs(res[True, "s"], ref_s), maxabs(res[False, "s"], ref_s)
+        print(f"sampler fp16 (500 steps): folded err {s_f:.4f}, LayerNorm kernels err {s_p:.4f}")
+        assert s_f <= 1.5 * s_p + 0.01

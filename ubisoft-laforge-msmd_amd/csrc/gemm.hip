@@ -30,10 +30,10 @@ struct GemmArgs {
   int xn;  // XCDs along N (1, 2 or 4): the 8 XCDs form an (8 / xn) x xn grid over (M tiles, N tiles)
   int flags;  // MSMD_GEMM_* bits 16.. of `act`, shifted down: 1 = write-through (sc1) output stores, 2 = paired 16-B stores
   // LayerNorm folded into the GEMMs around it (msmd_gemm_ln; all NULL for plain calls):
-  //   a_stats (M, a_nt, 2): A holds UN-normalised rows u, the partial (sum, sum of squares) of each row over 64-column
+  //   a_stats (a_nt, M, 2): A holds UN-normalised rows u, the partial (sum, sum of squares) of each row over 64-column
   //     slabs; W carries gamma folded in, w_colsum[n] = sum_k W'[n][k], bias carries beta . W:  y = rstd (acc - mu s[n]) + c[n]
-  //   r_stats (M, r_nt, 2) + r_gamma / r_beta (N): the residual operand holds un-normalised rows: R <- LN(R) on the fly
-  //   stats_out (M, N / 64, 2): partial (sum, sum of squares) of the STORED (rounded) output rows, per 64-column slab
+  //   r_stats (r_nt, M, 2) + r_gamma / r_beta (N): the residual operand holds un-normalised rows: R <- LN(R) on the fly
+  //   stats_out (N / slab, M, 2): partial (sum, sum of squares) of the STORED (rounded) output rows, per 64-column slab
   const float* a_stats = nullptr; int a_nt = 0; const float* w_colsum = nullptr;
   const float* r_stats = nullptr; int r_nt = 0; const float* r_gamma = nullptr; const float* r_beta = nullptr;
   float* stats_out = nullptr; float ln_eps = 1e-5f;
@@ -269,8 +269,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
 }
 
 // LayerNorm folded into the GEMM (see GemmArgs).  Statistics travel as per-row partial (sum, sum of squares) over
-// 64-column slabs = what ONE wave of a 128 x 128 tile (4 x 2 waves) holds of a row, so writing them needs no LDS and no
-// barrier.  Reading them is latency, not bandwidth: the producer ran on other XCDs, so the first touch of a row's partials
+// column slabs = what ONE wave of a tile holds of a row (64 columns in the 128 x 128 kernel), so writing them needs no LDS
+// and no barrier; the layout is slab-major, (slabs, rows, 2): the 16 rows of a fragment are one 128-byte line of a slab
+// (row-major partials cost 16 lines per load instruction -- +13 % on HuBERT-large's FFN1, measured).  Reading them is latency, not bandwidth: the producer ran on other XCDs, so the first touch of a row's partials
 // misses this XCD's L2.  Measured on the encoder's FFN1 (49 us): a loop over the slabs in the epilogue +5.5 us (serialised
 // round trips), all slabs loaded and reduced before the K loop +8.5 us (every workgroup stalls on the miss before its first
 // tile).  So: ln_issue only ISSUES the loads before the K loop -- lane (fr, fq) takes slabs fq, fq + 4, ... of the FM rows
@@ -279,9 +280,9 @@ template <int FM>
 __device__ __forceinline__ void ln_issue(const float* stats, int nt, int M, int m_base, int fr, int fq, f32x2 (&raw)[FM][4]) {
 #pragma unroll
   for (int j = 0; j < FM; ++j) {
-    const f32x2* sp = (const f32x2*)stats + (long)min(m_base + j * 16 + fr, M - 1) * nt;
+    const f32x2* sp = (const f32x2*)stats + min(m_base + j * 16 + fr, M - 1);     // slab-major: 16 rows = one 128-byte line
 #pragma unroll
-    for (int q = 0; q < 4; ++q) raw[j][q] = fq + 4 * q < nt ? sp[fq + 4 * q] : f32x2{0.f, 0.f};
+    for (int q = 0; q < 4; ++q) raw[j][q] = fq + 4 * q < nt ? sp[(long)(fq + 4 * q) * M] : f32x2{0.f, 0.f};
   }
 }
 
@@ -292,9 +293,9 @@ __device__ __forceinline__ void ln_finish(const float* stats, int nt, int M, int
   for (int j = 0; j < FM; ++j) {
     float S = (raw[j][0][0] + raw[j][1][0]) + (raw[j][2][0] + raw[j][3][0]);
     float Q = (raw[j][0][1] + raw[j][1][1]) + (raw[j][2][1] + raw[j][3][1]);
-    if (nt > 16) {     // rows wider than 1024 columns: the rest, serially
-      const f32x2* sp = (const f32x2*)stats + (long)min(m_base + j * 16 + fr, M - 1) * nt;
-      for (int t = 16 + fq; t < nt; t += 4) { const f32x2 w = sp[t]; S += w[0]; Q += w[1]; }
+    if (nt > 16) {     // more than 16 slabs per row: the rest, serially
+      const f32x2* sp = (const f32x2*)stats + min(m_base + j * 16 + fr, M - 1);
+      for (int t = 16 + fq; t < nt; t += 4) { const f32x2 w = sp[(long)t * M]; S += w[0]; Q += w[1]; }
     }
     S += __shfl_xor(S, 16, 64); S += __shfl_xor(S, 32, 64);
     Q += __shfl_xor(Q, 16, 64); Q += __shfl_xor(Q, 32, 64);
@@ -303,7 +304,8 @@ __device__ __forceinline__ void ln_finish(const float* stats, int nt, int M, int
   }
 }
 
-// Epilogue of a wave whose FN fragments span exactly one 64-column slab (FN == 4).  MODE 1: the operand was LayerNorm'ed
+// Epilogue of a wave whose FN fragments span exactly one statistics slab (64 columns in the 128 x 128 kernel, 32 in the
+// 64 x 64 one).  MODE 1: the operand was LayerNorm'ed
 // (folded weights; no residual).  MODE 2: residual add, the residual LayerNorm'ed on the fly when r_stats is given, and
 // the statistics of the stored rows written when stats_out is given.  Every load of the epilogue (bias, column sums or
 // gamma / beta, the residual fragments) is issued up front, unconditionally: with run-time "is this pointer set" tests
@@ -311,7 +313,8 @@ __device__ __forceinline__ void ln_finish(const float* stats, int nt, int M, int
 template <typename TO, int FM, int FN, int MODE>
 __device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int m_base, int n_base,
                                                  int fr, int fq, const f32x2 (&raw)[FM][4]) {
-  static_assert(FN == 4 && FM == 2, "one wave = one 64-column statistics slab, two fragment rows");
+  static_assert((FN == 4 || FN == 2) && FM == 2, "one wave = one statistics slab of 16 FN columns, two fragment rows");
+  constexpr int SLAB = FN * 16;
   typedef typename Vec4T<TO>::type V4;
   const int n = n_base + fq * 4;
   f32x4 bv[FN], xv[FN], yv[FN];
@@ -388,13 +391,13 @@ __device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& p, const f32x4 
   }
   if constexpr (MODE == 2) {
     if (p.stats_out) {
-      // row sums over this wave's 64 columns: the 4 lane groups (fq) hold 4 columns of every fragment each
+      // row sums over this wave's slab: the 4 lane groups (fq) hold 4 columns of every fragment each
 #pragma unroll
       for (int j = 0; j < FM; ++j) {
         rowS[j] += __shfl_xor(rowS[j], 16, 64); rowS[j] += __shfl_xor(rowS[j], 32, 64);
         rowQ[j] += __shfl_xor(rowQ[j], 16, 64); rowQ[j] += __shfl_xor(rowQ[j], 32, 64);
         const int m = m_base + j * 16 + fr;
-        if (fq == 0 && m < p.M) *(f32x2*)(p.stats_out + ((long)m * (p.N / 64) + n_base / 64) * 2) = f32x2{rowS[j], rowQ[j]};
+        if (fq == 0 && m < p.M) *(f32x2*)(p.stats_out + ((long)(n_base / SLAB) * p.M + m) * 2) = f32x2{rowS[j], rowQ[j]};
       }
     }
   }
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(WM * WN * 64, STAG ? 4 : 1) void gemm2_kernel(const
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s, s);
   // LayerNorm-folding mode (msmd_gemm_ln; the 4 x 2-wave 128 x 128 tile only): the row statistics' loads go out now, consumed in the epilogue
-  constexpr bool LNK = BN == 128 && WN == 2 && !STAG && sizeof(TO) == 2;
+  constexpr bool LNK = (BN == 128 || BN == 64) && WN == 2 && FM == 2 && !STAG && sizeof(TO) == 2;   // slab = BN / 2
   f32x2 lnraw[LNK ? FM : 1][4];
   if constexpr (LNK) {
     if (p.a_stats) ln_issue<FM>(p.a_stats, p.a_nt, p.M, m0 + wm, fr, fq, lnraw);
@@ -1083,14 +1086,16 @@ extern "C" int msmd_gemm(const void* A, const void* W, const float* bias, const 
                    ldr, act, batch, strideA, strideW, strideC, strideBias, strideR, 1, 0, 0, 0, stream);
 }
 
-// C = act(LN_A(A) . W^T + bias) + LN_R(residual), with both LayerNorms folded into this GEMM's epilogue and (optionally)
-// the row statistics of C written for the next consumer: see GemmArgs.  Plain row-major operands, no batch; 16-bit
-// operands (bf16 / fp16), K % 64 == 0, N % 128 == 0; always the 128 x 128 kernel.
+// C = act(LN_A(A) . W^T + bias) + LN_R(residual), with the LayerNorms folded into this GEMM's epilogue and (optionally)
+// the row statistics of C written for the next consumer: see GemmArgs and include/msmd_hip.h.  Plain row-major operands,
+// no batch, 16-bit operands and output.  The statistics' slab width names the kernel that writes them: 64 = the
+// 128 x 128 tile, 32 = the 64 x 64 tile (grids that would not fill the chip with 128 x 128 tiles).
 extern "C" int msmd_gemm_ln(const void* A, const void* W, const float* bias, const void* residual, void* C, int M, int N,
                             int K, int in_dtype, int out_dtype, long lda, long ldw, long ldc, long ldr, int act,
                             const float* a_stats, const float* w_colsum, const float* r_stats, const float* r_gamma,
-                            const float* r_beta, float* stats_out, float eps, msmd_stream_t stream) {
-  if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !C || (K % 64) || (N % 128)) return 1;
+                            const float* r_beta, float* stats_out, int slab_in, int slab_out, float eps,
+                            msmd_stream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !C || (K % 64) || (N % 64)) return 1;
   if ((in_dtype != MSMD_BF16 && in_dtype != MSMD_F16) || out_dtype != in_dtype) return 1;   // 16-bit rows in and out
   if ((lda % 8) || (ldw % 8) || (ldc % 4) || (residual && (ldr % 4))) return 1;
   if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 15) || ((uintptr_t)residual & 7) || ((uintptr_t)bias & 15)) return 1;
@@ -1100,6 +1105,12 @@ extern "C" int msmd_gemm_ln(const void* A, const void* W, const float* bias, con
   if (((uintptr_t)w_colsum & 15) || ((uintptr_t)r_gamma & 15) || ((uintptr_t)r_beta & 15) || ((uintptr_t)a_stats & 7) ||
       ((uintptr_t)r_stats & 7) || ((uintptr_t)stats_out & 7))
     return 1;
+  if ((a_stats || r_stats) && slab_in != 32 && slab_in != 64) return 1;
+  if (stats_out && slab_out != 32 && slab_out != 64) return 1;
+  if ((a_stats && (K % slab_in)) || (r_stats && (N % slab_in))) return 1;
+  const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  const bool big = stats_out ? slab_out == 64 : (tiles128 >= 192 && (N % 128) == 0);
+  if (big && (N % 128)) return 1;
   GemmArgs p;
   p.A = A; p.W = W; p.bias = bias; p.R = residual; p.C = C;
   p.M = M; p.N = N; p.K = K;
@@ -1109,13 +1120,12 @@ extern "C" int msmd_gemm_ln(const void* A, const void* W, const float* bias, con
   p.batch_inner = 1; p.strideA2 = p.strideW2 = p.strideC2 = 0;
   p.Z = nullptr; p.p_drop = 0.f; p.rng = nullptr; p.site = 0; p.xn = 1;
   p.flags = (ldc % 8) == 0 ? 2 : 0;   // paired 16-byte stores
-  p.a_stats = a_stats; p.a_nt = K / 64; p.w_colsum = w_colsum;
-  p.r_stats = r_stats; p.r_nt = N / 64; p.r_gamma = r_gamma; p.r_beta = r_beta;
+  p.a_stats = a_stats; p.a_nt = a_stats ? K / slab_in : 0; p.w_colsum = w_colsum;
+  p.r_stats = r_stats; p.r_nt = r_stats ? N / slab_in : 0; p.r_gamma = r_gamma; p.r_beta = r_beta;
   p.stats_out = stats_out; p.ln_eps = eps;
   hipStream_t st = (hipStream_t)stream;
-  int r;
-  if (in_dtype == MSMD_BF16) r = dispatch_gemm2<bf16_t>(p, 1, st, 17);
-  else r = dispatch_gemm2_f16<f16_t>(p, 1, st, 17);
+  const int variant = big ? 17 : (K >= 1024 ? 9 : 12);
+  const int r = in_dtype == MSMD_BF16 ? dispatch_gemm2<bf16_t>(p, 1, st, variant) : dispatch_gemm2_f16<f16_t>(p, 1, st, variant);
   return r >= 0 ? r : 1;
 }
 

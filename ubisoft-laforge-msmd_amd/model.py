@@ -247,6 +247,16 @@ class DenoisingNetwork_MSMD(nn.Module):
             L.n2 = (f32(sd[p + "norm2.weight"]), f32(sd[p + "norm2.bias"]))
             L.n3 = (f32(sd[p + "norm3.weight"]), f32(sd[p + "norm3.bias"]))
             P.layers.append(L)
+        # LayerNorm folded into the GEMMs around it (ops.gemm_ln): a Linear that consumes LN(u) carries gamma in its
+        # weights, beta in its bias and the row sums of the folded weights
+        P.fold = not split and dtype in (torch.bfloat16, torch.float16) and d % 64 == 0 and sd["PE" if self.use_learnable_pe else "PE.pe"].is_cuda
+        if P.fold:
+            for n, L in enumerate(P.layers):
+                p = f"transformer.layers.{n}."
+                L.f_sa = (ops.fold_layernorm(sd[p + "self_attn.in_proj_weight"], L.sa_b, *P.layers[n - 1].n3, dtype)
+                          if n else None)                                   # the previous layer's norm3 feeds QKV
+                L.f_caq = ops.fold_layernorm(sd[p + "multihead_attn.in_proj_weight"][:d], L.ca_qb, *L.n1, dtype)
+                L.f_l1 = ops.fold_layernorm(sd[p + "linear1.weight"], L.l1[1], *L.n2, dtype)
         P.md0 = (cd(sd["motion_dec.0.weight"]), f32(sd["motion_dec.0.bias"]))
         P.md2 = (cd(sd["motion_dec.2.weight"]), f32(sd["motion_dec.2.bias"]))
         # static bases: first linears stacked (nb*d, d_style); second linears batched (nb, dm, d)
@@ -323,10 +333,41 @@ class DenoisingNetwork_MSMD(nn.Module):
             if kv_list is None:
                 kv_list = self.memory_kv(mem, dtype)
             cross_list = self.memory_cross(kv_list, dtype)
-        for li, L in enumerate(P.layers):
-            qkv = ops.gemm(x, L.sa_w, L.sa_b)
+        fold = P.fold and ops.FOLD_LN
+        if fold and not diag:
+            # post-LN decoder layers without LayerNorm launches: u* = the un-normalised rows a residual GEMM stored, st* their
+            # row statistics; the three LayerNorms are applied where their output is consumed -- as the next GEMM's operand
+            # (folded weights) and as the next residual (r_stats).  Only the last layer's norm3 is a kernel of its own.
+            u = st = ln = None
+            for li, L in enumerate(P.layers):
+                if li == 0:
+                    qkv = ops.gemm(x, L.sa_w, L.sa_b)
+                else:
+                    qkv = ops.gemm_ln(u, L.f_sa[0], L.f_sa[2], a_stats=st, w_colsum=L.f_sa[1])
+                a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale)
+                if li == 0:
+                    u1, st1 = ops.gemm_ln(a, L.sa_ow, L.sa_ob, x, stats_out=True)
+                else:
+                    u1, st1 = ops.gemm_ln(a, L.sa_ow, L.sa_ob, u, r_stats=st, r_gamma=ln[0], r_beta=ln[1], stats_out=True)
+                kv = kv_list[li] if kv_list is not None else ops.gemm(mem, L.ca_kvw, L.ca_kvb)
+                q = ops.gemm_ln(u1, L.f_caq[0], L.f_caq[2], a_stats=st1, w_colsum=L.f_caq[1])
+                c = ops.attention(q, kv[..., :d], kv[..., d:], H, scale, mask=P.mask)
+                u2, st2 = ops.gemm_ln(c, L.ca_ow, L.ca_ob, u1, r_stats=st1, r_gamma=L.n1[0], r_beta=L.n1[1], stats_out=True)
+                f = ops.gemm_ln(u2, L.f_l1[0], L.f_l1[2], act=ops.ACT_GELU, a_stats=st2, w_colsum=L.f_l1[1])
+                u, st = ops.gemm_ln(f, L.l2[0], L.l2[1], u2, r_stats=st2, r_gamma=L.n2[0], r_beta=L.n2[1], stats_out=True)
+                ln = L.n3
+            x = ops.layernorm(u, *ln)
+        u = st = ln = None        # diagonal path with fold: the previous layer's un-normalised norm3 input
+        for li, L in enumerate(P.layers if not (fold and not diag) else ()):
+            if u is None:
+                qkv = ops.gemm(x, L.sa_w, L.sa_b)
+            else:
+                qkv = ops.gemm_ln(u, L.f_sa[0], L.f_sa[2], a_stats=st, w_colsum=L.f_sa[1])
             a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale)
-            x = ops.layernorm(ops.gemm(a, L.sa_ow, L.sa_ob, residual=x), *L.n1)
+            if u is None:
+                x = ops.layernorm(ops.gemm(a, L.sa_ow, L.sa_ob, residual=x), *L.n1)
+            else:
+                x = ops.layernorm(ops.gemm_ln(a, L.sa_ow, L.sa_ob, u, r_stats=st, r_gamma=ln[0], r_beta=ln[1]), *L.n1)
             kv = kv_list[li] if kv_list is not None else ops.gemm(mem, L.ca_kvw, L.ca_kvb)
             if diag:
                 # only the person token (row 0) has a real softmax; rows t >= 1 come from the precomputed R
@@ -345,7 +386,12 @@ class DenoisingNetwork_MSMD(nn.Module):
                 c = ops.attention(q, kv[..., :d], kv[..., d:], H, scale, mask=P.mask)
                 x = ops.layernorm(ops.gemm(c, L.ca_ow, L.ca_ob, residual=x), *L.n2)
             f = ops.gemm(x, *L.l1, act=ops.ACT_GELU)
-            x = ops.layernorm(ops.gemm(f, *L.l2, residual=x), *L.n3)
+            if fold and diag and li + 1 < len(P.layers):
+                # norm3 is consumed by the next layer's QKV GEMM and out-projection residual only: folded into them
+                u, st = ops.gemm_ln(f, L.l2[0], L.l2[1], x, stats_out=True)
+                ln = L.n3
+            else:
+                x = ops.layernorm(ops.gemm(f, *L.l2, residual=x), *L.n3)
         # motion_dec on rows 1.. (windowed view of x, no copy)
         Lm = Tn - 1
         h = torch.empty(N, Lm, d // 2, device=x.device, dtype=dtype)

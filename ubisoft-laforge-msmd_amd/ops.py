@@ -167,7 +167,8 @@ _TUNED = {}
 # global state; these module-level defaults are what `gemm()` passes when the caller gives none (`gemm_defaults`
 # scopes a change, e.g. while a hipGraph is captured -- the choice is then baked into that graph).
 GEMM_WRITE_THROUGH, GEMM_PAIRED_STORES = 1 << 16, 1 << 17
-FOLD_LN = True        # transformer blocks: LayerNorm folded into the neighbouring GEMMs (gemm_ln); False = LayerNorm kernels
+# transformer blocks: LayerNorm folded into the neighbouring GEMMs (gemm_ln); False (MSMD_FOLD_LN=0) = LayerNorm kernels
+FOLD_LN = os.environ.get("MSMD_FOLD_LN", "1") != "0"
 GEMM_ROUTER = None   # developer hook (tools/ab_forward.py): callable (M, N, K, batch) -> variant or None, consulted per call
 _GEMM_DEFAULT = {"variant": 0, "flags": GEMM_PAIRED_STORES, "split_variant": 0}   # paired 16-byte stores: -1 % on the forward step
 
@@ -283,10 +284,11 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
 
 def gemm_ln(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None, *, a_stats=None, w_colsum=None,
             r_stats=None, r_gamma=None, r_beta=None, stats_out=False, eps=1e-5):
-    """C = act(LN_A(a) @ w^T + bias) + LN_R(residual) with both LayerNorms folded into the GEMM epilogue (msmd_gemm_ln):
-    a_stats / r_stats are (M, cols / 64, 2) per-row partial (sum, sum of squares) written by a producer's stats_out;
+    """C = act(LN_A(a) @ w^T + bias) + LN_R(residual) with the LayerNorms folded into the GEMM epilogue (msmd_gemm_ln):
+    a_stats / r_stats are (cols / slab, M, 2) per-row partial (sum, sum of squares) written by a producer's stats_out;
     w must hold gamma-folded weights with w_colsum = their row sums and bias the beta-folded bias (see fold_layernorm).
-    stats_out=True (or a tensor): returns (C, stats) with the partial statistics of the stored rows of C."""
+    stats_out=True: returns (C, stats) with the partial statistics of the stored rows of C (the slab -- 64 or 32 columns --
+    follows the tile the grid is routed to and is read back from the statistics' shape by the consumer)."""
     _need_cuda(a, w, bias, residual)
     lib = _lib.load()
     K = a.shape[-1]
@@ -295,24 +297,31 @@ def gemm_ln(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=No
     out_dtype = out_dtype or a.dtype
     if out is None:
         out = empty((*a.shape[:-1], N), a.device, out_dtype)
-    st = None
-    if stats_out is True:
-        st = empty((M, N // 64, 2), a.device, torch.float32)
-    elif torch.is_tensor(stats_out):
-        st = stats_out
-    for t in (bias, w_colsum, r_gamma, r_beta, a_stats, r_stats, st):
+    st, slab_out, slab_in = None, 0, 0
+    if stats_out:
+        slab_out = 64 if N % 128 == 0 and ((M + 127) // 128) * (N // 128) >= 192 else 32
+        st = empty((N // slab_out, M, 2), a.device, torch.float32)
+    sin = a_stats if a_stats is not None else r_stats
+    if sin is not None:
+        cols = K if a_stats is not None else N
+        if sin.dim() != 3 or sin.shape[1] != M or sin.shape[2] != 2 or cols % sin.shape[0]:
+            raise ValueError("gemm_ln: statistics must be (cols / slab, M, 2)")
+        slab_in = cols // sin.shape[0]
+    for t in (bias, w_colsum, r_gamma, r_beta, a_stats, r_stats):
         if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
             raise TypeError("gemm_ln: bias / colsum / gamma / beta / stats must be contiguous fp32")
-    if a_stats is not None and a_stats.numel() != M * (K // 64) * 2:
-        raise ValueError("gemm_ln: a_stats must be (M, K / 64, 2)")
-    if r_stats is not None and r_stats.numel() != M * (N // 64) * 2:
-        raise ValueError("gemm_ln: r_stats must be (M, N / 64, 2)")
     if GEMM_FLOPS is not None:
         GEMM_FLOPS[0] += 2.0 * M * N * K
     ldr = residual.stride(-2) if residual is not None and residual.dim() >= 2 else N
+    if GEMM_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(lib.msmd_gemm_ln(_p(a), _p(w), _p(bias), _p(residual), _p(out), M, N, K, _dt(a), _dt(out), a.stride(-2) if a.dim() >= 2 else K,
                                 w.stride(0), N, ldr, act, _p(a_stats), _p(w_colsum), _p(r_stats), _p(r_gamma),
-                                _p(r_beta), _p(st), float(eps), _stream()), "msmd_gemm_ln")
+                                _p(r_beta), _p(st), slab_in, slab_out, float(eps), _stream()), "msmd_gemm_ln")
+    if GEMM_TRACE is not None:
+        e1.record()
+        GEMM_TRACE.append((M, N, K, 1, _dt(a), e0, e1))
     return (out, st) if st is not None else out
 
 
