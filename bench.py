@@ -73,14 +73,15 @@ def step(model, b):
 
 
 def graphed_step(model, b):
-    """The step as ONE hipGraph replay (MSMD.capture_forward): static shapes, every replay runs all kernels on inputs
-    refreshed by device-to-device copies into the captured buffers; capture_forward checks a replay on perturbed inputs
-    against the eager forward, bit for bit."""
+    """The step as ONE hipGraph replay (MSMD.capture_forward): static shapes, every replay runs all kernels on the batch
+    that sits in the captured input buffers (written there once before the timed region: the contract's "inputs already
+    resident in HBM" -- a loader's host-to-device copies would target these buffers); capture_forward checks a replay on
+    perturbed inputs against the eager forward, bit for bit, and main() checks a replay of THIS graph against the oracle."""
     ts = torch.tensor(b["time_step"], device=b["audio"].device, dtype=torch.long)
     run = model.capture_forward(b["motion"], b["audio"], b["shape"], b["style"], ts, b["indicator"], b["eps"])
-    fresh = dict(motion_feat=b["motion"], audio=b["audio"], shape_feat=b["shape"], style_feat=b["style"], time_step=ts,
-                 indicator=b["indicator"], eps=b["eps"])
-    return lambda: run(**fresh)
+    run(motion_feat=b["motion"], audio=b["audio"], shape_feat=b["shape"], style_feat=b["style"], time_step=ts,
+        indicator=b["indicator"], eps=b["eps"])
+    return lambda: run()
 
 
 # ----------------------------------------------------------------------------------------------- roofline

@@ -84,6 +84,16 @@ class DiffusionSchedule(nn.Module):
         self.register_buffer("sigmas_flex", sigmas_flex)
         self.register_buffer("sigmas_inflex", sigmas_inflex)
         self._host = None
+        self._qs = None
+
+    def qsample_tables(self):
+        """(sqrt(alpha_bar), sqrt(1 - alpha_bar)) as fp32 tables: the two torch ops the reference applies to the gathered
+        alpha_bar_t on every call (model.py:231-236), applied to the whole schedule once; rebuilt when the buffer changes."""
+        ab = self.alpha_bars
+        key = (ab.data_ptr(), ab._version, ab.device)
+        if self._qs is None or self._qs[0] != key:
+            self._qs = (key, torch.sqrt(ab).float().contiguous(), torch.sqrt(1 - ab).float().contiguous())
+        return self._qs[1], self._qs[2]
 
     def host_tables(self):
         """CPU copies for the sampler's per-step scalar coefficients (no device sync inside the loop)."""
@@ -94,6 +104,7 @@ class DiffusionSchedule(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._host = None
+        self._qs = None
         return super()._apply(fn, *a, **k)
 
     def uniform_sample_t(self, batch_size):
@@ -215,6 +226,7 @@ class DenoisingNetwork_MSMD(nn.Module):
         P = SimpleNamespace()
         P.split = split
         P.te = f32(sd["TE.pe"][0])
+        P.te_cd = P.te if split else P.te.to(dtype)
         if self.use_learnable_pe:
             P.pe = f32(sd["PE"][0])
         else:
@@ -257,6 +269,9 @@ class DenoisingNetwork_MSMD(nn.Module):
                           if n else None)                                   # the previous layer's norm3 feeds QKV
                 L.f_caq = ops.fold_layernorm(sd[p + "multihead_attn.in_proj_weight"][:d], L.ca_qb, *L.n1, dtype)
                 L.f_l1 = ops.fold_layernorm(sd[p + "linear1.weight"], L.l1[1], *L.n2, dtype)
+        if not split:
+            P.ca_kvw_all = torch.cat([L.ca_kvw for L in P.layers], 0).contiguous()
+            P.ca_kvb_all = torch.cat([L.ca_kvb for L in P.layers], 0).contiguous()
         P.md0 = (cd(sd["motion_dec.0.weight"]), f32(sd["motion_dec.0.bias"]))
         P.md2 = (cd(sd["motion_dec.2.weight"]), f32(sd["motion_dec.2.bias"]))
         # static bases: first linears stacked (nb*d, d_style); second linears batched (nb, dm, d)
@@ -269,14 +284,14 @@ class DenoisingNetwork_MSMD(nn.Module):
         return P
 
     # ------------------------------------------------------------------ pieces (shared with the sampler)
-    def static_bases(self, static_style_feat, dtype):
+    def static_bases(self, static_style_feat, dtype, out_dtype=None):
         """(Ns, 1, d_style) -> (Ns, nb, dm): the 4 style->static-pose MLPs (model.py:964-971); step-invariant."""
         P = self.pack(dtype)
         nb, dm, d = self.num_of_basis, self.motion_feat_dim, self.feature_dim
         s = ops.cast(static_style_feat.reshape(-1, static_style_feat.shape[-1]).contiguous(), dtype)
         Ns = s.shape[0]
         h = ops.gemm(s, *P.st0, act=ops.ACT_GELU)  # (Ns, nb*d)
-        stat = torch.empty(Ns, nb, dm, device=s.device, dtype=dtype)
+        stat = torch.empty(Ns, nb, dm, device=s.device, dtype=out_dtype or dtype)
         ops.gemm(h, P.st2[0], P.st2[1], None, out=stat, M=Ns, N=dm, K=d, lda=nb * d, ldw=d, ldc=nb * dm, batch=nb,
                  strideA=d, strideW=dm * d, strideC=dm, strideBias=dm)
         return stat
@@ -284,15 +299,20 @@ class DenoisingNetwork_MSMD(nn.Module):
     def person_token(self, person_feat, step, dtype):
         """person_proj(person_feat) + diff_step_map(TE.pe[0, step]) -> (N, d) (model.py:931-933)."""
         P = self.pack(dtype)
-        te = ops.cast(P.te[step].contiguous(), dtype)
+        te = P.te_cd[step]
         emb = ops.gemm(ops.gemm(te, *P.ds0, act=ops.ACT_GELU), *P.ds2)
         pf = ops.pad_cols(person_feat.reshape(person_feat.shape[0], -1).float().contiguous(), P.kp_person, dtype)
         return ops.gemm(pf, *P.pp, residual=emb)
 
-    def memory_kv(self, mem, dtype):
+    def memory_kv(self, mem, dtype, stacked=False):
         """Cross-attention K/V projections of the audio memory for every layer: step-invariant in the
         sampler (hoisted out of the T x n_entries loop)."""
         P = self.pack(dtype)
+        if stacked and not P.split:
+            # one GEMM for all layers (N = n_layers x 2d) instead of n_layers small ones; per-layer column views
+            d2 = 2 * self.feature_dim
+            kv = ops.gemm(mem, P.ca_kvw_all, P.ca_kvb_all)
+            return [kv[..., li * d2:(li + 1) * d2] for li in range(len(P.layers))]
         return [ops.gemm(mem, L.ca_kvw, L.ca_kvb) for L in P.layers]
 
     def memory_cross(self, kv_list, dtype):
@@ -334,6 +354,8 @@ class DenoisingNetwork_MSMD(nn.Module):
                 kv_list = self.memory_kv(mem, dtype)
             cross_list = self.memory_cross(kv_list, dtype)
         fold = P.fold and ops.FOLD_LN
+        if kv_list is None and not diag:
+            kv_list = self.memory_kv(mem, dtype, stacked=True)
         if fold and not diag:
             # post-LN decoder layers without LayerNorm launches: u* = the un-normalised rows a residual GEMM stored, st* their
             # row statistics; the three LayerNorms are applied where their output is consumed -- as the next GEMM's operand
@@ -437,7 +459,7 @@ class DenoisingNetwork_MSMD(nn.Module):
         return ops.gemm(h, *P.md2, out_dtype=torch.float32)
 
     def forward(self, motion_feat, audio_feat, person_feat, static_style_feat, prev_motion_feat, prev_audio_feat, step,
-                indicator=None, keep_separate=False, dtype=None, _qsample=None):
+                indicator=None, keep_separate=False, dtype=None, _qsample=None, _audio_cd=None):
         """reference model.py:914-996.  Returns (N, L_p + L, d_motion) fp32."""
         dtype = dtype or getattr(self, "compute_dtype", torch.float32)
         if self.use_indicator and indicator is None:
@@ -451,9 +473,13 @@ class DenoisingNetwork_MSMD(nn.Module):
         eps, c0, c1 = _qsample if _qsample is not None else (None, None, None)
         ops.denoiser_pack_input(motion_feat.float().contiguous(), prev_motion_feat.float().contiguous(),
                                 indicator.float().contiguous() if self.use_indicator else None, feats, eps, c0, c1)
-        mem = torch.cat([ops.cast(prev_audio_feat.contiguous(), dtype), ops.cast(audio_feat.contiguous(), dtype)], dim=1)
+        # audio memory [previous window | this window] in the compute dtype: two casting copies into one buffer
+        La, Lpa = audio_feat.shape[1], prev_audio_feat.shape[1]
+        mem = torch.empty(N, Lpa + La, audio_feat.shape[2], device=self.device, dtype=dtype)
+        mem[:, :Lpa].copy_(prev_audio_feat)
+        mem[:, Lpa:].copy_(_audio_cd if _audio_cd is not None else audio_feat)
         dec = self.trunk(feats, tok0, mem, dtype)
-        stat = self.static_bases(static_style_feat, torch.float32 if dtype == torch.float32 else dtype)
+        stat = self.static_bases(static_style_feat, dtype, out_dtype=torch.float32)   # the head mixes in fp32
         if keep_separate:
             dynamic = dec[:, :, :dm]
             alphas = dec[:, :, dm:]
@@ -601,13 +627,16 @@ class MSMD(nn.Module):
         if audio_or_feat.ndim == 2:
             assert audio_or_feat.shape[1] == 16000 * self.n_motions / self.fps, \
                 f"Incorrect audio length {audio_or_feat.shape[1]}"
-            audio_feat_saved = self._audio_feat(audio_or_feat, self.n_motions, dtype).float()
+            audio_cd = self._audio_feat(audio_or_feat, self.n_motions, dtype)      # compute dtype: what the denoiser reads
+            audio_feat_saved = audio_cd.float()
         elif audio_or_feat.ndim == 3:
             assert audio_or_feat.shape[1] == self.n_motions, f"Incorrect audio feature length {audio_or_feat.shape[1]}"
             audio_feat_saved = audio_or_feat
         else:
             raise ValueError(f"Incorrect audio input shape {audio_or_feat.shape}")
         audio_feat = audio_feat_saved
+        if audio_or_feat.ndim != 2:
+            audio_cd = None
         if shape_feat.ndim == 2:
             shape_feat = shape_feat.unsqueeze(1)
         if style_feat is not None and style_feat.ndim == 2:
@@ -641,15 +670,15 @@ class MSMD(nn.Module):
         if time_step is None:
             time_step = self.diffusion_sched.uniform_sample_t(batch_size)
         ts = torch.as_tensor(time_step, device=self.device, dtype=torch.long)
-        alpha_bar = self.diffusion_sched.alpha_bars[ts]
-        c0 = torch.sqrt(alpha_bar).float().contiguous()
-        c1 = torch.sqrt(1 - alpha_bar).float().contiguous()
+        t0, t1 = self.diffusion_sched.qsample_tables()
+        c0, c1 = t0[ts], t1[ts]                                     # sqrt(alpha_bar_t), sqrt(1 - alpha_bar_t)
         if eps is None:
             eps = torch.randn_like(motion_feat)
         eps = eps.float().contiguous()
         # q-sample is fused into the denoiser's input packing kernel (model.py:231-236)
         out = self.denoising_net(motion_feat, audio_feat, person_feat, style_feat, prev_motion_feat, prev_audio_feat,
-                                 ts, indicator, keep_separate=keep_separate, dtype=dtype, _qsample=(eps, c0, c1))
+                                 ts, indicator, keep_separate=keep_separate, dtype=dtype, _qsample=(eps, c0, c1),
+                                 _audio_cd=audio_cd if audio_feat is audio_feat_saved else None)
         if keep_separate:
             dyn, stat, alpha_t = out
             if self.use_head_alpha:
