@@ -517,7 +517,7 @@ def test_gemm_store_flags_and_variants_are_bit_identical(dtype):
     b = torch.randn(N, generator=g).to(DEV)
     r = torch.randn(M, N, generator=g).to(DEV, dtype)
     ref = o.gemm(a, w, b, r, act=o.ACT_GELU, variant=17, flags=0)
-    variants = (0, 9, 12, 17) + ((13,) if dtype == torch.bfloat16 else ())
+    variants = (0, 9, 12, 14, 17) + ((13,) if dtype == torch.bfloat16 else ())
     for v in variants:
         for fl in (0, o.GEMM_WRITE_THROUGH, o.GEMM_PAIRED_STORES, o.GEMM_WRITE_THROUGH | o.GEMM_PAIRED_STORES):
             c = o.gemm(a, w, b, r, act=o.ACT_GELU, variant=v, flags=fl)

@@ -64,7 +64,7 @@ def test_split_gemm_matches_float64(M, N, K):
     r = synth.normalish(f"sgemm/r/{M}x{N}", (M, N))
     ref = a.astype(np.float64) @ w.astype(np.float64).T + b
     ws = o.to_split(dev(w))
-    for variant in (0, 1, 5):   # heuristic, 128 x 128, 64 x 64: per-call hint (MSMD_GEMM_VARIANT), no library state
+    for variant in (0, 1, 5, 14):   # heuristic, 128 x 128, 64 x 64, 256 x 64: per-call hint (MSMD_GEMM_VARIANT), no library state
         c = o.gemm(o.to_split(dev(a)), ws, dev(b), variant=variant).cpu().numpy()
         assert maxabs(c, ref) < 4e-6, (variant, maxabs(c, ref))
     c32 = o.gemm(dev(a), dev(w), dev(b)).cpu().numpy()

@@ -26,7 +26,10 @@ for s, e, n in step:
     by[k][0] += (e - s) / 1e3; by[k][1] += 1
 for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:22]:
     print(f"  {t:8.1f} us  x{c:3d}  avg {t / c:7.2f}  {k}")
-big = sorted(((g, step[i][2][:50], step[i + 1][2][:50]) for i, g in enumerate(gaps)), reverse=True)[:8]
+print("longest single launches:")
+for s_, e_, n_ in sorted(step, key=lambda r: r[0] - r[1])[:14]:
+    print(f"  {(e_ - s_) / 1e3:8.1f} us  at +{(s_ - step[0][0]) / 1e3:7.1f}  {n_[:70]}")
+big = sorted(((g, step[i][2][:50], step[i + 1][2][:50]) for i, g in enumerate(gaps)), reverse=True)[:3]
 print("largest gaps (us, after kernel -> before kernel):")
 for g, x, y in big:
     print(f"  {g:6.2f}  {x} -> {y}")

@@ -878,6 +878,7 @@ static int dispatch_gemm2s(GemmArgs& p, int batch, hipStream_t st, int variant) 
   switch (variant) {
     case 1: return launch_gemm2s<TO, 128, 128, 4, 2, 2>(p, batch, st);   // 64 KB, 2 workgroups / CU (default)
     case 5: return launch_gemm2s<TO, 64, 64, 2, 2, 4>(p, batch, st);     // small grids
+    case 14: return launch_gemm2s<TO, 256, 64, 8, 1, 2>(p, batch, st);   // narrow outputs (N <= 64): the positional conv
 #ifdef MSMD_EXPERIMENTAL
     case 2: return launch_gemm2s<TO, 128, 128, 4, 2, 4>(p, batch, st);   // 128 KB, deep ring
     case 3: return launch_gemm2s<TO, 128, 128, 2, 2, 2>(p, batch, st);   // 4 waves of 64 x 64
@@ -896,7 +897,7 @@ static int dispatch_gemm2s(GemmArgs& p, int batch, hipStream_t st, int variant) 
   }
 }
 
-// Product variants: 17 = 128 x 128, 8 waves (4 x 2), 2-stage ring, fragment reads of both k-steps issued first (default
+// Product variants: 14 = 256 x 64 for narrow outputs; 17 = 128 x 128, 8 waves (4 x 2), 2-stage ring, fragment reads of both k-steps issued first (default
 // once the grid fills the chip); 13 = the same tile with the compiler's own read / multiply interleave; 9 / 12 = 64 x 64
 // tiles with a 4- / 2-stage ring for grids that would not fill the chip.  Every other family that was built and measured
 //  lives in exp/gemm_variants.inc and is compiled only with -DMSMD_EXPERIMENTAL.
@@ -906,6 +907,7 @@ static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
     case 9: return launch_gemm2<TO, 64, 64, 2, 2, 4>(p, batch, st);
     case 12: return launch_gemm2<TO, 64, 64, 2, 2, 2>(p, batch, st);
     case 13: return launch_gemm2<TO, 128, 128, 4, 2, 2>(p, batch, st);
+    case 14: return launch_gemm2<TO, 256, 64, 8, 1, 2, true>(p, batch, st);   // narrow outputs (N <= 64): 8 waves of 32 x 64
     case 17: return launch_gemm2<TO, 128, 128, 4, 2, 2, true>(p, batch, st);
 #ifdef MSMD_EXPERIMENTAL
     case 41: return launch_gemm2<TO, 128, 128, 4, 2, 2, true, bf16_t, true>(p, batch, st);   // 17 with waves 4-7 staggered: -25 % (5c)
@@ -917,10 +919,15 @@ static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
     case 5: return launch_gemm2<TO, 256, 256, 2, 4, 2>(p, batch, st);
     case 6: return launch_gemm2<TO, 128, 256, 2, 4, 3>(p, batch, st);
     case 7: return launch_gemm2<TO, 64, 128, 1, 4, 4>(p, batch, st);
-    case 8: return launch_gemm2<TO, 128, 64, 4, 1, 4>(p, batch, st);
+    // positional-conv candidates (N = 48 per group, 6400 x 48 x 6144 x 16 groups; variant 9: 140 us, 12: 120 us):
+    case 42: return launch_gemm2<TO, 256, 64, 4, 1, 2>(p, batch, st);         // 94 us
+    case 43: return launch_gemm2<TO, 256, 64, 4, 1, 2, true>(p, batch, st);   // 86 us   (product variant 14, 8 waves: 85 us)
+    case 44: return launch_gemm2<TO, 128, 64, 4, 1, 2, true>(p, batch, st);   // 124 us
+    case 46: return launch_gemm2<TO, 256, 64, 4, 1, 3, true>(p, batch, st);   // 148 us (one workgroup per CU)
+    case 8: return launch_gemm2<TO, 128, 64, 4, 1, 4>(p, batch, st);          // 190 us
     case 10: return launch_gemm2<TO, 128, 64, 2, 2, 3>(p, batch, st);
     case 11: return launch_gemm2<TO, 64, 128, 2, 2, 3>(p, batch, st);
-    case 14: return launch_gemm2<TO, 128, 64, 2, 2, 2>(p, batch, st);
+    case 47: return launch_gemm2<TO, 128, 64, 2, 2, 2>(p, batch, st);
     case 15: return launch_gemm2<TO, 64, 128, 2, 2, 2>(p, batch, st);
     case 16: return launch_gemm2<TO, 128, 128, 2, 4, 2>(p, batch, st);
     case 18: return launch_gemm2<TO, 128, 128, 2, 4, 2, true>(p, batch, st);
@@ -969,6 +976,7 @@ static int dispatch_gemm2_f16(GemmArgs& p, int batch, hipStream_t st, int varian
   switch (variant) {
     case 9: return launch_gemm2<TO, 64, 64, 2, 2, 4, false, f16_t>(p, batch, st);
     case 12: return launch_gemm2<TO, 64, 64, 2, 2, 2, false, f16_t>(p, batch, st);
+    case 14: return launch_gemm2<TO, 256, 64, 8, 1, 2, true, f16_t>(p, batch, st);
     case 17: return launch_gemm2<TO, 128, 128, 4, 2, 2, true, f16_t>(p, batch, st);
     default: return -1;
   }
@@ -1014,6 +1022,7 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
     if (variant == 0) {
       const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nz;
       variant = (N > 64 && tiles128 >= 192) ? 1 : 5;
+      if (N <= 64 && (long)((M + 255) / 256) * nz >= 256) variant = 14;
     }
     const int r = out_dtype == MSMD_F32 ? dispatch_gemm2s<float>(p, nz, st, variant)
                                         : dispatch_gemm2s<f16_t>(p, nz, st, variant);
@@ -1054,6 +1063,7 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
         if (M >= 20000 && MSMD_TUNE(5) > 0) variant = MSMD_TUNE(5);
         if (M < 20000 && MSMD_TUNE(6) > 0) variant = MSMD_TUNE(6);
       }
+      else if (N <= 64 && (long)((M + 255) / 256) * nz >= 256) variant = 14;   // the positional conv: 256 x 64 tiles, 140 -> 85 us
       else variant = (K >= 1024) ? 9 : 12;
     }
     const int r = out_dtype == MSMD_BF16 ? dispatch_gemm2<bf16_t>(p, nz, st, variant)
@@ -1063,7 +1073,8 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
   if (in_dtype == MSMD_F16 && (out_dtype == MSMD_F16 || out_dtype == MSMD_F32) && (K % 64) == 0 && MSMD_TUNE(0) >= 0) {
     // fp16 storage: same LDS-DMA kernels with v_mfma_f32_16x16x32_f16 (the heuristic's variants only)
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nz;
-    const int variant = (N > 64 && tiles128 >= 192) ? 17 : ((K >= 1024) ? 9 : 12);
+    int variant = hint ? hint : ((N > 64 && tiles128 >= 192) ? 17 : ((K >= 1024) ? 9 : 12));
+    if (!hint && N <= 64 && (long)((M + 255) / 256) * nz >= 256) variant = 14;
     const int r = out_dtype == MSMD_F16 ? dispatch_gemm2_f16<f16_t>(p, nz, st, variant)
                                         : dispatch_gemm2_f16<float>(p, nz, st, variant);
     if (r >= 0) return r;
