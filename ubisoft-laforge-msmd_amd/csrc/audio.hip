@@ -194,6 +194,106 @@ __global__ __launch_bounds__(256) void conv0_gn_gelu_kernel(const float* __restr
   }
 }
 
+// 16-bit outputs: the conv on the matrix pipe.  The kernel above is bound by its vector instructions (about 30 per output:
+// 10 conv FMAs, scale / shift, the erf GELU, the conversion) -- 210 M outputs x 30 / 39 T lane-ops/s = 160 us at B = 32.
+// Here one v_mfma_f32_16x16x32 yields 16 channels x 16 frames: the 10 taps sit in the 32-deep K as hi / lo pairs of
+// BOTH operands (x = xh + xl, w = wh + wl in the output's 16-bit type; xh.wh + xl.wh + xh.wl = 30 slots, the dropped
+// xl.wl term is 2^-16 relative: far below the output's own rounding), so the vector ALU is left with scale / shift +
+// GELU (gelu_poly16: no transcendentals) + conversion (about 14 per output).
+//   K slots (8 per lane group fq):  g0 = xh[0..7].wh[0..7]   g1 = xl[0..7].wh[0..7]   g2 = xh[0..7].wl[0..7]
+//                                   g3 = [xh8 xh9 xl8 xl9 xh8 xh9 0 0] . [wh8 wh9 wh8 wh9 wl8 wl9 0 0]
+//   Weight operand rows are permuted so that a lane ends up with 8 CONSECUTIVE channels of its frame after two MFMAs
+//   (fragment pair P, Q over 32 channels: row 4 q + e of P = channel 8 q + e, of Q = channel 8 q + 4 + e): one 16-byte
+//   store per lane and pair, 64-byte runs per frame.
+// Block = 4 waves x 32 frames; the weight image (C x 64 B) and the per-channel scale / shift live in LDS.
+template <typename TO>
+__global__ __launch_bounds__(256) void conv0_mfma_kernel(const float* __restrict__ audio, const float* __restrict__ w0,
+                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, TO* __restrict__ out, int L, int r,
+                                                         int rep, int C, int T0) {
+  constexpr int FR = 128, FW = 2;           // frames per block, frame fragments (of 16) per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char c0_smem[];
+  float* xs = (float*)c0_smem;                                  // FR * 5 + 5 samples (+ pad to 16 B)
+  constexpr int XS_BYTES = ((FR * C0_S + C0_K) * 4 + 15) & ~15;
+  unsigned char* wimg = c0_smem + XS_BYTES;                     // C rows x 64 B: the MFMA weight operand, fragment-major
+  float* ssc = (float*)(wimg + (long)C * 64);                   // C scale, C shift
+  float* ssh = ssc + C;
+  const int b = blockIdx.y, t0 = blockIdx.x * FR;
+  const int nt = min(FR, T0 - t0);
+  const int ns = nt * C0_S + (C0_K - C0_S);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int i = tid; i < ns; i += 256) xs[i] = audio[(long)b * L + pad_src(t0 * C0_S + i, L, r, rep)];
+  for (int i = ns + tid; i < FR * C0_S + C0_K; i += 256) xs[i] = 0.f;
+  // weight image: image row R = 16 j + rho (fragment j, operand row rho = 4 q + e) holds channel
+  //   32 (j / 2) + 8 q + 4 (j & 1) + e
+  for (int R = tid; R < C; R += 256) {
+    const int j = R >> 4, rho = R & 15, c = 32 * (j >> 1) + 8 * (rho >> 2) + 4 * (j & 1) + (rho & 3);
+    TO wh[C0_K], wl[C0_K];
+#pragma unroll
+    for (int k = 0; k < C0_K; ++k) {
+      const float w = w0[c * C0_K + k];
+      wh[k] = (TO)w;
+      wl[k] = (TO)(w - (float)wh[k]);
+    }
+    typedef typename Vec8T<TO>::type V8;
+    V8* dst = (V8*)(wimg + (long)R * 64);
+    dst[0] = V8{wh[0], wh[1], wh[2], wh[3], wh[4], wh[5], wh[6], wh[7]};
+    dst[1] = dst[0];
+    dst[2] = V8{wl[0], wl[1], wl[2], wl[3], wl[4], wl[5], wl[6], wl[7]};
+    dst[3] = V8{wh[8], wh[9], wh[8], wh[9], wl[8], wl[9], (TO)0.f, (TO)0.f};
+  }
+  for (int c = tid; c < C; c += 256) {
+    const float mean = stats[((long)b * C + c) * 2], rstd = stats[((long)b * C + c) * 2 + 1];
+    const float sc = rstd * gamma[c];
+    ssc[c] = sc;
+    ssh[c] = beta[c] - mean * sc;
+  }
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  // signal operands of this wave's FW frame fragments
+  u32x4 xop[FW];
+#pragma unroll
+  for (int f = 0; f < FW; ++f) {
+    const float* xp = xs + ((wid * FW + f) * 16 + fr) * C0_S;
+    TO xh[C0_K], xl[C0_K];
+#pragma unroll
+    for (int k = 0; k < C0_K; ++k) {
+      const float x = xp[k];
+      xh[k] = (TO)x;
+      xl[k] = (TO)(x - (float)xh[k]);
+    }
+    typedef typename Vec8T<TO>::type V8;
+    const V8 g0 = V8{xh[0], xh[1], xh[2], xh[3], xh[4], xh[5], xh[6], xh[7]};
+    const V8 g1 = V8{xl[0], xl[1], xl[2], xl[3], xl[4], xl[5], xl[6], xl[7]};
+    const V8 g3 = V8{xh[8], xh[9], xl[8], xl[9], xh[8], xh[9], (TO)0.f, (TO)0.f};
+    const V8 sel = fq == 0 ? g0 : (fq == 1 ? g1 : (fq == 2 ? g0 : g3));
+    xop[f] = __builtin_bit_cast(u32x4, sel);
+  }
+  for (int jj = 0; jj < C / 32; ++jj) {
+    const u32x4 wP = *(const u32x4*)(wimg + (long)((2 * jj) * 16 + fr) * 64 + fq * 16);
+    const u32x4 wQ = *(const u32x4*)(wimg + (long)((2 * jj + 1) * 16 + fr) * 64 + fq * 16);
+    const int c0 = 32 * jj + 8 * fq;
+    const f32x4 sc0 = *(const f32x4*)(ssc + c0), sc1 = *(const f32x4*)(ssc + c0 + 4);
+    const f32x4 sh0 = *(const f32x4*)(ssh + c0), sh1 = *(const f32x4*)(ssh + c0 + 4);
+#pragma unroll
+    for (int f = 0; f < FW; ++f) {
+      const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 yP = mfma16<TO>(wP, xop[f], z), yQ = mfma16<TO>(wQ, xop[f], z);
+      const int t = (wid * FW + f) * 16 + fr;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = gelu_poly16(fmaf(yP[e], sc0[e], sh0[e]));
+        o[4 + e] = gelu_poly16(fmaf(yQ[e], sc1[e], sh1[e]));
+      }
+      if (t < nt)
+        *(typename Vec8T<TO>::type*)(out + ((long)b * T0 + t0 + t) * C + c0) =
+            typename Vec8T<TO>::type{(TO)o[0], (TO)o[1], (TO)o[2], (TO)o[3], (TO)o[4], (TO)o[5], (TO)o[6], (TO)o[7]};
+    }
+  }
+}
+
 extern "C" int msmd_conv0_gn_gelu(const float* audio, const float* w0, const float* stats, const float* gamma,
                                   const float* beta, void* out, int B, int L, int reflect_len, int replicate_len,
                                   int C, int out_dtype, msmd_stream_t stream) {
@@ -208,7 +308,22 @@ extern "C" int msmd_conv0_gn_gelu(const float* audio, const float* w0, const flo
   } else if (out_dtype == MSMD_F32)
     hipLaunchKernelGGL(conv0_gn_gelu_kernel<float>, grid, block, 0, (hipStream_t)stream, audio, w0, stats, gamma, beta,
                        (float*)out, L, reflect_len, replicate_len, C, T0);
-  else if (out_dtype == MSMD_F16)
+  else if ((C & 31) == 0 && C <= 1024) {
+    // 16-bit outputs: the conv on the matrix pipe (conv0_mfma_kernel)
+    const size_t lds = (((128 * C0_S + C0_K) * 4 + 15) & ~15) + (size_t)C * 64 + (size_t)C * 8;
+    dim3 g2((T0 + 127) / 128, B);
+    if (out_dtype == MSMD_F16) {
+      static bool attr = false;
+      if (!attr) { (void)hipFuncSetAttribute((const void*)conv0_mfma_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+      hipLaunchKernelGGL(conv0_mfma_kernel<f16_t>, g2, block, lds, (hipStream_t)stream, audio, w0, stats, gamma, beta,
+                         (f16_t*)out, L, reflect_len, replicate_len, C, T0);
+    } else {
+      static bool attr = false;
+      if (!attr) { (void)hipFuncSetAttribute((const void*)conv0_mfma_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+      hipLaunchKernelGGL(conv0_mfma_kernel<bf16_t>, g2, block, lds, (hipStream_t)stream, audio, w0, stats, gamma, beta,
+                         (bf16_t*)out, L, reflect_len, replicate_len, C, T0);
+    }
+  } else if (out_dtype == MSMD_F16)
     hipLaunchKernelGGL(conv0_gn_gelu_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, audio, w0, stats, gamma,
                        beta, (f16_t*)out, L, reflect_len, replicate_len, C, T0);
   else
@@ -266,7 +381,7 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float v = (y[e] - mean) * rstd * g[e] + be[e];
-      o[e] = sizeof(TO) == 2 ? gelu_fast(v) : gelu_erf(v);
+      o[e] = sizeof(TO) == 2 ? gelu_poly16(v) : gelu_erf(v);
     }
     TO* op = out + ((long)b * T0 + t0 + t) * C + c0;
     if constexpr (sizeof(TO) == 4) {

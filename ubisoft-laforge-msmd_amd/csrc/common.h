@@ -162,6 +162,25 @@ __device__ __forceinline__ float erf_fast(float x) {
 }
 __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
+// GELU for 16-BIT OUTPUTS without transcendentals: Phi(t) = 0.5 + t P(t^2) on |t| <= 4.25 (near-minimax fit of the normal
+// CDF, |Phi error| <= 8.5e-6), t = clamp(x): |error| <= 5.5e-5 everywhere, <= 1.9e-4 relative for x > -2 -- below half an
+// ulp of bf16 and under fp16's own rounding.  12 full-rate vector instructions against 12 + v_rcp_f32 + v_exp_f32 (quarter
+// rate: 20 issue slots) for gelu_fast: the conv0 kernel and the GELU GEMM epilogues are bound by exactly these.
+__device__ __forceinline__ float gelu_poly16(float x) {
+  const float t = __builtin_amdgcn_fmed3f(x, -4.25f, 4.25f);
+  const float u = t * t;
+  float p = 5.564819092e-11f;
+  p = fmaf(p, u, -5.327732033e-09f);
+  p = fmaf(p, u, 2.255421094e-07f);
+  p = fmaf(p, u, -5.626418897e-06f);
+  p = fmaf(p, u, 9.341863915e-05f);
+  p = fmaf(p, u, -1.108560711e-03f);
+  p = fmaf(p, u, 9.815970436e-03f);
+  p = fmaf(p, u, -6.634449214e-02f);
+  p = fmaf(p, u, 3.989023268e-01f);
+  return x * fmaf(t, p, 0.5f);
+}
+
 // exp(x) for x <= 0 (softmax numerators) at ~1 ulp from ONE v_exp_f32: t = x log2(e) with the product's rounding error
 // and log2(e)'s own fp32 rounding carried separately (r) and applied as exp2(t) (1 + r ln 2).  libm's expf is ~25
 // VALU instructions, this is 7; __expf alone (x * log2e rounded once) is off by up to |x| * 2^-24 relative.

@@ -78,9 +78,9 @@ __device__ __forceinline__ long a_row_offset(const GemmArgs& p, int m) {
 
 // Epilogue shared by both kernels: lane holds row m = ..+fr, columns n = ..+fq*4 + {0..3} of each 16x16 fragment.
 template <typename TO> __device__ __forceinline__ float act_out(float x, int act) {
-  // bf16 outputs keep 8 significant bits: the cheap erf (|err| < 1.5e-7) is far below half an ulp there;
+  // 16-bit outputs: the transcendental-free GELU (|err| <= 5.5e-5, common.h) is below their own rounding;
   // fp32 outputs (parity mode) use the exact erff.
-  if (act == MSMD_ACT_GELU) return sizeof(TO) == 2 ? gelu_fast(x) : gelu_erf(x);
+  if (act == MSMD_ACT_GELU) return sizeof(TO) == 2 ? gelu_poly16(x) : gelu_erf(x);
   if (act == MSMD_ACT_ELU) return elu1(x);
   return x;
 }
@@ -700,7 +700,7 @@ __device__ __forceinline__ void gemm_epilogue_split(const GemmArgs& p, const f32
 #pragma unroll
       // GELU through the 12-instruction erf (|abs err| <= 1.5e-7, i.e. <= 0.5 |x| 1.5e-7 on the output: the size of an
       // fp32 rounding error at these magnitudes); libm's erff would be ~15 % of an FFN1 launch
-      for (int e = 0; e < 4; ++e) v[e] = act_out<f16_t>(acc[i][j][e] + bv[e], p.act);
+      for (int e = 0; e < 4; ++e) { const float x_ = acc[i][j][e] + bv[e]; v[e] = p.act == MSMD_ACT_GELU ? gelu_fast(x_) : apply_act(x_, p.act); }
       if (R) {
         float r[4];
         load4_split(R + (long)m * 2 * p.ldr, n, r);
