@@ -49,32 +49,26 @@ extern "C" int msmd_pad_audio(const float* audio, float* out, int B, int L, int 
 
 __global__ __launch_bounds__(256) void conv0_moments_partial(const float* __restrict__ audio, float* __restrict__ ws,
                                                              int L, int r, int rep, int T0, int pass) {
-  // pass 0: ws[b][split][0] = sum of padded samples (for mu).  pass 1: S and R of the centred signal.
+  // ws[b][split][0] = the shift mu; [1..] = S and R of the shifted signal over this split's frames.
   __shared__ double red[4][C0_NMOM];
   const int b = blockIdx.y, split = blockIdx.x;
   const int per = (T0 + C0_SPLITS - 1) / C0_SPLITS;
   const int t_begin = split * per, t_end = min(T0, t_begin + per);
-  const int Lp = L + 4 * r + 2 * rep;
   float* out = ws + ((long)b * C0_SPLITS + split) * C0_NMOM;
   const float* xa = audio + (long)b * L;
-  if (pass == 0) {
-    // samples [5*t_begin, 5*t_end) partition the first 5*T0 samples; the last split adds the 5-sample tail
-    // the split that owns the last frame also owns the (k - s)-sample tail; empty splits own nothing
-    const int s0 = t_begin * C0_S;
-    const int s1 = (t_begin >= T0) ? s0 : (t_end == T0 ? min(Lp, T0 * C0_S + C0_K - C0_S) : t_end * C0_S);
-    double acc = 0.0;
-    for (int i = s0 + threadIdx.x; i < s1; i += 256) acc += (double)xa[pad_src(i, L, r, rep)];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][0] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) out[0] = (float)(red[0][0] + red[1][0] + red[2][0] + red[3][0]);
-    return;
-  }
-  // mu from pass 0 (all splits)
-  double tot = 0.0;
-  for (int s = 0; s < C0_SPLITS; ++s) tot += (double)ws[((long)b * C0_SPLITS + s) * C0_NMOM];
+  // Centre of the moments: the mean of the clip's first min(256, n) padded samples, computed by EVERY block in the same
+  // order (all splits of a clip must shift by the same constant; any constant near the mean removes the
+  // E[y^2] - mean^2 cancellation, the finish kernel's algebra is exact for whatever shift was used).  One launch instead
+  // of the former mean pass + moments pass.
   const int n_used = T0 * C0_S + C0_K - C0_S;
-  const float mu = (float)(tot / (double)n_used);
+  {
+    double v = threadIdx.x < min(256, n_used) ? (double)xa[pad_src(threadIdx.x, L, r, rep)] : 0.0;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][0] = v;
+    __syncthreads();
+  }
+  const float mu = (float)((red[0][0] + red[1][0] + red[2][0] + red[3][0]) / (double)min(256, n_used));
+  if (threadIdx.x == 0) out[0] = mu;
   float m[C0_NMOM];
 #pragma unroll
   for (int i = 0; i < C0_NMOM; ++i) m[i] = 0.f;
@@ -115,7 +109,7 @@ __global__ void conv0_stats_finish(const float* __restrict__ ws, const float* __
   __syncthreads();
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double n_used = (double)(T0 * C0_S + C0_K - C0_S), mu = mom[0] / n_used;
+  const double mu = (double)ws[(long)b * C0_SPLITS * C0_NMOM];      // the shift every split used
   double w[C0_K], wsum = 0.0, ws1 = 0.0, q = 0.0;
   for (int k = 0; k < C0_K; ++k) { w[k] = (double)w0[c * C0_K + k]; wsum += w[k]; ws1 += w[k] * mom[1 + k]; }
   int idx = 1 + C0_K;
@@ -135,7 +129,6 @@ extern "C" int msmd_conv0_stats(const float* audio, const float* w0, float* stat
   if (T0 <= 0) return 1;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(C0_SPLITS, B);
-  hipLaunchKernelGGL(conv0_moments_partial, grid, dim3(256), 0, st, audio, ws, L, reflect_len, replicate_len, T0, 0);
   hipLaunchKernelGGL(conv0_moments_partial, grid, dim3(256), 0, st, audio, ws, L, reflect_len, replicate_len, T0, 1);
   hipLaunchKernelGGL(conv0_stats_finish, dim3((C + 255) / 256, B), dim3(256), 0, st, ws, w0, stats, C, T0, eps);
   MSMD_RETURN_LAST();
