@@ -3,6 +3,7 @@ through ctypes and do not show up here: this lists exactly the glue that is NOT 
 import collections
 import os
 import sys
+import traceback
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,6 +24,7 @@ tr.step(batch, it=1)
 torch.cuda.synchronize()
 counts = collections.Counter()
 bytes_ = collections.Counter()
+by_line = collections.Counter()
 
 
 class Count(TorchDispatchMode):
@@ -36,6 +38,12 @@ class Count(TorchDispatchMode):
         shp = next((tuple(a.shape) for a in args if torch.is_tensor(a)), ())
         t = out if torch.is_tensor(out) else None
         counts[(name, shp)] += 1
+        where = "autograd engine (backward of a torch op)"
+        for fr in reversed(traceback.extract_stack()[:-1]):
+            if "msmd_amd" in fr.filename:
+                where = f"{os.path.basename(fr.filename)}:{fr.lineno}"
+                break
+        by_line[(where, name)] += 1
         if t is not None:
             bytes_[(name, shp)] += t.numel() * t.element_size()
         return out
@@ -50,6 +58,9 @@ by_name = collections.Counter()
 for (n, s), c in counts.items():
     by_name[n] += c
 print("by op:", by_name.most_common(25))
+print("by calling line of this package (top 60):")
+for (w, n), c in by_line.most_common(60):
+    print(f"  {w:44s} {n:28s} x{c}")
 print("largest by bytes written:")
 for (n, s), b in bytes_.most_common(40):
     print(f"  {n:28s} {str(s):28s} x{counts[(n, s)]:4d}  {b / 1e6:9.1f} MB")

@@ -11,7 +11,9 @@ f = glob.glob("/tmp/tl/**/*kernel_trace.csv", recursive=True)[0]
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "?"))) for r in csv.DictReader(open(f))]
 rows.sort()
 # steps start at the conv0 moments kernel; take the LAST complete step but one (inside the timed replays)
-starts = [i for i, r in enumerate(rows) if "conv0_moments_partial" in r[2]]
+import os
+delim = os.environ.get("DELIM", "conv0_moments_partial")      # a kernel that runs once per step (training: DELIM=adam_kernel)
+starts = [i for i, r in enumerate(rows) if delim in r[2]]
 starts = starts[0::2] if len(starts) > 1 and starts[1] - starts[0] < 3 else starts
 a, b = starts[-3], starts[-2]
 step = rows[a:b]
@@ -24,13 +26,12 @@ by = collections.defaultdict(lambda: [0.0, 0])
 for s, e, n, *_ in step:
     k = n.split("(")[0][:90]
     by[k][0] += (e - s) / 1e3; by[k][1] += 1
-for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:22]:
+for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get('TOP', '22'))]:
     print(f"  {t:8.1f} us  x{c:3d}  avg {t / c:7.2f}  {k}")
 print("longest single launches:")
 for s_, e_, n_, *_ in sorted(step, key=lambda r: r[0] - r[1])[:14]:
     print(f"  {(e_ - s_) / 1e3:8.1f} us  at +{(s_ - step[0][0]) / 1e3:7.1f}  {n_[:70]}")
 big = sorted(((g, step[i][2][:50], step[i + 1][2][:50]) for i, g in enumerate(gaps)), reverse=True)[:3]
-import os
 if os.environ.get("SEQ"):
     print("sequence (index, us, grid / workgroup, kernel):")
     for i, (s_, e_, n_, gx, wx) in enumerate(step):

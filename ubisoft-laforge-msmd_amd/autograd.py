@@ -56,18 +56,38 @@ class WeightCache:
 CACHE = WeightCache()
 
 
+class FusedAlias:
+    """A weight operand that is a VIEW of the flat parameter arena spanning several parameters (Q | K | V of an encoder
+    layer, laid out next to each other: dp.ADJACENT) or part of one (the Q / KV rows of nn.MultiheadAttention's
+    in_proj_weight): `w`, `b` plain tensors for the forward, `wgrad`, `bgrad` the same regions of the gradient arena for
+    the backward's wgrad GEMM to add into, `owners` the leaf parameters to report as written.  No torch.cat / slice nodes
+    in the autograd graph, no per-iteration cast / transpose of a temporary, no accumulate kernels."""
+
+    def __init__(self, w, b, wgrad, bgrad, owners):
+        self.w, self.b, self.wgrad, self.bgrad, self.owners = w, b, wgrad, bgrad, list(owners)
+
+
+FUSED = {}   # (kind, id(module), layer index) -> FusedAlias; filled by the Trainer (direct-gradient mode only)
+
+
 class WeightArena:
     """bf16 casts and transposes of all 8-aligned 2-D trainable weights living in one flat fp32 parameter arena, kept
     in two bf16 arenas and rewritten by ONE kernel launch (msmd_cast_transpose_multi) after every optimizer step;
     LinearFn finds them through CACHE.persistent, so an iteration issues no per-weight cast / transpose launches."""
 
-    def __init__(self, flat_param, params):
+    def __init__(self, flat_param, params, aliases=(), skip=()):
+        """aliases: plain 2-D views of the arena (FusedAlias.w) that get their own cast / transpose; skip: parameters
+        that are only ever used through an alias."""
         self.flat = flat_param
         rows, self.views = [], []
         off = tiles = 0
         base = flat_param.data_ptr()
-        for p in params:
-            if p.ndim != 2 or not p.requires_grad or p.shape[0] % 8 or p.shape[1] % 8 or not p.is_contiguous():
+        skip = {id(p) for p in skip}
+        alias_ids = {id(t) for t in aliases}
+        for p in list(params) + list(aliases):
+            if id(p) in skip:
+                continue
+            if p.ndim != 2 or not (p.requires_grad or id(p) in alias_ids) or p.shape[0] % 8 or p.shape[1] % 8 or not p.is_contiguous():
                 continue
             src = (p.data_ptr() - base) // 4
             if src < 0 or src + p.numel() > flat_param.numel():
@@ -128,9 +148,11 @@ class LinearFn(torch.autograd.Function):
     """y = act(x @ w.T + b) + residual   (x: (..., K) compute dtype; w (N, K), b (N) fp32 master parameters)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, act, p_drop=0.0, site=0):
+    def forward(ctx, x, w, b, residual, act, p_drop=0.0, site=0, alias=None):
         """y = dropout_p(act(x W^T + b)) + residual in ONE GEMM launch: the epilogue also writes the pre-activation z
-        (needed by the backward) when there is an activation, and applies the Philox keep mask."""
+        (needed by the backward) when there is an activation, and applies the Philox keep mask.  alias (FusedAlias):
+        w / b are arena views without autograd history; the backward adds dW / db into alias.wgrad / alias.bgrad."""
+        ctx.alias = alias
         dtype = x.dtype
         wc, wct = CACHE.get(w, dtype)
         K = w.shape[1]
@@ -170,6 +192,14 @@ class LinearFn(torch.autograd.Function):
             dzp = dz2 if wct.shape[1] == N else ops.pad_cols(dz2, wct.shape[1], dtype)
             dx = ops.gemm(dzp, wct).reshape(*xin.shape[:-1], wct.shape[0])
         want_b = ctx.has_b and ctx.needs_input_grad[2]
+        if ctx.alias is not None:
+            fa = ctx.alias
+            ops.gemm_tn(dz2, xin.reshape(M, Kp), out=fa.wgrad.view(N, Kp), colsum_out=fa.bgrad, accumulate=True)
+            if GRAD_WRITTEN is not None:
+                for o in fa.owners:
+                    GRAD_WRITTEN(o)
+            dres = dy if ctx.has_r and ctx.needs_input_grad[3] else None
+            return dx, None, None, dres, None, None, None, None
         direct = (DIRECT_GRAD and ctx.needs_input_grad[1] and dtype == torch.bfloat16 and N % 8 == 0 and Kp == ctx.K
                   and w.is_leaf and w.grad is not None and w.grad.is_contiguous() and USE_GEMM_TN)
         if direct:
@@ -210,7 +240,7 @@ class LinearFn(torch.autograd.Function):
         elif want_b:
             db = ops.colsum(dz2)
         dres = dy if ctx.has_r and ctx.needs_input_grad[3] else None
-        return dx, dw, db, dres, None, None, None
+        return dx, dw, db, dres, None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -459,6 +489,11 @@ def cross_attention(q, kv, n_heads, scale, mask=None, p_drop=0.0):
 
 def linear(x, w, b=None, act=ACT_NONE, residual=None):
     return LinearFn.apply(x, w, b, residual, act)
+
+
+def linear_alias(x, fa, act=ACT_NONE, residual=None):
+    """linear() on a FusedAlias operand (arena views; gradients go straight into the gradient arena)."""
+    return LinearFn.apply(x, fa.w, fa.b, residual, act, 0.0, 0, fa)
 
 
 def layer_norm(x, gamma, beta, post_add=None):

@@ -65,10 +65,26 @@ def timed_steps(step_fn, steps: int, warmup: int, sync=None, device=None):
 ALIGN = 64  # elements: every tensor starts on a 256-byte boundary of its arena (kernels need 16-byte operands)
 
 
+# Groups of parameters that must sit NEXT TO EACH OTHER in the arenas, in the given order, so that their concatenation is a
+# view (the fused Q/K/V projection of an encoder layer: autograd.FusedAlias).  Set by the Trainer before it builds the arenas;
+# a group is honoured only if all members are trainable and whole multiples of ALIGN elements.
+ADJACENT = []
+
+
 def flat_layout(params):
     """Arena layout shared by the parameter arena, the gradient arena and the Adam moments: trainable parameters
-    in REVERSE registration order, each offset rounded up to ALIGN elements.  Returns (ordered params, offsets, total)."""
+    in REVERSE registration order (ADJACENT groups pulled together at their first member's place), each offset rounded
+    up to ALIGN elements.  Returns (ordered params, offsets, total)."""
     ps = [p for p in params if p.requires_grad][::-1]
+    have = {id(p) for p in ps}
+    for grp in ADJACENT:
+        if not all(id(p) in have and p.numel() % ALIGN == 0 for p in grp):
+            continue
+        ids = {id(p) for p in grp}
+        first = min(i for i, p in enumerate(ps) if id(p) in ids)
+        rest = [p for p in ps if id(p) not in ids]
+        n_before = sum(1 for p in ps[:first] if id(p) not in ids)
+        ps = rest[:n_before] + list(grp) + rest[n_before:]
     offs, off = [], 0
     for p in ps:
         offs.append(off)

@@ -176,9 +176,14 @@ def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
         bq, bk, bv = (g(p + f"attention.{k}_proj.bias") for k in "qkv")
         ln1 = (g(p + "layer_norm.weight"), g(p + "layer_norm.bias"))
         ln2 = (g(p + "final_layer_norm.weight"), g(p + "final_layer_norm.bias"))
-        wqkv, bqkv = torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0)
+        fa = ag.FUSED.get(("enc_qkv", id(enc), n)) if ag.DIRECT_GRAD else None
+        if fa is not None:      # Q | K | V sit next to each other in the arenas: the fused operand is a view
+            qkv_proj = lambda t: ag.linear_alias(t, fa)
+        else:
+            wqkv, bqkv = torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0)
+            qkv_proj = lambda t: ag.linear(t, wqkv, bqkv)
         if stable:   # HubertEncoderLayerStableLayerNorm
-            a = ag.self_attention(ag.linear(ag.layer_norm(h, *ln1), wqkv, bqkv), H, (d // H) ** -0.5,
+            a = ag.self_attention(qkv_proj(ag.layer_norm(h, *ln1)), H, (d // H) ** -0.5,
                                   p_drop=c.attention_dropout)
             h = ag.linear_dropout(a, g(p + "attention.out_proj.weight"), g(p + "attention.out_proj.bias"),
                                   c.hidden_dropout, residual=h)
@@ -188,7 +193,7 @@ def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
             h = ag.linear_dropout(f, g(p + "feed_forward.output_dense.weight"),
                                   g(p + "feed_forward.output_dense.bias"), c.hidden_dropout, residual=h)
         else:
-            a = ag.self_attention(ag.linear(h, wqkv, bqkv), H, (d // H) ** -0.5, p_drop=c.attention_dropout)
+            a = ag.self_attention(qkv_proj(h), H, (d // H) ** -0.5, p_drop=c.attention_dropout)
             h = ag.layer_norm(ag.linear_dropout(a, g(p + "attention.out_proj.weight"),
                                                 g(p + "attention.out_proj.bias"), c.hidden_dropout, residual=h), *ln1)
             f = ag.linear_dropout(h, g(p + "feed_forward.intermediate_dense.weight"),
@@ -202,6 +207,80 @@ def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
     if stable:
         h = ag.layer_norm(h, g("encoder.layer_norm.weight"), g("encoder.layer_norm.bias"))
     return h
+
+
+# ----------------------------------------------------------------------------- fused operands as arena views
+def adjacent_parameter_groups(model):
+    """dp.ADJACENT for this model: per encoder layer [q.weight, k.weight, v.weight] and [q.bias, k.bias, v.bias]."""
+    enc = model.audio_encoder
+    groups = []
+    for n in range(enc.config.num_hidden_layers):
+        p = f"encoder.layers.{n}.attention."
+        for kind in ("weight", "bias"):
+            try:
+                groups.append([enc.get_parameter(p + f"{x}_proj.{kind}") for x in "qkv"])
+            except AttributeError:
+                pass
+    return groups
+
+
+def build_fused_aliases(model, flat_param, grad_arena):
+    """autograd.FUSED for this model (the Trainer calls this once both arenas exist): encoder layers' fused QKV operand;
+    the decoder layers' cross-attention Q and KV rows of in_proj_weight / in_proj_bias.  Returns (aliases, parameters
+    that are only used through an alias)."""
+    base = flat_param.data_ptr()
+
+    def views(p, r0=None, r1=None, rows=None, cols=None):
+        """(arena view, gradient-arena view) of rows [r0, r1) of parameter p, or of `rows` x `cols` starting at p."""
+        off = (p.data_ptr() - base) // 4
+        if rows is None:
+            inner = p[0].numel() if p.dim() > 1 else 1
+            off += r0 * inner
+            shape = (r1 - r0,) + tuple(p.shape[1:])
+        else:
+            shape = (rows, cols) if cols else (rows,)
+        n = 1
+        for s_ in shape:
+            n *= s_
+        return flat_param[off:off + n].view(shape), grad_arena[off:off + n].view(shape)
+
+    aliases, only = [], []
+    enc = model.audio_encoder
+    d = enc.config.hidden_size
+    for n in range(enc.config.num_hidden_layers):
+        p = f"encoder.layers.{n}.attention."
+        try:
+            ws = [enc.get_parameter(p + f"{x}_proj.weight") for x in "qkv"]
+            bs = [enc.get_parameter(p + f"{x}_proj.bias") for x in "qkv"]
+        except AttributeError:
+            continue
+        if not all(t.requires_grad for t in ws + bs):
+            continue
+        adjacent = all(ws[i + 1].data_ptr() == ws[i].data_ptr() + 4 * ws[i].numel() for i in range(2)) and \
+            all(bs[i + 1].data_ptr() == bs[i].data_ptr() + 4 * bs[i].numel() for i in range(2))
+        if not adjacent:
+            continue
+        w, wg = views(ws[0], rows=3 * d, cols=d)
+        b, bg = views(bs[0], rows=3 * d)
+        fa = ag.FusedAlias(w, b, wg, bg, ws + bs)
+        ag.FUSED[("enc_qkv", id(enc), n)] = fa
+        aliases.append(fa)
+        only += ws
+    net = model.denoising_net
+    dd = net.feature_dim
+    for n in range(net.n_layers):
+        p = f"transformer.layers.{n}.multihead_attn."
+        wp, bp = net.get_parameter(p + "in_proj_weight"), net.get_parameter(p + "in_proj_bias")
+        if not (wp.requires_grad and bp.requires_grad):
+            continue
+        for kind, r0, r1 in (("dec_q", 0, dd), ("dec_kv", dd, 3 * dd)):
+            w, wg = views(wp, r0, r1)
+            b, bg = views(bp, r0, r1)
+            fa = ag.FusedAlias(w, b, wg, bg, [wp, bp])
+            ag.FUSED[(kind, id(net), n)] = fa
+            aliases.append(fa)
+        only.append(wp)
+    return aliases, only
 
 
 class ActFn(torch.autograd.Function):
@@ -261,9 +340,14 @@ def denoiser_train(net, motion_noisy, audio_feat, person_feat, static_style_feat
         a = ag.self_attention(qkv, H, scale, p_drop=pd)
         x = ag.layer_norm(ag.linear_dropout(a, g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias"), pd,
                                             residual=x), g(p + "norm1.weight"), g(p + "norm1.bias"))
-        w, b = g(p + "multihead_attn.in_proj_weight"), g(p + "multihead_attn.in_proj_bias")
-        q = ag.linear(x, w[:d], b[:d])
-        kv = ag.linear(mem, w[d:], b[d:])
+        fq = ag.FUSED.get(("dec_q", id(net), n)) if ag.DIRECT_GRAD else None
+        if fq is not None:      # rows of in_proj_weight as arena views: no slice nodes, gradients straight into the arena
+            q = ag.linear_alias(x, fq)
+            kv = ag.linear_alias(mem, ag.FUSED[("dec_kv", id(net), n)])
+        else:
+            w, b = g(p + "multihead_attn.in_proj_weight"), g(p + "multihead_attn.in_proj_bias")
+            q = ag.linear(x, w[:d], b[:d])
+            kv = ag.linear(mem, w[d:], b[d:])
         cattn = ag.cross_attention(q, kv, H, scale, mask, p_drop=pd)
         x = ag.layer_norm(ag.linear_dropout(cattn, g(p + "multihead_attn.out_proj.weight"),
                                             g(p + "multihead_attn.out_proj.bias"), pd, residual=x),

@@ -162,9 +162,14 @@ class Trainer:
         # optimizer param groups of the reference: style encoder first, then the model (same lr)
         params = [p for p in style_enc.parameters() if p.requires_grad] + \
                  [p for p in model.parameters() if p.requires_grad]
-        self.flat_param = dp.flatten_parameters(params)
-        self.reducer = dp.GradBucketReducer(params, bucket_mb=bucket_mb, process_group=process_group)
-        self.weight_arena = (ag.WeightArena(self.flat_param, params) if model.compute_dtype == torch.bfloat16 else None)
+        # the encoder layers' Q / K / V projections next to each other in the arenas: the fused QKV operand is a view
+        dp.ADJACENT = tg.adjacent_parameter_groups(model)
+        try:
+            self.flat_param = dp.flatten_parameters(params)
+            self.reducer = dp.GradBucketReducer(params, bucket_mb=bucket_mb, process_group=process_group)
+        finally:
+            dp.ADJACENT = []
+        self.weight_arena = None
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
         self.opt_step = 0
@@ -189,6 +194,13 @@ class Trainer:
         # weight gradients are added straight into the arena by the wgrad GEMM when bucket launches do not hang
         # on per-parameter autograd hooks (graph mode launches them from finish(); world 1 launches nothing)
         self.direct_grad = self.use_graph or self.reducer.world == 1
+        for key in [k for k in ag.FUSED if k[1] in (id(model.audio_encoder), id(model.denoising_net))]:
+            del ag.FUSED[key]       # a recycled module id must never meet an older trainer's views
+        aliases, only_aliased = (tg.build_fused_aliases(model, self.flat_param, self.reducer.arena)
+                                 if self.direct_grad and model.compute_dtype == torch.bfloat16 else ([], []))
+        self._aliases = aliases     # keeps the alias tensors (and with them their cache keys) alive
+        if model.compute_dtype == torch.bfloat16:
+            self.weight_arena = ag.WeightArena(self.flat_param, params, aliases=[a.w for a in aliases], skip=only_aliased)
         # Philox (seed, step) for dropout masks: device memory, advanced once per iteration
         self.noise_state = torch.tensor([0x5EED0000 + 7919 * dp.env_rank()[0], 0], dtype=torch.int64, device=self.device)
 
@@ -215,7 +227,8 @@ class Trainer:
             "style_enc": self.style_enc.state_dict(),
             "iter": int(it),
             "optimizer": {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "step": self.opt_step,
-                          "layout": [(n, int(p.numel())) for n, p in self._named_trainable()]},
+                          "layout": [(n, int(p.numel())) for n, p in self._named_trainable()],
+                          "arena_order": self._arena_names()},
             "scheduler": {"sched_step": self.sched_step, "n_calls": self._lr.calls, "lr": self.current_lr()},
             "rng": {"numpy": self.rng.get_state(), "noise_state": self.noise_state.cpu(), "rank": dp.env_rank()[0]},
         }, path)
@@ -232,8 +245,19 @@ class Trainer:
         if opt is not None:
             if [(n, k) for n, k in opt["layout"]] != [(n, int(p.numel())) for n, p in self._named_trainable()]:
                 raise ValueError("optimizer state layout does not match this model's trainable parameters")
-            self.exp_avg.copy_(opt["exp_avg"])
-            self.exp_avg_sq.copy_(opt["exp_avg_sq"])
+            # the flat moments are stored in the WRITER's arena order (older checkpoints: plain reverse registration
+            # order; since round 3 the encoder's Q / K / V parameters are pulled together): copy parameter by parameter
+            names = dict((n, p) for n, p in self._named_trainable())
+            saved_order = opt.get("arena_order") or [n for n, _ in self._named_trainable()][::-1]
+            base = self.flat_param.data_ptr()
+            off = 0
+            for n in saved_order:
+                p = names[n]
+                k = p.numel()
+                dst = (p.data_ptr() - base) // 4
+                self.exp_avg[dst:dst + k].copy_(opt["exp_avg"][off:off + k])
+                self.exp_avg_sq[dst:dst + k].copy_(opt["exp_avg_sq"][off:off + k])
+                off += (k + dp.ALIGN - 1) // dp.ALIGN * dp.ALIGN
             self.opt_step = int(opt["step"])
         sch = ck.get("scheduler")
         if sch is not None:   # the schedulers are pure functions of their call count: rebuild and replay
@@ -255,6 +279,11 @@ class Trainer:
                 self.noise_state.copy_(torch.tensor([0x5EED0000 + 7919 * rank, int(rng["noise_state"][1])],
                                                     dtype=torch.int64))
         return int(ck.get("iter", 0))
+
+    def _arena_names(self):
+        """Trainable parameter names in arena order (the order of the flat Adam moments)."""
+        base = self.flat_param.data_ptr()
+        return [n for n, p in sorted(self._named_trainable(), key=lambda np_: np_[1].data_ptr() - base)]
 
     def _named_trainable(self):
         out = [("style_enc." + n, p) for n, p in self.style_enc.named_parameters() if p.requires_grad]
