@@ -144,6 +144,24 @@ DIRECT_GRAD = False
 GRAD_WRITTEN = None
 
 
+_MASKS = {}
+
+
+def _mask_u8(mask):
+    """The uint8 form of a (static) boolean attention mask, converted once per mask tensor and version."""
+    if mask is None:
+        return None
+    if mask.dtype == torch.uint8 and mask.is_contiguous():
+        return mask
+    key = id(mask)
+    e = _MASKS.get(key)
+    if e is None or e[0]() is not mask or e[1] != (mask._version, mask.data_ptr()):
+        if len(_MASKS) > 64:
+            _MASKS.clear()
+        e = _MASKS[key] = (weakref.ref(mask), (mask._version, mask.data_ptr()), mask.to(torch.uint8).contiguous())
+    return e[2]
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x @ w.T + b) + residual   (x: (..., K) compute dtype; w (N, K), b (N) fp32 master parameters)."""
 
@@ -285,7 +303,7 @@ class AttentionFn(torch.autograd.Function):
         P = torch.empty(B, H, Tq, Tkp, device=q.device, dtype=dt)
         ops.gemm_batched2(q, k, P, Tq, Tk, 64, q.stride(1), k.stride(1), Tkp, B, q.stride(0), k.stride(0), H * Tq * Tkp,
                           H, 64, 64, Tq * Tkp)
-        m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
+        m8 = _mask_u8(mask)
         ops.softmax_rows_(P, Tk, Tkp, Tq, scale, m8)
         site = TrainNoise.next_site() if p_drop > 0.0 else 0
         Pv = ops.dropout(P, p_drop, TrainNoise.state, site) if p_drop > 0.0 else P   # dropped probabilities feed P.V
@@ -417,7 +435,7 @@ class FusedSelfAttnFn(torch.autograd.Function):
     def forward(ctx, qkv, n_heads, scale, mask, p_drop, site):
         d = qkv.shape[-1] // 3
         qkv = qkv.contiguous()
-        m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
+        m8 = _mask_u8(mask)
         o = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], n_heads, scale, m8, p_drop=p_drop,
                           rng_state=TrainNoise.state, site=site)
         ctx.save_for_backward(qkv, m8)
@@ -441,7 +459,7 @@ class FusedCrossAttnFn(torch.autograd.Function):
     def forward(ctx, q, kv, n_heads, scale, mask, p_drop, site):
         d = q.shape[-1]
         q, kv = q.contiguous(), kv.contiguous()
-        m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
+        m8 = _mask_u8(mask)
         o = ops.attention(q, kv[..., :d], kv[..., d:], n_heads, scale, m8, p_drop=p_drop, rng_state=TrainNoise.state,
                           site=site)
         ctx.save_for_backward(q, kv, m8)

@@ -325,18 +325,26 @@ __global__ __launch_bounds__(64 * NW) void attn_whole_kernel(const AttnArgs p) {
       s[f] = mfma16<T>(a, qf[g], s[f]);
     }
   }
-  // ---- mask: the ragged last fragment and the explicit mask (wave-uniform conditions)
+  // ---- mask: the ragged last fragment and the explicit mask (wave-uniform conditions).  The lane's 4 keys of a
+  // fragment are 4 consecutive mask bytes: one (unaligned) 4-byte load instead of four byte loads where the row has them
   if ((p.Tk & 15) || p.mask) {
+    const uint8_t* mrow = p.mask ? p.mask + (long)qrow * p.Tk : nullptr;
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       if (f >= nf || !(p.mask || f == nf - 1)) continue;
+      const int k0 = 16 * f + 4 * fq;
+      unsigned m4 = 0;
+      if (mrow) {
+        if (k0 + 4 <= p.Tk) __builtin_memcpy(&m4, mrow + k0, 4);
+        else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int key = 16 * f + 4 * fq + e;
-        bool dead = key >= p.Tk;
-        if (p.mask && !dead) dead = p.mask[(long)qrow * p.Tk + key] != 0;
-        if (dead) s[f][e] = -INFINITY;
+          for (int e = 0; e < 4; ++e)
+            if (k0 + e < p.Tk) m4 |= (unsigned)(mrow[k0 + e] != 0) << (8 * e);
+        }
       }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k0 + e >= p.Tk || ((m4 >> (8 * e)) & 0xff)) s[f][e] = -INFINITY;
     }
   }
   // ---- softmax over the whole row: p = exp2(s c - m c), c = scale log2(e)
