@@ -581,3 +581,25 @@ def test_gemm_ln_folds_layernorm_into_producer_and_consumer(dtype, M):
         o.gemm_ln(a.to(DEV), w1[:700].to(DEV).contiguous(), None)
     with pytest.raises(Exception):
         o.gemm_ln(a.to(DEV).float(), w1.to(DEV).float(), None)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_attention_prefetch_reads_the_ranges_and_changes_nothing(dtype):
+    """msmd_attention_prefetch: the launch also pulls byte ranges (the next GEMMs' weights) through the memory-side cache.
+    The attention output must be bit-identical to msmd_attention's, whatever the ranges' sizes (below one wave-load,
+    not a multiple of 1 KB, larger than one grid sweep), and the ranges must come back untouched."""
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(21)
+    for B, H, T in ((3, 12, 200), (2, 8, 111)):
+        d = 64 * H
+        qkv = torch.randn(B, T, 3 * d, generator=g).to(DEV, dtype)
+        ref = o.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, 0.125)
+        ranges = [torch.randn(n, generator=g).to(DEV) for n in (100, 1000, 70001, 3_000_000)]
+        keep = [r.clone() for r in ranges]
+        out = o.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, 0.125, prefetch=ranges)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        assert all(torch.equal(a, b) for a, b in zip(ranges, keep))
+        # None entries and more than four tensors are tolerated (the first four live ones are used)
+        out = o.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, 0.125, prefetch=[None] + ranges + ranges)
+        assert torch.equal(out, ref)

@@ -891,7 +891,7 @@ static int dispatch_gemm2s(GemmArgs& p, int batch, hipStream_t st, int variant) 
     case 11: return launch_gemm3<TO, f16_t, 2, 128, 128, 4, 2, 4>(p, batch, st);   // 1 workgroup / CU, pipelined reads
     case 12: return launch_gemm3<TO, f16_t, 2, 128, 128, 4, 2, 3>(p, batch, st);
     case 13: return launch_gemm3<TO, f16_t, 2, 128, 128, 2, 4, 4>(p, batch, st);
-    case 14: return launch_gemm3<TO, f16_t, 2, 128, 128, 4, 2, 4, 4>(p, batch, st);   // + 4 loader waves
+    case 15: return launch_gemm3<TO, f16_t, 2, 128, 128, 4, 2, 4, 4>(p, batch, st);   // + 4 loader waves
 #endif
     default: return -1;
   }
@@ -919,6 +919,11 @@ static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
     case 5: return launch_gemm2<TO, 256, 256, 2, 4, 2>(p, batch, st);
     case 6: return launch_gemm2<TO, 128, 256, 2, 4, 3>(p, batch, st);
     case 7: return launch_gemm2<TO, 64, 128, 1, 4, 4>(p, batch, st);
+    // more, smaller tiles with a deeper ring for the M = 6400 encoder shapes (round 3: see DESIGN 5c for the numbers)
+    case 48: return launch_gemm2<TO, 128, 64, 4, 2, 3, true>(p, batch, st);   // 72 KB: 2 workgroups / CU, 2 stages in flight each
+    case 49: return launch_gemm2<TO, 128, 64, 4, 2, 2, true>(p, batch, st);   // 48 KB: 3 workgroups / CU
+    case 50: return launch_gemm2<TO, 64, 128, 2, 4, 3, true>(p, batch, st);
+    case 51: return launch_gemm2<TO, 128, 64, 4, 2, 4, true>(p, batch, st);   // 96 KB: 1 workgroup / CU, 3 stages in flight
     // positional-conv candidates (N = 48 per group, 6400 x 48 x 6144 x 16 groups; variant 9: 140 us, 12: 120 us):
     case 42: return launch_gemm2<TO, 256, 64, 4, 1, 2>(p, batch, st);         // 94 us
     case 43: return launch_gemm2<TO, 256, 64, 4, 1, 2, true>(p, batch, st);   // 86 us   (product variant 14, 8 waves: 85 us)

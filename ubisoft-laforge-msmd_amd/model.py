@@ -366,14 +366,16 @@ class DenoisingNetwork_MSMD(nn.Module):
                     qkv = ops.gemm(x, L.sa_w, L.sa_b)
                 else:
                     qkv = ops.gemm_ln(u, L.f_sa[0], L.f_sa[2], a_stats=st, w_colsum=L.f_sa[1])
-                a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale)
+                a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale,
+                                  prefetch=(L.sa_ow, L.f_caq[0], L.ca_ow))      # the weights the next launches read
                 if li == 0:
                     u1, st1 = ops.gemm_ln(a, L.sa_ow, L.sa_ob, x, stats_out=True)
                 else:
                     u1, st1 = ops.gemm_ln(a, L.sa_ow, L.sa_ob, u, r_stats=st, r_gamma=ln[0], r_beta=ln[1], stats_out=True)
                 kv = kv_list[li] if kv_list is not None else ops.gemm(mem, L.ca_kvw, L.ca_kvb)
                 q = ops.gemm_ln(u1, L.f_caq[0], L.f_caq[2], a_stats=st1, w_colsum=L.f_caq[1])
-                c = ops.attention(q, kv[..., :d], kv[..., d:], H, scale, mask=P.mask)
+                nxt = P.layers[li + 1].f_sa[0] if li + 1 < len(P.layers) else P.md0[0]
+                c = ops.attention(q, kv[..., :d], kv[..., d:], H, scale, mask=P.mask, prefetch=(L.f_l1[0], L.l2[0], nxt))
                 u2, st2 = ops.gemm_ln(c, L.ca_ow, L.ca_ob, u1, r_stats=st1, r_gamma=L.n1[0], r_beta=L.n1[1], stats_out=True)
                 f = ops.gemm_ln(u2, L.f_l1[0], L.f_l1[2], act=ops.ACT_GELU, a_stats=st2, w_colsum=L.f_l1[1])
                 u, st = ops.gemm_ln(f, L.l2[0], L.l2[1], u2, r_stats=st2, r_gamma=L.n2[0], r_beta=L.n2[1], stats_out=True)

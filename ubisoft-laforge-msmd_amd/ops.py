@@ -8,6 +8,7 @@ be captured in a hipGraph (torch.cuda.CUDAGraph).
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 import torch
@@ -167,6 +168,8 @@ _TUNED = {}
 # global state; these module-level defaults are what `gemm()` passes when the caller gives none (`gemm_defaults`
 # scopes a change, e.g. while a hipGraph is captured -- the choice is then baked into that graph).
 GEMM_WRITE_THROUGH, GEMM_PAIRED_STORES = 1 << 16, 1 << 17
+# attention launches also pull the layer's remaining weights through the memory-side cache (msmd_attention_prefetch)
+PREFETCH_WEIGHTS = os.environ.get("MSMD_PREFETCH", "1") != "0"
 # transformer blocks: LayerNorm folded into the neighbouring GEMMs (gemm_ln); False (MSMD_FOLD_LN=0) = LayerNorm kernels
 FOLD_LN = os.environ.get("MSMD_FOLD_LN", "1") != "0"
 GEMM_ROUTER = None   # developer hook (tools/ab_forward.py): callable (M, N, K, batch) -> variant or None, consulted per call
@@ -421,7 +424,8 @@ def dropout(x, p, rng_state, site, residual=None, out=None):
     return out
 
 
-def attention(q, k, v, n_heads, scale, mask=None, out=None, p_drop=0.0, rng_state=None, site=0, out_dtype=None):
+def attention(q, k, v, n_heads, scale, mask=None, out=None, p_drop=0.0, rng_state=None, site=0, out_dtype=None,
+              prefetch=None):
     """q: (B, Tq, H*64) view, k/v: (B, Tk, H*64) views (last dim contiguous; may be slices of a packed QKV).
     Split q / k / v (parity-grade speed mode): msmd_attention_f16x2; out_dtype SPLIT (default) or torch.float32."""
     _need_cuda(q, k, v)
@@ -454,6 +458,16 @@ def attention(q, k, v, n_heads, scale, mask=None, out=None, p_drop=0.0, rng_stat
                                               q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
                                               out.stride(0), out.stride(1), float(scale), _p(m), float(p_drop),
                                               _p(rng_state), int(site), _dt(q), _stream()), "msmd_attention_dropout")
+        return out
+    if prefetch and PREFETCH_WEIGHTS:
+        # up to four tensors (the weights of the GEMMs that follow) pulled through the memory-side cache by this launch
+        ts = [t for t in prefetch if t is not None and t.is_cuda and t.is_contiguous()][:4]
+        ptrs = (ctypes.c_void_p * 4)(*([t.data_ptr() for t in ts] + [None] * (4 - len(ts))))
+        nbytes = (ctypes.c_long * 4)(*([t.numel() * t.element_size() for t in ts] + [0] * (4 - len(ts))))
+        _lib.check(lib.msmd_attention_prefetch(_p(q), _p(k), _p(v), _p(out), B, n_heads, Tq, Tk, q.stride(0), q.stride(1),
+                                               k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0),
+                                               out.stride(1), float(scale), _p(m), _dt(q), ptrs, nbytes, len(ts),
+                                               _stream()), "msmd_attention_prefetch")
         return out
     _lib.check(lib.msmd_attention(_p(q), _p(k), _p(v), _p(out), B, n_heads, Tq, Tk, q.stride(0), q.stride(1),
                                   k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),

@@ -326,7 +326,9 @@ class Wav2Vec2Model(nn.Module):
                     qkv = ops.gemm(h, L.wqkv, L.bqkv)
                 else:
                     qkv = ops.gemm_ln(u, L.f_qkv[0], L.f_qkv[2], a_stats=st, w_colsum=L.f_qkv[1], eps=eps)
-                a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale)
+                nxt = P.layers[n + 1].f_qkv[0] if n + 1 < len(P.layers) else None
+                a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale,
+                                  prefetch=(L.wo, L.f_w1[0], L.w2, nxt))
                 if n == 0:
                     u1, st1 = ops.gemm_ln(a, L.wo, L.bo, h, stats_out=True)
                 else:
