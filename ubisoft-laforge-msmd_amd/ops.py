@@ -424,6 +424,19 @@ def dropout(x, p, rng_state, site, residual=None, out=None):
     return out
 
 
+def _prefetch_ranges(tensors):
+    """(pointer array, byte-count array, count) of the first four live, contiguous device tensors (Split: its storage)."""
+    ts = []
+    for t in tensors:
+        t = t.t if isinstance(t, Split) else t
+        if t is not None and t.is_cuda and t.is_contiguous():
+            ts.append(t)
+    ts = ts[:4]
+    ptrs = (ctypes.c_void_p * 4)(*([t.data_ptr() for t in ts] + [None] * (4 - len(ts))))
+    nbytes = (ctypes.c_long * 4)(*([t.numel() * t.element_size() for t in ts] + [0] * (4 - len(ts))))
+    return ptrs, nbytes, len(ts)
+
+
 def attention(q, k, v, n_heads, scale, mask=None, out=None, p_drop=0.0, rng_state=None, site=0, out_dtype=None,
               prefetch=None):
     """q: (B, Tq, H*64) view, k/v: (B, Tk, H*64) views (last dim contiguous; may be slices of a packed QKV).
@@ -442,6 +455,13 @@ def attention(q, k, v, n_heads, scale, mask=None, out=None, p_drop=0.0, rng_stat
         if mask is not None:
             assert mask.dtype in (torch.bool, torch.uint8) and mask.shape == (Tq, Tk) and mask.is_contiguous()
             m = mask
+        if prefetch and PREFETCH_WEIGHTS:
+            ptrs, nbytes, n = _prefetch_ranges(prefetch)
+            _lib.check(lib.msmd_attention_f16x2_prefetch(_p(q), _p(k), _p(v), _p(out), B, n_heads, Tq, Tk, q.stride(0),
+                                                         q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                                                         out.stride(0), out.stride(1), float(scale), _p(m), _dt(out),
+                                                         ptrs, nbytes, n, _stream()), "msmd_attention_f16x2_prefetch")
+            return out
         _lib.check(lib.msmd_attention_f16x2(_p(q), _p(k), _p(v), _p(out), B, n_heads, Tq, Tk, q.stride(0), q.stride(1),
                                             k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0),
                                             out.stride(1), float(scale), _p(m), _dt(out), _stream()),
@@ -461,12 +481,10 @@ def attention(q, k, v, n_heads, scale, mask=None, out=None, p_drop=0.0, rng_stat
         return out
     if prefetch and PREFETCH_WEIGHTS:
         # up to four tensors (the weights of the GEMMs that follow) pulled through the memory-side cache by this launch
-        ts = [t for t in prefetch if t is not None and t.is_cuda and t.is_contiguous()][:4]
-        ptrs = (ctypes.c_void_p * 4)(*([t.data_ptr() for t in ts] + [None] * (4 - len(ts))))
-        nbytes = (ctypes.c_long * 4)(*([t.numel() * t.element_size() for t in ts] + [0] * (4 - len(ts))))
+        ptrs, nbytes, n = _prefetch_ranges(prefetch)
         _lib.check(lib.msmd_attention_prefetch(_p(q), _p(k), _p(v), _p(out), B, n_heads, Tq, Tk, q.stride(0), q.stride(1),
                                                k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0),
-                                               out.stride(1), float(scale), _p(m), _dt(q), ptrs, nbytes, len(ts),
+                                               out.stride(1), float(scale), _p(m), _dt(q), ptrs, nbytes, n,
                                                _stream()), "msmd_attention_prefetch")
         return out
     _lib.check(lib.msmd_attention(_p(q), _p(k), _p(v), _p(out), B, n_heads, Tq, Tk, q.stride(0), q.stride(1),
