@@ -215,6 +215,13 @@ int msmd_attention_dropout(const void* Q, const void* K, const void* V, void* O,
                            long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
                            float p_drop, const unsigned long* rng_state, unsigned int site, int dtype,
                            msmd_stream_t stream);
+/* msmd_attention_dropout with msmd_attention_prefetch's byte ranges. */
+int msmd_attention_dropout_prefetch(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
+                                    long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
+                                    long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
+                                    float p_drop, const unsigned long* rng_state, unsigned int site, int dtype,
+                                    const void* const* prefetch_ptrs, const long* prefetch_bytes, int n_prefetch,
+                                    msmd_stream_t stream);
 
 /* y = x * keep / (1 - p) (+ residual): nn.Dropout in training mode (HF hidden / activation / feat_proj dropout,
  * decoder-layer dropout1-3, PositionalEncoding dropout, style-encoder dropouts; utils/model_common.py:101,

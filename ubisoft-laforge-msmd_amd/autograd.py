@@ -432,12 +432,12 @@ class FusedSelfAttnFn(torch.autograd.Function):
     (msmd_attention_bwd, P recomputed); the gradient comes back as ONE packed tensor (no slice / cat glue)."""
 
     @staticmethod
-    def forward(ctx, qkv, n_heads, scale, mask, p_drop, site):
+    def forward(ctx, qkv, n_heads, scale, mask, p_drop, site, prefetch=None):
         d = qkv.shape[-1] // 3
         qkv = qkv.contiguous()
         m8 = _mask_u8(mask)
         o = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], n_heads, scale, m8, p_drop=p_drop,
-                          rng_state=TrainNoise.state, site=site)
+                          rng_state=TrainNoise.state, site=site, prefetch=prefetch)
         ctx.save_for_backward(qkv, m8)
         ctx.cfg = (n_heads, scale, d, p_drop, site)
         return o
@@ -449,7 +449,7 @@ class FusedSelfAttnFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         ops.attention_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], do.contiguous(), dqkv[..., :d],
                           dqkv[..., d:2 * d], dqkv[..., 2 * d:], H, scale, m8, p_drop, TrainNoise.state, site)
-        return dqkv, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None
 
 
 class FusedCrossAttnFn(torch.autograd.Function):
@@ -487,13 +487,20 @@ def _pdrop(p):
     return float(p) if (TrainNoise.active and p > 0.0) else 0.0
 
 
-def self_attention(qkv, n_heads, scale, mask=None, p_drop=0.0):
+def cast_of(w, dtype=torch.bfloat16):
+    """The compute-dtype cast of a weight as LinearFn will read it (a view of the weight arena when there is one, else
+    None: nothing worth prefetching)."""
+    e = CACHE.persistent.get((id(w), dtype))
+    return e[2] if e is not None and e[0]() is w else None
+
+
+def self_attention(qkv, n_heads, scale, mask=None, p_drop=0.0, prefetch=None):
     """softmax(scale Q K^T) V on a packed (B, T, 3 d) projection; p_drop = attention-probability dropout, applied
-    in train mode only."""
+    in train mode only.  prefetch: tensors the launch also pulls through the memory-side cache (ops.attention)."""
     d = qkv.shape[-1] // 3
     p_drop = _pdrop(p_drop)
     if _fusable(qkv, qkv.shape[1]):
-        return FusedSelfAttnFn.apply(qkv, n_heads, scale, mask, p_drop, TrainNoise.next_site() if p_drop else 0)
+        return FusedSelfAttnFn.apply(qkv, n_heads, scale, mask, p_drop, TrainNoise.next_site() if p_drop else 0, prefetch)
     return attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], n_heads, scale, mask, p_drop)
 
 

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const AttnArgs p) {
   constexpr int KROW = BF ? 128 : 256;  // bytes per K row in LDS (64 elements)
   constexpr int VROW = BF ? 128 : 272;  // fp32 V rows padded to 68 floats
   constexpr int NCH = BF ? 8 : 16;      // 16-B chunks per 64-element row
-  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * KROW + 64 * VROW];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * KROW + 64 * VROW + 1024];   // K, V tiles + 1 KB prefetch sink
   unsigned char* sK = smem;
   unsigned char* sV = smem + 64 * KROW;
 
@@ -78,6 +78,22 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const AttnArgs p) {
     }
   };
   prefetch(0);
+  // msmd_attention_prefetch / training: byte ranges (the weights of the GEMMs that follow) pulled through the memory-side
+  // cache by this launch -- LDS-DMA loads into a sink nobody reads, issued next to the first K / V tile's loads (see
+  // attn_whole_kernel)
+  if (p.pf_bytes[0] > 0) {
+    typedef __attribute__((address_space(3))) void lds_sink_t;
+    typedef __attribute__((address_space(1))) const void gbl_src_t;
+    const long stride = (long)gridDim.x * gridDim.y * gridDim.z * NT * 16;
+    const long wave0 = ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NT + (tid & ~63)) * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const char* base = (const char*)p.pf_ptr[r];
+      const long nb = p.pf_bytes[r] & ~1023L;
+      for (long off = wave0; off < nb; off += stride)
+        __builtin_amdgcn_global_load_lds((gbl_src_t*)(base + off + lane * 16), (lds_sink_t*)(smem + 64 * KROW + 64 * VROW), 16, 0, 0);
+    }
+  }
   for (int kv0 = 0; kv0 < p.Tk; kv0 += 64) {
     __syncthreads();
     // ---- stage the prefetched K and V tiles (rows beyond Tk are zero-filled)
@@ -723,6 +739,18 @@ extern "C" int msmd_attention_dropout(const void* Q, const void* K, const void* 
                                       unsigned int site, int dtype, msmd_stream_t stream) {
   return attention_impl(Q, K, V, O, B, H, Tq, Tk, q_bstride, q_tstride, k_bstride, k_tstride, v_bstride, v_tstride,
                         o_bstride, o_tstride, scale, mask, p_drop, rng_state, site, dtype, stream);
+}
+
+// msmd_attention_dropout with msmd_attention_prefetch's byte ranges (the training forward: the layer's bf16 weight casts).
+extern "C" int msmd_attention_dropout_prefetch(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq,
+                                               int Tk, long q_bstride, long q_tstride, long k_bstride, long k_tstride,
+                                               long v_bstride, long v_tstride, long o_bstride, long o_tstride, float scale,
+                                               const uint8_t* mask, float p_drop, const unsigned long* rng_state,
+                                               unsigned int site, int dtype, const void* const* prefetch_ptrs,
+                                               const long* prefetch_bytes, int n_prefetch, msmd_stream_t stream) {
+  return attention_impl(Q, K, V, O, B, H, Tq, Tk, q_bstride, q_tstride, k_bstride, k_tstride, v_bstride, v_tstride,
+                        o_bstride, o_tstride, scale, mask, p_drop, rng_state, site, dtype, stream, prefetch_ptrs,
+                        prefetch_bytes, n_prefetch);
 }
 
 // Split-pair attention (inference): Q / K / V in MSMD_F16X2 storage, O in fp32 (out_dtype MSMD_F32) or split storage.

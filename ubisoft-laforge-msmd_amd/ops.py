@@ -473,6 +473,14 @@ def attention(q, k, v, n_heads, scale, mask=None, out=None, p_drop=0.0, rng_stat
     if mask is not None:
         assert mask.dtype in (torch.bool, torch.uint8) and mask.shape == (Tq, Tk) and mask.is_contiguous()
         m = mask
+    if p_drop > 0.0 and prefetch and PREFETCH_WEIGHTS:
+        ptrs, nbytes, n = _prefetch_ranges(prefetch)
+        _lib.check(lib.msmd_attention_dropout_prefetch(_p(q), _p(k), _p(v), _p(out), B, n_heads, Tq, Tk, q.stride(0),
+                                                       q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                                                       out.stride(0), out.stride(1), float(scale), _p(m), float(p_drop),
+                                                       _p(rng_state), int(site), _dt(q), ptrs, nbytes, n, _stream()),
+                   "msmd_attention_dropout_prefetch")
+        return out
     if p_drop > 0.0:
         _lib.check(lib.msmd_attention_dropout(_p(q), _p(k), _p(v), _p(out), B, n_heads, Tq, Tk, q.stride(0),
                                               q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),

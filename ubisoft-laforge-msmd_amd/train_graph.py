@@ -182,9 +182,16 @@ def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
         else:
             wqkv, bqkv = torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0)
             qkv_proj = lambda t: ag.linear(t, wqkv, bqkv)
+        # the attention launch also pulls the layer's remaining weight casts (and the next layer's QKV) through the
+        # memory-side cache: the GEMMs behind it would otherwise read them from HBM inside their K loops
+        nfa = ag.FUSED.get(("enc_qkv", id(enc), n + 1)) if ag.DIRECT_GRAD else None
+        pf = tuple(t for t in (ag.cast_of(g(p + "attention.out_proj.weight")),
+                               ag.cast_of(g(p + "feed_forward.intermediate_dense.weight")),
+                               ag.cast_of(g(p + "feed_forward.output_dense.weight")),
+                               ag.cast_of(nfa.w) if nfa is not None else None) if t is not None) or None
         if stable:   # HubertEncoderLayerStableLayerNorm
             a = ag.self_attention(qkv_proj(ag.layer_norm(h, *ln1)), H, (d // H) ** -0.5,
-                                  p_drop=c.attention_dropout)
+                                  p_drop=c.attention_dropout, prefetch=pf)
             h = ag.linear_dropout(a, g(p + "attention.out_proj.weight"), g(p + "attention.out_proj.bias"),
                                   c.hidden_dropout, residual=h)
             f = ag.linear_dropout(ag.layer_norm(h, *ln2), g(p + "feed_forward.intermediate_dense.weight"),
@@ -193,7 +200,7 @@ def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
             h = ag.linear_dropout(f, g(p + "feed_forward.output_dense.weight"),
                                   g(p + "feed_forward.output_dense.bias"), c.hidden_dropout, residual=h)
         else:
-            a = ag.self_attention(qkv_proj(h), H, (d // H) ** -0.5, p_drop=c.attention_dropout)
+            a = ag.self_attention(qkv_proj(h), H, (d // H) ** -0.5, p_drop=c.attention_dropout, prefetch=pf)
             h = ag.layer_norm(ag.linear_dropout(a, g(p + "attention.out_proj.weight"),
                                                 g(p + "attention.out_proj.bias"), c.hidden_dropout, residual=h), *ln1)
             f = ag.linear_dropout(h, g(p + "feed_forward.intermediate_dense.weight"),
