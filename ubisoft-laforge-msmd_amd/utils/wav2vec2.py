@@ -295,12 +295,14 @@ class Wav2Vec2Model(nn.Module):
             # pre-LN blocks without LayerNorm launches: every residual GEMM also writes the row statistics of what it
             # stored, the GEMM that consumes LN(h) applies them in its epilogue (include/msmd_hip.h msmd_gemm_ln)
             h, st = y, None                     # y comes from the grouped positional conv: no statistics yet
-            for L in P.layers:
+            for li, L in enumerate(P.layers):
                 if st is None:
                     qkv = ops.gemm(ops.layernorm(h, *L.ln1, eps=eps), L.wqkv, L.bqkv)
                 else:
                     qkv = ops.gemm_ln(h, L.f_qkv[0], L.f_qkv[2], a_stats=st, w_colsum=L.f_qkv[1], eps=eps)
-                a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale)
+                nxt = P.layers[li + 1].f_qkv[0] if li + 1 < len(P.layers) else None
+                a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale,
+                                  prefetch=(L.wo, L.f_w1[0], L.w2, nxt))
                 h, st = ops.gemm_ln(a, L.wo, L.bo, h, stats_out=True)
                 f = ops.gemm_ln(h, L.f_w1[0], L.f_w1[2], act=ops.ACT_GELU, a_stats=st, w_colsum=L.f_w1[1], eps=eps)
                 h, st = ops.gemm_ln(f, L.w2, L.b2, h, stats_out=True)
