@@ -341,6 +341,16 @@ def test_trainer_vertex_space_branch_steps_through_flame():
     tot = [float(o["loss"]) for o in outs]
     assert all(np.isfinite(v) for v in vert + tot) and vert[0] > 0
     assert tot[-1] < tot[0], tot
+    # the same branch under hipGraph capture (the FLAME kinematics used to read its parent table back from the device
+    # inside the capture): first step of a fresh trainer, captured, against the eager trainer's first step
+    torch.manual_seed(0)
+    model2 = get_diffusion_model(args, DEV).eval()
+    se2 = get_style_encoder(args, "vae2").to(DEV).eval()
+    trg = Trainer(args, model2, se2, flame=fl, coef_stats=stats, use_graph=True)
+    og = [trg.step(batch, it=i, draws=draws) for i in range(1, 4)]
+    torch.cuda.synchronize()
+    assert all(np.isfinite(float(o["loss"])) for o in og)
+    assert abs(float(og[0]["vert"]) - vert[0]) <= 2e-3 * abs(vert[0]), (float(og[0]["vert"]), vert[0])
 
 
 def test_trainer_train_mode_noise_eager_and_graph():
