@@ -293,7 +293,8 @@ template <typename T, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_whole_kernel(const AttnArgs p) {
   static_assert(sizeof(T) == 2, "16-bit storage modes");
   constexpr int NF = ATTN_WHOLE_NF, ROWS = 16 * NF, NT = 64 * NW;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * ROWS * 128 + 1024];   // K, V images + 1 KB prefetch sink
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * ROWS * 128];           // K, V images
+  __shared__ __attribute__((aligned(16))) unsigned char pf_sink[1024];                  // prefetch sink: an object of its own (no alias with the images)
   unsigned char* sK = smem;
   unsigned char* sV = smem + ROWS * 128;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -334,19 +335,25 @@ __global__ __launch_bounds__(64 * NW) void attn_whole_kernel(const AttnArgs p) {
   // ---- prefetch ranges (msmd_attention_prefetch): 16 bytes per lane and load, the whole grid sweeps each range.  LDS-DMA
   // into a 1 KB sink every wave overwrites -- no register waits for data nobody wants.  The point is HBM -> Infinity
   // Cache traffic under this compute-light kernel instead of stalls in the next GEMMs' K loops.  Measured placements
-  // (encoder launch, 14 MB of weights): here 16.4 -> 19.8 us (the compiler orders every later LDS access behind the DMA);
-  // dedicated prefetch workgroups in an extra blockIdx.x 26 us; in both cases the layer's GEMMs give back 14-17 us.
+  // (encoder launch, 14 MB of weights, 16.4 us without): here with the builtin 19.8 us, with the inline-asm DMA below 18.2;
+  // dedicated prefetch workgroups in an extra blockIdx.x 26 us; the layer's GEMMs give back 14-17 us in every case.
+  // the Q fragments must have LANDED before the first prefetch load goes out: vmcnt retires in order, so a wait for Q
+  // issued after them would be a wait for all of them (the compiler emits vmcnt(0) in front of the first MFMA otherwise)
+  asm volatile("" ::"v"(qf[0]), "v"(qf[1]));
   if (p.pf_bytes[0] > 0) {
     typedef __attribute__((address_space(3))) void lds_sink_t;
-    typedef __attribute__((address_space(1))) const void gbl_src_t;
+    const unsigned sink_lds = (unsigned)(uintptr_t)(lds_sink_t*)pf_sink;     // LDS byte address of the sink (M0 for the DMA)
     const long stride = (long)gridDim.x * gridDim.y * gridDim.z * NT * 16;
     const long wave0 = ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NT + (tid & ~63)) * 16;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const char* base = (const char*)p.pf_ptr[r];
       const long nb = p.pf_bytes[r] & ~1023L;       // whole 1 KB wave-loads
+      // (inline asm, not the builtin: the compiler orders EVERY later LDS read behind a builtin LDS-DMA -- vmcnt(0) in front
+      // of the first K fragment read, i.e. the prefetch latency in the critical path: 16.4 -> 19.8 us.  Its own vmcnt
+      // arithmetic stays safe: loads it does not know about can only make its waits longer, never shorter.)
       for (long off = wave0; off < nb; off += stride)
-        __builtin_amdgcn_global_load_lds((gbl_src_t*)(base + off + lane * 16), (lds_sink_t*)(smem + 2 * ROWS * 128), 16, 0, 0);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(base + off + lane * 16), "s"(sink_lds) : "m0", "memory");
     }
   }
 
