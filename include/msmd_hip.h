@@ -145,6 +145,12 @@ long msmd_gemm_tn_workspace(int M, int N, int K, int batch);
 int msmd_layernorm(const void* x, const void* residual, const float* gamma, const float* beta,
                    const float* post_add, void* y, int rows, int cols, float eps, int act,
                    int in_dtype, int out_dtype, msmd_stream_t stream);
+/* y = LN_{gamma, beta}( LN_{pre_gamma, pre_beta}(x) + residual ), 16-bit rows: two consecutive post-LN LayerNorms with a branch
+ * added in between (nn.TransformerDecoderLayer norm1 -> + cross-attention branch -> norm2, reference model.py:874-878) in one
+ * launch; the inner result is rounded to the storage type as the separate launch would have stored it. */
+int msmd_layernorm_pre(const void* x, const float* pre_gamma, const float* pre_beta, const void* residual,
+                       const float* gamma, const float* beta, void* y, int rows, int cols, float eps, int dtype,
+                       msmd_stream_t stream);
 
 /* msmd_layernorm on fp32 input with the row ALSO written in MSMD_F16X2 split storage (y_split; cols % 32 == 0):
  * in the parity-grade speed mode a LayerNorm output is the next contraction's A operand (split) and the residual of
@@ -205,6 +211,13 @@ int msmd_attention_f16x2_prefetch(const void* Q, const void* K, const void* V, v
 int msmd_person_query_attention(const void* x, long x_seq_stride, const void* Wq, const float* bq, const void* K,
                                 const void* V, long kv_bstride, long kv_tstride, void* out, int N, int H, int Tk, int d,
                                 float scale, int dtype, msmd_stream_t stream);
+/* msmd_person_query_attention with the LayerNorm in front of the query projection folded in (the decoder's norm1 in the
+ * sampler's diagonal path): x row 0 is un-normalised, Wq / bq are the gamma / beta folded operands (as for msmd_gemm_ln's
+ * operand form), wq_colsum[r] = sum_k Wq'[r][k]; mean / rstd of the row are computed in the kernel. */
+int msmd_person_query_attention_ln(const void* x, long x_seq_stride, const void* Wq, const float* bq,
+                                   const float* wq_colsum, float ln_eps, const void* K, const void* V, long kv_bstride,
+                                   long kv_tstride, void* out, int N, int H, int Tk, int d, float scale, int dtype,
+                                   msmd_stream_t stream);
 
 /* Training-mode attention forward: as msmd_attention with attention-probability dropout p_drop (HF
  * attention_dropout, nn.MultiheadAttention(dropout=0.1) inside the decoder / encoder layers).  The keep mask is

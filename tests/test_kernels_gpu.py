@@ -603,3 +603,31 @@ def test_attention_prefetch_reads_the_ranges_and_changes_nothing(dtype):
         # None entries and more than four tensors are tolerated (the first four live ones are used)
         out = o.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, 0.125, prefetch=[None] + ranges + ranges)
         assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_layernorm_pre_and_folded_person_query(dtype):
+    """msmd_layernorm_pre = the two launches LayerNorm -> (+ residual) -> LayerNorm it replaces (the inner result is rounded
+    to the storage type as the first launch stored it: equal up to the rare last-bit flip where the compiler contracted
+    the affine differently in the two kernels); msmd_person_query_attention_ln = the
+    person query on LayerNorm'ed rows through folded weights, against the unfused pair within the 16-bit modes' error."""
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(31)
+    N, T, d, H, Tk = 70, 111, 512, 8, 110
+    u = (torch.randn(N, T, d, generator=g) * 1.7 + 0.2).to(DEV, dtype)
+    R = torch.randn(N, T, d, generator=g).to(DEV, dtype)
+    g1, b1 = (torch.rand(d, generator=g) + 0.5).to(DEV), (torch.randn(d, generator=g) * 0.1).to(DEV)
+    g2, b2 = (torch.rand(d, generator=g) + 0.5).to(DEV), (torch.randn(d, generator=g) * 0.1).to(DEV)
+    x1 = o.layernorm(u, g1, b1)
+    ref = o.layernorm(x1, g2, b2, residual=R)
+    got = o.layernorm_pre(u, g1, b1, R, g2, b2)
+    diff = (got.float() - ref.float()).abs()
+    assert float((diff == 0).float().mean()) > 0.99 and float(diff.max()) <= (6e-2 if dtype == torch.bfloat16 else 8e-3)
+    wq = (torch.randn(d, d, generator=g) / math.sqrt(d)).to(DEV)
+    bq = torch.randn(d, generator=g).to(DEV)
+    kv = torch.randn(N, Tk, 2 * d, generator=g).to(DEV, dtype)
+    a_ref = o.person_query_attention(x1, wq.to(dtype), bq, kv, H, 0.125)
+    wf, cs, bf = o.fold_layernorm(wq, bq, g1, b1, dtype)
+    a_got = o.person_query_attention(u, wf, bf, kv, H, 0.125, wq_colsum=cs)
+    tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
+    assert maxabs(a_got.float().cpu().numpy(), a_ref.float().cpu().numpy()) < tol

@@ -67,3 +67,25 @@ for mode in ("no prefetch", "prefetch next weights on a side stream"):
         gr.replay()
     e1.record(); torch.cuda.synchronize()
     print(f"64 cold weight copies, {mode}: {e0.elapsed_time(e1) / 320 * 1e3:6.1f} us per launch", flush=True)
+
+# ---- conv1 of the feature extractor on HALF the batch (M = 16 x 6407 windows, K = 3 x 512, N = 512): its input, conv0's output,
+# is 210 MB -- inside the Infinity Cache if it was JUST written (and if writes allocate there).  Producer stand-in: a copy_ into A.
+from msmd_amd.utils.wav2vec2 import CONV_KERNEL, CONV_STRIDE
+Bh, T0, C = 16, 12815, 512
+x = torch.randn(Bh, T0, C, device="cuda", generator=g).to(torch.bfloat16)
+x_src = x.clone()
+w = (torch.randn(C, 3 * C, device="cuda", generator=g) / 40).to(torch.bfloat16)
+bias1 = torch.randn(C, device="cuda", generator=g)
+junk = torch.empty(640 << 20, device="cuda", dtype=torch.uint8)
+for mode in ("input just written (producer -> consumer)", "input evicted (640 MB touched in between)"):
+    ts = []
+    for _ in range(6):
+        x.copy_(x_src)                      # the producer: writes all of x
+        if mode.startswith("input evicted"):
+            junk.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.conv1d_cl(x, w, bias1, kernel=3, stride=2, act=ops.ACT_GELU)
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    print(f"conv1 on 16 clips, {mode}: {sorted(ts)[len(ts) // 2]:6.1f} us", flush=True)

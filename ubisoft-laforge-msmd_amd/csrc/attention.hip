@@ -343,6 +343,7 @@ __global__ __launch_bounds__(64 * NW) void attn_whole_kernel(const AttnArgs p) {
   if (p.pf_bytes[0] > 0) {
     typedef __attribute__((address_space(3))) void lds_sink_t;
     const unsigned sink_lds = (unsigned)(uintptr_t)(lds_sink_t*)pf_sink;     // LDS byte address of the sink (M0 for the DMA)
+    unsigned m0_keep;                                                         // M0 is restored around every DMA
     const long stride = (long)gridDim.x * gridDim.y * gridDim.z * NT * 16;
     const long wave0 = ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NT + (tid & ~63)) * 16;
 #pragma unroll
@@ -353,7 +354,8 @@ __global__ __launch_bounds__(64 * NW) void attn_whole_kernel(const AttnArgs p) {
       // of the first K fragment read, i.e. the prefetch latency in the critical path: 16.4 -> 19.8 us.  Its own vmcnt
       // arithmetic stays safe: loads it does not know about can only make its waits longer, never shorter.)
       for (long off = wave0; off < nb; off += stride)
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(base + off + lane * 16), "s"(sink_lds) : "m0", "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_keep) : "v"(base + off + lane * 16), "s"(sink_lds) : "memory");
     }
   }
 
@@ -842,7 +844,11 @@ __global__ __launch_bounds__(256) void person_query_attention_kernel(const T* __
                                                                      const T* __restrict__ Wq, const float* __restrict__ bq,
                                                                      const T* __restrict__ K, const T* __restrict__ V,
                                                                      long kv_bstride, long kv_tstride, T* __restrict__ out,
-                                                                     int N, int H, int Tk, int d, float scale) {
+                                                                     int N, int H, int Tk, int d, float scale,
+                                                                     const float* __restrict__ wq_colsum = nullptr,
+                                                                     float ln_eps = 1e-5f) {
+  // wq_colsum (msmd_person_query_attention_ln): x row 0 is UN-normalised; Wq carries the LayerNorm weight folded in, bq the
+  // folded bias, wq_colsum[r] = sum_k Wq'[r][k]: q = rstd (Wq' x0 - mu s) + bq with mu / rstd of x0 computed here
   __shared__ float sq[4][64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = lane >> 3, c = lane & 7;
@@ -869,9 +875,12 @@ __global__ __launch_bounds__(256) void person_query_attention_kernel(const T* __
   float qv[8];
 #pragma unroll
   for (int rb = 0; rb < 8; ++rb) qv[rb] = 0.f;
+  float xs1 = 0.f, xs2 = 0.f;          // sum and sum of squares of this lane's part of x0 (the 8 lanes of a group cover it)
   for (int i = 0; i < nch; ++i) {
     float xv[8];
     load8<T>(x0 + (c + 8 * i) * 8, xv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { xs1 += xv[e]; xs2 = fmaf(xv[e], xv[e], xs2); }
 #pragma unroll
     for (int rb = 0; rb < 8; ++rb) {
       float wv[8];
@@ -880,10 +889,18 @@ __global__ __launch_bounds__(256) void person_query_attention_kernel(const T* __
       for (int e = 0; e < 8; ++e) qv[rb] = fmaf(xv[e], wv[e], qv[rb]);
     }
   }
+  float ln_mu = 0.f, ln_rs = 1.f;
+  if (wq_colsum) {
+    const float inv = 1.0f / (float)d;
+    ln_mu = group8_sum(xs1) * inv;
+    ln_rs = rsqrtf(fmaxf(group8_sum(xs2) * inv - ln_mu * ln_mu, 0.f) + ln_eps);
+  }
 #pragma unroll
   for (int rb = 0; rb < 8; ++rb) {
-    const float t = group8_sum(qv[rb]);
-    if (c == 0) sq[wid][rb * 8 + g] = (t + (bq ? bq[h * 64 + rb * 8 + g] : 0.f)) * scale;
+    float t = group8_sum(qv[rb]);
+    const int r = h * 64 + rb * 8 + g;
+    if (wq_colsum) t = ln_rs * (t - ln_mu * wq_colsum[r]);
+    if (c == 0) sq[wid][rb * 8 + g] = (t + (bq ? bq[r] : 0.f)) * scale;
   }
   __builtin_amdgcn_wave_barrier();
   float q8[8];
@@ -948,9 +965,9 @@ __global__ __launch_bounds__(256) void person_query_attention_kernel(const T* __
   }
 }
 
-extern "C" int msmd_person_query_attention(const void* x, long x_seq_stride, const void* Wq, const float* bq,
-                                           const void* K, const void* V, long kv_bstride, long kv_tstride, void* out,
-                                           int N, int H, int Tk, int d, float scale, int dtype, msmd_stream_t stream) {
+static int person_query_impl(const void* x, long x_seq_stride, const void* Wq, const float* bq, const void* K,
+                             const void* V, long kv_bstride, long kv_tstride, void* out, int N, int H, int Tk, int d,
+                             float scale, int dtype, msmd_stream_t stream, const float* wq_colsum, float ln_eps) {
   if (N <= 0 || H <= 0 || Tk <= 0 || Tk > 512 || d != H * 64 || !x || !Wq || !K || !V || !out) return 1;
   const int E = 8;
   if (x_seq_stride % E || kv_bstride % E || kv_tstride % E || ((uintptr_t)x & 15) || ((uintptr_t)Wq & 15) ||
@@ -962,10 +979,10 @@ extern "C" int msmd_person_query_attention(const void* x, long x_seq_stride, con
   do {                                                                                                                 \
     if (Tk <= 128)                                                                                                     \
       hipLaunchKernelGGL((person_query_attention_kernel<T, 16>), grid, block, 0, st, (const T*)x, x_seq_stride,         \
-                         (const T*)Wq, bq, (const T*)K, (const T*)V, kv_bstride, kv_tstride, (T*)out, N, H, Tk, d, scale); \
+                         (const T*)Wq, bq, (const T*)K, (const T*)V, kv_bstride, kv_tstride, (T*)out, N, H, Tk, d, scale, wq_colsum, ln_eps); \
     else                                                                                                               \
       hipLaunchKernelGGL((person_query_attention_kernel<T, 64>), grid, block, 0, st, (const T*)x, x_seq_stride,         \
-                         (const T*)Wq, bq, (const T*)K, (const T*)V, kv_bstride, kv_tstride, (T*)out, N, H, Tk, d, scale); \
+                         (const T*)Wq, bq, (const T*)K, (const T*)V, kv_bstride, kv_tstride, (T*)out, N, H, Tk, d, scale, wq_colsum, ln_eps); \
   } while (0)
   if (dtype == MSMD_F32) LAUNCH_PQA(float);
   else if (dtype == MSMD_BF16) LAUNCH_PQA(bf16_t);
@@ -973,4 +990,22 @@ extern "C" int msmd_person_query_attention(const void* x, long x_seq_stride, con
   else return 1;
 #undef LAUNCH_PQA
   MSMD_RETURN_LAST();
+}
+
+extern "C" int msmd_person_query_attention(const void* x, long x_seq_stride, const void* Wq, const float* bq,
+                                           const void* K, const void* V, long kv_bstride, long kv_tstride, void* out,
+                                           int N, int H, int Tk, int d, float scale, int dtype, msmd_stream_t stream) {
+  return person_query_impl(x, x_seq_stride, Wq, bq, K, V, kv_bstride, kv_tstride, out, N, H, Tk, d, scale, dtype, stream,
+                           nullptr, 0.f);
+}
+
+// The same with the LayerNorm in front of the query projection folded in: x row 0 un-normalised, Wq / bq the gamma / beta
+// folded operands (msmd_gemm_ln's operand form), wq_colsum the row sums of the folded Wq.
+extern "C" int msmd_person_query_attention_ln(const void* x, long x_seq_stride, const void* Wq, const float* bq,
+                                              const float* wq_colsum, float ln_eps, const void* K, const void* V,
+                                              long kv_bstride, long kv_tstride, void* out, int N, int H, int Tk, int d,
+                                              float scale, int dtype, msmd_stream_t stream) {
+  if (!wq_colsum || !bq) return 1;
+  return person_query_impl(x, x_seq_stride, Wq, bq, K, V, kv_bstride, kv_tstride, out, N, H, Tk, d, scale, dtype, stream,
+                           wq_colsum, ln_eps);
 }

@@ -28,23 +28,62 @@ template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, const float*
 
 // cols % 4 == 0, cols <= 4 * 64 * MAXC
 // SPLIT2: additionally (y may then be NULL) write the row in MSMD_F16X2 split storage to y2 (cols % 32 == 0)
+// pre_g / pre_b (msmd_layernorm_pre): x holds UN-normalised rows and is first normalised with (pre_g, pre_b) -- rounded to
+// the storage type, as the separate LayerNorm launch it replaces would have stored it -- before the residual is added:
+//   y = LN_{gamma, beta}( LN_{pre}(x) + residual )       one launch for norm1 -> (+ cross-attention branch) -> norm2
 template <typename TI, typename TO, int MAXC, bool SPLIT2 = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, const TI* __restrict__ res,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         const float* __restrict__ post, TO* __restrict__ y, int rows,
-                                                        int cols, float eps, int act, f16_t* __restrict__ y2 = nullptr) {
+                                                        int cols, float eps, int act, f16_t* __restrict__ y2 = nullptr,
+                                                        const float* __restrict__ pre_g = nullptr,
+                                                        const float* __restrict__ pre_b = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nchunk = cols >> 2;
   float v[MAXC][4];
   float s = 0.f;
+  if (pre_g) {      // wave-uniform: the pre-normalisation pass over the row (its own mean / variance)
+    float s0 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = i * 64 + lane;
+      if (c < nchunk) {
+        load4<TI>(x + (long)row * cols + c * 4, v[i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s0 += v[i][e];
+      }
+    }
+    const float mean0 = wave_sum(s0) / (float)cols;
+    float q0 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = i * 64 + lane;
+      if (c < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean0; q0 += d * d; }
+      }
+    }
+    const float rstd0 = 1.0f / sqrtf(wave_sum(q0) / (float)cols + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = i * 64 + lane;
+      if (c < nchunk) {
+        float g0[4], b0[4];
+        load4<float>(pre_g + c * 4, g0);
+        load4<float>(pre_b + c * 4, b0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = (float)(TI)((v[i][e] - mean0) * rstd0 * g0[e] + b0[e]);
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
     const int c = i * 64 + lane;
     if (c < nchunk) {
-      load4<TI>(x + (long)row * cols + c * 4, v[i]);
+      if (!pre_g) load4<TI>(x + (long)row * cols + c * 4, v[i]);
       if (res) {
         float r[4];
         load4<TI>(res + (long)row * cols + c * 4, r);
@@ -102,17 +141,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
 
 template <typename TI, typename TO>
 static int launch_ln(const void* x, const void* res, const float* g, const float* b, const float* post, void* y,
-                     int rows, int cols, float eps, int act, hipStream_t st) {
+                     int rows, int cols, float eps, int act, hipStream_t st, const float* pre_g = nullptr,
+                     const float* pre_b = nullptr) {
   dim3 grid((rows + 3) / 4), block(256);
+  f16_t* none = nullptr;
   if (cols <= 4 * 64 * 2)
     hipLaunchKernelGGL((layernorm_kernel<TI, TO, 2>), grid, block, 0, st, (const TI*)x, (const TI*)res, g, b, post,
-                       (TO*)y, rows, cols, eps, act);
+                       (TO*)y, rows, cols, eps, act, none, pre_g, pre_b);
   else if (cols <= 4 * 64 * 4)
     hipLaunchKernelGGL((layernorm_kernel<TI, TO, 4>), grid, block, 0, st, (const TI*)x, (const TI*)res, g, b, post,
-                       (TO*)y, rows, cols, eps, act);
+                       (TO*)y, rows, cols, eps, act, none, pre_g, pre_b);
   else if (cols <= 4 * 64 * 16)
     hipLaunchKernelGGL((layernorm_kernel<TI, TO, 16>), grid, block, 0, st, (const TI*)x, (const TI*)res, g, b, post,
-                       (TO*)y, rows, cols, eps, act);
+                       (TO*)y, rows, cols, eps, act, none, pre_g, pre_b);
   else
     return 1;
   MSMD_RETURN_LAST();
@@ -160,6 +201,20 @@ extern "C" int msmd_layernorm(const void* x, const void* residual, const float* 
     return launch_ln<f16_t, float>(x, residual, gamma, beta, post_add, y, rows, cols, eps, act, st);
   if (in_dtype == MSMD_F32 && out_dtype == MSMD_F16)
     return launch_ln<float, f16_t>(x, residual, gamma, beta, post_add, y, rows, cols, eps, act, st);
+  return 1;
+}
+
+// y = LN_{gamma, beta}( LN_{pre_gamma, pre_beta}(x) + residual ): two consecutive post-LN LayerNorms with a branch added in
+// between (nn.TransformerDecoderLayer: norm1 -> + cross-attention branch -> norm2) in ONE launch; 16-bit rows.
+extern "C" int msmd_layernorm_pre(const void* x, const float* pre_gamma, const float* pre_beta, const void* residual,
+                                  const float* gamma, const float* beta, void* y, int rows, int cols, float eps, int dtype,
+                                  msmd_stream_t stream) {
+  if (rows <= 0 || cols <= 0 || (cols & 3) || !x || !y || !gamma || !beta || !pre_gamma || !pre_beta) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MSMD_BF16)
+    return launch_ln<bf16_t, bf16_t>(x, residual, gamma, beta, nullptr, y, rows, cols, eps, 0, st, pre_gamma, pre_beta);
+  if (dtype == MSMD_F16)
+    return launch_ln<f16_t, f16_t>(x, residual, gamma, beta, nullptr, y, rows, cols, eps, 0, st, pre_gamma, pre_beta);
   return 1;
 }
 

@@ -388,23 +388,29 @@ class DenoisingNetwork_MSMD(nn.Module):
             else:
                 qkv = ops.gemm_ln(u, L.f_sa[0], L.f_sa[2], a_stats=st, w_colsum=L.f_sa[1])
             a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale)
-            if u is None:
-                x = ops.layernorm(ops.gemm(a, L.sa_ow, L.sa_ob, residual=x), *L.n1)
-            else:
-                x = ops.layernorm(ops.gemm_ln(a, L.sa_ow, L.sa_ob, u, r_stats=st, r_gamma=ln[0], r_beta=ln[1]), *L.n1)
+            fused_pq = getattr(self, "fused_person_query", N >= 64)
+            # norm1 without a launch of its own (diagonal path, fused person query): its two consumers apply it -- the
+            # person-token query projection through folded weights, the norm2 launch as its first stage (layernorm_pre)
+            fold_n1 = fold and diag and fused_pq
+            u1 = ops.gemm(a, L.sa_ow, L.sa_ob, residual=x) if u is None else \
+                ops.gemm_ln(a, L.sa_ow, L.sa_ob, u, r_stats=st, r_gamma=ln[0], r_beta=ln[1])
+            if not fold_n1:
+                x = ops.layernorm(u1, *L.n1)
             kv = kv_list[li] if kv_list is not None else ops.gemm(mem, L.ca_kvw, L.ca_kvb)
             if diag:
                 # only the person token (row 0) has a real softmax; rows t >= 1 come from the precomputed R
                 R = cross_list[li]
                 # same-box A/B in the sampler graph: fused -1 % at N = 192 sequences, +1.5 % at N = 3 (a longer serial
                 # chain per wave than the two more parallel launches), so it is used from 64 sequences up
-                if getattr(self, "fused_person_query", N >= 64):
+                if fold_n1:
+                    a0 = ops.person_query_attention(u1, L.f_caq[0], L.f_caq[2], kv, H, scale, wq_colsum=L.f_caq[1])
+                elif fused_pq:
                     a0 = ops.person_query_attention(x, L.ca_qw_valu, L.ca_qb, kv, H, scale)      # (N, d), one launch
                 else:
                     q0 = ops.gemm(x, L.ca_qw, L.ca_qb, M=N, K=d, lda=Tn * d)                    # (N, d) from x[:, 0]
                     a0 = ops.attention(q0.view(N, 1, d), kv[..., :d], kv[..., d:], H, scale)     # (N, 1, d)
                 ops.gemm(a0, L.ca_ow, L.ca_ob, None, ops.ACT_NONE, out=R, M=N, K=d, ldc=Tn * d)  # -> R[:, 0]
-                x = ops.layernorm(x, *L.n2, residual=R)
+                x = ops.layernorm_pre(u1, *L.n1, R, *L.n2) if fold_n1 else ops.layernorm(x, *L.n2, residual=R)
             else:
                 q = ops.gemm(x, L.ca_qw, L.ca_qb)
                 c = ops.attention(q, kv[..., :d], kv[..., d:], H, scale, mask=P.mask)

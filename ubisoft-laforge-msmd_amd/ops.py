@@ -411,6 +411,17 @@ def layernorm(x, gamma, beta, residual=None, post_add=None, act=ACT_NONE, eps=1e
     return y
 
 
+def layernorm_pre(x, pre_gamma, pre_beta, residual, gamma, beta, eps=1e-5):
+    """LN_{gamma, beta}(LN_{pre}(x) + residual) in one launch (16-bit rows): msmd_layernorm_pre."""
+    _need_cuda(x, gamma, beta, pre_gamma, pre_beta)
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().msmd_layernorm_pre(_p(x), _p(pre_gamma), _p(pre_beta), _p(residual), _p(gamma), _p(beta), _p(y),
+                                              rows, cols, eps, _dt(x), _stream()), "msmd_layernorm_pre")
+    return y
+
+
 def dropout(x, p, rng_state, site, residual=None, out=None):
     """y = x * keep / (1 - p) (+ residual); keep = Philox(rng_state[seed, step], site, element / 4).  Calling it on
     the upstream gradient with the same (rng_state, site) is the backward."""
@@ -929,7 +940,7 @@ def act_fwd(z, act):
     return y
 
 
-def person_query_attention(x, wq, bq, kv, n_heads, scale):
+def person_query_attention(x, wq, bq, kv, n_heads, scale, wq_colsum=None, eps=1e-5):
     """Row 0 of every sequence of x (N, T, d): softmax(scale (x0 Wq^T + bq)_h K_h^T) V_h against kv (N, Tk, 2d) =
     [K | V]; returns (N, d).  One launch for the projection and the Tq = 1 attention (msmd_person_query_attention)."""
     _need_cuda(x, wq, kv)
@@ -940,6 +951,12 @@ def person_query_attention(x, wq, bq, kv, n_heads, scale):
     if not (x.dtype == wq.dtype == kv.dtype):
         raise TypeError("person_query_attention: x, wq, kv must share a dtype")
     out = torch.empty(N, d, device=x.device, dtype=x.dtype)
+    if wq_colsum is not None:      # the LayerNorm in front of the projection folded in (wq / bq folded, x un-normalised)
+        _lib.check(_lib.load().msmd_person_query_attention_ln(_p(x), x.stride(0), _p(wq), _p(bq), _p(wq_colsum), float(eps),
+                                                              _p(kv), _p(kv[..., d:]), kv.stride(0), kv.stride(1), _p(out),
+                                                              N, n_heads, Tk, d, float(scale), _dt(x), _stream()),
+                   "msmd_person_query_attention_ln")
+        return out
     _lib.check(_lib.load().msmd_person_query_attention(_p(x), x.stride(0), _p(wq), _p(bq), _p(kv), _p(kv[..., d:]),
                                                        kv.stride(0), kv.stride(1), _p(out), N, n_heads, Tk, d,
                                                        float(scale), _dt(x), _stream()), "msmd_person_query_attention")
