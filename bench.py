@@ -548,7 +548,7 @@ def run_forward(a, rank, world, device):
                 runs = [graphed_step(model, b)] + [graphed_step(model, synth_batch(a.batch, 1000 + 16 * rank + i, device))
                                                    for i in range(1, S)]
                 run = runs[0]
-                launch = "one hipGraph replay per step (inputs refreshed by D2D copies)"
+                launch = "one hipGraph replay per step (the batch sits in the captured input buffers)"
                 if S > 1:
                     torch.cuda.synchronize()
                     serial = []
@@ -579,7 +579,7 @@ def run_forward(a, rank, world, device):
                             with torch.cuda.stream(streams[i]):
                                 runs[i]()
                         launch = (f"{S} steps in flight: hipGraph replays issued round-robin on {S} HIP streams, one captured graph + "
-                                  f"input buffers + batch per stream (inputs refreshed by D2D copies; concurrent replays verified "
+                                  f"input buffers + batch per stream (each batch written once into its captured buffers; concurrent replays verified "
                                   f"bit-equal to one-at-a-time replays before timing)")
                     else:
                         print("[bench] concurrent replays differ from serial ones; timing one stream", file=sys.stderr)
@@ -614,6 +614,9 @@ def run_forward(a, rank, world, device):
     if single_ms is not None:
         out["single_stream_ms_per_step"] = round(single_ms, 3)   # one step at a time (latency of a step)
     if n > 1:
+        if not a.no_roofline:     # rank 0's dominant kernel (no collective inside: the other ranks wait at the closing barrier)
+            out["roofline"] = roofline_leg(model, b, a.dtype)
+        out["cpu_baseline"] = None    # timed at N = 1 only
         return out
     ref = None
     if not a.no_cpu_baseline:
