@@ -784,11 +784,13 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if os.environ.get("MSMD_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from msmd_amd import dp
-    dp.init("nccl", device)
+    # MSMD_DIST_BACKEND=gloo + MSMD_ONE_DEVICE=1: rehearsal of the N-rank control flow on ONE GPU (tools/bench_two_ranks_one_gpu.sh);
+    # the real launch is RCCL ("nccl"), one device per rank
+    dp.init(os.environ.get("MSMD_DIST_BACKEND", "nccl"), device)
     if world > 1:
         import torch.distributed as td
         world = td.get_world_size()    # what RCCL actually sees

@@ -239,6 +239,58 @@ def test_grad_bucket_reducer_world_2_gloo(tmp_path):
     assert out["err"] < 1e-6 and out["unused"] == 0.0 and out["n"] == 512 + 64 + 256 + 64 + 64  # 64-element aligned slots
 
 
+def test_grad_bucket_reducer_ranks_skip_different_layers_world_2_gloo(tmp_path):
+    """Eager DP with LayerDrop: every rank skips a DIFFERENT layer, so the buckets complete in different orders on the two
+    ranks (and one never completes before finish()).  The collective sequence must still be the same everywhere -- hook
+    launches go out in bucket order, finish() sends the rest -- and the result the sum of what each rank produced."""
+    script = tmp_path / "ld.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, json
+        sys.path.insert(0, {ROOT!r})
+        import torch, torch.distributed as td
+        from msmd_amd import dp
+        rank, world = dp.init("gloo")
+        torch.manual_seed(0)
+        layers = [torch.nn.Linear(16, 16) for _ in range(6)]
+        params = [p for l in layers for p in l.parameters()]
+        red = dp.GradBucketReducer(params, bucket_mb=0.0005)
+        assert len(red.buckets) >= 6
+        x = torch.randn(4, 16)
+
+        def run(skip):
+            h = x
+            for i, l in enumerate(layers):
+                if i != skip:
+                    h = h + torch.tanh(l(h))
+            return h.pow(2).mean()
+
+        red.zero_grad()
+        run(skip=1 + 3 * rank).backward()          # rank 0 skips layer 1, rank 1 skips layer 4
+        flat, scale = red.finish()
+        got = [p.grad.clone() for p in params]
+        ref = [torch.zeros_like(p) for p in params]
+        for r in range(world):
+            for p in params:
+                p.grad = None
+            run(skip=1 + 3 * r).backward()
+            for a, p in zip(ref, params):
+                if p.grad is not None:
+                    a += p.grad
+        err = max(float((a - b).abs().max()) for a, b in zip(got, ref))
+        if rank == 0:
+            print(json.dumps(dict(err=err, buckets=len(red.buckets))))
+        td.destroy_process_group()
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29621")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29621", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["err"] < 1e-6, out
+
+
 def test_grad_bucket_reducer_accumulation_rearm_and_write_sequence_world_2_gloo(tmp_path):
     """(1) Gradient accumulation with a parameter that is unused in micro-step 1: the arrival counters are re-armed
     per backward (`begin_backward`), so no bucket is reduced before the stepping micro-step's backward has finished

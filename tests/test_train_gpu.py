@@ -534,3 +534,28 @@ def test_backward_with_the_side_stream_busy_equals_backward_alone(use_graph, mon
         red.standin = None
         tr._optimizer_step()
     assert worst < 1e-5
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """bench.py's N-rank control flow with N = 2 on ONE GPU (gloo rendezvous, both ranks on cuda:0; the real launch is RCCL,
+    one device per rank): forward line and training line must come out -- barriers, max-over-ranks timing, rank-0-only
+    legs, the bucket reducer's exchange in capture / replay / eager modes with train-mode LayerDrop drawing different
+    layers per rank.  (Found in round 3: capture_all() launched all-reduces inside a capture; eager LayerDrop made the
+    ranks launch their buckets in different orders.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MSMD_DIST_BACKEND="gloo", MSMD_ONE_DEVICE="1")
+    for mode, port in (("forward", "29531"), ("train", "29532")):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2",
+                            "--steps", "2", "--warmup", "1", "--mode", mode, "--no-cpu-baseline"],
+                           capture_output=True, text=True, env=env, timeout=900, cwd=root)
+        assert r.returncode == 0, (mode, r.stderr[-3000:])
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+        assert len(lines) == 1, (mode, r.stdout[-2000:])
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+        assert "roofline" in d

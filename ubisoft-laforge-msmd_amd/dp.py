@@ -138,6 +138,12 @@ class GradBucketReducer:
             self.buckets.append((start, total, members))
         self.pending = [len(m) for _, _, m in self.buckets]
         self.launched = [False] * len(self.buckets)
+        # Hook-driven launches go out strictly in bucket-index order (`next_launch`): ranks may complete buckets in different
+        # orders -- LayerDrop skips a different layer on every rank in eager mode, so its bucket never completes there -- and
+        # a collective sequence that differs between ranks mismatches payloads or hangs.  A bucket that is complete but
+        # sits behind an incomplete one waits for finish(), which launches the rest in the same index order everywhere.
+        self.ready = [False] * len(self.buckets)
+        self.next_launch = 0
         self.cuda = dev.type == "cuda"
         self.side = torch.cuda.Stream(device=dev) if self.cuda else None
         self.works = []
@@ -176,6 +182,8 @@ class GradBucketReducer:
         reduced while backward is still adding into it."""
         self.pending = [len(m) for _, _, m in self.buckets]
         self.launched = [False] * len(self.buckets)
+        self.ready = [False] * len(self.buckets)
+        self.next_launch = 0
         self.works = []
         self.write_count = 0
 
@@ -217,8 +225,12 @@ class GradBucketReducer:
             p.grad = self.arena[off:off + n].view_as(p)
         self.on_write(p)
         self.pending[b] -= 1
-        if self.pending[b] == 0 and self.enabled:
-            self._launch(b)
+        if self.pending[b] == 0:
+            self.ready[b] = True
+        if self.enabled:
+            while self.next_launch < len(self.buckets) and self.ready[self.next_launch]:
+                self._launch(self.next_launch)
+                self.next_launch += 1
 
     def exchange_only(self):
         """All buckets' all-reduce with nothing to overlap with (bench.py: the exchange's own duration).  The arena's

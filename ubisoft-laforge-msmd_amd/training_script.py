@@ -538,6 +538,9 @@ class Trainer:
         saved = self.reducer.arena.clone()
         segmented = self.segment_graphs
         red = self.reducer
+        # no exchange from inside a warm-up or a capture, whoever calls (step() disables the hooks' launches itself, but
+        # capture_all() is also called directly): buckets are launched by the replay loop / finish() only
+        was_enabled, red.enabled = red.enabled, False
         # warm-up on a side stream (allocator / lazy init), then capture; gradients written by both are discarded.
         # Segmented mode: the warm-up also RECORDS the backward's gradient-write sequence (autograd accumulations and
         # direct arena writes), from which the capture knows after which write each bucket is final.
@@ -605,6 +608,7 @@ class Trainer:
                     ag.GRAD_WRITTEN = None
                 torch.cuda.current_stream().wait_stream(cs)
         ag.TrainNoise.spec_masks = None
+        red.enabled = was_enabled
         self._invalidate_caches()             # cached casts now live in the graph's pool: eager code must re-make them
         self.reducer.arena.copy_(saved)
         self.reducer.begin_backward()
