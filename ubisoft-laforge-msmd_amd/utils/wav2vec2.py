@@ -339,9 +339,11 @@ class Wav2Vec2Model(nn.Module):
                 u, st = ops.gemm_ln(f, L.w2, L.b2, u1, r_stats=st1, r_gamma=L.ln1[0], r_beta=L.ln1[1], stats_out=True, eps=eps)
                 ln = L.ln2
             return ops.layernorm(u, *ln, eps=eps)
-        for L in P.layers:
+        for li, L in enumerate(P.layers):
             qkv = ops.gemm(h, L.wqkv, L.bqkv)
-            a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, (d // H) ** -0.5)
+            nxt = P.layers[li + 1].wqkv if li + 1 < len(P.layers) else None
+            a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, (d // H) ** -0.5,
+                              prefetch=None if P.split else (L.wo, L.w1, L.w2, nxt))
             h = ops.layernorm(ops.gemm(a, L.wo, L.bo, residual=h), *L.ln1, eps=c.layer_norm_eps)
             f = ops.gemm(h, L.w1, L.b1, act=ops.ACT_GELU)
             h = ops.layernorm(ops.gemm(f, L.w2, L.b2, residual=h), *L.ln2, eps=c.layer_norm_eps)
