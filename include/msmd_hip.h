@@ -116,6 +116,15 @@ int msmd_gemm_ex(const void* A, const void* W, const float* bias, const void* re
 /* Two-level batched GEMM C[zo][zi] = A[zo][zi] . W[zo][zi]^T (no bias / residual / activation): operand z =
  * zo * batch_inner + zi starts at base + zo * stride_o + zi * stride_i.  Used by the explicit (materialised-P)
  * training attention, where zo = batch and zi = head index into packed (B, T, H*64) tensors. */
+/* dZ = keep_mask / (1 - p_drop) * act'(Z) * (A . W^T)  (16-bit; C and Z contiguous (M, N), N % 4 == 0): the data gradient of a
+ * Linear whose input was dropout(act(Z)), with the backward of that activation + dropout applied in the GEMM epilogue (mask
+ * regenerated from (rng_state, site) as by msmd_gemm_ex / msmd_act_bwd_dropout; p_drop = 0: no mask).  One launch for
+ * autograd's  linear2.backward -> dropout.backward -> GELU.backward  of nn.TransformerEncoder/DecoderLayer and the HF
+ * feed-forward blocks (reference model.py:874-878, utils/wav2vec2.py). */
+int msmd_gemm_actbwd(const void* A, const void* W, const void* Z, void* C, int M, int N, int K, int in_dtype, int out_dtype,
+                     long lda, long ldw, int act, float p_drop, const unsigned long* rng_state, unsigned int site,
+                     msmd_stream_t stream);
+
 int msmd_gemm_batched2(const void* A, const void* W, void* C, int M, int N, int K, int in_dtype, int out_dtype,
                        long lda, long ldw, long ldc, int batch_outer, long strideA_o, long strideW_o, long strideC_o,
                        int batch_inner, long strideA_i, long strideW_i, long strideC_i, msmd_stream_t stream);

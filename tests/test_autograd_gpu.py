@@ -292,3 +292,46 @@ def test_weight_arena_refresh_matches_per_weight_casts():
     key = (id(params[0]), torch.bfloat16)
     assert key in ag.CACHE.persistent
     ag.CACHE.persistent.clear()
+
+
+def test_ffn_node_matches_two_linear_nodes_and_gemm_actbwd_matches_the_unfused_pair():
+    """autograd.ffn (FFNFn: one node, msmd_gemm_actbwd in the middle of its backward) against the two LinearFn nodes it
+    replaces -- same dropout sites, so same masks: outputs bit-equal, gradients within the 16-bit rounding of one
+    intermediate (the fused epilogue evaluates GELU' with the fast erf / exp)."""
+    import math
+    from msmd_amd import autograd as ag, ops
+    g = torch.Generator(device="cpu").manual_seed(3)
+    M, d, dff = 333, 256, 1024
+    x0 = torch.randn(7, M // 7 + 1, d, generator=g)[:, :47].contiguous().to(DEV, torch.bfloat16)
+    res0 = torch.randn_like(x0.float()).to(DEV, torch.bfloat16)
+    w1 = (torch.randn(dff, d, generator=g) / math.sqrt(d)).to(DEV).requires_grad_(True)
+    b1 = (torch.randn(dff, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    w2 = (torch.randn(d, dff, generator=g) / math.sqrt(dff)).to(DEV).requires_grad_(True)
+    b2 = (torch.randn(d, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    dy = torch.randn_like(x0.float()).to(torch.bfloat16)
+    ag.TrainNoise.state = torch.tensor([1234, 5], dtype=torch.int64, device=DEV)
+    outs = {}
+    for fused in (False, True):
+        for active in (False, True):
+            ag.TrainNoise.active, ag.TrainNoise.site = active, 0
+            x = x0.clone().requires_grad_(True)
+            res = res0.clone().requires_grad_(True)
+            for t in (w1, b1, w2, b2):
+                t.grad = None
+            if fused:
+                y = ag.ffn(x, w1, b1, w2, b2, 0.1, 0.2, residual=res)
+            else:
+                y = ag.linear_dropout(ag.linear_dropout(x, w1, b1, 0.1, act=ops.ACT_GELU), w2, b2, 0.2, residual=res)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            outs[fused, active] = [y.detach().float()] + [t.grad.float().clone() for t in (x, res, w1, b1, w2, b2)]
+    ag.TrainNoise.active = False
+    for active in (False, True):
+        a, b = outs[False, active], outs[True, active]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])          # forward output, residual gradient
+        for name, u, v in zip(("dx", "dw1", "db1", "dw2", "db2"), [a[1]] + a[3:], [b[1]] + b[3:]):
+            scale = float(u.abs().max())
+            assert float((u - v).abs().max()) <= 1.5e-2 * scale + 1e-6, (name, active, float((u - v).abs().max()), scale)
+        assert torch.equal(a[5], b[5]) and torch.equal(a[6], b[6])          # dW2, db2 do not pass through the fused launch
+    # dropout really on in the active pass
+    assert not torch.equal(outs[True, False][0], outs[True, True][0])

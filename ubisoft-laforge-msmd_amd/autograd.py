@@ -162,6 +162,64 @@ def _mask_u8(mask):
     return e[2]
 
 
+def _param_grads(dz2, xin, w, b_ref, has_b, K, need_w, need_b, alias):
+    """dW, db of y = x W^T + b from dz2 (M, N) and the saved input xin (..., Kp): returned, or -- direct-gradient mode /
+    FusedAlias operands -- added straight into the gradient arena (then None is returned for them)."""
+    dtype = xin.dtype
+    N = w.shape[0]
+    Kp = xin.shape[-1]
+    M = xin.numel() // Kp
+    dw = db = None
+    want_b = has_b and need_b
+    if alias is not None:
+        fa = alias
+        ops.gemm_tn(dz2, xin.reshape(M, Kp), out=fa.wgrad.view(N, Kp), colsum_out=fa.bgrad, accumulate=True)
+        if GRAD_WRITTEN is not None:
+            for o in fa.owners:
+                GRAD_WRITTEN(o)
+        return None, None
+    direct = (DIRECT_GRAD and need_w and dtype == torch.bfloat16 and N % 8 == 0 and Kp == K
+              and w.is_leaf and w.grad is not None and w.grad.is_contiguous() and USE_GEMM_TN)
+    if direct:
+        # accumulate dW (and db) straight into the parameters' .grad views of the flat gradient arena: no fp32
+        # temporary, no autograd add kernel per parameter and window
+        bgrad = None
+        if want_b:
+            b_leaf = b_ref
+            if b_leaf is not None and b_leaf.grad is not None and b_leaf.grad.is_contiguous():
+                bgrad = b_leaf.grad
+        ops.gemm_tn(dz2, xin.reshape(M, Kp), out=w.grad.view(N, Kp), colsum_out=bgrad, accumulate=True)
+        if GRAD_WRITTEN is not None:
+            GRAD_WRITTEN(w)
+            if bgrad is not None:
+                GRAD_WRITTEN(b_ref)
+        if want_b and bgrad is None:
+            db = ops.colsum(dz2)
+    elif need_w and dtype == torch.bfloat16 and N % 8 == 0 and USE_GEMM_TN:
+        # dW = dZ^T X straight from the row-major operands (transposing LDS reads), bias gradient fused
+        x2 = xin.reshape(M, Kp)
+        if want_b:
+            dwe, db = ops.gemm_tn(dz2, x2, want_colsum=True)
+        else:
+            dwe = ops.gemm_tn(dz2, x2)
+        dw = dwe[:, :K].reshape(w.shape)
+    elif need_w:
+        dzT = ops.transpose2d(dz2, 8)                      # (N, Mp)
+        # x^T with 8 extra rows: row Kp is all ones, so column Kp of the product is the bias gradient
+        # (dz^T . 1) for free inside the wgrad GEMM instead of a separate column-sum pass.
+        Mp = dzT.shape[1]
+        xT = torch.zeros(Kp + 8, Mp, device=xin.device, dtype=dtype)
+        ops.transpose(xin.reshape(M, Kp), xT, M, Kp, Kp, Mp)
+        xT[Kp, :M] = 1
+        dwe = ops.gemm(dzT, xT, out_dtype=torch.float32)   # (N, Kp + 8) fp32
+        dw = dwe[:, :K].reshape(w.shape)
+        if want_b:
+            db = dwe[:, Kp].contiguous()
+    elif want_b:
+        db = ops.colsum(dz2)
+    return dw, db
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x @ w.T + b) + residual   (x: (..., K) compute dtype; w (N, K), b (N) fp32 master parameters)."""
 
@@ -209,56 +267,67 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dzp = dz2 if wct.shape[1] == N else ops.pad_cols(dz2, wct.shape[1], dtype)
             dx = ops.gemm(dzp, wct).reshape(*xin.shape[:-1], wct.shape[0])
-        want_b = ctx.has_b and ctx.needs_input_grad[2]
-        if ctx.alias is not None:
-            fa = ctx.alias
-            ops.gemm_tn(dz2, xin.reshape(M, Kp), out=fa.wgrad.view(N, Kp), colsum_out=fa.bgrad, accumulate=True)
-            if GRAD_WRITTEN is not None:
-                for o in fa.owners:
-                    GRAD_WRITTEN(o)
-            dres = dy if ctx.has_r and ctx.needs_input_grad[3] else None
-            return dx, None, None, dres, None, None, None, None
-        direct = (DIRECT_GRAD and ctx.needs_input_grad[1] and dtype == torch.bfloat16 and N % 8 == 0 and Kp == ctx.K
-                  and w.is_leaf and w.grad is not None and w.grad.is_contiguous() and USE_GEMM_TN)
-        if direct:
-            # accumulate dW (and db) straight into the parameters' .grad views of the flat gradient arena: no fp32
-            # temporary, no autograd add kernel per parameter and window
-            bgrad = None
-            if want_b:
-                b_leaf = ctx.b_ref
-                if b_leaf is not None and b_leaf.grad is not None and b_leaf.grad.is_contiguous():
-                    bgrad = b_leaf.grad
-            ops.gemm_tn(dz2, xin.reshape(M, Kp), out=w.grad.view(N, Kp), colsum_out=bgrad, accumulate=True)
-            if GRAD_WRITTEN is not None:
-                GRAD_WRITTEN(w)
-                if bgrad is not None:
-                    GRAD_WRITTEN(ctx.b_ref)
-            if want_b and bgrad is None:
-                db = ops.colsum(dz2)
-        elif ctx.needs_input_grad[1] and dtype == torch.bfloat16 and N % 8 == 0 and USE_GEMM_TN:
-            # dW = dZ^T X straight from the row-major operands (transposing LDS reads), bias gradient fused
-            x2 = xin.reshape(M, Kp)
-            if want_b:
-                dwe, db = ops.gemm_tn(dz2, x2, want_colsum=True)
-            else:
-                dwe = ops.gemm_tn(dz2, x2)
-            dw = dwe[:, :ctx.K].reshape(w.shape)
-        elif ctx.needs_input_grad[1]:
-            dzT = ops.transpose2d(dz2, 8)                      # (N, Mp)
-            # x^T with 8 extra rows: row Kp is all ones, so column Kp of the product is the bias gradient
-            # (dz^T . 1) for free inside the wgrad GEMM instead of a separate column-sum pass.
-            Mp = dzT.shape[1]
-            xT = torch.zeros(Kp + 8, Mp, device=xin.device, dtype=dtype)
-            ops.transpose(xin.reshape(M, Kp), xT, M, Kp, Kp, Mp)
-            xT[Kp, :M] = 1
-            dwe = ops.gemm(dzT, xT, out_dtype=torch.float32)   # (N, Kp + 8) fp32
-            dw = dwe[:, :ctx.K].reshape(w.shape)
-            if want_b:
-                db = dwe[:, Kp].contiguous()
-        elif want_b:
-            db = ops.colsum(dz2)
+        dw, db = _param_grads(dz2, xin, w, ctx.b_ref, ctx.has_b, ctx.K, ctx.needs_input_grad[1], ctx.needs_input_grad[2],
+                              ctx.alias)
         dres = dy if ctx.has_r and ctx.needs_input_grad[3] else None
         return dx, dw, db, dres, None, None, None, None
+
+
+class FFNFn(torch.autograd.Function):
+    """y = dropout_p2(W2 dropout_p1(act(W1 x + b1)) + b2) + residual as ONE autograd node: two GEMM launches forward (as two
+    LinearFn nodes would), and a backward whose middle -- linear2's data gradient, the first dropout's and the
+    activation's backward -- is ONE launch (msmd_gemm_actbwd) instead of a GEMM + an elementwise pass over the
+    (rows, d_ff) tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual, act, p1, site1, p2, site2):
+        dtype = x.dtype
+        w1c, _ = CACHE.get(w1, dtype)
+        w2c, _ = CACHE.get(w2, dtype)
+        xin = x.contiguous()
+        z1 = torch.empty(*xin.shape[:-1], w1.shape[0], device=x.device, dtype=dtype)
+        f = ops.gemm(xin, w1c, b1.detach().float().contiguous(), None, act, z_out=z1, p_drop=p1,
+                     rng_state=TrainNoise.state if p1 > 0 else None, site=site1)
+        res = residual.contiguous() if residual is not None else None
+        y = ops.gemm(f, w2c, b2.detach().float().contiguous(), res, ACT_NONE, p_drop=p2,
+                     rng_state=TrainNoise.state if p2 > 0 else None, site=site2)
+        ctx.save_for_backward(xin, z1, f, w1, w2)
+        ctx.cfg = (act, p1, site1, p2, site2, residual is not None)
+        ctx.refs = (b1 if b1.is_leaf else None, b2 if b2.is_leaf else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xin, z1, f, w1, w2 = ctx.saved_tensors
+        act, p1, site1, p2, site2, has_r = ctx.cfg
+        dtype = xin.dtype
+        dy = dy.contiguous()
+        dz2 = ops.dropout(dy, p2, TrainNoise.state, site2) if p2 > 0.0 else dy
+        M = xin.numel() // xin.shape[-1]
+        dz2 = dz2.reshape(M, w2.shape[0])
+        _, w1ct = CACHE.get(w1, dtype)
+        _, w2ct = CACHE.get(w2, dtype)
+        dw2, db2 = _param_grads(dz2, f, w2, ctx.refs[1], True, w2.shape[1], ctx.needs_input_grad[3], ctx.needs_input_grad[4], None)
+        # linear2's data gradient with dropout1's and the activation's backward in its epilogue
+        dz1 = ops.gemm_act_bwd(dz2, w2ct, z1.reshape(M, -1), act, p1, TrainNoise.state if p1 > 0 else None, site1)
+        dw1, db1 = _param_grads(dz1, xin, w1, ctx.refs[0], True, w1.shape[1], ctx.needs_input_grad[1], ctx.needs_input_grad[2], None)
+        dx = ops.gemm(dz1, w1ct).reshape(xin.shape) if ctx.needs_input_grad[0] else None
+        dres = dy if has_r and ctx.needs_input_grad[5] else None
+        return dx, dw1, db1, dw2, db2, dres, None, None, None, None, None
+
+
+def ffn(x, w1, b1, w2, b2, p_act, p_out, residual=None, act=ops.ACT_GELU):
+    """The transformer feed-forward block dropout(W2 dropout(act(W1 x))) + residual.  One fused node (FFNFn) when the shapes
+    allow the fused epilogues (16-bit, 8-aligned widths); else the two LinearFn nodes."""
+    ok = (x.dtype in (torch.bfloat16, torch.float16) and w1.shape[0] % 8 == 0 and w1.shape[1] % 8 == 0
+          and w2.shape[0] % 8 == 0 and b1 is not None and b2 is not None and USE_GEMM_TN)
+    if not ok:
+        return linear_dropout(linear_dropout(x, w1, b1, p_act, act=act), w2, b2, p_out, residual=residual)
+    if not TrainNoise.active:
+        p_act = p_out = 0.0
+    s1 = TrainNoise.next_site() if p_act > 0 else 0
+    s2 = TrainNoise.next_site() if p_out > 0 else 0
+    return FFNFn.apply(x, w1, b1, w2, b2, residual, act, float(p_act), s1, float(p_out), s2)
 
 
 class LayerNormFn(torch.autograd.Function):

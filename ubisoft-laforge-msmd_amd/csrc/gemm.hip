@@ -28,7 +28,8 @@ struct GemmArgs {
   // residual add; the keep mask is Philox(rng, site, (m * N + n) / 4), i.e. msmd_dropout's on a contiguous (M, N) C
   void* Z; float p_drop; const unsigned long* rng; unsigned site;
   int xn;  // XCDs along N (1, 2 or 4): the 8 XCDs form an (8 / xn) x xn grid over (M tiles, N tiles)
-  int flags;  // MSMD_GEMM_* bits 16.. of `act`, shifted down: 1 = write-through (sc1) output stores, 2 = paired 16-B stores
+  int flags;  // MSMD_GEMM_* bits 16.. of `act`, shifted down: 1 = write-through (sc1) output stores, 2 = paired 16-B stores;
+              // 8 (internal, msmd_gemm_actbwd) = Z is an INPUT: C = keep_mask / (1 - p) * act'(Z) * (A W^T), no bias / residual
   // LayerNorm folded into the GEMMs around it (msmd_gemm_ln; all NULL for plain calls):
   //   a_stats (a_nt, M, 2): A holds UN-normalised rows u, the partial (sum, sum of squares) of each row over 64-column
   //     slabs; W carries gamma folded in, w_colsum[n] = sum_k W'[n][k], bias carries beta . W:  y = rstd (acc - mu s[n]) + c[n]
@@ -138,9 +139,15 @@ __device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const 
     TO* crow = C + (long)j * 16 * p.ldc;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[i][e];
-    if (p.Z) store4_out<TO>((TO*)p.Z + (crow + i * 16 - (TO*)p.C), v, wt);
+    if (p.flags & 8) {    // the backward of y = dropout(act(z)) applied to this data gradient: z read where C goes
+      const V4 z4 = *(const V4*)((const TO*)p.Z + (crow + i * 16 - (TO*)p.C));
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = act_out<TO>(v[e], p.act);
+      for (int e = 0; e < 4; ++e) v[e] *= act_grad_fast((float)z4[e], p.act);
+    } else {
+      if (p.Z) store4_out<TO>((TO*)p.Z + (crow + i * 16 - (TO*)p.C), v, wt);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = act_out<TO>(v[e], p.act);
+    }
     if (p.p_drop > 0.f) {
       const long idx = (long)(m_base + j * 16 + fr) * p.N + (n_base + i * 16 + fq * 4);
       const Philox4 rb = dropout_bits(p.rng, p.site, (unsigned long)(idx >> 2));
@@ -223,14 +230,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[e];
       TO* cp = C + (long)m * p.ldc + n;
-      if (p.Z) {
-        TO* zp = (TO*)p.Z + (cp - (TO*)p.C);
+      if (p.flags & 8) {
+        const TO* zp = (const TO*)p.Z + (cp - (TO*)p.C);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (n + e < p.N) zp[e] = (TO)v[e];
-      }
+          if (n + e < p.N) v[e] *= act_grad_fast((float)zp[e], p.act);
+      } else {
+        if (p.Z) {
+          TO* zp = (TO*)p.Z + (cp - (TO*)p.C);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = act_out<TO>(v[e], p.act);
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) zp[e] = (TO)v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_out<TO>(v[e], p.act);
+      }
       if (p.p_drop > 0.f) {   // launcher guarantees N % 4 == 0 and ldc == N here
         const Philox4 rb = dropout_bits(p.rng, p.site, (unsigned long)(((long)m * p.N + n) >> 2));
         const unsigned thr = dropout_threshold(p.p_drop);
@@ -991,10 +1005,11 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
                      int in_dtype, int out_dtype, long lda, int rows_per_batch, long a_batch_stride, long ldw, long ldc,
                      long ldr, int act, int batch, long strideA, long strideW, long strideC, long strideBias,
                      long strideR, int batch_inner, long strideA2, long strideW2, long strideC2, msmd_stream_t stream,
-                     void* z_out = nullptr, float p_drop = 0.f, const unsigned long* rng = nullptr, unsigned site = 0) {
+                     void* z_out = nullptr, float p_drop = 0.f, const unsigned long* rng = nullptr, unsigned site = 0,
+                     int internal_flags = 0) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch_inner <= 0 || !A || !W || !C) return 1;
   const int hint = (act >> 8) & 0xff;  // caller-chosen kernel variant (host-side autotune), 0 = heuristic below
-  const int flags = (act >> 16) & 0xff;  // MSMD_GEMM_WRITE_THROUGH / MSMD_GEMM_PAIRED_STORES (include/msmd_hip.h)
+  const int flags = ((act >> 16) & 0x7) | internal_flags;  // MSMD_GEMM_WRITE_THROUGH / MSMD_GEMM_PAIRED_STORES (include/msmd_hip.h)
   act &= 0xff;
   if (in_dtype == MSMD_F16X2) {
     // split-pair operands: logical sizes in, fp16 strides (x 2) into the kernel; 32-element blocks must stay whole
@@ -1153,6 +1168,17 @@ extern "C" int msmd_gemm_ex(const void* A, const void* W, const float* bias, con
   return gemm_impl(A, W, bias, residual, C, M, N, K, in_dtype, out_dtype, lda, rows_per_batch, a_batch_stride, ldw, ldc,
                    ldr, act, batch, strideA, strideW, strideC, strideBias, strideR, 1, 0, 0, 0, stream, z_out, p_drop,
                    rng_state, site);
+}
+
+// dZ = keep_mask / (1 - p) * act'(Z) * (A . W^T): the data gradient of a Linear whose INPUT was dropout(act(Z)) -- the product
+// and the backward of the activation + dropout in one launch (A = the upstream gradient, W = the transposed weight cast,
+// Z = the forward's pre-activation, C and Z contiguous (M, N)).  Replaces msmd_gemm + msmd_act_bwd_dropout / msmd_act_bwd.
+extern "C" int msmd_gemm_actbwd(const void* A, const void* W, const void* Z, void* C, int M, int N, int K, int in_dtype,
+                                int out_dtype, long lda, long ldw, int act, float p_drop, const unsigned long* rng_state,
+                                unsigned int site, msmd_stream_t stream) {
+  if (!Z || in_dtype != out_dtype || (in_dtype != MSMD_BF16 && in_dtype != MSMD_F16) || (N & 3) || ((uintptr_t)Z & 7)) return 1;
+  return gemm_impl(A, W, nullptr, nullptr, C, M, N, K, in_dtype, out_dtype, lda, 0, 0, ldw, N, 0, act & 0x3ffff, 1, 0, 0, 0, 0,
+                   0, 1, 0, 0, 0, stream, const_cast<void*>(Z), p_drop, rng_state, site, 8);
 }
 
 extern "C" int msmd_gemm_batched2(const void* A, const void* W, void* C, int M, int N, int K, int in_dtype,

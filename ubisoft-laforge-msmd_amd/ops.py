@@ -337,6 +337,31 @@ def fold_layernorm(w, b, gamma, beta, dtype):
     return wf, cs, bf
 
 
+def gemm_act_bwd(dy, wt, z, act, p_drop=0.0, rng_state=None, site=0):
+    """dz = keep_mask / (1 - p) * act'(z) * (dy @ wt^T): msmd_gemm_actbwd (the data gradient of the Linear AFTER an
+    activation + dropout, with their backward in its epilogue).  dy (..., K) 16-bit, wt (N, K) = the transposed weight
+    cast, z (..., N) the forward's pre-activation."""
+    _need_cuda(dy, wt, z)
+    K = dy.shape[-1]
+    M = dy.numel() // K
+    N = wt.shape[0]
+    if z.numel() != M * N or not z.is_contiguous() or not dy.is_contiguous():
+        raise ValueError("gemm_act_bwd: z must be the contiguous (M, N) pre-activation")
+    out = torch.empty_like(z)
+    if GEMM_FLOPS is not None:
+        GEMM_FLOPS[0] += 2.0 * M * N * K
+    if GEMM_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.load().msmd_gemm_actbwd(_p(dy), _p(wt), _p(z), _p(out), M, N, K, _dt(dy), _dt(out), K, wt.stride(0),
+                                            act | (_GEMM_DEFAULT["flags"] & GEMM_PAIRED_STORES), float(p_drop), _p(rng_state),
+                                            int(site), _stream()), "msmd_gemm_actbwd")
+    if GEMM_TRACE is not None:
+        e1.record()
+        GEMM_TRACE.append((M, N, K, 1, _dt(dy), e0, e1))
+    return out
+
+
 def exp_set_tuning(key, value):
     """Developer builds only (make -C csrc EXP=1; MSMD_LIB=.../libmsmd_hip_exp.so): msmd_exp_set_tuning(key, value).
     The product library has no such switch -- use the per-call `variant` / `flags` / `splits` arguments."""

@@ -194,21 +194,19 @@ def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
                                   p_drop=c.attention_dropout, prefetch=pf)
             h = ag.linear_dropout(a, g(p + "attention.out_proj.weight"), g(p + "attention.out_proj.bias"),
                                   c.hidden_dropout, residual=h)
-            f = ag.linear_dropout(ag.layer_norm(h, *ln2), g(p + "feed_forward.intermediate_dense.weight"),
-                                  g(p + "feed_forward.intermediate_dense.bias"), c.activation_dropout,
-                                  act=ops.ACT_GELU)
-            h = ag.linear_dropout(f, g(p + "feed_forward.output_dense.weight"),
-                                  g(p + "feed_forward.output_dense.bias"), c.hidden_dropout, residual=h)
+            h = ag.ffn(ag.layer_norm(h, *ln2), g(p + "feed_forward.intermediate_dense.weight"),
+                       g(p + "feed_forward.intermediate_dense.bias"), g(p + "feed_forward.output_dense.weight"),
+                       g(p + "feed_forward.output_dense.bias"), c.activation_dropout, c.hidden_dropout, residual=h)
         else:
             a = ag.self_attention(qkv_proj(h), H, (d // H) ** -0.5, p_drop=c.attention_dropout, prefetch=pf)
             h = ag.layer_norm(ag.linear_dropout(a, g(p + "attention.out_proj.weight"),
                                                 g(p + "attention.out_proj.bias"), c.hidden_dropout, residual=h), *ln1)
-            f = ag.linear_dropout(h, g(p + "feed_forward.intermediate_dense.weight"),
-                                  g(p + "feed_forward.intermediate_dense.bias"), c.activation_dropout,
-                                  act=ops.ACT_GELU)
-            h = ag.layer_norm(ag.linear_dropout(f, g(p + "feed_forward.output_dense.weight"),
-                                                g(p + "feed_forward.output_dense.bias"), c.hidden_dropout,
-                                                residual=h), *ln2)
+            # feed-forward block as one autograd node: its backward's middle (linear2's data gradient + dropout + GELU
+            # backward) is one launch
+            h = ag.layer_norm(ag.ffn(h, g(p + "feed_forward.intermediate_dense.weight"),
+                                     g(p + "feed_forward.intermediate_dense.bias"),
+                                     g(p + "feed_forward.output_dense.weight"), g(p + "feed_forward.output_dense.bias"),
+                                     c.activation_dropout, c.hidden_dropout, residual=h), *ln2)
         if skip_flag is not None:
             h = torch.where(skip_flag, h_in, h)
     if stable:
@@ -359,8 +357,8 @@ def denoiser_train(net, motion_noisy, audio_feat, person_feat, static_style_feat
         x = ag.layer_norm(ag.linear_dropout(cattn, g(p + "multihead_attn.out_proj.weight"),
                                             g(p + "multihead_attn.out_proj.bias"), pd, residual=x),
                           g(p + "norm2.weight"), g(p + "norm2.bias"))
-        f = ag.linear_dropout(x, g(p + "linear1.weight"), g(p + "linear1.bias"), pd, act=ops.ACT_GELU)
-        x = ag.layer_norm(ag.linear_dropout(f, g(p + "linear2.weight"), g(p + "linear2.bias"), pd, residual=x),
+        x = ag.layer_norm(ag.ffn(x, g(p + "linear1.weight"), g(p + "linear1.bias"), g(p + "linear2.weight"),
+                                 g(p + "linear2.bias"), pd, pd, residual=x),
                           g(p + "norm3.weight"), g(p + "norm3.bias"))
     dec = ag.linear(ag.linear(x[:, 1:].contiguous(), g("motion_dec.0.weight"), g("motion_dec.0.bias"),
                               act=ops.ACT_GELU), g("motion_dec.2.weight"), g("motion_dec.2.bias")).float()
