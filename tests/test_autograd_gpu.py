@@ -335,3 +335,14 @@ def test_ffn_node_matches_two_linear_nodes_and_gemm_actbwd_matches_the_unfused_p
         assert torch.equal(a[5], b[5]) and torch.equal(a[6], b[6])          # dW2, db2 do not pass through the fused launch
     # dropout really on in the active pass
     assert not torch.equal(outs[True, False][0], outs[True, True][0])
+    # x + FFN(x) (residual is the input itself): one gradient for x, equal to the sum autograd forms from the two-node form
+    ag.TrainNoise.active, ag.TrainNoise.site = True, 0
+    xa = x0.clone().requires_grad_(True)
+    ag.ffn(xa, w1, b1, w2, b2, 0.1, 0.2, residual=xa).backward(dy)
+    ag.TrainNoise.site = 0
+    xb = x0.clone().requires_grad_(True)
+    ag.linear_dropout(ag.linear_dropout(xb, w1, b1, 0.1, act=ops.ACT_GELU), w2, b2, 0.2, residual=xb).backward(dy)
+    ag.TrainNoise.active = False
+    torch.cuda.synchronize()
+    d = (xa.grad.float() - xb.grad.float()).abs().max()
+    assert float(d) <= 1.5e-2 * float(xb.grad.float().abs().max())

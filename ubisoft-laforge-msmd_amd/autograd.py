@@ -280,7 +280,10 @@ class FFNFn(torch.autograd.Function):
     (rows, d_ff) tensor."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, residual, act, p1, site1, p2, site2):
+    def forward(ctx, x, w1, b1, w2, b2, residual, act, p1, site1, p2, site2, residual_is_x=False):
+        """residual_is_x: the block is x + FFN(x) (post-LN layers): x itself is the residual operand, and the backward
+        returns ONE gradient for x -- the upstream gradient rides into linear1's data-gradient GEMM as its residual instead
+        of an autograd accumulation kernel."""
         dtype = x.dtype
         w1c, _ = CACHE.get(w1, dtype)
         w2c, _ = CACHE.get(w2, dtype)
@@ -288,18 +291,18 @@ class FFNFn(torch.autograd.Function):
         z1 = torch.empty(*xin.shape[:-1], w1.shape[0], device=x.device, dtype=dtype)
         f = ops.gemm(xin, w1c, b1.detach().float().contiguous(), None, act, z_out=z1, p_drop=p1,
                      rng_state=TrainNoise.state if p1 > 0 else None, site=site1)
-        res = residual.contiguous() if residual is not None else None
+        res = xin if residual_is_x else (residual.contiguous() if residual is not None else None)
         y = ops.gemm(f, w2c, b2.detach().float().contiguous(), res, ACT_NONE, p_drop=p2,
                      rng_state=TrainNoise.state if p2 > 0 else None, site=site2)
         ctx.save_for_backward(xin, z1, f, w1, w2)
-        ctx.cfg = (act, p1, site1, p2, site2, residual is not None)
+        ctx.cfg = (act, p1, site1, p2, site2, residual is not None, residual_is_x)
         ctx.refs = (b1 if b1.is_leaf else None, b2 if b2.is_leaf else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         xin, z1, f, w1, w2 = ctx.saved_tensors
-        act, p1, site1, p2, site2, has_r = ctx.cfg
+        act, p1, site1, p2, site2, has_r, res_is_x = ctx.cfg
         dtype = xin.dtype
         dy = dy.contiguous()
         dz2 = ops.dropout(dy, p2, TrainNoise.state, site2) if p2 > 0.0 else dy
@@ -311,9 +314,11 @@ class FFNFn(torch.autograd.Function):
         # linear2's data gradient with dropout1's and the activation's backward in its epilogue
         dz1 = ops.gemm_act_bwd(dz2, w2ct, z1.reshape(M, -1), act, p1, TrainNoise.state if p1 > 0 else None, site1)
         dw1, db1 = _param_grads(dz1, xin, w1, ctx.refs[0], True, w1.shape[1], ctx.needs_input_grad[1], ctx.needs_input_grad[2], None)
-        dx = ops.gemm(dz1, w1ct).reshape(xin.shape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dz1, w1ct, residual=dy.reshape(M, -1) if res_is_x else None).reshape(xin.shape)
         dres = dy if has_r and ctx.needs_input_grad[5] else None
-        return dx, dw1, db1, dw2, db2, dres, None, None, None, None, None
+        return dx, dw1, db1, dw2, db2, dres, None, None, None, None, None, None
 
 
 def ffn(x, w1, b1, w2, b2, p_act, p_out, residual=None, act=ops.ACT_GELU):
@@ -327,6 +332,8 @@ def ffn(x, w1, b1, w2, b2, p_act, p_out, residual=None, act=ops.ACT_GELU):
         p_act = p_out = 0.0
     s1 = TrainNoise.next_site() if p_act > 0 else 0
     s2 = TrainNoise.next_site() if p_out > 0 else 0
+    if residual is x:       # x + FFN(x): one gradient for x out of the node (the sum is made in a GEMM epilogue)
+        return FFNFn.apply(x, w1, b1, w2, b2, None, act, float(p_act), s1, float(p_out), s2, True)
     return FFNFn.apply(x, w1, b1, w2, b2, residual, act, float(p_act), s1, float(p_out), s2)
 
 
