@@ -112,7 +112,8 @@ def test_layernorm(dtype):
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,H,Tq,Tk,masked", [(2, 12, 200, 200, False), (3, 8, 111, 110, True), (1, 8, 111, 111, False),
-                                              (1, 2, 500, 500, False), (2, 8, 100, 100, False)])
+                                              (1, 2, 500, 500, False), (2, 8, 100, 100, False), (2, 8, 261, 261, False),
+                                              (2, 8, 261, 260, True), (1, 4, 300, 209, False)])
 def test_attention(dtype, B, H, Tq, Tk, masked):
     o = ops()
     d = H * 64
@@ -122,7 +123,7 @@ def test_attention(dtype, B, H, Tq, Tk, masked):
     td = torch.float32
     if dtype == "bf16":
         q, k, v, td = bf16_round(q), bf16_round(k), bf16_round(v), torch.bfloat16
-    mask = od.alignment_mask(10, 100, 1) if masked else None
+    mask = od.alignment_mask(10, Tk - 10, 1) if masked else None      # (1 + 10 + L) x (10 + L)
     qh = q.reshape(B, Tq, H, 64).transpose(0, 2, 1, 3)
     kh = k.reshape(B, Tk, H, 64).transpose(0, 2, 1, 3)
     vh = v.reshape(B, Tk, H, 64).transpose(0, 2, 1, 3)

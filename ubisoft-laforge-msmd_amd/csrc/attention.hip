@@ -287,14 +287,17 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const AttnArgs p) {
 // the loop over key tiles with its two barriers per tile is gone.  Same operand layouts, same MFMA order per output as
 // attn_kernel -- but exp2 arguments are taken against the global row maximum instead of the running one, so results
 // differ from attn_kernel in the last bit of a few probabilities (both within the 16-bit modes' tolerance).
-constexpr int ATTN_WHOLE_NF = 13;   // key fragments of 16: Tk <= 208
+constexpr int ATTN_WHOLE_NF = 13;   // key fragments of 16 of the default instantiation: Tk <= 208 (52 KB: three workgroups per CU)
+// NF = 17 (Tk <= 272: the decoder at n_motions = 250; 68 KB, two workgroups per CU) takes the same kernel: 25 us against 39 for the
+// tiled kernel.  NF = 32 (Tk <= 512: HuBERT-large's 10 s clips; 128 KB, ONE workgroup per CU, 152 registers) was built and
+// measured: 118 us against the tiled kernel's 85 -- not kept.
 
-template <typename T, int NW>
+template <typename T, int NW, int NF = ATTN_WHOLE_NF>
 __global__ __launch_bounds__(64 * NW) void attn_whole_kernel(const AttnArgs p) {
   static_assert(sizeof(T) == 2, "16-bit storage modes");
-  constexpr int NF = ATTN_WHOLE_NF, ROWS = 16 * NF, NT = 64 * NW;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * ROWS * 128];           // K, V images
-  __shared__ __attribute__((aligned(16))) unsigned char pf_sink[1024];                  // prefetch sink: an object of its own (no alias with the images)
+  constexpr int ROWS = 16 * NF, NT = 64 * NW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                   // K, V images (2 x ROWS x 128 B) + 1 KB prefetch sink
+  unsigned char* pf_sink = smem + 2 * ROWS * 128;
   unsigned char* sK = smem;
   unsigned char* sV = smem + ROWS * 128;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(64 * NW) void attn_whole_kernel(const AttnArgs p) {
   asm volatile("" ::"v"(qf[0]), "v"(qf[1]));
   if (p.pf_bytes[0] > 0) {
     typedef __attribute__((address_space(3))) void lds_sink_t;
-    const unsigned sink_lds = (unsigned)(uintptr_t)(lds_sink_t*)pf_sink;     // LDS byte address of the sink (M0 for the DMA)
+    const unsigned sink_lds = (unsigned)(uintptr_t)(lds_sink_t*)smem + 2 * ROWS * 128;   // LDS byte address of the sink (M0 for the DMA)
     unsigned m0_keep;                                                         // M0 is restored around every DMA
     const long stride = (long)gridDim.x * gridDim.y * gridDim.z * NT * 16;
     const long wave0 = ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NT + (tid & ~63)) * 16;
@@ -688,19 +691,30 @@ static int attention_impl(const void* Q, const void* K, const void* V, void* O, 
     if (pf_ptrs[i] && pf_bytes[i] >= 16 && ((uintptr_t)pf_ptrs[i] & 15) == 0) { p.pf_ptr[j] = pf_ptrs[i]; p.pf_bytes[j] = pf_bytes[i]; ++j; }
   int nw = attn_waves(Tq, H, B);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype != MSMD_F32 && p_drop == 0.f && Tk <= 16 * ATTN_WHOLE_NF) {
+  if (dtype != MSMD_F32 && p_drop == 0.f && Tk <= 272) {
     // short sequences: all keys staged once, plain softmax (attn_whole_kernel).  One workgroup per (batch, head) when the
     // queries fit (K / V read once): in the forward step T = 200 runs 16.4 us with 13 waves against 17.5 with 7 (two
     // workgroups per head) and 19.8 for attn_kernel; T = 111 6.6 us with 7 waves against 7.8.
-    nw = Tq <= 112 ? 7 : 13;
-    dim3 grid((Tq + 16 * nw - 1) / (16 * nw), H, B), block(64 * nw);
-    if (dtype == MSMD_BF16) {
-      if (nw == 7) hipLaunchKernelGGL((attn_whole_kernel<bf16_t, 7>), grid, block, 0, st, p);
-      else hipLaunchKernelGGL((attn_whole_kernel<bf16_t, 13>), grid, block, 0, st, p);
-    } else {
-      if (nw == 7) hipLaunchKernelGGL((attn_whole_kernel<f16_t, 7>), grid, block, 0, st, p);
-      else hipLaunchKernelGGL((attn_whole_kernel<f16_t, 13>), grid, block, 0, st, p);
-    }
+#define MSMD_ATTN_W(T, NWV, NFV)                                                                                     \
+  do {                                                                                                               \
+    constexpr int lds_ = 2 * 16 * NFV * 128 + 1024;                                                                  \
+    static bool attr_ = false;                                                                                       \
+    auto k_ = attn_whole_kernel<T, NWV, NFV>;                                                                         \
+    if (!attr_) { (void)hipFuncSetAttribute((const void*)k_, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); attr_ = true; } \
+    dim3 grid_((Tq + 16 * NWV - 1) / (16 * NWV), H, B);                                                               \
+    hipLaunchKernelGGL(k_, grid_, dim3(64 * NWV), lds_, st, p);                                                       \
+  } while (0)
+#define MSMD_ATTN_WT(T)                                                                  \
+  do {                                                                                   \
+    if (Tk <= 16 * ATTN_WHOLE_NF) {                                                      \
+      if (Tq <= 112) MSMD_ATTN_W(T, 7, ATTN_WHOLE_NF);                                   \
+      else MSMD_ATTN_W(T, 13, ATTN_WHOLE_NF);                                            \
+    } else MSMD_ATTN_W(T, 9, 17);                                                        \
+  } while (0)
+    if (dtype == MSMD_BF16) MSMD_ATTN_WT(bf16_t);
+    else MSMD_ATTN_WT(f16_t);
+#undef MSMD_ATTN_WT
+#undef MSMD_ATTN_W
     MSMD_RETURN_LAST();
   }
   dim3 grid((Tq + 16 * nw - 1) / (16 * nw), H, B), block(64 * nw);
