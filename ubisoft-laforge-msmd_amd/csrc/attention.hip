@@ -296,10 +296,10 @@ template <typename T, int NW, int NF = ATTN_WHOLE_NF>
 __global__ __launch_bounds__(64 * NW) void attn_whole_kernel(const AttnArgs p) {
   static_assert(sizeof(T) == 2, "16-bit storage modes");
   constexpr int ROWS = 16 * NF, NT = 64 * NW;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                   // K, V images (2 x ROWS x 128 B) + 1 KB prefetch sink
-  unsigned char* pf_sink = smem + 2 * ROWS * 128;
+  // K, V images of `rows` rows each (the launcher sizes the allocation by Tk, not by NF: T = 111 takes 29 KB and four
+  // workgroups share a CU where the full 208-row images allowed three) + 1 KB prefetch sink
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
-  unsigned char* sV = smem + ROWS * 128;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -310,6 +310,7 @@ __global__ __launch_bounds__(64 * NW) void attn_whole_kernel(const AttnArgs p) {
   const T* Vb = (const T*)p.V + (long)b * p.vb + h * 64;
   const int nf = (p.Tk + 15) >> 4;            // fragments that hold keys
   const int rows = min(((nf + 1) & ~1) * 16, ROWS);   // staged rows: whole fragment PAIRS (the PV product takes 32 keys), zero-filled
+  unsigned char* sV = smem + rows * 128;
 
   // every load of the kernel goes out here: K, V chunks (16 B), then this lane's Q fragments
   constexpr int NPF = (ROWS * 8 + NT - 1) / NT;
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(64 * NW) void attn_whole_kernel(const AttnArgs p) {
   asm volatile("" ::"v"(qf[0]), "v"(qf[1]));
   if (p.pf_bytes[0] > 0) {
     typedef __attribute__((address_space(3))) void lds_sink_t;
-    const unsigned sink_lds = (unsigned)(uintptr_t)(lds_sink_t*)smem + 2 * ROWS * 128;   // LDS byte address of the sink (M0 for the DMA)
+    const unsigned sink_lds = (unsigned)(uintptr_t)(lds_sink_t*)smem + 2 * rows * 128;   // LDS byte address of the sink (M0 for the DMA)
     unsigned m0_keep;                                                         // M0 is restored around every DMA
     const long stride = (long)gridDim.x * gridDim.y * gridDim.z * NT * 16;
     const long wave0 = ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NT + (tid & ~63)) * 16;
@@ -697,10 +698,12 @@ static int attention_impl(const void* Q, const void* K, const void* V, void* O, 
     // workgroups per head) and 19.8 for attn_kernel; T = 111 6.6 us with 7 waves against 7.8.
 #define MSMD_ATTN_W(T, NWV, NFV)                                                                                     \
   do {                                                                                                               \
-    constexpr int lds_ = 2 * 16 * NFV * 128 + 1024;                                                                  \
+    constexpr int lds_max_ = 2 * 16 * NFV * 128 + 1024;                                                              \
+    const int rows_ = std::min((((Tk + 15) / 16 + 1) & ~1) * 16, 16 * NFV);                                           \
+    const int lds_ = 2 * rows_ * 128 + 1024;                                                                         \
     static bool attr_ = false;                                                                                       \
     auto k_ = attn_whole_kernel<T, NWV, NFV>;                                                                         \
-    if (!attr_) { (void)hipFuncSetAttribute((const void*)k_, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); attr_ = true; } \
+    if (!attr_) { (void)hipFuncSetAttribute((const void*)k_, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max_); attr_ = true; } \
     dim3 grid_((Tq + 16 * NWV - 1) / (16 * NWV), H, B);                                                               \
     hipLaunchKernelGGL(k_, grid_, dim3(64 * NWV), lds_, st, p);                                                       \
   } while (0)
