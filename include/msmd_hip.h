@@ -204,12 +204,7 @@ int msmd_attention_f16x2(const void* Q, const void* K, const void* V, void* O, i
                          long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
                          long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
                          int out_dtype, msmd_stream_t stream);
-/* msmd_attention_f16x2 with msmd_attention_prefetch's byte ranges (the split-storage weights of the GEMMs that follow). */
-int msmd_attention_f16x2_prefetch(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
-                                  long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
-                                  long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
-                                  int out_dtype, const void* const* prefetch_ptrs, const long* prefetch_bytes,
-                                  int n_prefetch, msmd_stream_t stream);
+
 
 /* Person-token cross-attention query, projection + Tq = 1 attention fused (one wave per sequence and head):
  *   out[n, h*64:(h+1)*64] = softmax(scale * (x[n] Wq_h^T + bq_h) K_h[n]^T) V_h[n]     (no mask, head_dim 64, Tk <= 512)

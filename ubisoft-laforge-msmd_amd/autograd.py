@@ -325,7 +325,7 @@ def ffn(x, w1, b1, w2, b2, p_act, p_out, residual=None, act=ops.ACT_GELU):
     """The transformer feed-forward block dropout(W2 dropout(act(W1 x))) + residual.  One fused node (FFNFn) when the shapes
     allow the fused epilogues (16-bit, 8-aligned widths); else the two LinearFn nodes."""
     ok = (x.dtype in (torch.bfloat16, torch.float16) and w1.shape[0] % 8 == 0 and w1.shape[1] % 8 == 0
-          and w2.shape[0] % 8 == 0 and b1 is not None and b2 is not None and USE_GEMM_TN)
+          and w2.shape[0] % 64 == 0 and b1 is not None and b2 is not None and USE_GEMM_TN)
     if not ok:
         return linear_dropout(linear_dropout(x, w1, b1, p_act, act=act), w2, b2, p_out, residual=residual)
     if not TrainNoise.active:

@@ -471,7 +471,7 @@ __device__ __forceinline__ int vsw(int row) { return ((row & 3) << 2) | ((row >>
 
 template <typename TO, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_split_kernel(const AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 64 * 256 + 1024];   // K, V tiles + 1 KB prefetch sink
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 64 * 256];
   unsigned char* sK = smem;
   unsigned char* sV = smem + 64 * 256;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -511,21 +511,6 @@ __global__ __launch_bounds__(64 * NW) void attn_split_kernel(const AttnArgs p) {
     }
   };
   prefetch(0);
-  // msmd_attention_f16x2_prefetch: the layer's remaining (split-storage) weights pulled through the memory-side cache by
-  // this launch, as in attn_whole_kernel: LDS-DMA loads into a sink nobody reads, issued next to the first K / V tile's loads
-  if (p.pf_bytes[0] > 0) {
-    typedef __attribute__((address_space(3))) void lds_sink_t;
-    typedef __attribute__((address_space(1))) const void gbl_src_t;
-    const long stride = (long)gridDim.x * gridDim.y * gridDim.z * NT * 16;
-    const long wave0 = ((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NT + (tid & ~63)) * 16;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const char* base = (const char*)p.pf_ptr[r];
-      const long nb = p.pf_bytes[r] & ~1023L;
-      for (long off = wave0; off < nb; off += stride)
-        __builtin_amdgcn_global_load_lds((gbl_src_t*)(base + off + lane * 16), (lds_sink_t*)(smem + 2 * 64 * 256), 16, 0, 0);
-    }
-  }
   for (int kv0 = 0; kv0 < p.Tk; kv0 += 64) {
     __syncthreads();
 #pragma unroll
@@ -781,11 +766,10 @@ extern "C" int msmd_attention_dropout_prefetch(const void* Q, const void* K, con
 
 // Split-pair attention (inference): Q / K / V in MSMD_F16X2 storage, O in fp32 (out_dtype MSMD_F32) or split storage.
 // Strides in logical elements, multiples of 32.
-static int attention_f16x2_impl(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
-                                long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
-                                long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
-                                int out_dtype, msmd_stream_t stream, const void* const* pf_ptrs, const long* pf_bytes,
-                                int n_pf) {
+extern "C" int msmd_attention_f16x2(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
+                                    long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
+                                    long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
+                                    int out_dtype, msmd_stream_t stream) {
   if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || !Q || !K || !V || !O) return 1;
   if (out_dtype != MSMD_F32 && out_dtype != MSMD_F16X2) return 1;
   if (q_tstride % 32 || k_tstride % 32 || v_tstride % 32 || q_bstride % 32 || k_bstride % 32 || v_bstride % 32) return 1;
@@ -793,9 +777,6 @@ static int attention_f16x2_impl(const void* Q, const void* K, const void* V, voi
   if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)V & 15) || ((uintptr_t)O & 15)) return 1;
   AttnArgs p{Q, K, V, O, B, H, Tq, Tk, q_bstride, q_tstride, k_bstride, k_tstride, v_bstride, v_tstride,
              o_bstride, o_tstride, scale, mask, 0.f, nullptr, 0u};
-  if (n_pf < 0 || n_pf > 4 || (n_pf > 0 && (!pf_ptrs || !pf_bytes))) return 1;
-  for (int i = 0, j = 0; i < n_pf; ++i)
-    if (pf_ptrs[i] && pf_bytes[i] >= 16 && ((uintptr_t)pf_ptrs[i] & 15) == 0) { p.pf_ptr[j] = pf_ptrs[i]; p.pf_bytes[j] = pf_bytes[i]; ++j; }
   const int nw = attn_waves(Tq, H, B);
   dim3 grid((Tq + 16 * nw - 1) / (16 * nw), H, B), block(64 * nw);
   hipStream_t st = (hipStream_t)stream;
@@ -812,22 +793,7 @@ static int attention_f16x2_impl(const void* Q, const void* K, const void* V, voi
   MSMD_RETURN_LAST();
 }
 
-extern "C" int msmd_attention_f16x2(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
-                                    long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
-                                    long v_tstride, long o_bstride, long o_tstride, float scale, const uint8_t* mask,
-                                    int out_dtype, msmd_stream_t stream) {
-  return attention_f16x2_impl(Q, K, V, O, B, H, Tq, Tk, q_bstride, q_tstride, k_bstride, k_tstride, v_bstride, v_tstride,
-                              o_bstride, o_tstride, scale, mask, out_dtype, stream, nullptr, nullptr, 0);
-}
 
-extern "C" int msmd_attention_f16x2_prefetch(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq,
-                                             int Tk, long q_bstride, long q_tstride, long k_bstride, long k_tstride,
-                                             long v_bstride, long v_tstride, long o_bstride, long o_tstride, float scale,
-                                             const uint8_t* mask, int out_dtype, const void* const* prefetch_ptrs,
-                                             const long* prefetch_bytes, int n_prefetch, msmd_stream_t stream) {
-  return attention_f16x2_impl(Q, K, V, O, B, H, Tq, Tk, q_bstride, q_tstride, k_bstride, k_tstride, v_bstride, v_tstride,
-                              o_bstride, o_tstride, scale, mask, out_dtype, stream, prefetch_ptrs, prefetch_bytes, n_prefetch);
-}
 
 // ---------------------------------------------------------------------------------------------------
 // Person-token cross-attention query (sampler fast path, diagonal alignment mask): row 0 of every sequence is the only

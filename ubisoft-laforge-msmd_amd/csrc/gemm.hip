@@ -108,7 +108,9 @@ template <typename TO> __device__ __forceinline__ void store4_out(TO* p, const f
 }
 
 // Interior tiles (fully inside M x N, vector-aligned): straight-line code, no per-element bounds checks.
-template <typename TO, int FM, int FN>
+// AB: the kernel also serves msmd_gemm_actbwd (flags bit 3).  Only the LDS-DMA 16-bit kernels carry that code: in the v1 /
+// fp32 kernels it cost 272 bytes of scratch (fp32 mode 23.8 -> 34 ms).
+template <typename TO, int FM, int FN, bool AB = false>
 __device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int z, int m_base,
                                                        int n_base, int fr, int fq) {
   TO* __restrict__ C = (TO*)p.C + (z / p.batch_inner) * p.strideC + (z % p.batch_inner) * p.strideC2 +
@@ -139,7 +141,7 @@ __device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const 
     TO* crow = C + (long)j * 16 * p.ldc;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[i][e];
-    if (p.flags & 8) {    // the backward of y = dropout(act(z)) applied to this data gradient: z read where C goes
+    if (AB && (p.flags & 8)) {    // the backward of y = dropout(act(z)) applied to this data gradient: z read where C goes
       const V4 z4 = *(const V4*)((const TO*)p.Z + (crow + i * 16 - (TO*)p.C));
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= act_grad_fast((float)z4[e], p.act);
@@ -203,11 +205,11 @@ __device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const 
   }
 }
 
-template <typename TO, int FM, int FN>
+template <typename TO, int FM, int FN, bool AB = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int z, int m_base,
                                               int n_base, int fr, int fq) {
   if (p.vec_ok && m_base + FM * 16 <= p.M && n_base + FN * 16 <= p.N) {
-    gemm_epilogue_interior<TO, FM, FN>(p, acc, z, m_base, n_base, fr, fq);
+    gemm_epilogue_interior<TO, FM, FN, AB>(p, acc, z, m_base, n_base, fr, fq);
     return;
   }
   TO* __restrict__ C = (TO*)p.C + (z / p.batch_inner) * p.strideC + (z % p.batch_inner) * p.strideC2;
@@ -230,7 +232,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[e];
       TO* cp = C + (long)m * p.ldc + n;
-      if (p.flags & 8) {
+      if (AB && (p.flags & 8)) {
         const TO* zp = (const TO*)p.Z + (cp - (TO*)p.C);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(WM * WN * 64, STAG ? 4 : 1) void gemm2_kernel(const
       stage ^= 1;
     }
     if (late) multiply();
-    gemm_epilogue<TO, FM, FN>(p, acc, z, m0 + wm, n0 + wn, fr, fq);
+    gemm_epilogue<TO, FM, FN, sizeof(TO) == 2>(p, acc, z, m0 + wm, n0 + wn, fr, fq);
     return;
   }
   for (int kt = 0; kt < nk; ++kt) {
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(WM * WN * 64, STAG ? 4 : 1) void gemm2_kernel(const
     if (p.a_stats) { gemm_epilogue_ln<TO, FM, FN, 1>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
     if (p.r_stats || p.stats_out) { gemm_epilogue_ln<TO, FM, FN, 2>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
   }
-  gemm_epilogue<TO, FM, FN>(p, acc, z, m0 + wm, n0 + wn, fr, fq);
+  gemm_epilogue<TO, FM, FN, sizeof(TO) == 2>(p, acc, z, m0 + wm, n0 + wn, fr, fq);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1177,6 +1179,7 @@ extern "C" int msmd_gemm_actbwd(const void* A, const void* W, const void* Z, voi
                                 int out_dtype, long lda, long ldw, int act, float p_drop, const unsigned long* rng_state,
                                 unsigned int site, msmd_stream_t stream) {
   if (!Z || in_dtype != out_dtype || (in_dtype != MSMD_BF16 && in_dtype != MSMD_F16) || (N & 3) || ((uintptr_t)Z & 7)) return 1;
+  if (K % 64) return 1;      // the LDS-DMA kernels only (the others do not carry this epilogue)
   return gemm_impl(A, W, nullptr, nullptr, C, M, N, K, in_dtype, out_dtype, lda, 0, 0, ldw, N, 0, act & 0x3ffff, 1, 0, 0, 0, 0,
                    0, 1, 0, 0, 0, stream, const_cast<void*>(Z), p_drop, rng_state, site, 8);
 }

@@ -491,13 +491,6 @@ def attention(q, k, v, n_heads, scale, mask=None, out=None, p_drop=0.0, rng_stat
         if mask is not None:
             assert mask.dtype in (torch.bool, torch.uint8) and mask.shape == (Tq, Tk) and mask.is_contiguous()
             m = mask
-        if prefetch and PREFETCH_WEIGHTS:
-            ptrs, nbytes, n = _prefetch_ranges(prefetch)
-            _lib.check(lib.msmd_attention_f16x2_prefetch(_p(q), _p(k), _p(v), _p(out), B, n_heads, Tq, Tk, q.stride(0),
-                                                         q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-                                                         out.stride(0), out.stride(1), float(scale), _p(m), _dt(out),
-                                                         ptrs, nbytes, n, _stream()), "msmd_attention_f16x2_prefetch")
-            return out
         _lib.check(lib.msmd_attention_f16x2(_p(q), _p(k), _p(v), _p(out), B, n_heads, Tq, Tk, q.stride(0), q.stride(1),
                                             k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0),
                                             out.stride(1), float(scale), _p(m), _dt(out), _stream()),
