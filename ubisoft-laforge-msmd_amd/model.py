@@ -387,7 +387,11 @@ class DenoisingNetwork_MSMD(nn.Module):
                 qkv = ops.gemm(x, L.sa_w, L.sa_b)
             else:
                 qkv = ops.gemm_ln(u, L.f_sa[0], L.f_sa[2], a_stats=st, w_colsum=L.f_sa[1])
-            a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale)
+            nxt = None
+            if li + 1 < len(P.layers):
+                nxt = P.layers[li + 1].f_sa[0] if (fold and diag) else P.layers[li + 1].sa_w
+            a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale,
+                              prefetch=None if P.split else (L.sa_ow, L.l1[0], L.l2[0], nxt))   # the layer's next weights
             fused_pq = getattr(self, "fused_person_query", N >= 64)
             # norm1 without a launch of its own (diagonal path, fused person query): its two consumers apply it -- the
             # person-token query projection through folded weights, the norm2 launch as its first stage (layernorm_pre)
