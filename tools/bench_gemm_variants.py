@@ -16,6 +16,8 @@ shapes = [("conv1", 205024, 512, 1536), ("conv3", 51232, 512, 1536), ("conv5", 1
           ("dec_ffn1", 21120, 2048, 512), ("big", 16384, 4096, 3072)]
 if os.environ.get("SHAPES") == "encoder":      # the forward step's encoder layers: M = 32 x 200 rows
     shapes = [("out", 6400, 768, 768), ("ffn2", 6400, 768, 3072), ("ffn1", 6400, 3072, 768), ("qkv", 6400, 2304, 768)]
+if os.environ.get("SHAPES") == "sampler":      # the sampler's decoder layers: M = 192 x 111 rows
+    shapes = [("sa_out", 21312, 512, 512), ("ffn2", 21312, 512, 2048), ("ffn1", 21312, 2048, 512), ("qkv", 21312, 1536, 512)]
 if os.environ.get("SHAPES") == "denoiser":     # the forward step's decoder layers: M = 32 x 111 rows
     shapes = [("sa_out", 3552, 512, 512), ("ffn2", 3552, 512, 2048), ("ffn1", 3552, 2048, 512), ("qkv", 3552, 1536, 512),
               ("kv_all", 3520, 8192, 512), ("md0", 3520, 256, 512)]

@@ -329,80 +329,93 @@ __device__ __forceinline__ void ln_finish(const float* stats, int nt, int M, int
 template <typename TO, int FM, int FN, int MODE>
 __device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int m_base, int n_base,
                                                  int fr, int fq, const f32x2 (&raw)[FM][4]) {
-  static_assert((FN == 4 || FN == 2) && FM == 2, "one wave = one statistics slab of 16 FN columns, two fragment rows");
+  static_assert((FN == 4 || FN == 2) && (FM == 2 || FM == 3), "one wave = one statistics slab of 16 FN columns, 2 or 3 fragment rows");
   constexpr int SLAB = FN * 16;
+  // fragment columns whose operands are requested together: all of them for the two-row tiles; two at a time for the
+  // 192-row tile, whose kernel has 128 registers for everything (all four would need 166: one workgroup per CU)
+  constexpr int IB = FM == 3 ? 2 : FN;
   typedef typename Vec4T<TO>::type V4;
   const int n = n_base + fq * 4;
-  f32x4 bv[FN], xv[FN], yv[FN];
-  V4 rr[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FN; ++i) bv[i] = *(const f32x4*)(p.bias + n + i * 16);
-  if constexpr (MODE == 1) {
-#pragma unroll
-    for (int i = 0; i < FN; ++i) xv[i] = *(const f32x4*)(p.w_colsum + n + i * 16);
-  } else {
-#pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      const TO* rp = (const TO*)p.R + (long)min(m_base + j * 16 + fr, p.M - 1) * p.ldr + n;
-#pragma unroll
-      for (int i = 0; i < FN; ++i) rr[j][i] = *(const V4*)(rp + i * 16);
-    }
-    if (p.r_stats) {
-#pragma unroll
-      for (int i = 0; i < FN; ++i) { xv[i] = *(const f32x4*)(p.r_gamma + n + i * 16); yv[i] = *(const f32x4*)(p.r_beta + n + i * 16); }
-    } else {
-#pragma unroll
-      for (int i = 0; i < FN; ++i) { xv[i] = f32x4{1.f, 1.f, 1.f, 1.f}; yv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    }
-  }
   float mu[FM], rs[FM];
 #pragma unroll
   for (int j = 0; j < FM; ++j) { mu[j] = 0.f; rs[j] = 1.f; }      // (r - 0) * 1 * 1 + 0 == r exactly: the plain residual
   if constexpr (MODE == 1) ln_finish<FM>(p.a_stats, p.a_nt, p.M, m_base, fr, fq, raw, 1.0f / (float)p.K, p.ln_eps, mu, rs);
   else if (p.r_stats) ln_finish<FM>(p.r_stats, p.r_nt, p.M, m_base, fr, fq, raw, 1.0f / (float)p.N, p.ln_eps, mu, rs);
-
   float rowS[FM], rowQ[FM];
 #pragma unroll
   for (int j = 0; j < FM; ++j) rowS[j] = rowQ[j] = 0.f;
   const bool odd = fq & 1;
   const bool pair = sizeof(TO) == 2 && (p.flags & 2);
 #pragma unroll
-  for (int i = 0; i < FN; ++i) {
-    V4 o[FM];
+  for (int i0 = 0; i0 < FN; i0 += IB) {
+    f32x4 bv[IB], xv[IB], yv[IB];
+    V4 rr[FM][IB];
 #pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      float v[4];
+    for (int ii = 0; ii < IB; ++ii) bv[ii] = *(const f32x4*)(p.bias + n + (i0 + ii) * 16);
+    if constexpr (MODE == 1) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float x = acc[i][j][e];
-        if constexpr (MODE == 1) x = rs[j] * (x - mu[j] * xv[i][e]);
-        v[e] = act_out<TO>(x + bv[i][e], p.act);
-        if constexpr (MODE == 2) v[e] += fmaf(((float)rr[j][i][e] - mu[j]) * rs[j], xv[i][e], yv[i][e]);
+      for (int ii = 0; ii < IB; ++ii) xv[ii] = *(const f32x4*)(p.w_colsum + n + (i0 + ii) * 16);
+    } else {
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const TO* rp = (const TO*)p.R + (long)min(m_base + j * 16 + fr, p.M - 1) * p.ldr + n;
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) rr[j][ii] = *(const V4*)(rp + (i0 + ii) * 16);
       }
-      if constexpr (sizeof(TO) == 4) o[j] = V4{v[0], v[1], v[2], v[3]};
-      else o[j] = pack4<TO>(v[0], v[1], v[2], v[3]);
-      if constexpr (MODE == 2) {
+      if (p.r_stats) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float w = (float)o[j][e]; rowS[j] += w; rowQ[j] = fmaf(w, w, rowQ[j]); }   // of what the consumer will read
-      }
-    }
-    if constexpr (sizeof(TO) == 2) {
-      if (pair) {     // lanes l and l ^ 16 swap one fragment row: one 16-byte store each (see gemm_epilogue_interior)
-        const u32x2 a = __builtin_bit_cast(u32x2, o[0]), b = __builtin_bit_cast(u32x2, o[1]);
-        const u32x2 send = odd ? a : b;
-        u32x2 recv;
-        recv[0] = __shfl_xor(send[0], 16, 64);
-        recv[1] = __shfl_xor(send[1], 16, 64);
-        const u32x4 w = odd ? u32x4{recv[0], recv[1], b[0], b[1]} : u32x4{a[0], a[1], recv[0], recv[1]};
-        const int m = m_base + (odd ? 16 : 0) + fr;
-        if (m < p.M) *(u32x4*)((TO*)p.C + (long)m * p.ldc + n + i * 16 - (odd ? 4 : 0)) = w;
-        continue;
+        for (int ii = 0; ii < IB; ++ii) { xv[ii] = *(const f32x4*)(p.r_gamma + n + (i0 + ii) * 16); yv[ii] = *(const f32x4*)(p.r_beta + n + (i0 + ii) * 16); }
+      } else {
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) { xv[ii] = f32x4{1.f, 1.f, 1.f, 1.f}; yv[ii] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       }
     }
 #pragma unroll
-    for (int j = 0; j < FM; ++j) {
-      const int m = m_base + j * 16 + fr;
-      if (m < p.M) *(V4*)((TO*)p.C + (long)m * p.ldc + n + i * 16) = o[j];
+    for (int ii = 0; ii < IB; ++ii) {
+      const int i = i0 + ii;
+      V4 o[FM];
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = acc[i][j][e];
+          if constexpr (MODE == 1) x = rs[j] * (x - mu[j] * xv[ii][e]);
+          v[e] = act_out<TO>(x + bv[ii][e], p.act);
+          if constexpr (MODE == 2) v[e] += fmaf(((float)rr[j][ii][e] - mu[j]) * rs[j], xv[ii][e], yv[ii][e]);
+        }
+        if constexpr (sizeof(TO) == 4) o[j] = V4{v[0], v[1], v[2], v[3]};
+        else o[j] = pack4<TO>(v[0], v[1], v[2], v[3]);
+        if constexpr (MODE == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float w = (float)o[j][e]; rowS[j] += w; rowQ[j] = fmaf(w, w, rowQ[j]); }   // of what the consumer will read
+        }
+      }
+      bool stored = false;
+      if constexpr (sizeof(TO) == 2) {
+        if (pair) {     // lanes l and l ^ 16 swap one fragment row: one 16-byte store each (see gemm_epilogue_interior)
+          const u32x2 a = __builtin_bit_cast(u32x2, o[0]), b = __builtin_bit_cast(u32x2, o[1]);
+          const u32x2 send = odd ? a : b;
+          u32x2 recv;
+          recv[0] = __shfl_xor(send[0], 16, 64);
+          recv[1] = __shfl_xor(send[1], 16, 64);
+          const u32x4 w = odd ? u32x4{recv[0], recv[1], b[0], b[1]} : u32x4{a[0], a[1], recv[0], recv[1]};
+          const int m = m_base + (odd ? 16 : 0) + fr;
+          if (m < p.M) *(u32x4*)((TO*)p.C + (long)m * p.ldc + n + i * 16 - (odd ? 4 : 0)) = w;
+          if constexpr (FM == 3) {   // the third fragment row of the 192-row tile has no partner: plain 8-byte stores
+            const int m2 = m_base + 32 + fr;
+            if (m2 < p.M) *(V4*)((TO*)p.C + (long)m2 * p.ldc + n + i * 16) = o[2];
+          }
+          stored = true;
+        }
+      }
+      if (!stored) {
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          const int m = m_base + j * 16 + fr;
+          if (m < p.M) *(V4*)((TO*)p.C + (long)m * p.ldc + n + i * 16) = o[j];
+        }
+      }
     }
   }
   if constexpr (MODE == 2) {
@@ -582,9 +595,12 @@ __global__ __launch_bounds__(WM * WN * 64, STAG ? 4 : 1) void gemm2_kernel(const
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s, s);
   // LayerNorm-folding mode (msmd_gemm_ln; the 4 x 2-wave 128 x 128 tile only): the row statistics' loads go out now, consumed in the epilogue
-  constexpr bool LNK = (BN == 128 || BN == 64) && WN == 2 && FM == 2 && !STAG && sizeof(TO) == 2;   // slab = BN / 2
-  f32x2 lnraw[LNK ? FM : 1][4];
-  if constexpr (LNK) {
+  constexpr bool LNK = (BN == 128 || BN == 64) && WN == 2 && (FM == 2 || FM == 3) && !STAG && sizeof(TO) == 2;   // slab = BN / 2
+  // the 192-row tile has no registers to spare during the K loop (124 of 128): its statistics are loaded in the epilogue instead
+  // (one batched round trip; with two workgroups per CU and grids of many rounds it hides under the neighbour's K loop)
+  constexpr bool LN_LATE = FM == 3;
+  f32x2 lnraw[(LNK && !LN_LATE) ? FM : 1][4];
+  if constexpr (LNK && !LN_LATE) {
     if (p.a_stats) ln_issue<FM>(p.a_stats, p.a_nt, p.M, m0 + wm, fr, fq, lnraw);
     else if (p.r_stats) ln_issue<FM>(p.r_stats, p.r_nt, p.M, m0 + wm, fr, fq, lnraw);
   }
@@ -683,9 +699,19 @@ __global__ __launch_bounds__(WM * WN * 64, STAG ? 4 : 1) void gemm2_kernel(const
     }
     stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
   }
-  if constexpr (LNK) {
+  if constexpr (LNK && !LN_LATE) {
     if (p.a_stats) { gemm_epilogue_ln<TO, FM, FN, 1>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
     if (p.r_stats || p.stats_out) { gemm_epilogue_ln<TO, FM, FN, 2>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
+  }
+  if constexpr (LNK && LN_LATE) {
+    if (p.a_stats || p.r_stats || p.stats_out) {
+      f32x2 late[FM][4];
+      if (p.a_stats) ln_issue<FM>(p.a_stats, p.a_nt, p.M, m0 + wm, fr, fq, late);
+      else if (p.r_stats) ln_issue<FM>(p.r_stats, p.r_nt, p.M, m0 + wm, fr, fq, late);
+      if (p.a_stats) gemm_epilogue_ln<TO, FM, FN, 1>(p, acc, m0 + wm, n0 + wn, fr, fq, late);
+      else gemm_epilogue_ln<TO, FM, FN, 2>(p, acc, m0 + wm, n0 + wn, fr, fq, late);
+      return;
+    }
   }
   gemm_epilogue<TO, FM, FN, sizeof(TO) == 2>(p, acc, z, m0 + wm, n0 + wn, fr, fq);
 }
@@ -924,6 +950,7 @@ static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
     case 12: return launch_gemm2<TO, 64, 64, 2, 2, 2>(p, batch, st);
     case 13: return launch_gemm2<TO, 128, 128, 4, 2, 2>(p, batch, st);
     case 14: return launch_gemm2<TO, 256, 64, 8, 1, 2, true>(p, batch, st);   // narrow outputs (N <= 64): 8 waves of 32 x 64
+    case 15: return launch_gemm2<TO, 192, 128, 4, 2, 2, true>(p, batch, st);  // tall grids (M >= 16 k): 80 KB, still 2 workgroups / CU
     case 17: return launch_gemm2<TO, 128, 128, 4, 2, 2, true>(p, batch, st);
 #ifdef MSMD_EXPERIMENTAL
     case 41: return launch_gemm2<TO, 128, 128, 4, 2, 2, true, bf16_t, true>(p, batch, st);   // 17 with waves 4-7 staggered: -25 % (5c)
@@ -949,7 +976,7 @@ static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
     case 10: return launch_gemm2<TO, 128, 64, 2, 2, 3>(p, batch, st);
     case 11: return launch_gemm2<TO, 64, 128, 2, 2, 3>(p, batch, st);
     case 47: return launch_gemm2<TO, 128, 64, 2, 2, 2>(p, batch, st);
-    case 15: return launch_gemm2<TO, 64, 128, 2, 2, 2>(p, batch, st);
+    case 56: return launch_gemm2<TO, 64, 128, 2, 2, 2>(p, batch, st);
     case 16: return launch_gemm2<TO, 128, 128, 2, 4, 2>(p, batch, st);
     case 18: return launch_gemm2<TO, 128, 128, 2, 4, 2, true>(p, batch, st);
     case 19: return launch_gemm2<TO, 64, 64, 2, 2, 2, true>(p, batch, st);
@@ -998,6 +1025,7 @@ static int dispatch_gemm2_f16(GemmArgs& p, int batch, hipStream_t st, int varian
     case 9: return launch_gemm2<TO, 64, 64, 2, 2, 4, false, f16_t>(p, batch, st);
     case 12: return launch_gemm2<TO, 64, 64, 2, 2, 2, false, f16_t>(p, batch, st);
     case 14: return launch_gemm2<TO, 256, 64, 8, 1, 2, true, f16_t>(p, batch, st);
+    case 15: return launch_gemm2<TO, 192, 128, 4, 2, 2, true, f16_t>(p, batch, st);
     case 17: return launch_gemm2<TO, 128, 128, 4, 2, 2, true, f16_t>(p, batch, st);
     default: return -1;
   }
@@ -1079,7 +1107,13 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
     int variant = MSMD_TUNE(0) ? MSMD_TUNE(0) : hint;
     if (variant == 0) {
       const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nz;
-      if (N > 64 && tiles128 >= 192) {
+      const long tiles192 = (long)((M + 191) / 192) * ((N + 127) / 128) * nz;
+      if (N > 64 && M >= 16000 && tiles192 >= 400) {
+        // tall grids: 192 x 128 tiles (76.8 FLOP per staged byte instead of 64, still two workgroups per CU).  Measured against
+        // the 128 x 128 tile: conv1 454 -> 379 us, 21312 x 512 x 2048 58.7 -> 49.6, 21312 x 2048 x 512 76.6 -> 64.7; worse
+        // below ~16 k rows (12800 x 512 x 1024: 22 -> 28 us) and mixed at M = 6400
+        variant = 15;
+      } else if (N > 64 && tiles128 >= 192) {
         variant = MSMD_TUNE(4) ? 13 : 17;  // 128x128, 8 waves (4x2), 2-stage ring, 2 workgroups/CU, fragment reads pipelined
         // experiment knobs (tools/ab_graph.py): 5 = variant for M >= 20000 (conv stack), 6 = variant for the rest
         if (M >= 20000 && MSMD_TUNE(5) > 0) variant = MSMD_TUNE(5);
@@ -1097,6 +1131,7 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nz;
     int variant = hint ? hint : ((N > 64 && tiles128 >= 192) ? 17 : ((K >= 1024) ? 9 : 12));
     if (!hint && N <= 64 && (long)((M + 255) / 256) * nz >= 256) variant = 14;
+    if (!hint && N > 64 && M >= 16000 && (long)((M + 191) / 192) * ((N + 127) / 128) * nz >= 400) variant = 15;
     const int r = out_dtype == MSMD_F16 ? dispatch_gemm2_f16<f16_t>(p, nz, st, variant)
                                         : dispatch_gemm2_f16<float>(p, nz, st, variant);
     if (r >= 0) return r;
@@ -1157,7 +1192,8 @@ extern "C" int msmd_gemm_ln(const void* A, const void* W, const float* bias, con
   p.r_stats = r_stats; p.r_nt = r_stats ? N / slab_in : 0; p.r_gamma = r_gamma; p.r_beta = r_beta;
   p.stats_out = stats_out; p.ln_eps = eps;
   hipStream_t st = (hipStream_t)stream;
-  const int variant = big ? 17 : (K >= 1024 ? 9 : 12);
+  int variant = big ? 17 : (K >= 1024 ? 9 : 12);
+  if (big && M >= 16000 && (long)((M + 191) / 192) * (N / 128) >= 400) variant = 15;    // tall grids: the 192 x 128 tile (same 64-column slabs)
   const int r = in_dtype == MSMD_BF16 ? dispatch_gemm2<bf16_t>(p, 1, st, variant) : dispatch_gemm2_f16<f16_t>(p, 1, st, variant);
   return r >= 0 ? r : 1;
 }
