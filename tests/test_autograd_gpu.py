@@ -203,6 +203,10 @@ def test_fused_attention_dropout_forward_and_backward(Tq, Tk, masked):
     valid = P > 1e-6                                   # tiny probabilities may round to 0 in bf16: not "dropped"
     rate = keep[valid].float().mean().item()
     assert abs(rate - (1 - pd)) < 0.03, rate
+    # the tiled kernel (fp32 operands take it; 16-bit ones take the whole-sequence kernel at these lengths) draws the SAME mask
+    p32 = ops.attention(q.float(), k.float(), eye.float(), H, scale, m8, p_drop=pd, rng_state=state, site=site)
+    keep32 = p32.reshape(B, Tq, H, 64)[..., :Tk].permute(0, 2, 1, 3) != 0
+    assert torch.equal(keep32[valid], keep[valid])
     assert float((pdrop - P.detach() * keep / (1 - pd)).abs().max()) < 1e-2
     o_ref = ((P * keep / (1 - pd)) @ heads(vf)).transpose(1, 2).reshape(B, Tq, d)
     o_ref.backward(do.float())

@@ -24,7 +24,7 @@ print(f"{len(step)} kernels in one replay: wall {wall:.1f} us (start to next ste
       f"(median gap {sorted(gaps)[len(gaps) // 2]:.2f} us, overlapped {sum(-g for g in gaps if g < 0):.1f} us)")
 by = collections.defaultdict(lambda: [0.0, 0])
 for s, e, n, *_ in step:
-    k = n.split("(")[0][:90]
+    k = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:90]
     by[k][0] += (e - s) / 1e3; by[k][1] += 1
 for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get('TOP', '22'))]:
     print(f"  {t:8.1f} us  x{c:3d}  avg {t / c:7.2f}  {k}")

@@ -206,15 +206,15 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const AttnArgs p) {
     ps += __shfl_xor(ps, 32, 64);
     l_run = l_run * alpha + ps;
     if (p.p_drop > 0.f) {  // drop probabilities AFTER the softmax denominator; the 1/(1-p) factor is applied to O
-      const unsigned thr = dropout_threshold(p.p_drop);
+      const unsigned thr = dropout_threshold16(p.p_drop);
       const unsigned long rowbase = ((unsigned long)(b * p.H + h) * p.Tq + qrow) * 128ul;
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        const Philox4 r = dropout_bits(p.rng_state, p.site, rowbase + (unsigned long)((kv0 >> 2) + 4 * f + fq));
-        s[f][0] = r.x >= thr ? s[f][0] : 0.f;
-        s[f][1] = r.y >= thr ? s[f][1] : 0.f;
-        s[f][2] = r.z >= thr ? s[f][2] : 0.f;
-        s[f][3] = r.w >= thr ? s[f][3] : 0.f;
+      for (int pr = 0; pr < 2; ++pr) {   // one generator block per fragment pair (common.h: dropout_value16)
+        const Philox4 r = dropout_bits(p.rng_state, p.site, rowbase + (unsigned long)(4 * ((kv0 >> 5) + pr) + fq));
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[2 * pr + o][e] = dropout_value16(r, e, o) >= thr ? s[2 * pr + o][e] : 0.f;
       }
     }
     if (!__all(alpha == 1.0f)) {   // the running maximum moved for some query of this wave: rescale the accumulators
@@ -423,6 +423,22 @@ __global__ __launch_bounds__(64 * NW) void attn_whole_kernel(const AttnArgs p) {
   }
   ps += __shfl_xor(ps, 16, 64);
   ps += __shfl_xor(ps, 32, 64);
+  if (p.p_drop > 0.f) {   // training: drop probabilities AFTER the denominator (same Philox stream as attn_kernel and the
+                          // backward: common.h dropout_value16); the 1 / (1 - p) factor goes on O
+    const unsigned thr = dropout_threshold16(p.p_drop);
+    const unsigned long rowbase = ((unsigned long)(b * p.H + h) * p.Tq + qrow) * 128ul;
+#pragma unroll
+    for (int pr = 0; pr < (NF + 1) / 2; ++pr) {   // one generator block per fragment pair (common.h: dropout_value16)
+      if (2 * pr >= nf) continue;
+      const Philox4 r = dropout_bits(p.rng_state, p.site, rowbase + (unsigned long)(4 * pr + fq));
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        if (2 * pr + o >= NF) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[2 * pr + o][e] = dropout_value16(r, e, o) >= thr ? s[2 * pr + o][e] : 0.f;
+      }
+    }
+  }
 
   // ---- O^T = V^T . P^T over fragment pairs (32 keys per MFMA)
   f32x4 acc_o[4];
@@ -450,7 +466,7 @@ __global__ __launch_bounds__(64 * NW) void attn_whole_kernel(const AttnArgs p) {
     }
   }
   if (query < p.Tq) {
-    const float inv = 1.0f / ps;
+    const float inv = 1.0f / (ps * (1.0f - p.p_drop));
     T* Op = (T*)p.O + (long)b * p.ob + (long)query * p.ot + h * 64;
 #pragma unroll
     for (int d = 0; d < 4; ++d)
@@ -677,7 +693,7 @@ static int attention_impl(const void* Q, const void* K, const void* V, void* O, 
     if (pf_ptrs[i] && pf_bytes[i] >= 16 && ((uintptr_t)pf_ptrs[i] & 15) == 0) { p.pf_ptr[j] = pf_ptrs[i]; p.pf_bytes[j] = pf_bytes[i]; ++j; }
   int nw = attn_waves(Tq, H, B);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype != MSMD_F32 && p_drop == 0.f && Tk <= 272) {
+  if (dtype != MSMD_F32 && Tk <= 272) {
     // short sequences: all keys staged once, plain softmax (attn_whole_kernel).  One workgroup per (batch, head) when the
     // queries fit (K / V read once): in the forward step T = 200 runs 16.4 us with 13 waves against 17.5 with 7 (two
     // workgroups per head) and 19.8 for attn_kernel; T = 111 6.6 us with 7 waves against 7.8.

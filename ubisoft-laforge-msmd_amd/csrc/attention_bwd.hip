@@ -53,15 +53,29 @@ __device__ __forceinline__ bf16x8 frag8(const u32x2 lo, const u32x2 hi) {
   return __builtin_bit_cast(bf16x8, (u32x4{lo[0], lo[1], hi[0], hi[1]}));
 }
 
-// global (rows x 64 bf16, row stride ts) -> swizzled LDS image, rows >= valid zero-filled, `rows` image rows
-__device__ __forceinline__ void stage_rows(unsigned char* img, const bf16_t* src, long ts, int valid, int rows, int tid) {
-  for (int id = tid; id < rows * 8; id += 256) {
-    const int row = id >> 3, ch = id & 7;
-    u32x4 v = u32x4{0u, 0u, 0u, 0u};
-    if (row < valid) v = *(const u32x4*)(src + (long)row * ts + ch * 8);
-    *(u32x4*)(img + img_off(row, ch)) = v;
+// global (rows x 64 bf16, row stride ts) -> swizzled LDS image of ROWS rows, rows >= valid zero-filled.  Two halves so
+// that a caller can put ALL its loads in flight before the first LDS write (one memory latency per staging step instead
+// of one per 16-byte chunk: the rolled loop this replaces waited for every load before its store).
+template <int ROWS>
+struct RowStage {
+  static constexpr int N = ROWS * 8 / 256;
+  static_assert(ROWS * 8 % 256 == 0, "whole passes of the 256 threads");
+  u32x4 v[N];
+  __device__ __forceinline__ void load(const bf16_t* src, long ts, int valid, int tid) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+      v[i] = *(const u32x4*)(src + (long)min(row, valid - 1) * ts + ch * 8);   // valid >= 1: always an address of the tensor
+    }
   }
-}
+  __device__ __forceinline__ void store(unsigned char* img, int valid, int tid) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+      *(u32x4*)(img + img_off(row, ch)) = row < valid ? v[i] : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+};
 
 template <int NKF>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const AbArgs p) {
@@ -85,8 +99,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AbArgs p) {
   const bf16_t* Vg = p.V + b * p.v_bs + h * 64;
   const bf16_t* dOg = p.dO + b * p.do_bs + h * 64;
 
-  stage_rows(sK, Kg, p.k_ts, p.Tk, KROWS, tid);
-  stage_rows(sV, Vg, p.v_ts, p.Tk, KROWS, tid);
+  {
+    RowStage<KROWS> rk, rv;
+    rk.load(Kg, p.k_ts, p.Tk, tid);
+    rv.load(Vg, p.v_ts, p.Tk, tid);
+    rk.store(sK, p.Tk, tid);
+    rv.store(sV, p.Tk, tid);
+  }
 
   f32x4 accV[MAXF][4], accK[MAXF][4];
 #pragma unroll
@@ -95,11 +114,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AbArgs p) {
     for (int d = 0; d < 4; ++d) accV[i][d] = accK[i][d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nqt = (p.Tq + 63) / 64;
+  constexpr bool AHEAD = NKF < 16;   // 16 key fragments leave no registers for rows in flight across phase B
+  RowStage<64> rq, rdo;   // the NEXT q tile's Q / dO rows, in flight while the current tile is computed
+  if (AHEAD) {
+    rq.load(Qg, p.q_ts, p.Tq, tid);
+    rdo.load(dOg, p.do_ts, p.Tq, tid);
+  }
   for (int qt = 0; qt < nqt; ++qt) {
     const int q0 = qt * 64;
     __syncthreads();  // previous tile's readers of sQ / sdO / sP / sdS are done (and K / V staged on the first pass)
-    stage_rows(sQ, Qg + (long)q0 * p.q_ts, p.q_ts, p.Tq - q0, 64, tid);
-    stage_rows(sdO, dOg + (long)q0 * p.do_ts, p.do_ts, p.Tq - q0, 64, tid);
+    if (!AHEAD) {
+      rq.load(Qg + (long)q0 * p.q_ts, p.q_ts, p.Tq - q0, tid);
+      rdo.load(dOg + (long)q0 * p.do_ts, p.do_ts, p.Tq - q0, tid);
+    }
+    rq.store(sQ, p.Tq - q0, tid);
+    rdo.store(sdO, p.Tq - q0, tid);
     __syncthreads();
 
     // ---------------- phase A: this wave's 16 q rows against all keys
@@ -110,6 +139,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AbArgs p) {
     for (int ks = 0; ks < 2; ++ks) {
       qf[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(sQ + img_off(qrow, 4 * ks + fq)));
       dof[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(sdO + img_off(qrow, 4 * ks + fq)));
+    }
+    // the lane's 4 keys of a fragment are 4 consecutive mask bytes: ONE 4-byte load per fragment, all of them issued
+    // before the score MFMAs (the byte loads this replaces were each waited for: 4 NKF round trips per q tile)
+    unsigned m4[NKF];
+    int fq4 = 4 * fq;
+    asm volatile("" : "+v"(fq4));   // opaque per tile: the NKF offsets / shifts below are recomputed, not kept in registers across tiles
+    if (p.mask) {
+      const uint8_t* mrow4 = p.mask + (long)min(qglob, p.Tq - 1) * p.Tk;
+      if (p.Tk >= 4) {
+#pragma unroll
+        for (int f = 0; f < NKF; ++f) __builtin_memcpy(&m4[f], mrow4 + min(16 * f + fq4, p.Tk - 4), 4);
+      } else {   // every live key is one of the row's first Tk < 4 bytes
+        unsigned m = 0;
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+          if (e < p.Tk) m |= (unsigned)mrow4[e] << (8 * e);
+#pragma unroll
+        for (int f = 0; f < NKF; ++f) m4[f] = m;
+      }
     }
     f32x4 s[NKF], dp[NKF];
     unsigned long keep = ~0ul;  // 4 keep bits per key fragment
@@ -125,17 +173,27 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AbArgs p) {
       }
     }
     // s[f][e] = S^T[key = 16 f + 4 fq + e][q = fr]: softmax over keys = over (f, e) in-lane and over fq across lanes
-    const uint8_t* mrow = p.mask ? p.mask + (long)min(qglob, p.Tq - 1) * p.Tk : nullptr;
+    // (selects only: the short-circuit form of these tests compiled to three branches per element)
+#pragma unroll
+    for (int f = 0; f < NKF; ++f)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[f][e] = 16 * f + 4 * fq + e >= p.Tk ? -3.0e38f : s[f][e] * p.scale;
+    if (p.mask) {
+      const int tk4 = max(p.Tk - 4, 0);
+#pragma unroll
+      for (int f = 0; f < NKF; ++f) {
+        // the 4 bytes were loaded from min(k0, Tk - 4): the byte of key k0 + e sits (k0 - that) bytes further up
+        // (3 at most for a live key; a shift that runs off the word belongs to keys >= Tk, dead already)
+        const unsigned m = m4[f] >> ((8 * max(16 * f + fq4 - tk4, 0)) & 31);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[f][e] = ((m >> (8 * e)) & 0xffu) ? -3.0e38f : s[f][e];
+      }
+    }
     float mx = -3.0e38f;
 #pragma unroll
     for (int f = 0; f < NKF; ++f)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int key = 16 * f + 4 * fq + e;
-        const bool dead = key >= p.Tk || (mrow && mrow[min(key, p.Tk - 1)]);
-        s[f][e] = dead ? -3.0e38f : s[f][e] * p.scale;
-        mx = fmaxf(mx, s[f][e]);
-      }
+      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[f][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float l = 0.f;
@@ -152,18 +210,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AbArgs p) {
     const float inv_l = l > 0.f ? 1.0f / l : 0.f;
     float delta = 0.f;
     if (p.p_drop > 0.f) {  // same Philox mask as the forward: dP <- dP o keep / (1 - p)
-      const unsigned thr = dropout_threshold(p.p_drop);
+      const unsigned thr = dropout_threshold16(p.p_drop);
       const float c = 1.0f / (1.0f - p.p_drop);
       const unsigned long rowbase = ((unsigned long)blockIdx.x * p.Tq + min(qglob, p.Tq - 1)) * 128ul;
 #pragma unroll
-      for (int f = 0; f < NKF; ++f) {
-        const Philox4 r = dropout_bits(p.rng_state, p.site, rowbase + (unsigned long)(4 * f + fq));
-        dp[f][0] = r.x >= thr ? dp[f][0] * c : 0.f;
-        dp[f][1] = r.y >= thr ? dp[f][1] * c : 0.f;
-        dp[f][2] = r.z >= thr ? dp[f][2] * c : 0.f;
-        dp[f][3] = r.w >= thr ? dp[f][3] * c : 0.f;
-        const unsigned long k4 = (r.x >= thr ? 1u : 0u) | (r.y >= thr ? 2u : 0u) | (r.z >= thr ? 4u : 0u) | (r.w >= thr ? 8u : 0u);
-        keep = (keep & ~(15ul << (4 * f))) | (k4 << (4 * f));
+      for (int pr = 0; pr < NKP; ++pr) {   // one generator block per fragment pair, as the forward kernels (common.h)
+        const Philox4 r = dropout_bits(p.rng_state, p.site, rowbase + (unsigned long)(4 * pr + fq));
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          const int f = 2 * pr + o;
+          if (f >= NKF) continue;
+          unsigned long k4 = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool kp = dropout_value16(r, e, o) >= thr;
+            dp[f][e] = kp ? dp[f][e] * c : 0.f;
+            k4 |= (unsigned long)kp << e;
+          }
+          keep = (keep & ~(15ul << (4 * f))) | (k4 << (4 * f));
+        }
       }
     }
 #pragma unroll
@@ -219,6 +284,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AbArgs p) {
       }
     }
     __syncthreads();  // P / dS images complete
+    if (AHEAD && qt + 1 < nqt) {   // issued HERE: phase B holds few registers, and its MFMAs cover the loads' latency
+      rq.load(Qg + (long)(q0 + 64) * p.q_ts, p.q_ts, p.Tq - q0 - 64, tid);
+      rdo.load(dOg + (long)(q0 + 64) * p.do_ts, p.do_ts, p.Tq - q0 - 64, tid);
+    }
 
     // ---------------- phase B: dV^T[d][key] += dO^T[d][q] P[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key]
 #pragma unroll

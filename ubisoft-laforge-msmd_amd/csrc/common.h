@@ -43,6 +43,15 @@ __device__ __forceinline__ Philox4 dropout_bits(const unsigned long* __restrict_
 }
 // keep iff uniform [0,1) >= p  <=>  bits >= p * 2^32
 __device__ __forceinline__ unsigned dropout_threshold(float p) { return (unsigned)fminf(p * 4294967296.0f, 4294967295.0f); }
+// Attention-probability dropout draws 16-bit values: one Philox4 block serves the lane's 8 keys of a fragment PAIR (key
+// fragment f even: low halves of the 4 words, odd: high halves), counter = row * 128 + 4 * (f / 2) + fq -- half the
+// generator work of a 32-bit value per key (the generator was as much VALU work as the rest of the forward kernel).
+// keep <=> value >= threshold16(p); P(drop) = floor(p * 65536) / 65536.
+__device__ __forceinline__ unsigned dropout_threshold16(float p) { return (unsigned)fminf(p * 65536.0f, 65535.0f); }
+__device__ __forceinline__ unsigned dropout_value16(const Philox4& r, int e, int odd) {
+  const unsigned w = e == 0 ? r.x : e == 1 ? r.y : e == 2 ? r.z : r.w;
+  return odd ? w >> 16 : w & 0xffffu;
+}
 
 // Developer knobs: only the experimental build (make EXP=1, -DMSMD_EXPERIMENTAL) has them; in the product library every
 // MSMD_TUNE(k) is the constant 0 and the code it guards folds away (no process-global state: re-entrant per stream).
