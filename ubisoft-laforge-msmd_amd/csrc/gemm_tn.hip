@@ -278,10 +278,11 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 }  // namespace
 
 // Contraction splits: fill the 512 workgroup slots of the chip (2 per CU at 64 KB of LDS), never more; the slab
-// reduction costs splits x N x K x 4 B of traffic, so large outputs take at most 4.
+// reduction costs splits x N x K x 4 B of traffic, so large outputs take at most 4 (6 while 4 would leave more than half
+// of the slots empty: 768 x 768 = 36 tiles, M = 6400: 30.2 us with 4, 24.8 with 6, 26.2 with 8 -- tools/bench_gemm_tn.py).
 static long tn_auto_splits(long tiles, long nk_elems) {
   long s = 512 / (tiles > 0 ? tiles : 1);
-  const long cap = nk_elems >= (1 << 19) ? 4 : 8;
+  const long cap = nk_elems >= (1 << 19) ? (tiles * 4 < 256 ? 6 : 4) : 8;
   return max(1L, min(s, cap));
 }
 
