@@ -509,6 +509,13 @@ int msmd_act_bwd_dropout(const void* dy, const void* z, void* dz, long n, int ac
 int msmd_layernorm_bwd(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma, float* dbeta,
                        int rows, int cols, float eps, int dtype, void* ws, long ws_bytes, msmd_stream_t stream);
 long msmd_layernorm_bwd_workspace(int rows, int cols);
+/* msmd_layernorm_bwd that also writes dx_drop = dropout_mask(dx) / (1 - p) (mask of msmd_dropout / msmd_gemm_ex at
+ * (rng_state, site): index = element / 4): the gradient the Linear in front of a post-LN block's LayerNorm wants
+ * (x = residual + dropout_p(Linear(..)); reference: nn.TransformerDecoderLayer / HF Wav2Vec2EncoderLayer under
+ * loss.backward(), training_script.py:196).  cols % 4 == 0, 16-byte aligned tensors. */
+int msmd_layernorm_bwd_dropout(const void* dy, const void* x, const float* gamma, void* dx, void* dx_drop, float* dgamma,
+                               float* dbeta, int rows, int cols, float eps, float p_drop, const unsigned long* rng_state,
+                               unsigned int site, int dtype, void* ws, long ws_bytes, msmd_stream_t stream);
 /* In place row softmax of scale * s over the first `cols` entries of rows with stride ld (the ld - cols padding
  * columns are zeroed), optional (Tq, cols) byte mask (row r uses mask row r % Tq);
  * backward (in place on dP): dS = scale * P o (dP - rowsum(dP o P)). */

@@ -350,3 +350,56 @@ def test_ffn_node_matches_two_linear_nodes_and_gemm_actbwd_matches_the_unfused_p
     torch.cuda.synchronize()
     d = (xa.grad.float() - xb.grad.float()).abs().max()
     assert float(d) <= 1.5e-2 * float(xb.grad.float().abs().max())
+
+
+@pytest.mark.gpu
+def test_layernorm_backward_hands_the_dropped_gradient_to_the_linear_in_front_of_it(monkeypatch):
+    """Post-LN blocks h = LN(res + dropout(Linear(a))) and LN(x + FFN(x)): msmd_layernorm_bwd_dropout writes the dropped copy
+    of dx the Linear's backward needs (autograd._tag_dropped / _dropped_by_producer).  Bit-equal gradients with the side
+    channel on and off; the fused launch really is taken (no msmd_dropout call in the backward); and a LayerNorm whose
+    input has a SECOND consumer must not have its dropped copy used (the engine hands the Linear a sum)."""
+    import math
+    from msmd_amd import autograd as ag, ops
+    g = torch.Generator(device="cpu").manual_seed(11)
+    B, T, d, dff = 3, 37, 256, 512
+    mk = lambda *s: torch.randn(*s, generator=g)
+    a0, r0 = mk(B, T, d).to(DEV, torch.bfloat16), mk(B, T, d).to(DEV, torch.bfloat16)
+    P = [(mk(d, d) / math.sqrt(d)), mk(d) * 0.1, 1 + 0.1 * mk(d), 0.1 * mk(d), mk(dff, d) / math.sqrt(d), mk(dff) * 0.1,
+         mk(d, dff) / math.sqrt(dff), mk(d) * 0.1, 1 + 0.1 * mk(d), 0.1 * mk(d)]
+    P = [t.to(DEV).requires_grad_(True) for t in P]
+    wo, bo, g1, be1, w1, b1, w2, b2, g2, be2 = P
+    dy = mk(B, T, d).to(DEV, torch.bfloat16)
+    ag.TrainNoise.state = torch.tensor([77, 3], dtype=torch.int64, device=DEV)
+    calls = []
+    real_dropout = ops.dropout
+    monkeypatch.setattr(ops, "dropout", lambda *a_, **k_: (calls.append(1), real_dropout(*a_, **k_))[1])
+
+    def run(fuse, second_consumer):
+        monkeypatch.setattr(ag, "FUSE_LN_DROPOUT_BWD", fuse)
+        ag.TrainNoise.active, ag.TrainNoise.site = True, 0
+        a, r = a0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        for t in P:
+            t.grad = None
+        u = ag.linear_dropout(a, wo, bo, 0.1, residual=r)
+        h = ag.layer_norm(u, g1, be1)
+        y = ag.layer_norm(ag.ffn(h, w1, b1, w2, b2, 0.1, 0.2, residual=h), g2, be2)
+        if second_consumer:
+            y = y + u * 0.5
+        torch.cuda.synchronize()
+        del calls[:]
+        y.backward(dy)
+        torch.cuda.synchronize()
+        n = len(calls)
+        ag.TrainNoise.active = False
+        return [t.grad.float().clone() for t in (a, r, *P)], n
+
+    ref, n_ref = run(False, False)
+    got, n_got = run(True, False)
+    assert n_ref == 2 and n_got == 0, (n_ref, n_got)
+    for i, (u, v) in enumerate(zip(ref, got)):
+        assert torch.equal(u, v), i
+    ref2, _ = run(False, True)
+    got2, n2 = run(True, True)
+    assert n2 == 1            # the out-projection's gradient is a sum now: its own dropout launch; the FFN still takes the copy
+    for i, (u, v) in enumerate(zip(ref2, got2)):
+        assert torch.equal(u, v), i

@@ -9,6 +9,7 @@ Training attention materialises P (needed by the backward) with batched GEMMs + 
 """
 from __future__ import annotations
 
+import os
 import weakref
 
 import torch
@@ -251,9 +252,12 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         xin, z, w = ctx.saved_tensors
         dtype = xin.dtype
-        dy = dy.contiguous()
         p_drop, site = ctx.drop
-        if p_drop > 0.0:
+        dropped = _dropped_by_producer(dy, p_drop, site) if ctx.act == ACT_NONE else None
+        dy = dy.contiguous()
+        if dropped is not None:
+            dz = dropped
+        elif p_drop > 0.0:
             dz = (ops.dropout(dy, p_drop, TrainNoise.state, site) if ctx.act == ACT_NONE
                   else ops.act_bwd_dropout(dy, z, ctx.act, p_drop, TrainNoise.state, site))
         else:
@@ -304,8 +308,9 @@ class FFNFn(torch.autograd.Function):
         xin, z1, f, w1, w2 = ctx.saved_tensors
         act, p1, site1, p2, site2, has_r, res_is_x = ctx.cfg
         dtype = xin.dtype
+        dropped = _dropped_by_producer(dy, p2, site2)
         dy = dy.contiguous()
-        dz2 = ops.dropout(dy, p2, TrainNoise.state, site2) if p2 > 0.0 else dy
+        dz2 = dropped if dropped is not None else (ops.dropout(dy, p2, TrainNoise.state, site2) if p2 > 0.0 else dy)
         M = xin.numel() // xin.shape[-1]
         dz2 = dz2.reshape(M, w2.shape[0])
         _, w1ct = CACHE.get(w1, dtype)
@@ -333,15 +338,52 @@ def ffn(x, w1, b1, w2, b2, p_act, p_out, residual=None, act=ops.ACT_GELU):
     s1 = TrainNoise.next_site() if p_act > 0 else 0
     s2 = TrainNoise.next_site() if p_out > 0 else 0
     if residual is x:       # x + FFN(x): one gradient for x out of the node (the sum is made in a GEMM epilogue)
-        return FFNFn.apply(x, w1, b1, w2, b2, None, act, float(p_act), s1, float(p_out), s2, True)
-    return FFNFn.apply(x, w1, b1, w2, b2, residual, act, float(p_act), s1, float(p_out), s2)
+        return _tag_dropout(FFNFn.apply(x, w1, b1, w2, b2, None, act, float(p_act), s1, float(p_out), s2, True), float(p_out), s2)
+    return _tag_dropout(FFNFn.apply(x, w1, b1, w2, b2, residual, act, float(p_act), s1, float(p_out), s2), float(p_out), s2)
+
+
+# Post-LN blocks: h = LayerNorm(residual + dropout_p(Linear(..))).  The Linear's backward needs dropout_mask(dy) with dy = the
+# LayerNorm's dx; the LayerNorm backward launch can write that tensor next to dx (msmd_layernorm_bwd_dropout) instead of a
+# separate msmd_dropout launch over the same rows.  The two autograd nodes stay separate and talk through attributes:
+#   forward : the Linear / FFN node's OUTPUT tensor carries _msmd_drop = (p, site); layer_norm() reads it off its input;
+#   backward: the LayerNorm node attaches _msmd_dropped = (p, site, version, tensor) to the dx it RETURNS; the Linear node
+#             uses it only if it finds it on the very tensor it is handed, at the same version -- if the LayerNorm was not
+#             the only consumer, the engine hands over a sum (another tensor, or this one after an in-place add_ that
+#             bumps its version) and the node falls back to its own msmd_dropout launch.
+FUSE_LN_DROPOUT_BWD = os.environ.get("MSMD_FUSE_LN_DROPOUT_BWD", "1") != "0"
+
+
+def _tag_dropout(y, p, site):
+    if FUSE_LN_DROPOUT_BWD and p > 0.0:
+        y._msmd_drop = (float(p), int(site))
+    return y
+
+
+def _dropped_by_producer(dy, p, site):
+    st = getattr(dy, "_msmd_dropped", None)
+    if st is None or p <= 0.0:
+        return None
+    sp, ssite, ver, t = st
+    if sp == p and ssite == site and ver == dy._version and t.shape == dy.shape and t.dtype == dy.dtype:
+        return t
+    return None
+
+
+def _tag_dropped(res, drop):
+    """res = ops.layernorm_bwd(...): (dx, dg, db[, dx_dropped]) -> (dx, dg, db) with the dropped copy attached to dx."""
+    if drop is None:
+        return res
+    dx, dg, db, dxd = res
+    dx._msmd_dropped = (drop[0], drop[1], dx._version, dxd)
+    return dx, dg, db
 
 
 class LayerNormFn(torch.autograd.Function):
-    """y = LayerNorm(x) * gamma + beta (+ post_add constant row)."""
+    """y = LayerNorm(x) * gamma + beta (+ post_add constant row).  drop = (p, site) of the dropout-Linear that produced x."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, post_add):
+    def forward(ctx, x, gamma, beta, post_add, drop=None):
+        ctx.drop = drop if (drop is not None and x.dtype == torch.bfloat16 and x.shape[-1] % 4 == 0) else None
         x = x.contiguous()
         g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         y = ops.layernorm(x, g, b, post_add=post_add)
@@ -353,16 +395,18 @@ class LayerNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, g = ctx.saved_tensors
         refs = ctx.refs
+        drop = (ctx.drop[0], TrainNoise.state, ctx.drop[1]) if ctx.drop is not None else None
         if (DIRECT_GRAD and refs is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
                 and all(r.grad is not None and r.grad.is_contiguous() and r.grad.dtype == torch.float32 for r in refs)):
             # the kernel accumulates dgamma / dbeta: aim it at the parameters' .grad views of the gradient arena
-            dx, _, _ = ops.layernorm_bwd(dy.contiguous(), x, g, dg_out=refs[0].grad.view(-1), db_out=refs[1].grad.view(-1))
+            dx = _tag_dropped(ops.layernorm_bwd(dy.contiguous(), x, g, dg_out=refs[0].grad.view(-1),
+                                                db_out=refs[1].grad.view(-1), drop=drop), ctx.drop)[0]
             if GRAD_WRITTEN is not None:
                 GRAD_WRITTEN(refs[0])
                 GRAD_WRITTEN(refs[1])
-            return dx, None, None, None
-        dx, dg, db = ops.layernorm_bwd(dy.contiguous(), x, g)
-        return dx, dg, db, None
+            return dx, None, None, None, None
+        dx, dg, db = _tag_dropped(ops.layernorm_bwd(dy.contiguous(), x, g, drop=drop), ctx.drop)
+        return dx, dg, db, None, None
 
 
 class AttentionFn(torch.autograd.Function):
@@ -499,7 +543,9 @@ def linear_dropout(x, w, b, p, residual=None, act=ACT_NONE):
     if not TrainNoise.active or p <= 0.0:
         return linear(x, w, b, act=act, residual=residual)
     if w.shape[0] % 4 == 0:   # mask index needs N % 4 == 0 (every Linear on the path); else compose
-        return LinearFn.apply(x, w, b, residual, act, float(p), TrainNoise.next_site())
+        site = TrainNoise.next_site()
+        y = LinearFn.apply(x, w, b, residual, act, float(p), site)
+        return _tag_dropout(y, float(p), site) if act == ACT_NONE else y
     return dropout(linear(x, w, b, act=act), p, residual)
 
 
@@ -597,8 +643,11 @@ def linear_alias(x, fa, act=ACT_NONE, residual=None):
     return LinearFn.apply(x, fa.w, fa.b, residual, act, 0.0, 0, fa)
 
 
-def layer_norm(x, gamma, beta, post_add=None):
-    return LayerNormFn.apply(x, gamma, beta, post_add)
+def layer_norm(x, gamma, beta, post_add=None, sole_consumer=True):
+    """sole_consumer=False: x also feeds something else (pre-LN blocks: the residual stream), so the LayerNorm's dx is not
+    the whole gradient of the Linear that produced x and the dropped copy would go unused."""
+    drop = getattr(x, "_msmd_drop", None) if (sole_consumer and FUSE_LN_DROPOUT_BWD and TrainNoise.active) else None
+    return LayerNormFn.apply(x, gamma, beta, post_add, drop)
 
 
 def attention(q, k, v, n_heads, scale, mask=None, p_drop=0.0):

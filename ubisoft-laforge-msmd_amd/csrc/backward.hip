@@ -254,9 +254,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd4_kernel(const T* __restrict
                                                              const float* __restrict__ gamma, T* __restrict__ dx,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                              int rows, int cols, float eps, int rows_per_block,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial, T* __restrict__ dx_drop,
+                                                             float p_drop, const unsigned long* __restrict__ rng_state,
+                                                             unsigned site) {
   typedef typename Vec4<T>::type V4;
   __shared__ float sg[4][NCH * 256 + 4], sb[4][NCH * 256 + 4];
+  const unsigned thr = dropout_threshold(p_drop);
+  const float drop_c = 1.0f / (1.0f - p_drop);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float ag[NCH][4], abt[NCH][4], gam[NCH][4];
 #pragma unroll
@@ -327,7 +331,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd4_kernel(const T* __restrict
         ag[i][j] += dyv[i][j] * xv[i][j];
         abt[i][j] += dyv[i][j];
       }
-      if (c < cols) *(V4*)(dx + (long)row * cols + c) = o;
+      if (c < cols) {
+        *(V4*)(dx + (long)row * cols + c) = o;
+        if (dx_drop) {   // the dropped copy the producing Linear's backward wants: mask of msmd_dropout / the GEMM epilogue
+                         // (index = element / 4), applied to the ROUNDED dx as the separate msmd_dropout launch would
+          const Philox4 r = dropout_bits(rng_state, site, (unsigned long)(((long)row * cols + c) >> 2));
+          V4 od;
+          od[0] = from_f32<T>(r.x >= thr ? to_f32(o[0]) * drop_c : 0.f);
+          od[1] = from_f32<T>(r.y >= thr ? to_f32(o[1]) * drop_c : 0.f);
+          od[2] = from_f32<T>(r.z >= thr ? to_f32(o[2]) * drop_c : 0.f);
+          od[3] = from_f32<T>(r.w >= thr ? to_f32(o[3]) * drop_c : 0.f);
+          *(V4*)(dx_drop + (long)row * cols + c) = od;
+        }
+      }
     }
   }
 #pragma unroll
@@ -358,10 +374,14 @@ extern "C" long msmd_layernorm_bwd_workspace(int rows, int cols) {
   return (long)((rows + rpb - 1) / rpb) * 2 * cols * (long)sizeof(float);
 }
 
-extern "C" int msmd_layernorm_bwd(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma,
-                                  float* dbeta, int rows, int cols, float eps, int dtype, void* ws, long ws_bytes,
-                                  msmd_stream_t stream) {
+static int layernorm_bwd_impl(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma,
+                              float* dbeta, int rows, int cols, float eps, int dtype, void* ws, long ws_bytes,
+                              msmd_stream_t stream, void* dx_drop, float p_drop, const unsigned long* rng_state,
+                              unsigned site) {
   if (rows <= 0 || cols <= 0 || cols > 1024) return 1;
+  if (dx_drop && (!(p_drop > 0.f && p_drop < 1.f) || !rng_state || (cols & 3) || ((uintptr_t)dx_drop & 15) ||
+                  ((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)dx & 15)))
+    return 1;   // the dropped copy exists in the 4-wide kernels only
   float* partial = (ws && ws_bytes >= msmd_layernorm_bwd_workspace(rows, cols)) ? (float*)ws : nullptr;
   const int rpb = rows >= 2048 ? 16 : 8;  // rows per workgroup: 1 atomic per column per workgroup
   dim3 grid((rows + rpb - 1) / rpb), block(256);
@@ -370,7 +390,7 @@ extern "C" int msmd_layernorm_bwd(const void* dy, const void* x, const float* ga
   if (cols % 4 == 0 && aligned) {
 #define LN4(T, NCH)                                                                                                  \
   hipLaunchKernelGGL((layernorm_bwd4_kernel<T, NCH>), grid, block, 0, st, (const T*)dy, (const T*)x, gamma, (T*)dx, \
-                     dgamma, dbeta, rows, cols, eps, rpb, partial)
+                     dgamma, dbeta, rows, cols, eps, rpb, partial, (T*)dx_drop, p_drop, rng_state, site)
     if (dtype == MSMD_F32) {
       if (cols <= 256) LN4(float, 1); else if (cols <= 512) LN4(float, 2); else if (cols <= 768) LN4(float, 3); else LN4(float, 4);
     } else {
@@ -399,6 +419,25 @@ extern "C" int msmd_layernorm_bwd(const void* dy, const void* x, const float* ga
     hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((cols + 31) / 32, 2), dim3(256), 0, st, partial, dgamma, dbeta,
                        (int)grid.x, cols);
   MSMD_RETURN_LAST();
+}
+
+extern "C" int msmd_layernorm_bwd(const void* dy, const void* x, const float* gamma, void* dx, float* dgamma,
+                                  float* dbeta, int rows, int cols, float eps, int dtype, void* ws, long ws_bytes,
+                                  msmd_stream_t stream) {
+  return layernorm_bwd_impl(dy, x, gamma, dx, dgamma, dbeta, rows, cols, eps, dtype, ws, ws_bytes, stream, nullptr, 0.f,
+                            nullptr, 0u);
+}
+
+// msmd_layernorm_bwd that ALSO writes dx_drop = dropout_mask(dx) / (1 - p): when the LayerNorm's input is
+// residual + dropout_p(Linear(..)) (every post-LN transformer block), the Linear's backward needs exactly that tensor,
+// and this saves its msmd_dropout launch (mask = Philox(rng_state, site, element / 4), as the forward GEMM epilogue drew it).
+extern "C" int msmd_layernorm_bwd_dropout(const void* dy, const void* x, const float* gamma, void* dx, void* dx_drop,
+                                          float* dgamma, float* dbeta, int rows, int cols, float eps, float p_drop,
+                                          const unsigned long* rng_state, unsigned int site, int dtype, void* ws,
+                                          long ws_bytes, msmd_stream_t stream) {
+  if (!dx_drop) return 1;
+  return layernorm_bwd_impl(dy, x, gamma, dx, dgamma, dbeta, rows, cols, eps, dtype, ws, ws_bytes, stream, dx_drop,
+                            p_drop, rng_state, site);
 }
 
 // ---------------------------------------------------------------------------------------------------

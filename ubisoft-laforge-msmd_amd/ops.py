@@ -1003,9 +1003,10 @@ def act_bwd(dy, z, act):
     return dz
 
 
-def layernorm_bwd(dy, x, gamma, eps=1e-5, dg_out=None, db_out=None):
+def layernorm_bwd(dy, x, gamma, eps=1e-5, dg_out=None, db_out=None, drop=None):
     """dx, dgamma, dbeta.  With dg_out / db_out (fp32, cols) the parameter gradients are ACCUMULATED into those
-    buffers (e.g. the parameters' .grad views) instead of fresh tensors."""
+    buffers (e.g. the parameters' .grad views) instead of fresh tensors.  drop = (p, rng_state, site): the launch also
+    writes dropout_mask(dx) / (1 - p) (what the Linear in front of the LayerNorm wants); returned as a 4th value."""
     lib = _lib.load()
     cols = x.shape[-1]
     rows = x.numel() // cols
@@ -1017,6 +1018,13 @@ def layernorm_bwd(dy, x, gamma, eps=1e-5, dg_out=None, db_out=None):
         dg, db = dg_out, db_out
     nws = lib.msmd_layernorm_bwd_workspace(rows, cols)
     ws = torch.empty(nws, device=x.device, dtype=torch.uint8)
+    if drop is not None:
+        p_drop, rng_state, site = drop
+        dxd = torch.empty_like(x)
+        _lib.check(lib.msmd_layernorm_bwd_dropout(_p(dy), _p(x), _p(gamma), _p(dx), _p(dxd), _p(dg), _p(db), rows, cols, eps,
+                                                  float(p_drop), _p(rng_state), int(site), _dt(x), _p(ws), nws, _stream()),
+                   "msmd_layernorm_bwd_dropout")
+        return dx, dg, db, dxd
     _lib.check(lib.msmd_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(dx), _p(dg), _p(db), rows, cols, eps, _dt(x),
                                       _p(ws), nws, _stream()), "msmd_layernorm_bwd")
     return dx, dg, db

@@ -190,11 +190,11 @@ def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
                                ag.cast_of(g(p + "feed_forward.output_dense.weight")),
                                ag.cast_of(nfa.w) if nfa is not None else None) if t is not None) or None
         if stable:   # HubertEncoderLayerStableLayerNorm
-            a = ag.self_attention(qkv_proj(ag.layer_norm(h, *ln1)), H, (d // H) ** -0.5,
+            a = ag.self_attention(qkv_proj(ag.layer_norm(h, *ln1, sole_consumer=False)), H, (d // H) ** -0.5,
                                   p_drop=c.attention_dropout, prefetch=pf)
             h = ag.linear_dropout(a, g(p + "attention.out_proj.weight"), g(p + "attention.out_proj.bias"),
                                   c.hidden_dropout, residual=h)
-            h = ag.ffn(ag.layer_norm(h, *ln2), g(p + "feed_forward.intermediate_dense.weight"),
+            h = ag.ffn(ag.layer_norm(h, *ln2, sole_consumer=False), g(p + "feed_forward.intermediate_dense.weight"),
                        g(p + "feed_forward.intermediate_dense.bias"), g(p + "feed_forward.output_dense.weight"),
                        g(p + "feed_forward.output_dense.bias"), c.activation_dropout, c.hidden_dropout, residual=h)
         else:
