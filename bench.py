@@ -117,8 +117,8 @@ def roofline_leg(model, b, mode, steps=3, run_step=None):
         step_fn()
     torch.cuda.synchronize()
     trace, ops.GEMM_TRACE = ops.GEMM_TRACE, None
-    flops = ms = big_f = big_ms = 0.0
-    n_launch = big_n = 0
+    flops = ms = big_f = big_ms = tall_f = tall_ms = 0.0
+    n_launch = big_n = tall_n = 0
     kq = 32 if mode == "f16x2" else 64
     for (M, N, K, batch, dt, e0, e1) in trace:
         f = 2.0 * M * N * K * batch
@@ -128,6 +128,13 @@ def roofline_leg(model, b, mode, steps=3, run_step=None):
         n_launch += 1
         tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
         if N > 64 and tiles >= 192 and (mode == "fp32" or K % kq == 0):
+            # csrc/gemm.hip routes tall 16-bit grids (M >= 16000, >= 400 tiles of 192 x 128) to the 192 x 128 sibling of the
+            # 128 x 128 kernel: a different kernel name in the rocprofv3 summary, so it is reported beside, not inside
+            if mode in ("bf16", "fp16") and M >= 16000 and ((M + 191) // 192) * ((N + 127) // 128) >= 400:
+                tall_f += f
+                tall_ms += d
+                tall_n += 1
+                continue
             big_f += f
             big_ms += d
             big_n += 1
@@ -148,6 +155,11 @@ def roofline_leg(model, b, mode, steps=3, run_step=None):
                     "traffic is a constant from this round's --pmc passes in profiles/, not this run")
     if mode == "f16x2":
         out["mfma_issue_frac"] = round(3.0 * achieved / peak, 4)   # the MFMA pipe executes 3 products per algorithmic one
+    if tall_n:
+        ta = tall_f / (tall_ms * 1e-3) / 1e12
+        out["tile_192x128"] = dict(kernel=kernel.replace("128,128", "192,128") + " (csrc/gemm.hip; M >= 16000: the conv stack)",
+                                   launches_per_step=tall_n // steps, achieved=round(ta, 2), frac=round(ta / peak, 4),
+                                   ms_per_step_in_kernel=round(tall_ms / steps, 3), avg_launch_us=round(tall_ms / tall_n * 1e3, 2))
     return out
 
 
