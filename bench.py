@@ -157,6 +157,10 @@ def roofline_leg(model, b, mode, steps=3, run_step=None):
         out["mfma_issue_frac"] = round(3.0 * achieved / peak, 4)   # the MFMA pipe executes 3 products per algorithmic one
     if tall_n:
         ta = tall_f / (tall_ms * 1e-3) / 1e12
+        fam = (big_f + tall_f) / ((big_ms + tall_ms) * 1e-3) / 1e12
+        # both tile shapes of the one kernel template together (what rounds 1-2 reported as the dominant kernel's figure)
+        out["both_tiles"] = dict(achieved=round(fam, 2), frac=round(fam / peak, 4), launches_per_step=(big_n + tall_n) // steps,
+                                 ms_per_step_in_kernel=round((big_ms + tall_ms) / steps, 3))
         out["tile_192x128"] = dict(kernel=kernel.replace("128,128", "192,128") + " (csrc/gemm.hip; M >= 16000: the conv stack)",
                                    launches_per_step=tall_n // steps, achieved=round(ta, 2), frac=round(ta / peak, 4),
                                    ms_per_step_in_kernel=round(tall_ms / steps, 3), avg_launch_us=round(tall_ms / tall_n * 1e3, 2))
