@@ -403,3 +403,36 @@ def test_layernorm_backward_hands_the_dropped_gradient_to_the_linear_in_front_of
     assert n2 == 1            # the out-projection's gradient is a sum now: its own dropout launch; the FFN still takes the copy
     for i, (u, v) in enumerate(zip(ref2, got2)):
         assert torch.equal(u, v), i
+
+
+@pytest.mark.gpu
+def test_conv3_node_matches_the_shifted_view_linear_it_replaces(monkeypatch):
+    """train_graph.Conv3Fn (padded copy + windowed GEMM; windowed data-gradient GEMM; TN GEMM over the windows) against the
+    pad + cat-of-shifted-views + Linear path, and both against torch's conv1d autograd in fp32."""
+    import math
+    from msmd_amd import ops, train_graph as tg
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, T, C, Co = 3, 100, 512, 256
+    x0 = torch.randn(B, T, C, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(Co, C, 3, generator=g) / math.sqrt(3 * C)).to(DEV).requires_grad_(True)
+    b = (torch.randn(Co, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    dy = torch.randn(B, T, Co, generator=g).to(DEV, torch.bfloat16)
+    res = {}
+    for fn in (True, False):
+        monkeypatch.setattr(tg, "USE_CONV3_FN", fn)
+        x = x0.clone().requires_grad_(True)
+        w.grad = b.grad = None
+        y = tg._conv3(x, w, b, ops.ACT_NONE)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        res[fn] = (y.detach().float(), x.grad.float(), w.grad.clone(), b.grad.clone())
+    xr = x0.float().requires_grad_(True)
+    wr, br = w.detach().to(torch.bfloat16).float().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    yr = torch.nn.functional.conv1d(xr.transpose(1, 2), wr, br, padding=1).transpose(1, 2)
+    yr.backward(dy.float())
+    ref = (yr.detach(), xr.grad, wr.grad, br.grad)
+    assert torch.equal(res[True][0], res[False][0])                    # same K order, same kernel: bit-equal forward
+    for name, a, c, r in zip(("y", "dx", "dw", "db"), res[True], res[False], ref):
+        scale = float(r.abs().max())
+        assert float((a - r).abs().max()) <= 1e-2 * scale, (name, float((a - r).abs().max()), scale)
+        assert float((a - c).abs().max()) <= 1e-2 * scale, (name, "vs shifted views")

@@ -15,6 +15,8 @@ feature extractor runs the no-grad inference kernels (reference model.py:97: `_f
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -23,6 +25,9 @@ from . import ops
 from .utils.model_common import pad_audio_plan
 from .utils.wav2vec2 import compute_mask_indices, compute_mask_indices_hf
 from .utils.wav2vec2 import CONV_KERNEL, CONV_STRIDE  # noqa: F401
+
+
+USE_CONV3_FN = os.environ.get("MSMD_CONV3_FN", "1") != "0"
 
 
 def _p(tree, name):
@@ -379,8 +384,46 @@ def denoiser_train(net, motion_noisy, audio_feat, person_feat, static_style_feat
 
 
 # ----------------------------------------------------------------------------- style encoder
+class Conv3Fn(torch.autograd.Function):
+    """y = Conv1d(k=3, padding=1)(x) + b on a channels-last (B, T, C) tensor with the PACKED weight wp (Cout, 3 C), K index =
+    tap * C + c (style_encoder.py:137-140 convs).  Forward: one zero-padded copy + ONE windowed GEMM (msmd_gemm reads the
+    overlapping 3-frame windows in place: no (B, T, 3 C) im2col tensor).  Backward: data gradient = the same windowed GEMM on
+    the padded upstream gradient with tap-flipped, (ci <-> co)-swapped weights; weight + bias gradient = one TN GEMM that reads
+    the windows of the padded input in place.  Replaces pad + cat of three shifted views + Linear, whose backward alone was
+    3 slice-backwards (a fill and a strided copy each), 2 accumulations and the pad's backward per conv."""
+
+    @staticmethod
+    def forward(ctx, x, wp, b):
+        B, T, C = x.shape
+        xp = ops.group_pad(x.contiguous(), 1, 1).reshape(B, T + 2, C)
+        y = ops.conv1d_cl(xp, wp.detach().to(x.dtype).contiguous(), b.detach().float().contiguous(), kernel=3, stride=1)
+        ctx.save_for_backward(xp, wp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, wp = ctx.saved_tensors
+        B, Tp, C = xp.shape
+        T, Co, dt = Tp - 2, wp.shape[0], dy.dtype
+        dy = dy.contiguous()
+        dx = dwp = db = None
+        if ctx.needs_input_grad[0]:
+            # dx[s] = sum_{k', co} dyp[s + k'][co] * wp[co][2 - k'][ci],  dyp = dy padded by one frame on each side
+            w2 = wp.detach().reshape(Co, 3, C).flip(1).permute(2, 1, 0).reshape(C, 3 * Co).to(dt).contiguous()
+            dyp = ops.group_pad(dy, 1, 1).reshape(B, T + 2, Co)
+            dx = ops.conv1d_cl(dyp, w2, None, kernel=3, stride=1)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dwp, db = ops.gemm_tn(dy.reshape(B * T, Co), xp, want_colsum=True, M=B * T, N=Co, K=3 * C, lda=Co, ldb=C,
+                                  b_rows_per_window=T, b_window_stride=(T + 2) * C)
+        return dx, dwp, db
+
+
 def _conv3(x, w, b, act):
-    """Conv1d(k=3, padding=1) on channels-last x as a linear over the 3-frame window (torch.cat of shifted views)."""
+    """Conv1d(k=3, padding=1) on channels-last x: Conv3Fn (windowed GEMMs) for the 16-bit 64-aligned widths, else a linear over
+    the 3-frame window (torch.cat of shifted views)."""
+    if (act == ops.ACT_NONE and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 64 == 0 and w.shape[0] % 8 == 0
+            and b is not None and USE_CONV3_FN):
+        return Conv3Fn.apply(x, w.permute(0, 2, 1).reshape(w.shape[0], -1), b)
     xp = torch.nn.functional.pad(x, (0, 0, 1, 1))
     win = torch.cat([xp[:, :-2], xp[:, 1:-1], xp[:, 2:]], dim=-1)
     return ag.linear(win.contiguous(), w.permute(0, 2, 1).reshape(w.shape[0], -1), b, act=act)
