@@ -436,3 +436,41 @@ def test_conv3_node_matches_the_shifted_view_linear_it_replaces(monkeypatch):
         scale = float(r.abs().max())
         assert float((a - r).abs().max()) <= 1e-2 * scale, (name, float((a - r).abs().max()), scale)
         assert float((a - c).abs().max()) <= 1e-2 * scale, (name, "vs shifted views")
+
+
+@pytest.mark.gpu
+def test_junction_hands_the_residual_gradient_to_the_projection_gemm(monkeypatch):
+    """x -> QKV projection -> attention -> out-projection(+ x): with autograd.Junction the gradient of x comes out of the QKV
+    node's data-gradient GEMM (the residual gradient is its epilogue operand) instead of an accumulation kernel: same
+    gradients as the plain graph up to one 16-bit rounding, parameters' gradients bit-equal."""
+    import math
+    from msmd_amd import autograd as ag
+    g = torch.Generator(device="cpu").manual_seed(21)
+    B, T, d, H = 4, 60, 256, 4
+    x0 = torch.randn(B, T, d, generator=g).to(DEV, torch.bfloat16)
+    wqkv = (torch.randn(3 * d, d, generator=g) / math.sqrt(d)).to(DEV).requires_grad_(True)
+    bqkv = (torch.randn(3 * d, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    wo = (torch.randn(d, d, generator=g) / math.sqrt(d)).to(DEV).requires_grad_(True)
+    bo = (torch.randn(d, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    dy = torch.randn(B, T, d, generator=g).to(DEV, torch.bfloat16)
+    ag.TrainNoise.state = torch.tensor([5, 9], dtype=torch.int64, device=DEV)
+    out = {}
+    for use in (False, True):
+        monkeypatch.setattr(ag, "USE_JUNCTIONS", use)
+        ag.TrainNoise.active, ag.TrainNoise.site = True, 0
+        x = x0.clone().requires_grad_(True)
+        for t in (wqkv, bqkv, wo, bo):
+            t.grad = None
+        J = ag.Junction()
+        a = ag.self_attention(ag.linear(x, wqkv, bqkv, junction_in=J), H, 0.125, p_drop=0.1)
+        y = ag.linear_dropout(a, wo, bo, 0.1, residual=x, junction_out=J)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        ag.TrainNoise.active = False
+        assert J.paired == use and J.pending is None
+        out[use] = [y.detach().float(), x.grad.float()] + [t.grad.clone() for t in (wqkv, bqkv, wo, bo)]
+    assert torch.equal(out[False][0], out[True][0])
+    for u, v in zip(out[False][2:], out[True][2:]):
+        assert torch.equal(u, v)
+    scale = float(out[False][1].abs().max())
+    assert float((out[False][1] - out[True][1]).abs().max()) <= 1e-2 * scale

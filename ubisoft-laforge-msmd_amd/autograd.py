@@ -221,18 +221,39 @@ def _param_grads(dz2, xin, w, b_ref, has_b, K, need_w, need_b, alias):
     return dw, db
 
 
+class Junction:
+    """x feeds a Linear (the `jin` node: a block's QKV / Q projection) AND is the residual of a later Linear (the `jout`
+    node: the block's output projection).  Autograd would add the two gradients of x with an elementwise kernel per block;
+    with a Junction the jout node hands its residual gradient over instead of returning it, and the jin node passes it to
+    its data-gradient GEMM as the epilogue's residual operand.  Legal only when the jout node's input depends on the jin
+    node's output (then its backward runs first); the jin node raises if that was not so.  One Junction per block and pass."""
+    __slots__ = ("armed", "paired", "pending", "shape")
+
+    def __init__(self):
+        self.armed = self.paired = False
+        self.pending = self.shape = None
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x @ w.T + b) + residual   (x: (..., K) compute dtype; w (N, K), b (N) fp32 master parameters)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, act, p_drop=0.0, site=0, alias=None):
+    def forward(ctx, x, w, b, residual, act, p_drop=0.0, site=0, alias=None, jin=None, jout=None):
         """y = dropout_p(act(x W^T + b)) + residual in ONE GEMM launch: the epilogue also writes the pre-activation z
         (needed by the backward) when there is an activation, and applies the Philox keep mask.  alias (FusedAlias):
-        w / b are arena views without autograd history; the backward adds dW / db into alias.wgrad / alias.bgrad."""
+        w / b are arena views without autograd history; the backward adds dW / db into alias.wgrad / alias.bgrad.
+        jin / jout (Junction): see Junction -- the residual gradient of the jout node rides into the jin node's
+        data-gradient GEMM instead of an autograd accumulation kernel."""
         ctx.alias = alias
         dtype = x.dtype
         wc, wct = CACHE.get(w, dtype)
         K = w.shape[1]
+        ctx.jin = ctx.jout = None
+        if jin is not None and ctx.needs_input_grad[0] and wc.shape[1] == K and x.dtype in (torch.bfloat16, torch.float16):
+            ctx.jin, jin.armed, jin.shape = jin, True, tuple(x.shape)
+        if (jout is not None and jout.armed and residual is not None and ctx.needs_input_grad[3]
+                and tuple(residual.shape) == jout.shape and residual.dtype == x.dtype):
+            ctx.jout, jout.paired = jout, True
         xin = x if wc.shape[1] == K else ops.pad_cols(x.contiguous(), wc.shape[1], dtype)
         xin = xin.contiguous()
         bf = b.detach().float().contiguous() if b is not None else None
@@ -270,11 +291,18 @@ class LinearFn(torch.autograd.Function):
         wc, wct = CACHE.get(w, dtype)
         if ctx.needs_input_grad[0]:
             dzp = dz2 if wct.shape[1] == N else ops.pad_cols(dz2, wct.shape[1], dtype)
-            dx = ops.gemm(dzp, wct).reshape(*xin.shape[:-1], wct.shape[0])
+            jres = None
+            if ctx.jin is not None and ctx.jin.paired:
+                if ctx.jin.pending is None:   # the provider is downstream of this node in every legal use: it has run
+                    raise RuntimeError("Junction: the residual node's backward has not handed its gradient over")
+                jres, ctx.jin.pending = ctx.jin.pending.reshape(M, -1), None
+            dx = ops.gemm(dzp, wct, residual=jres).reshape(*xin.shape[:-1], wct.shape[0])
         dw, db = _param_grads(dz2, xin, w, ctx.b_ref, ctx.has_b, ctx.K, ctx.needs_input_grad[1], ctx.needs_input_grad[2],
                               ctx.alias)
         dres = dy if ctx.has_r and ctx.needs_input_grad[3] else None
-        return dx, dw, db, dres, None, None, None, None
+        if ctx.jout is not None and dres is not None:
+            ctx.jout.pending, dres = dres, None
+        return dx, dw, db, dres, None, None, None, None, None, None
 
 
 class FFNFn(torch.autograd.Function):
@@ -351,6 +379,7 @@ def ffn(x, w1, b1, w2, b2, p_act, p_out, residual=None, act=ops.ACT_GELU):
 #             the only consumer, the engine hands over a sum (another tensor, or this one after an in-place add_ that
 #             bumps its version) and the node falls back to its own msmd_dropout launch.
 FUSE_LN_DROPOUT_BWD = os.environ.get("MSMD_FUSE_LN_DROPOUT_BWD", "1") != "0"
+USE_JUNCTIONS = os.environ.get("MSMD_JUNCTIONS", "1") != "0"
 
 
 def _tag_dropout(y, p, site):
@@ -538,13 +567,13 @@ def dropout(x, p, residual=None):
     return DropoutFn.apply(x, residual, float(p), TrainNoise.next_site())
 
 
-def linear_dropout(x, w, b, p, residual=None, act=ACT_NONE):
+def linear_dropout(x, w, b, p, residual=None, act=ACT_NONE, junction_out=None):
     """dropout_p(act(x W^T + b)) + residual: eval mode keeps the residual fused in the GEMM epilogue."""
     if not TrainNoise.active or p <= 0.0:
-        return linear(x, w, b, act=act, residual=residual)
+        return linear(x, w, b, act=act, residual=residual, junction_out=junction_out)
     if w.shape[0] % 4 == 0:   # mask index needs N % 4 == 0 (every Linear on the path); else compose
         site = TrainNoise.next_site()
-        y = LinearFn.apply(x, w, b, residual, act, float(p), site)
+        y = LinearFn.apply(x, w, b, residual, act, float(p), site, None, None, junction_out if USE_JUNCTIONS else None)
         return _tag_dropout(y, float(p), site) if act == ACT_NONE else y
     return dropout(linear(x, w, b, act=act), p, residual)
 
@@ -634,13 +663,14 @@ def cross_attention(q, kv, n_heads, scale, mask=None, p_drop=0.0):
     return attention(q, kv[..., :d], kv[..., d:], n_heads, scale, mask, p_drop)
 
 
-def linear(x, w, b=None, act=ACT_NONE, residual=None):
-    return LinearFn.apply(x, w, b, residual, act)
+def linear(x, w, b=None, act=ACT_NONE, residual=None, junction_in=None, junction_out=None):
+    return LinearFn.apply(x, w, b, residual, act, 0.0, 0, None, junction_in if USE_JUNCTIONS else None,
+                          junction_out if USE_JUNCTIONS else None)
 
 
-def linear_alias(x, fa, act=ACT_NONE, residual=None):
+def linear_alias(x, fa, act=ACT_NONE, residual=None, junction_in=None):
     """linear() on a FusedAlias operand (arena views; gradients go straight into the gradient arena)."""
-    return LinearFn.apply(x, fa.w, fa.b, residual, act, 0.0, 0, fa)
+    return LinearFn.apply(x, fa.w, fa.b, residual, act, 0.0, 0, fa, junction_in if USE_JUNCTIONS else None, None)
 
 
 def layer_norm(x, gamma, beta, post_add=None, sole_consumer=True):

@@ -182,11 +182,12 @@ def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
         ln1 = (g(p + "layer_norm.weight"), g(p + "layer_norm.bias"))
         ln2 = (g(p + "final_layer_norm.weight"), g(p + "final_layer_norm.bias"))
         fa = ag.FUSED.get(("enc_qkv", id(enc), n)) if ag.DIRECT_GRAD else None
+        J = ag.Junction()       # h feeds the QKV projection and is the out-projection's residual (post-LN branch)
         if fa is not None:      # Q | K | V sit next to each other in the arenas: the fused operand is a view
-            qkv_proj = lambda t: ag.linear_alias(t, fa)
+            qkv_proj = lambda t, j=None: ag.linear_alias(t, fa, junction_in=j)
         else:
             wqkv, bqkv = torch.cat([wq, wk, wv], 0), torch.cat([bq, bk, bv], 0)
-            qkv_proj = lambda t: ag.linear(t, wqkv, bqkv)
+            qkv_proj = lambda t, j=None: ag.linear(t, wqkv, bqkv, junction_in=j)
         # the attention launch also pulls the layer's remaining weight casts (and the next layer's QKV) through the
         # memory-side cache: the GEMMs behind it would otherwise read them from HBM inside their K loops
         nfa = ag.FUSED.get(("enc_qkv", id(enc), n + 1)) if ag.DIRECT_GRAD else None
@@ -203,9 +204,10 @@ def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
                        g(p + "feed_forward.intermediate_dense.bias"), g(p + "feed_forward.output_dense.weight"),
                        g(p + "feed_forward.output_dense.bias"), c.activation_dropout, c.hidden_dropout, residual=h)
         else:
-            a = ag.self_attention(qkv_proj(h), H, (d // H) ** -0.5, p_drop=c.attention_dropout, prefetch=pf)
+            a = ag.self_attention(qkv_proj(h, J), H, (d // H) ** -0.5, p_drop=c.attention_dropout, prefetch=pf)
             h = ag.layer_norm(ag.linear_dropout(a, g(p + "attention.out_proj.weight"),
-                                                g(p + "attention.out_proj.bias"), c.hidden_dropout, residual=h), *ln1)
+                                                g(p + "attention.out_proj.bias"), c.hidden_dropout, residual=h,
+                                                junction_out=J), *ln1)
             # feed-forward block as one autograd node: its backward's middle (linear2's data gradient + dropout + GELU
             # backward) is one launch
             h = ag.layer_norm(ag.ffn(h, g(p + "feed_forward.intermediate_dense.weight"),
@@ -346,21 +348,22 @@ def denoiser_train(net, motion_noisy, audio_feat, person_feat, static_style_feat
     pd = 0.1  # nn.TransformerDecoderLayer default dropout (model.py:874-877 passes none): dropout1-3, FFN, attention
     for n in range(net.n_layers):
         p = f"transformer.layers.{n}."
-        qkv = ag.linear(x, g(p + "self_attn.in_proj_weight"), g(p + "self_attn.in_proj_bias"))
+        J1, J2 = ag.Junction(), ag.Junction()   # x -> (QKV | Q projection, the block's residual): one gradient, no add
+        qkv = ag.linear(x, g(p + "self_attn.in_proj_weight"), g(p + "self_attn.in_proj_bias"), junction_in=J1)
         a = ag.self_attention(qkv, H, scale, p_drop=pd)
         x = ag.layer_norm(ag.linear_dropout(a, g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias"), pd,
-                                            residual=x), g(p + "norm1.weight"), g(p + "norm1.bias"))
+                                            residual=x, junction_out=J1), g(p + "norm1.weight"), g(p + "norm1.bias"))
         fq = ag.FUSED.get(("dec_q", id(net), n)) if ag.DIRECT_GRAD else None
         if fq is not None:      # rows of in_proj_weight as arena views: no slice nodes, gradients straight into the arena
-            q = ag.linear_alias(x, fq)
+            q = ag.linear_alias(x, fq, junction_in=J2)
             kv = ag.linear_alias(mem, ag.FUSED[("dec_kv", id(net), n)])
         else:
             w, b = g(p + "multihead_attn.in_proj_weight"), g(p + "multihead_attn.in_proj_bias")
-            q = ag.linear(x, w[:d], b[:d])
+            q = ag.linear(x, w[:d], b[:d], junction_in=J2)
             kv = ag.linear(mem, w[d:], b[d:])
         cattn = ag.cross_attention(q, kv, H, scale, mask, p_drop=pd)
         x = ag.layer_norm(ag.linear_dropout(cattn, g(p + "multihead_attn.out_proj.weight"),
-                                            g(p + "multihead_attn.out_proj.bias"), pd, residual=x),
+                                            g(p + "multihead_attn.out_proj.bias"), pd, residual=x, junction_out=J2),
                           g(p + "norm2.weight"), g(p + "norm2.bias"))
         x = ag.layer_norm(ag.ffn(x, g(p + "linear1.weight"), g(p + "linear1.bias"), g(p + "linear2.weight"),
                                  g(p + "linear2.bias"), pd, pd, residual=x),
