@@ -25,6 +25,7 @@ torch.cuda.synchronize()
 counts = collections.Counter()
 bytes_ = collections.Counter()
 by_line = collections.Counter()
+slow = collections.Counter()      # ops with a non-contiguous (s) or broadcast operand: the generic strided elementwise kernels
 
 
 class Count(TorchDispatchMode):
@@ -44,6 +45,9 @@ class Count(TorchDispatchMode):
                 where = f"{os.path.basename(fr.filename)}:{fr.lineno}"
                 break
         by_line[(where, name)] += 1
+        ts = [a for a in list(args) + list((kwargs or {}).values()) if torch.is_tensor(a)]
+        if any(not a.is_contiguous() for a in ts) or len({tuple(a.shape) for a in ts if a.dim() > 0}) > 1:
+            slow[(where, name, " ".join(str(tuple(a.shape)) + ("" if a.is_contiguous() else "s") for a in ts))] += 1
         if t is not None:
             bytes_[(name, shp)] += t.numel() * t.element_size()
         return out
@@ -61,6 +65,9 @@ print("by op:", by_name.most_common(25))
 print("by calling line of this package (top 60):")
 for (w, n), c in by_line.most_common(60):
     print(f"  {w:44s} {n:28s} x{c}")
+print(f"ops with a strided (s) or broadcast operand: {sum(slow.values())}")
+for (w, n, shp), c in slow.most_common(70):
+    print(f"  {w:44s} {n:24s} x{c:3d}  {shp[:90]}")
 print("largest by bytes written:")
 for (n, s), b in bytes_.most_common(40):
     print(f"  {n:28s} {str(s):28s} x{counts[(n, s)]:4d}  {b / 1e6:9.1f} MB")
