@@ -132,6 +132,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AbArgs p) {
     __syncthreads();
 
     // ---------------- phase A: this wave's 16 q rows against all keys
+    // a wave whose 16 rows all lie past Tq (the ragged last q tile: T = 200 -> 8 live rows of 64) only zeroes its rows of
+    // the P / dS images; phase B skips the 32-row k-steps that hold no live row
+    const int live_rows = p.Tq - q0;
+    if (16 * w >= live_rows) {
+      if (16 * w < ((live_rows + 31) & ~31)) {   // rows of a k-step phase B still reads
+#pragma unroll
+        for (int f = 0; f < NKF; ++f) {
+          *(u32x2*)(sP + (16 * w + fr) * RS + f * 32 + fq * 8) = u32x2{0u, 0u};
+          *(u32x2*)(sdS + (16 * w + fr) * RS + f * 32 + fq * 8) = u32x2{0u, 0u};
+        }
+      }
+    } else {
     const int qrow = 16 * w + fr;      // tile-local q of this lane (operand column)
     const int qglob = q0 + qrow;
     bf16x8 qf[2], dof[2];
@@ -283,6 +295,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AbArgs p) {
         *(bf16x4*)(dst + 16 * d + 4 * fq) = o;
       }
     }
+    }
     __syncthreads();  // P / dS images complete
     if (AHEAD && qt + 1 < nqt) {   // issued HERE: phase B holds few registers, and its MFMAs cover the loads' latency
       rq.load(Qg + (long)(q0 + 64) * p.q_ts, p.q_ts, p.Tq - q0 - 64, tid);
@@ -292,6 +305,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AbArgs p) {
     // ---------------- phase B: dV^T[d][key] += dO^T[d][q] P[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key]
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      if (32 * ks >= live_rows) continue;   // no live q row in this k-step (wave-uniform)
       const int r0 = 32 * ks + 4 * fq + qp, r1 = r0 + 16;  // tile-local q rows this lane addresses
       bf16x8 ado[4], aq[4];
 #pragma unroll
