@@ -474,3 +474,46 @@ def test_junction_hands_the_residual_gradient_to_the_projection_gemm(monkeypatch
         assert torch.equal(u, v)
     scale = float(out[False][1].abs().max())
     assert float((out[False][1] - out[True][1]).abs().max()) <= 1e-2 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Tq,Tk,masked", [(200, 200, False), (250, 250, False), (111, 110, True), (300, 140, False)])
+def test_attention_dropout_mask_is_the_same_in_forward_and_backward_at_long_sequences(Tq, Tk, masked):
+    """The keep mask of attention-probability dropout at the lengths the training step runs (whole-sequence forward kernel with
+    13 / 17 key fragments, one or two workgroups per head; backward with 7 / 13 / 16): with V = one-hot rows the forward output IS
+    P_drop[q, key_c], with dO = ones on ONE query row the backward's dV IS P_drop[q*, :] -- the two must agree, zeros included."""
+    from msmd_amd import ops
+    B, H, pd, scale = 2, 3, 0.3, 0.125
+    d = H * 64
+    g = torch.Generator(device="cpu").manual_seed(Tq + Tk)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    q, k = mk(B, Tq, d), mk(B, Tk, d)
+    m8 = None
+    if masked:
+        m = torch.rand(Tq, Tk, generator=g) < 0.3
+        m[:, 0] = False
+        m8 = m.to(torch.uint8).contiguous().to(DEV)
+    keys = torch.arange(64) * (Tk - 1) // 63                     # 64 distinct keys spread over the row (Tk >= 64)
+    v = torch.zeros(B, Tk, d, device=DEV, dtype=torch.bfloat16)
+    for h in range(H):
+        v[:, keys, h * 64 + torch.arange(64)] = 1.0
+    state = torch.tensor([31, 2], dtype=torch.int64, device=DEV)
+    o = ops.attention(q, k, v, H, scale, m8, p_drop=pd, rng_state=state, site=5).float()       # o[b, q, h*64+c] = P_drop[q, keys[c]]
+    o0 = ops.attention(q, k, v, H, scale, m8).float()
+    for qs in (0, Tq // 2 + 3, Tq - 1):
+        do = torch.zeros(B, Tq, d, device=DEV, dtype=torch.bfloat16)
+        do[:, qs] = 1.0
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(k)
+        ops.attention_bwd(q, k, v, do, dq, dk, dv, H, scale, m8, pd, state, 5)
+        torch.cuda.synchronize()
+        for h in range(H):
+            fwd = o[:, qs, h * 64:(h + 1) * 64]                                  # (B, 64): P_drop[qs, keys[c]]
+            bwd = dv[:, keys.to(DEV), h * 64].float()                           # (B, 64): P_drop[qs, keys[c]] (any column)
+            p0 = o0[:, qs, h * 64:(h + 1) * 64]
+            sure = p0 > 2e-3                                                     # clear of bf16 underflow
+            assert torch.equal((fwd > 0)[sure], (bwd > 0)[sure]), (qs, h)
+            assert float((fwd - bwd).abs().max()) <= 0.03 * float(fwd.abs().max()) + 1e-4
+            kept = (fwd > 0)[sure].float().mean()
+            assert float((fwd[sure & (fwd > 0)] / p0[sure & (fwd > 0)] - 1 / (1 - pd)).abs().max()) < 0.05
+    rate = ((o > 0) & (o0 > 2e-3)).float().sum() / (o0 > 2e-3).float().sum()
+    assert abs(float(rate) - (1 - pd)) < 0.02, float(rate)
