@@ -221,6 +221,19 @@ def _param_grads(dz2, xin, w, b_ref, has_b, K, need_w, need_b, alias):
     return dw, db
 
 
+# Grad mode of the CALLER of the node about to run (inside Function.forward grad mode is always off): the wrappers below
+# set it right before .apply, and the forwards skip tensors only a backward would read (pre-activations) when it is off.
+_GRAD_ON = [True]
+
+
+def _apply(fn, *args):
+    _GRAD_ON[0] = torch.is_grad_enabled()
+    try:
+        return fn.apply(*args)
+    finally:
+        _GRAD_ON[0] = True
+
+
 class Junction:
     """x feeds a Linear (the `jin` node: a block's QKV / Q projection) AND is the residual of a later Linear (the `jout`
     node: the block's output projection).  Autograd would add the two gradients of x with an elementwise kernel per block;
@@ -259,7 +272,7 @@ class LinearFn(torch.autograd.Function):
         bf = b.detach().float().contiguous() if b is not None else None
         res = residual.contiguous() if residual is not None else None
         z = None
-        if act != ACT_NONE:
+        if act != ACT_NONE and _GRAD_ON[0]:   # no-grad passes (the reference's extra encoder pass) keep no z
             z = torch.empty(*xin.shape[:-1], w.shape[0], device=x.device, dtype=dtype)
         y = ops.gemm(xin, wc, bf, res, act, z_out=z, p_drop=p_drop, rng_state=TrainNoise.state if p_drop > 0 else None,
                      site=site)
@@ -320,7 +333,7 @@ class FFNFn(torch.autograd.Function):
         w1c, _ = CACHE.get(w1, dtype)
         w2c, _ = CACHE.get(w2, dtype)
         xin = x.contiguous()
-        z1 = torch.empty(*xin.shape[:-1], w1.shape[0], device=x.device, dtype=dtype)
+        z1 = torch.empty(*xin.shape[:-1], w1.shape[0], device=x.device, dtype=dtype) if _GRAD_ON[0] else None
         f = ops.gemm(xin, w1c, b1.detach().float().contiguous(), None, act, z_out=z1, p_drop=p1,
                      rng_state=TrainNoise.state if p1 > 0 else None, site=site1)
         res = xin if residual_is_x else (residual.contiguous() if residual is not None else None)
@@ -366,8 +379,8 @@ def ffn(x, w1, b1, w2, b2, p_act, p_out, residual=None, act=ops.ACT_GELU):
     s1 = TrainNoise.next_site() if p_act > 0 else 0
     s2 = TrainNoise.next_site() if p_out > 0 else 0
     if residual is x:       # x + FFN(x): one gradient for x out of the node (the sum is made in a GEMM epilogue)
-        return _tag_dropout(FFNFn.apply(x, w1, b1, w2, b2, None, act, float(p_act), s1, float(p_out), s2, True), float(p_out), s2)
-    return _tag_dropout(FFNFn.apply(x, w1, b1, w2, b2, residual, act, float(p_act), s1, float(p_out), s2), float(p_out), s2)
+        return _tag_dropout(_apply(FFNFn, x, w1, b1, w2, b2, None, act, float(p_act), s1, float(p_out), s2, True), float(p_out), s2)
+    return _tag_dropout(_apply(FFNFn, x, w1, b1, w2, b2, residual, act, float(p_act), s1, float(p_out), s2), float(p_out), s2)
 
 
 # Post-LN blocks: h = LayerNorm(residual + dropout_p(Linear(..))).  The Linear's backward needs dropout_mask(dy) with dy = the
@@ -573,7 +586,7 @@ def linear_dropout(x, w, b, p, residual=None, act=ACT_NONE, junction_out=None):
         return linear(x, w, b, act=act, residual=residual, junction_out=junction_out)
     if w.shape[0] % 4 == 0:   # mask index needs N % 4 == 0 (every Linear on the path); else compose
         site = TrainNoise.next_site()
-        y = LinearFn.apply(x, w, b, residual, act, float(p), site, None, None, junction_out if USE_JUNCTIONS else None)
+        y = _apply(LinearFn, x, w, b, residual, act, float(p), site, None, None, junction_out if USE_JUNCTIONS else None)
         return _tag_dropout(y, float(p), site) if act == ACT_NONE else y
     return dropout(linear(x, w, b, act=act), p, residual)
 
@@ -664,13 +677,13 @@ def cross_attention(q, kv, n_heads, scale, mask=None, p_drop=0.0):
 
 
 def linear(x, w, b=None, act=ACT_NONE, residual=None, junction_in=None, junction_out=None):
-    return LinearFn.apply(x, w, b, residual, act, 0.0, 0, None, junction_in if USE_JUNCTIONS else None,
-                          junction_out if USE_JUNCTIONS else None)
+    return _apply(LinearFn, x, w, b, residual, act, 0.0, 0, None, junction_in if USE_JUNCTIONS else None,
+                  junction_out if USE_JUNCTIONS else None)
 
 
 def linear_alias(x, fa, act=ACT_NONE, residual=None, junction_in=None):
     """linear() on a FusedAlias operand (arena views; gradients go straight into the gradient arena)."""
-    return LinearFn.apply(x, fa.w, fa.b, residual, act, 0.0, 0, fa, junction_in if USE_JUNCTIONS else None, None)
+    return _apply(LinearFn, x, fa.w, fa.b, residual, act, 0.0, 0, fa, junction_in if USE_JUNCTIONS else None, None)
 
 
 def layer_norm(x, gamma, beta, post_add=None, sole_consumer=True):
