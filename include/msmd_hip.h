@@ -225,7 +225,9 @@ int msmd_person_query_attention_ln(const void* x, long x_seq_stride, const void*
 
 /* Training-mode attention forward: as msmd_attention with attention-probability dropout p_drop (HF
  * attention_dropout, nn.MultiheadAttention(dropout=0.1) inside the decoder / encoder layers).  The keep mask is
- * Philox4x32-10(seed = rng_state[0], step = rng_state[1], site, (b, h, q, key / 4)); rng_state is DEVICE memory so a
+ * Philox4x32-10(seed = rng_state[0], step = rng_state[1], site, counter = ((b H + h) Tq + q) * 128 + 4 * (key / 32) + (key / 4) % 4):
+ * one block = the 16-bit draws of the 8 keys {16 f + 4 fq + e, f in a fragment pair} (even fragment: low halves of the 4 words, odd:
+ * high halves); keep <=> draw >= floor(65536 p).  msmd_attention_bwd regenerates the same mask.  rng_state is DEVICE memory so a
  * captured hipGraph draws fresh masks on every replay once the host side advances the step.  Tk <= 512. */
 int msmd_attention_dropout(const void* Q, const void* K, const void* V, void* O, int B, int H, int Tq, int Tk,
                            long q_bstride, long q_tstride, long k_bstride, long k_tstride, long v_bstride,
