@@ -517,3 +517,21 @@ def test_attention_dropout_mask_is_the_same_in_forward_and_backward_at_long_sequ
             assert float((fwd[sure & (fwd > 0)] / p0[sure & (fwd > 0)] - 1 / (1 - pd)).abs().max()) < 0.05
     rate = ((o > 0) & (o0 > 2e-3)).float().sum() / (o0 > 2e-3).float().sum()
     assert abs(float(rate) - (1 - pd)) < 0.02, float(rate)
+
+
+@pytest.mark.gpu
+def test_layerdrop_select_node_matches_torch_where():
+    from msmd_amd import train_graph as tg
+    g = torch.Generator(device="cpu").manual_seed(2)
+    a0 = torch.randn(4, 9, 64, generator=g).to(DEV, torch.bfloat16)
+    b0 = torch.randn(4, 9, 64, generator=g).to(DEV, torch.bfloat16)
+    dy = torch.randn(4, 9, 64, generator=g).to(DEV, torch.bfloat16)
+    for flag in (torch.tensor(True, device=DEV), torch.tensor(False, device=DEV)):
+        res = []
+        for fn in (lambda f, a, b: tg.LayerDropSelectFn.apply(f, a, b), torch.where):
+            a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            y = fn(flag, a * 2, b * 3)
+            y.backward(dy)
+            res.append((y.detach(), a.grad, b.grad))
+        for u, v in zip(*res):
+            assert torch.equal(u, v)

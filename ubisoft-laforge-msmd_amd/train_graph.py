@@ -28,6 +28,7 @@ from .utils.wav2vec2 import CONV_KERNEL, CONV_STRIDE  # noqa: F401
 
 
 USE_CONV3_FN = os.environ.get("MSMD_CONV3_FN", "1") != "0"
+USE_LAYERDROP_FN = os.environ.get("MSMD_LAYERDROP_FN", "1") != "0"
 
 
 def _p(tree, name):
@@ -135,6 +136,28 @@ def _fold_weight_norm(g, v):
 
 
 # ----------------------------------------------------------------------------- audio encoder
+_ZERO = {}
+
+
+class LayerDropSelectFn(torch.autograd.Function):
+    """Graph-safe LayerDrop: out = flag ? h_in : h for a 0-dim device flag.  torch.where's own backward builds a scalar-zero
+    tensor per operand (a fill launch each) next to its two selects; here the zero is made once per (device, dtype)."""
+
+    @staticmethod
+    def forward(ctx, flag, h_in, h):
+        ctx.save_for_backward(flag)
+        return torch.where(flag, h_in, h)
+
+    @staticmethod
+    def backward(ctx, g):
+        (flag,) = ctx.saved_tensors
+        key = (g.device, g.dtype)
+        z = _ZERO.get(key)
+        if z is None:
+            z = _ZERO[key] = torch.zeros((), device=g.device, dtype=g.dtype)
+        return None, torch.where(flag, g, z), torch.where(flag, z, g)
+
+
 def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
     """Differentiable counterpart of Wav2Vec2Model.encode (utils/wav2vec2.py): (B, L) audio -> (B, frame_num, 768)."""
     c = enc.config
@@ -215,7 +238,7 @@ def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
                                      g(p + "feed_forward.output_dense.weight"), g(p + "feed_forward.output_dense.bias"),
                                      c.activation_dropout, c.hidden_dropout, residual=h), *ln2)
         if skip_flag is not None:
-            h = torch.where(skip_flag, h_in, h)
+            h = LayerDropSelectFn.apply(skip_flag, h_in, h) if USE_LAYERDROP_FN else torch.where(skip_flag, h_in, h)
     if stable:
         h = ag.layer_norm(h, g("encoder.layer_norm.weight"), g("encoder.layer_norm.bias"))
     return h
