@@ -326,7 +326,7 @@ class Trainer:
                 styles.append(mu + e * torch.exp(0.5 * logvar))
                 mus.append(mu)
                 logvars.append(logvar)
-            losses = {k: torch.zeros((), device=self.device) for k in lw}
+            terms = {k: [] for k in lw}     # every loss term of both windows, summed per key and weighted in ONE pass below
             prev_motion = prev_audio = None
             for i in range(2):
                 audio, motion = audio_pair[i], motion_pair[i]
@@ -375,14 +375,42 @@ class Trainer:
                     pairs = zip(("noise", "vel", "smooth", "head_angle", "head_vel", "head_smooth", "head_trans"), tup)
                 for key, val in pairs:
                     if val is not None and torch.is_tensor(val) and lw.get(key, 0) > 0:
-                        losses[key] = losses[key] + val
-                losses["kl_div"] = losses["kl_div"] + tg.kl_train(mus[i], logvars[i])
-            loss = sum(losses[k] * lw[k] for k in losses if lw[k] > 0)
+                        terms[key].append(val)
+                terms["kl_div"].append(tg.kl_train(mus[i], logvars[i]))
+            losses, loss = self._combine_losses(terms, lw)
             loss.backward()
         noise.active = False    # module-level switch: never leak train-mode noise into other callers of the graph
         out = {k: v.detach() for k, v in losses.items()}
         out["loss"] = loss.detach()
         return out
+
+    def _combine_losses(self, terms, lw):
+        """per-key sums (for the log) and the weighted total of all loss terms: stack + two masked reductions instead of a zero
+        tensor, an add per term and a multiply-add per key (about forty 0-dim launches per iteration, most of them again in
+        the backward).  Same arithmetic order per key is NOT kept (fp32 sums of <= 4 terms); reference: training_script.py
+        :163-195 (loss_dict accumulation and the weighted sum)."""
+        keys = list(lw)
+        if os.environ.get("MSMD_STACK_LOSSES", "1") == "0":     # the term-by-term form, kept for comparison
+            losses = {k: sum(terms[k], torch.zeros((), device=self.device)) for k in keys}
+            return losses, sum(losses[k] * lw[k] for k in keys if lw[k] > 0)
+        flat, owner = [], []
+        for j, k in enumerate(keys):
+            for t in terms[k]:
+                flat.append(t.float().reshape(()))
+                owner.append(j)
+        sig = (tuple(owner), tuple(float(lw[k]) for k in keys))
+        cached = self._loss_consts.get(sig) if hasattr(self, "_loss_consts") else None
+        if cached is None:
+            if not hasattr(self, "_loss_consts"):
+                self._loss_consts = {}
+            sel = torch.zeros(len(keys), max(len(flat), 1))
+            for n, j in enumerate(owner):
+                sel[j, n] = 1.0
+            w = torch.tensor([float(lw[k]) if lw[k] > 0 else 0.0 for k in keys])
+            cached = self._loss_consts[sig] = (sel.to(self.device), w.to(self.device))
+        sel, w = cached
+        per_key = (sel * torch.stack(flat)).sum(dim=1)
+        return {k: per_key[j] for j, k in enumerate(keys)}, (per_key * w).sum()
 
     def _cfg_masks(self, draws, i, B):
         """Null-style / null-audio masks of the training forward (reference model.py:190-218, switched off by
