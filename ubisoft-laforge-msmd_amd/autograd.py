@@ -204,6 +204,18 @@ def _param_grads(dz2, xin, w, b_ref, has_b, K, need_w, need_b, alias):
         else:
             dwe = ops.gemm_tn(dz2, x2)
         dw = dwe[:, :K].reshape(w.shape)
+    elif need_w and dtype == torch.bfloat16 and USE_GEMM_TN and PAD_N_FOR_TN:
+        # N not a multiple of 8 (the 67 / 71-wide motion heads): zero-pad dZ's columns and take the same TN GEMM (3 launches
+        # instead of the 6 of the transposed-operand form below)
+        Np = (N + 7) // 8 * 8
+        dzp = ops.pad_cols(dz2.contiguous(), Np, dtype)
+        x2 = xin.reshape(M, Kp)
+        if want_b:
+            dwe, dbp = ops.gemm_tn(dzp, x2, want_colsum=True)
+            db = dbp[:N]
+        else:
+            dwe = ops.gemm_tn(dzp, x2)
+        dw = dwe[:N, :K].reshape(w.shape)
     elif need_w:
         dzT = ops.transpose2d(dz2, 8)                      # (N, Mp)
         # x^T with 8 extra rows: row Kp is all ones, so column Kp of the product is the bias gradient
@@ -393,6 +405,7 @@ def ffn(x, w1, b1, w2, b2, p_act, p_out, residual=None, act=ops.ACT_GELU):
 #             bumps its version) and the node falls back to its own msmd_dropout launch.
 FUSE_LN_DROPOUT_BWD = os.environ.get("MSMD_FUSE_LN_DROPOUT_BWD", "1") != "0"
 USE_JUNCTIONS = os.environ.get("MSMD_JUNCTIONS", "1") != "0"
+PAD_N_FOR_TN = os.environ.get("MSMD_PAD_N_FOR_TN", "1") != "0"
 
 
 def _tag_dropout(y, p, site):
