@@ -533,10 +533,11 @@ def _masked_mean(v, mask):
     return (v * w).sum() / (mask.sum().to(v.dtype) * per_row).clamp(min=1.0)
 
 
-def loss_no_vert_train(args, is_starting_sample, motion_coef_gt, target, prev_motion_coef, end_idx=None):
+def loss_no_vert_train(args, is_starting_sample, motion_coef_gt, target, prev_motion_coef, end_idx=None, halve=True):
     """Differentiable restatement of reference utils/common.py:198-442 (target='sample', l2/l1) on (N, 110, 67)
     tensors with PyTorch autograd ops (plumbing-sized data; the forward-only HIP versions live in utils/common.py).
-    Returns the reference's 7-tuple."""
+    Returns the reference's 7-tuple; halve=False returns the first six terms WITHOUT their final / 2 (the caller applies the
+    factor where it weights the terms: Trainer._combine_losses), the seventh is never halved."""
     crit = (lambda a, b: (a - b) ** 2) if args.criterion.lower() == "l2" else (lambda a, b: (a - b).abs())
     n_prev = args.n_prev_motions
     if is_starting_sample:
@@ -585,6 +586,8 @@ def loss_no_vert_train(args, is_starting_sample, motion_coef_gt, target, prev_mo
         v = d1(seq)
         a = d1(v)
         loss_head_trans = (crit(v[:, 2:4], v[:, 1:3]).mean(-1).mean(-1) + crit(a[:, 1:], a[:, :-1]).mean(-1).mean(-1)).mean()
+    if not halve:
+        return (loss_noise, loss_vel, loss_smooth, loss_head_angle, loss_head_vel, loss_head_smooth, loss_head_trans)
     return (loss_noise / 2, loss_vel / 2, loss_smooth / 2, loss_head_angle / 2, loss_head_vel / 2, loss_head_smooth / 2,
             loss_head_trans)
 

@@ -371,12 +371,15 @@ class Trainer:
                                             self.coef_stats, self.flame, end_idx)
                     pairs = ld.items()
                 else:
-                    tup = tg.loss_no_vert_train(args, i == 0, motion_in, target, prev_motion if i == 1 else None, end_idx)
-                    pairs = zip(("noise", "vel", "smooth", "head_angle", "head_vel", "head_smooth", "head_trans"), tup)
+                    tup = tg.loss_no_vert_train(args, i == 0, motion_in, target, prev_motion if i == 1 else None, end_idx,
+                                                halve=False)     # the / 2 of the first six terms rides in _combine_losses
+                    pairs = zip(("noise", "vel", "smooth", "head_angle", "head_vel", "head_smooth", "head_trans"),
+                                [(v, 0.5) for v in tup[:6]] + [(tup[6], 1.0)])
                 for key, val in pairs:
+                    val, sc = val if isinstance(val, tuple) else (val, 1.0)
                     if val is not None and torch.is_tensor(val) and lw.get(key, 0) > 0:
-                        terms[key].append(val)
-                terms["kl_div"].append(tg.kl_train(mus[i], logvars[i]))
+                        terms[key].append((val, sc))
+                terms["kl_div"].append((tg.kl_train(mus[i], logvars[i]), 1.0))
             losses, loss = self._combine_losses(terms, lw)
             loss.backward()
         noise.active = False    # module-level switch: never leak train-mode noise into other callers of the graph
@@ -391,21 +394,22 @@ class Trainer:
         :163-195 (loss_dict accumulation and the weighted sum)."""
         keys = list(lw)
         if os.environ.get("MSMD_STACK_LOSSES", "1") == "0":     # the term-by-term form, kept for comparison
-            losses = {k: sum(terms[k], torch.zeros((), device=self.device)) for k in keys}
+            losses = {k: sum((t * sc if sc != 1.0 else t for t, sc in terms[k]), torch.zeros((), device=self.device)) for k in keys}
             return losses, sum(losses[k] * lw[k] for k in keys if lw[k] > 0)
-        flat, owner = [], []
+        flat, owner, scales = [], [], []
         for j, k in enumerate(keys):
-            for t in terms[k]:
+            for t, sc in terms[k]:      # sc: a constant factor of the term (the reference's / 2), applied in the selection matrix
                 flat.append(t.float().reshape(()))
                 owner.append(j)
-        sig = (tuple(owner), tuple(float(lw[k]) for k in keys))
+                scales.append(float(sc))
+        sig = (tuple(owner), tuple(scales), tuple(float(lw[k]) for k in keys))
         cached = self._loss_consts.get(sig) if hasattr(self, "_loss_consts") else None
         if cached is None:
             if not hasattr(self, "_loss_consts"):
                 self._loss_consts = {}
             sel = torch.zeros(len(keys), max(len(flat), 1))
             for n, j in enumerate(owner):
-                sel[j, n] = 1.0
+                sel[j, n] = scales[n]
             w = torch.tensor([float(lw[k]) if lw[k] > 0 else 0.0 for k in keys])
             cached = self._loss_consts[sig] = (sel.to(self.device), w.to(self.device))
         sel, w = cached
