@@ -193,10 +193,10 @@ def cpu_baseline_leg(B, want_lbs=True):
     """oracle/torch_cpu.py on this host (reference arithmetic: fp32 torch CPU, eval mode).  Returns (json dict, the
     forward's `target` (B, 110, 67) as the in-run checker of the GPU modes)."""
     from msmd_amd import shapes, synth
-    from msmd_amd.config import default_args
+    from msmd_amd.config import synthetic_args
     from oracle import diffusion as od, flame as ofl, torch_cpu as tc
     ncpu = os.cpu_count() or 1
-    args = default_args()
+    args = synthetic_args()
     sd = tc.to_torch(synth.fill_state_dict(shapes.msmd_shapes(args)))
     sched = od.diffusion_schedule(500, "cosine")
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).float()
@@ -250,12 +250,12 @@ def cpu_train_baseline(n=2):
     sample; the frozen conv feature extractor gets no gradient, as in the reference (model.py:97).  The style encoder,
     the loss terms and Adam (< 2 % of the step's FLOPs) are left out, which flatters the CPU."""
     from msmd_amd import shapes, synth
-    from msmd_amd.config import default_args
+    from msmd_amd.config import synthetic_args
     from oracle import diffusion as od, torch_cpu as tc
     ncpu = os.cpu_count() or 1
     threads = min(64, ncpu)
     torch.set_num_threads(threads)
-    args = default_args()
+    args = synthetic_args()
     sd = tc.to_torch(synth.fill_state_dict(shapes.msmd_shapes(args)))
     for k, v in sd.items():
         if v.is_floating_point() and "feature_extractor" not in k:
@@ -310,7 +310,7 @@ def leg_sampler(device, B=64, T=500):
     cross-attention fast path and the hoisted step-invariant work remove ~30 % of the nominal ones); `fp16_vs_f16x2` is the
     drift of the fp16 sampler against the f16x2 one over all 500 steps under IDENTICAL injected noise (eager loops)."""
     from msmd_amd import ops, synth
-    from msmd_amd.config import default_args
+    from msmd_amd.config import synthetic_args
     from msmd_amd.model import get_diffusion_model
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
     af, style = t(synth.normalish("leg_samp_af", (B, 100, 512))), t(synth.normalish("leg_samp_style", (B, 256)))
@@ -319,7 +319,7 @@ def leg_sampler(device, B=64, T=500):
     noise = _LazyNoise((B, 100, 67), device, 77)
     out, x0 = {}, {}
     for dtype in ("fp16", "f16x2"):
-        model = get_diffusion_model(default_args(compute_dtype=dtype), device).eval()
+        model = get_diffusion_model(synthetic_args(compute_dtype=dtype), device).eval()
         model.sample(af, shape, style, indicator=ind, cfg_scale=1.15)      # warm-up: packs, captures the step graph
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -409,11 +409,11 @@ def leg_lbs(device, frames_list=(6400, 25600)):
 
 
 def leg_train(device, B=32, steps=5):
-    from msmd_amd.config import default_args
+    from msmd_amd.config import synthetic_args
     from msmd_amd.model import get_diffusion_model
     from msmd_amd.style_encoder import get_style_encoder
     from msmd_amd.training_script import Trainer, synthetic_batch
-    args = default_args(compute_dtype="bf16", lr=2e-5, warm_iter=5000)
+    args = synthetic_args(compute_dtype="bf16", lr=2e-5, warm_iter=5000)
     model = get_diffusion_model(args, device).train()
     se = get_style_encoder(args, "vae2").to(device).train()
     tr = Trainer(args, model, se, use_graph=True)
@@ -435,9 +435,9 @@ def leg_train(device, B=32, steps=5):
 
 def leg_hubert_large(device, B=32, steps=5):
     from msmd_amd import synth
-    from msmd_amd.config import default_args
+    from msmd_amd.config import synthetic_args
     from msmd_amd.model import get_diffusion_model
-    args = default_args(audio_model="hubert_large", compute_dtype="bf16", n_motions=250)
+    args = synthetic_args(audio_model="hubert_large", compute_dtype="bf16", n_motions=250)
     model = get_diffusion_model(args, device).eval()
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
     audio = t(synth.audio_clips(B, 160000, tag="hl_bench"))
@@ -540,9 +540,9 @@ def run_forward(a, rank, world, device):
     from msmd_amd import dp, ops
     for kv in [x for x in a.tune.split(",") if x]:   # developer library only (MSMD_LIB=.../libmsmd_hip_exp.so)
         ops.exp_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]))
-    from msmd_amd.config import default_args
+    from msmd_amd.config import synthetic_args
     from msmd_amd.model import get_diffusion_model
-    args = default_args(compute_dtype=a.dtype)
+    args = synthetic_args(compute_dtype=a.dtype)
     model = get_diffusion_model(args, device).eval()
     b = synth_batch(a.batch, rank, device)
 
@@ -686,11 +686,11 @@ def run_train(a, rank, world, device):
     """configs[2]: per-GPU local batch (default 32) x 2 windows; fwd + bwd + gradient all-reduce (RCCL, ~32 MB buckets on
     a side stream) + fused Adam."""
     from msmd_amd import dp
-    from msmd_amd.config import default_args
+    from msmd_amd.config import synthetic_args
     from msmd_amd.model import get_diffusion_model
     from msmd_amd.style_encoder import get_style_encoder
     from msmd_amd.training_script import Trainer, synthetic_batch
-    args = default_args(compute_dtype="bf16", lr=2e-5, warm_iter=5000)
+    args = synthetic_args(compute_dtype="bf16", lr=2e-5, warm_iter=5000)
     model = get_diffusion_model(args, device).train()
     se = get_style_encoder(args, "vae2").to(device).train()
     tr = Trainer(args, model, se, use_graph=not a.eager)

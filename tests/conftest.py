@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# No pretrained asset exists here or on the GPU box (no network): every model in the tests runs on the closed-form synthetic
+# weights of msmd_amd.synth, which Wav2Vec2Model.from_pretrained only hands out when asked (tests/test_host_cpu.py checks
+# that it raises otherwise and that it loads a local Hugging Face checkpoint when one exists).
+os.environ.setdefault("MSMD_SYNTHETIC_WEIGHTS", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")

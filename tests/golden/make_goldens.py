@@ -919,7 +919,68 @@ def g1_specaug(M, SE, mc):
     save("g1_specaug", **out)
 
 
-ALL = dict(g1_specaug=g1_specaug, g7_dataset=g7_dataset, g2_lr_schedule=g2_lr_schedule, g3_audio_large=g3_audio_large, g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
+# --------------------------------------------------------------------------- G9 public signatures of the drop-in surface
+SIGNATURE_TARGETS = {
+    # module (as imported by import_reference / by name) -> callables; "Class.method" walks one attribute
+    "model": ["get_diffusion_model", "MSMD.__init__", "MSMD.forward", "MSMD.extract_audio_feature", "MSMD.extract_audio_768_feature",
+              "MSMD.sample", "MSMD.sample_separate", "MSMD.sample_with_guide", "DenoisingNetwork_MSMD.__init__",
+              "DenoisingNetwork_MSMD.forward", "DiffusionSchedule.__init__", "DiffusionSchedule.uniform_sample_t",
+              "DiffusionSchedule.get_sigmas"],
+    "style_encoder": ["get_style_encoder", "StyleEncoder_VAE2.__init__", "StyleEncoder_VAE2.forward", "StyleEncoder_VAE2.sample"],
+    "utils.wav2vec2": ["Wav2Vec2Model.forward", "linear_interpolation", "_compute_mask_indices"],
+    "utils.hubert": ["HubertModel.forward", "linear_interpolation"],
+    "utils.model_common": ["pad_audio", "enc_dec_mask", "PositionalEncoding.__init__", "PositionalEncoding.forward"],
+    "utils.flame": ["FLAME.__init__", "FLAME.forward", "FLAME.seletec_3d68", "FLAME._find_dynamic_lmk_idx_and_bcoords"],
+    "utils.lbs": ["lbs", "blend_shapes", "vertices2joints", "batch_rodrigues", "transform_mat", "batch_rigid_transform",
+                  "vertices2landmarks", "rot_mat_to_euler", "find_dynamic_lmk_idx_and_bcoords"],
+    "utils.rotation_conversions": None,      # every public function
+    "utils.common": ["get_pose_input", "get_motion_coef", "get_coef_dict", "coef_dict_to_vertices", "compute_loss_no_vert",
+                     "compute_loss", "compute_KL_loss", "truncate_motion_coef_and_audio"],
+    "utils.scheduler": ["GradualWarmupScheduler.__init__", "GradualWarmupScheduler.get_lr", "GradualWarmupScheduler.step"],
+    "inference": ["infer_coeffs", "load_args", "load_model", "query_for_motion_coeff"],     # by AST: the script cannot be imported here
+}
+
+
+def signature_record(fn):
+    import inspect
+    out = []
+    for p in inspect.signature(fn).parameters.values():
+        out.append([p.name, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)])
+    return out
+
+
+def g9_signatures(M, SE, mc):
+    """Parameter lists (name, kind, default) of every callable of the drop-in surface, read from the reference's own
+    function objects; tests/test_host_cpu.py holds the product's callables against them."""
+    import importlib
+    import inspect
+    import json
+    rec = {}
+    for modname, names in SIGNATURE_TARGETS.items():
+        if modname == "inference":
+            tree = ast.parse(open(os.path.join(REF, "inference.py")).read())
+            import argparse as _ap
+            import torch.nn.functional as F
+            for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]:
+                ns = dict(torch=torch, F=F, math=math, argparse=_ap, np=np)
+                exec(compile(ast.Module(body=[fn], type_ignores=[]), "<reference inference.py>", "exec"), ns)
+                rec[f"inference.{fn.name}"] = signature_record(ns[fn.name])
+            continue
+        mod = importlib.import_module(modname)
+        if names is None:
+            names = [n for n, o in vars(mod).items() if inspect.isfunction(o) and o.__module__ == mod.__name__ and not n.startswith("_")]
+        for name in names:
+            obj = mod
+            for part in name.split("."):
+                obj = getattr(obj, part)
+            rec[f"{modname}.{name}"] = signature_record(obj)
+    path = os.path.join(HERE, "g9_signatures.json")
+    with open(path, "w") as f:
+        json.dump({"_versions": VERSIONS, "signatures": rec}, f, indent=1, sort_keys=True)
+    print(f"wrote {path}  ({len(rec)} callables)")
+
+
+ALL = dict(g9_signatures=g9_signatures, g1_specaug=g1_specaug, g7_dataset=g7_dataset, g2_lr_schedule=g2_lr_schedule, g3_audio_large=g3_audio_large, g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
            g3_forward=g3_forward, g3_style=g3_style, g3_sample=g3_sample, g3_infer=g3_infer,
            g4_flame=g4_flame, g4_rotations=g4_rotations, g5_losses=g5_losses, g6_train=g6_train,
            g5_losses_no_constrain_prev=g5_losses_no_constrain_prev, g3_denoiser_options=g3_denoiser_options, g4_lbs_blocks=g4_lbs_blocks,

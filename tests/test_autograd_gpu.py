@@ -535,3 +535,69 @@ def test_layerdrop_select_node_matches_torch_where():
             res.append((y.detach(), a.grad, b.grad))
         for u, v in zip(*res):
             assert torch.equal(u, v)
+
+
+@pytest.mark.gpu
+def test_fused_alias_operand_gets_gradients_without_a_grad_input_and_sees_in_place_writes_to_its_owners():
+    """autograd.FusedAlias (Q | K | V of an encoder layer as ONE arena view): (1) its node writes the owners' gradients even when
+    the activation fed to it does not require grad (the view itself carries no autograd history); (2) an in-place write to an
+    OWNER parameter -- load_state_dict, p.copy_(), a finite-difference probe -- moves the owner's version counter, not the
+    view's: the cached bf16 casts of the view must be dropped for it all the same; (3) with USE_GEMM_TN off the alias branch
+    takes the generic weight-gradient products and adds them into the same arena region."""
+    import math
+    from msmd_amd import autograd as ag
+    g = torch.Generator(device="cpu").manual_seed(3)
+    d, M = 128, 96
+    flat = torch.zeros(3 * d * d + 3 * d, device=DEV)
+    garena = torch.zeros_like(flat)
+    owners = []
+    for i in range(3):      # q, k, v weights next to each other, then the three biases: parameters are views of the flat arena
+        w = torch.nn.Parameter(torch.empty(0, device=DEV))
+        w.data = flat[i * d * d:(i + 1) * d * d].view(d, d)
+        w.data.copy_((torch.randn(d, d, generator=g) / math.sqrt(d)).to(DEV))
+        owners.append(w)
+    for i in range(3):
+        b = torch.nn.Parameter(torch.empty(0, device=DEV))
+        b.data = flat[3 * d * d + i * d:3 * d * d + (i + 1) * d]
+        b.data.copy_((torch.randn(d, generator=g) * 0.1).to(DEV))
+        owners.append(b)
+    fa = ag.FusedAlias(flat[:3 * d * d].view(3 * d, d), flat[3 * d * d:], garena[:3 * d * d].view(3 * d, d), garena[3 * d * d:], owners)
+    arena = ag.WeightArena(flat, [], aliases=[fa])
+    x = torch.randn(M, d, generator=g).to(DEV, torch.bfloat16)          # requires_grad False: e.g. a frozen feature map in front
+    dy = torch.randn(M, 3 * d, generator=g).to(DEV, torch.bfloat16)
+
+    def reference():
+        wf = flat[:3 * d * d].view(3 * d, d).to(torch.bfloat16).float()
+        return x.float() @ wf.t() + flat[3 * d * d:], dy.float().t() @ x.float(), dy.float().sum(0)
+
+    try:
+        y = ag.linear_alias(x, fa)
+        assert y.requires_grad, "the alias node must be part of the graph although no tensor input requires grad"
+        y.backward(dy)
+        y0, dw0, db0 = reference()
+        assert float((y.float() - y0).abs().max()) <= 0.06
+        assert float((garena[:3 * d * d].view(3 * d, d) - dw0).abs().max()) <= 2e-2 * float(dw0.abs().max())
+        assert float((garena[3 * d * d:] - db0).abs().max()) <= 2e-2 * float(db0.abs().max())
+        # (2) perturb K's weight in place through the OWNER (exactly what load_state_dict does): the next forward must see it
+        with torch.no_grad():
+            owners[1].mul_(-3.0)
+        y2 = ag.linear_alias(x, fa)
+        y2r, _, _ = reference()
+        assert float((y2.float() - y2r).abs().max()) <= 0.2, "stale bf16 cast of an aliased weight after an in-place owner write"
+        assert float((y2.float() - y.float()).abs().max()) > 1.0
+        arena.refresh()      # the optimizer-step path: casts rewritten, versions recorded
+        y3 = ag.linear_alias(x, fa)
+        assert torch.equal(y3, y2)
+        # (3) the generic weight-gradient path adds into the same region
+        garena.zero_()
+        old = ag.USE_GEMM_TN
+        ag.USE_GEMM_TN = False
+        try:
+            ag.linear_alias(x, fa).backward(dy)
+        finally:
+            ag.USE_GEMM_TN = old
+        _, dw1, db1 = reference()
+        assert float((garena[:3 * d * d].view(3 * d, d) - dw1).abs().max()) <= 2e-2 * float(dw1.abs().max())
+        assert float((garena[3 * d * d:] - db1).abs().max()) <= 2e-2 * float(db1.abs().max())
+    finally:
+        arena.release()

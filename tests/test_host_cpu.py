@@ -163,6 +163,128 @@ def test_state_dict_keys_and_checkpoint_compat():
         get_diffusion_model(default_args(architecture="bogus"), "cpu")
 
 
+def _tiny_hf_checkpoint(directory, model_type, fmt, spelling, layers=2, head_prefix=True):
+    """A Hugging Face checkpoint directory as `save_pretrained` of a task-head model writes it (config.json + weights,
+    encoder nested under `wav2vec2.` / `hubert.`, an lm_head beside it), filled with recognisable values."""
+    import json
+    cfg = dict(model_type=model_type, num_hidden_layers=layers, hidden_size=64, intermediate_size=128, num_attention_heads=4,
+               conv_dim=[32] * 7, conv_kernel=[10, 3, 3, 3, 3, 2, 2], conv_stride=[5, 2, 2, 2, 2, 2, 2],
+               num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, layer_norm_eps=1e-5, feat_extract_norm="group",
+               conv_bias=False, do_stable_layer_norm=False, hidden_dropout=0.1, attention_dropout=0.1, activation_dropout=0.1,
+               feat_proj_dropout=0.0, layerdrop=0.1, apply_spec_augment=True, mask_time_prob=0.05, mask_time_length=10,
+               mask_time_min_masks=2, vocab_size=32, architectures=["Wav2Vec2ForCTC"])
+    os.makedirs(directory, exist_ok=True)
+    with open(os.path.join(directory, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    sh = shapes.audio_encoder_shapes(layers, 64, 128, 32, 16, 4)
+    sd = {}
+    for i, (k, shape) in enumerate(sh.items()):
+        v = torch.from_numpy(synth.uniform("hf." + k, shape)) + float(i)       # every tensor distinguishable
+        if spelling == "parametrizations":
+            k = k.replace("weight_g", "parametrizations.weight.original0").replace("weight_v", "parametrizations.weight.original1")
+        sd[(model_type + "." if head_prefix else "") + k] = v.contiguous()
+    sd["lm_head.weight"] = torch.zeros(32, 64)
+    sd["lm_head.bias"] = torch.zeros(32)
+    if fmt == "safetensors":
+        from safetensors.torch import save_file
+        save_file(sd, os.path.join(directory, "model.safetensors"))
+    else:
+        torch.save(sd, os.path.join(directory, "pytorch_model.bin"))
+    return sh
+
+
+def test_from_pretrained_loads_a_local_hf_checkpoint_or_fails_loudly(tmp_path, monkeypatch):
+    """reference model.py:95 / :100: `Wav2Vec2Model.from_pretrained(hub id, cache_dir=...)`.  A local checkpoint in either
+    weight format, either weight-norm spelling, as a directory or inside the hub-cache layout, loads tensor for tensor;
+    without one the call raises unless synthetic weights were asked for by name."""
+    from msmd_amd.model import get_diffusion_model
+    from msmd_amd.utils.hubert import HubertModel
+    from msmd_amd.utils.wav2vec2 import Wav2Vec2Model
+    monkeypatch.delenv("MSMD_SYNTHETIC_WEIGHTS", raising=False)
+    monkeypatch.setenv("HF_HOME", str(tmp_path / "empty_home"))
+    monkeypatch.setenv("HOME", str(tmp_path / "empty_home"))
+    monkeypatch.delenv("HF_HUB_CACHE", raising=False)
+    # (1) nothing local: loud failure, from the class and through MSMD's constructor (reference-style args carry no switch)
+    with pytest.raises(FileNotFoundError, match="no local Hugging Face checkpoint"):
+        Wav2Vec2Model.from_pretrained("facebook/wav2vec2-base-960h", cache_dir=str(tmp_path / "hub"))
+    with pytest.raises(FileNotFoundError):
+        get_diffusion_model(default_args(encoder_layers=1, n_layers=1, hf_cache_dir=str(tmp_path / "hub")), "cpu")
+    # ... unless synthetic weights are requested explicitly
+    m = Wav2Vec2Model.from_pretrained("facebook/wav2vec2-base-960h", config=dict(num_hidden_layers=1), synthetic=True)
+    assert m.weights_source == "synthetic" and float(m.state_dict()["feature_projection.projection.weight"].abs().sum()) > 0
+    assert get_diffusion_model(default_args(encoder_layers=1, n_layers=1, audio_encoder_weights="synthetic"), "cpu").audio_encoder.weights_source == "synthetic"
+    bare = get_diffusion_model(default_args(encoder_layers=1, n_layers=1, audio_encoder_weights="checkpoint"), "cpu")
+    assert bare.audio_encoder.weights_source == "checkpoint"
+    # (2) a checkpoint directory, .bin + torch-2.0 spelling, encoder nested under `wav2vec2.` as in the 960h CTC checkpoint
+    d1 = tmp_path / "ckpt_bin"
+    sh = _tiny_hf_checkpoint(str(d1), "wav2vec2", "bin", "weight_g")
+    m = Wav2Vec2Model.from_pretrained(str(d1))
+    assert m.weights_source == str(d1) and m.config.hidden_size == 64 and m.config.num_hidden_layers == 2 and m.config.conv_dim == 32
+    got = m.state_dict()
+    for i, (k, shape) in enumerate(sh.items()):
+        if k == "masked_spec_embed":
+            continue
+        want = torch.from_numpy(synth.uniform("hf." + k, shape)) + float(i)
+        assert torch.equal(got[k], want), k
+    # (3) the hub-cache layout under cache_dir, safetensors + parametrizations spelling, HuBERT, through the hub id; a config
+    #     override cuts the depth (the checkpoint's extra layer is dropped, nothing else changes)
+    snap = tmp_path / "hub" / "models--facebook--hubert-base-ls960" / "snapshots" / "abc123"
+    sh = _tiny_hf_checkpoint(str(snap), "hubert", "safetensors", "parametrizations")
+    os.makedirs(snap.parent.parent / "refs", exist_ok=True)
+    (snap.parent.parent / "refs" / "main").write_text("abc123")
+    h = HubertModel.from_pretrained("facebook/hubert-base-ls960", cache_dir=str(tmp_path / "hub"), config=dict(num_hidden_layers=1))
+    assert h.weights_source == str(snap) and h.config.num_hidden_layers == 1
+    got = h.state_dict()
+    assert not any(".layers.1." in k for k in got)
+    idx = {k: i for i, k in enumerate(sh)}
+    for k in ("encoder.pos_conv_embed.conv.weight_g", "encoder.pos_conv_embed.conv.weight_v", "encoder.layers.0.attention.q_proj.weight",
+              "feature_extractor.conv_layers.3.conv.weight"):
+        assert torch.equal(got[k], torch.from_numpy(synth.uniform("hf." + k, sh[k])) + float(idx[k])), k
+    # HF_HOME is searched too (no cache_dir argument)
+    monkeypatch.setenv("HF_HOME", str(tmp_path))
+    assert HubertModel.from_pretrained("facebook/hubert-base-ls960").weights_source == str(snap)
+    # (4) a checkpoint with a missing encoder tensor is refused, not half-loaded
+    d3 = tmp_path / "ckpt_broken"
+    _tiny_hf_checkpoint(str(d3), "wav2vec2", "bin", "weight_g", head_prefix=False)
+    sd = torch.load(d3 / "pytorch_model.bin")
+    del sd["encoder.layers.1.feed_forward.output_dense.bias"]
+    torch.save(sd, d3 / "pytorch_model.bin")
+    with pytest.raises(KeyError, match="lacks 1 encoder tensors"):
+        Wav2Vec2Model.from_pretrained(str(d3))
+
+
+def test_public_signatures_match_the_reference():
+    """every callable of the drop-in surface takes the reference's parameters -- same names, same order, same
+    kinds, same defaults (tests/golden/g9_signatures.json, recorded from the reference's function objects by make_goldens.py).
+    The product may add parameters only AFTER them, and only optional ones (replay / injection hooks, keyword-only or defaulted)."""
+    import importlib
+    import inspect
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "g9_signatures.json")) as f:
+        ref = json.load(f)["signatures"]
+    assert len(ref) >= 70
+    problems = []
+    for qual, want in sorted(ref.items()):
+        modname = next(m for m in ("utils.rotation_conversions", "utils.model_common", "utils.wav2vec2", "utils.scheduler", "utils.hubert",
+                                   "utils.common", "utils.flame", "utils.lbs", "style_encoder", "inference", "model") if qual.startswith(m + "."))
+        obj = importlib.import_module("msmd_amd." + modname)
+        try:
+            for part in qual[len(modname) + 1:].split("."):
+                obj = getattr(obj, part)
+        except AttributeError:
+            problems.append(f"{qual}: missing")
+            continue
+        have = [[p.name, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)]
+                for p in inspect.signature(obj).parameters.values()]
+        if have[:len(want)] != want:
+            problems.append(f"{qual}: reference {want} != product {have[:len(want)]}")
+            continue
+        for name, kind, default in have[len(want):]:
+            if kind not in ("KEYWORD_ONLY", "VAR_KEYWORD") and default is None:
+                problems.append(f"{qual}: extra parameter {name!r} is neither keyword-only nor defaulted")
+    assert not problems, "\n".join(problems)
+
+
 def test_args_json_round_trip(tmp_path):
     from msmd_amd.utils.model_common import load_args, save_args
     a = default_args()

@@ -498,6 +498,12 @@ def test_lbs_building_blocks_match_reference():
     fi, bc = L.find_dynamic_lmk_idx_and_bcoords(v_shaped, full_pose, fl.dynamic_lmk_faces_idx,
                                                 fl.dynamic_lmk_bary_coords, fl.neck_kin_chain)
     assert np.array_equal(fi.cpu().numpy(), g["dyn_idx"]) and np.array_equal(bc.cpu().numpy(), g["dyn_bary"])
+    # FLAME's own method (reference utils/flame.py:126-172, what forward() uses) looks the tables up at PLUS the yaw, the
+    # module-level function above at minus the yaw: rows from the oracle's restatement of the method
+    fi2, bc2 = fl._find_dynamic_lmk_idx_and_bcoords(full_pose, fl.dynamic_lmk_faces_idx, fl.dynamic_lmk_bary_coords, fl.neck_kin_chain)
+    rows = ofl.dynamic_lmk_index(g["full_pose"], fl.neck_kin_chain.cpu().numpy())
+    assert np.array_equal(fi2.cpu().numpy(), fl.dynamic_lmk_faces_idx.cpu().numpy()[rows])
+    assert np.array_equal(bc2.cpu().numpy(), fl.dynamic_lmk_bary_coords.cpu().numpy()[rows])
     from msmd_amd.utils.wav2vec2 import _compute_mask_indices, compute_mask_indices
     np.random.seed(4)
     a = _compute_mask_indices((3, 199), 0.05, 10, None, 2)

@@ -5,10 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from msmd_amd import ops
-from msmd_amd.config import default_args
+from msmd_amd.config import synthetic_args
 from msmd_amd.model import get_diffusion_model
 key = int(sys.argv[1]); vals = [int(v) for v in sys.argv[2].split(",")]
-model = get_diffusion_model(default_args(compute_dtype=os.environ.get("DTYPE", "bf16")), "cuda").eval()
+model = get_diffusion_model(synthetic_args(compute_dtype=os.environ.get("DTYPE", "bf16")), "cuda").eval()
 b = bench.synth_batch(32, 0, "cuda")
 b["time_step"] = torch.tensor(b["time_step"], device="cuda", dtype=torch.long)
 for _ in range(3): bench.step(model, b)

@@ -4,9 +4,9 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
-from msmd_amd.config import default_args
+from msmd_amd.config import synthetic_args
 from msmd_amd.model import get_diffusion_model
-model = get_diffusion_model(default_args(compute_dtype="bf16"), "cuda").eval()
+model = get_diffusion_model(synthetic_args(compute_dtype="bf16"), "cuda").eval()
 bs = [bench.synth_batch(32, r, "cuda") for r in range(2)]
 fn = lambda i: model.audio_encoder.encode(bs[i]["audio"], 25, frame_num=200, dtype=torch.bfloat16, pad=True).float()
 refs = []

@@ -11,20 +11,20 @@ import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 
 import bench
-from msmd_amd.config import default_args
+from msmd_amd.config import synthetic_args
 from msmd_amd.model import get_diffusion_model
 
 if os.environ.get("AUDIO_MODEL") == "hubert_large":      # configs[3]: 10 s clips, 250 frames
     import numpy as np
     from msmd_amd import synth
-    model = get_diffusion_model(default_args(audio_model="hubert_large", compute_dtype="bf16", n_motions=250), "cuda").eval()
+    model = get_diffusion_model(synthetic_args(audio_model="hubert_large", compute_dtype="bf16", n_motions=250), "cuda").eval()
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to("cuda")
     b = dict(motion=t(synth.normalish("hl_motion", (8, 250, 67))), audio=t(synth.audio_clips(8, 160000, tag="hl_bench")),
              shape=torch.zeros(8, 100, device="cuda"), style=t(synth.normalish("hl_style", (8, 256))),
              time_step=torch.arange(1, 9, device="cuda"), indicator=torch.ones(8, 250, device="cuda"),
              eps=t(synth.normalish("hl_eps", (8, 250, 67))))
 else:
-    model = get_diffusion_model(default_args(compute_dtype=sys.argv[1] if len(sys.argv) > 1 else "bf16"), "cuda").eval()
+    model = get_diffusion_model(synthetic_args(compute_dtype=sys.argv[1] if len(sys.argv) > 1 else "bf16"), "cuda").eval()
     b = bench.synth_batch(32, 0, "cuda")
     b["time_step"] = torch.tensor(b["time_step"], device="cuda", dtype=torch.long)
 for _ in range(2):

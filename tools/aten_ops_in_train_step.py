@@ -9,13 +9,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 
-from msmd_amd.config import default_args
+from msmd_amd.config import synthetic_args
 from msmd_amd.model import get_diffusion_model
 from msmd_amd.style_encoder import get_style_encoder
 from msmd_amd.training_script import Trainer, synthetic_batch
 
 B = int(os.environ.get("B", "32"))
-args = default_args(compute_dtype="bf16", lr=2e-5, warm_iter=5000)
+args = synthetic_args(compute_dtype="bf16", lr=2e-5, warm_iter=5000)
 model = get_diffusion_model(args, "cuda").train()
 se = get_style_encoder(args, "vae2").to("cuda").train()
 tr = Trainer(args, model, se, use_graph=False)

@@ -3,11 +3,11 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from msmd_amd import synth
-from msmd_amd.config import default_args
+from msmd_amd.config import synthetic_args
 from msmd_amd.model import get_diffusion_model
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-args = default_args(audio_model="hubert_large", compute_dtype="bf16", n_motions=250)
+args = synthetic_args(audio_model="hubert_large", compute_dtype="bf16", n_motions=250)
 model = get_diffusion_model(args, "cuda").eval()
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
 audio = t(synth.audio_clips(B, 160000, tag="hl_bench"))

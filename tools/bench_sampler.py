@@ -6,9 +6,9 @@ if os.environ.get("TUNE"):   # e.g. TUNE="7=1,6=28": msmd_exp_set_tuning knobs f
     from msmd_amd import ops as _ops
     for kv in os.environ["TUNE"].split(","):
         _ops.exp_set_tuning(*(int(v) for v in kv.split("=")))
-from msmd_amd.config import default_args
+from msmd_amd.config import synthetic_args
 from msmd_amd.model import get_diffusion_model
-model = get_diffusion_model(default_args(compute_dtype=os.environ.get("DTYPE", "bf16")), "cuda").eval()
+model = get_diffusion_model(synthetic_args(compute_dtype=os.environ.get("DTYPE", "bf16")), "cuda").eval()
 if os.environ.get("PQA") == "0":
     model.denoising_net.fused_person_query = False
 T = int(os.environ.get("T", "500"))

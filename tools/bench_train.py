@@ -7,7 +7,7 @@ if os.environ.get("TUNE"):   # e.g. TUNE="7=1,6=28": msmd_exp_set_tuning knobs f
     for kv in os.environ["TUNE"].split(","):
         _ops.exp_set_tuning(*(int(v) for v in kv.split("=")))
 from msmd_amd import dp, autograd as ag
-from msmd_amd.config import default_args
+from msmd_amd.config import synthetic_args
 from msmd_amd.model import get_diffusion_model
 from msmd_amd.style_encoder import get_style_encoder
 from msmd_amd.training_script import Trainer, synthetic_batch
@@ -18,7 +18,7 @@ dev = torch.device("cuda", local_rank)
 dp.init("nccl", dev)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"
-args = default_args(compute_dtype=dtype, lr=2e-5, warm_iter=5000)
+args = synthetic_args(compute_dtype=dtype, lr=2e-5, warm_iter=5000)
 model = get_diffusion_model(args, dev)
 se = get_style_encoder(args, "vae2").to(dev)
 if os.environ.get('TRAIN_MODE'):

@@ -4,10 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from msmd_amd import ops
-from msmd_amd.config import default_args
+from msmd_amd.config import synthetic_args
 from msmd_amd.model import get_diffusion_model
 from msmd_amd.utils.model_common import pad_audio_plan
-model = get_diffusion_model(default_args(compute_dtype="bf16"), "cuda").eval()
+model = get_diffusion_model(synthetic_args(compute_dtype="bf16"), "cuda").eval()
 enc = model.audio_encoder
 bf = torch.bfloat16
 bs = [bench.synth_batch(32, r, "cuda") for r in range(2)]

@@ -13,14 +13,14 @@ import torch
 
 import bench
 from msmd_amd import ops
-from msmd_amd.config import default_args
+from msmd_amd.config import synthetic_args
 from msmd_amd.model import get_diffusion_model
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 KEEP = os.environ.get("KEEP", "1") == "1"
 STAGE = os.environ.get("STAGE", "enc")
 ops._GEMM_DEFAULT.update(variant=int(os.environ.get("VARIANT", "0")), flags=int(os.environ.get("FLAGS", "0")) << 16)
-model = get_diffusion_model(default_args(compute_dtype="bf16"), "cuda").eval()
+model = get_diffusion_model(synthetic_args(compute_dtype="bf16"), "cuda").eval()
 enc = model.audio_encoder
 bs = [bench.synth_batch(32, r, "cuda") for r in range(2)]
 

@@ -14,12 +14,12 @@ import torch
 
 import bench
 from msmd_amd import ops
-from msmd_amd.config import default_args
+from msmd_amd.config import synthetic_args
 from msmd_amd.model import get_diffusion_model
 from msmd_amd.utils.model_common import pad_audio_plan
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-model = get_diffusion_model(default_args(compute_dtype="bf16"), "cuda").eval()
+model = get_diffusion_model(synthetic_args(compute_dtype="bf16"), "cuda").eval()
 P = model.audio_encoder.pack_fe(torch.bfloat16)
 audio = [bench.synth_batch(32, r, "cuda")["audio"] for r in range(2)]
 r_, rep_ = pad_audio_plan(64000)

@@ -21,7 +21,7 @@ import torch
 
 from msmd_amd import autograd as ag
 from msmd_amd import ops, synth
-from msmd_amd.config import default_args
+from msmd_amd.config import synthetic_args
 from msmd_amd.model import get_diffusion_model
 from msmd_amd.style_encoder import get_style_encoder
 from msmd_amd.training_script import Trainer, synthetic_batch
@@ -36,7 +36,7 @@ ops._GEMM_DEFAULT.update(variant=int(os.environ.get("VARIANT", "0")), flags=int(
 if mode == "graph":
     os.environ["MSMD_SEGMENT_GRAPHS"] = "1"
 
-args = default_args(compute_dtype="bf16", encoder_layers=enc_l, n_layers=dec_l, lr=2e-5, warm_iter=0,
+args = synthetic_args(compute_dtype="bf16", encoder_layers=enc_l, n_layers=dec_l, lr=2e-5, warm_iter=0,
                     gradient_accumulation_steps=1)
 torch.manual_seed(0)
 model = get_diffusion_model(args, DEV)

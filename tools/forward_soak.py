@@ -8,12 +8,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import bench
-from msmd_amd.config import default_args
+from msmd_amd.config import synthetic_args
 from msmd_amd.model import get_diffusion_model
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 for dt in ("bf16", "fp16"):
-    model = get_diffusion_model(default_args(compute_dtype=dt), "cuda").eval()
+    model = get_diffusion_model(synthetic_args(compute_dtype=dt), "cuda").eval()
     runs = [bench.graphed_step(model, bench.synth_batch(32, i, "cuda")) for i in range(2)]
     refs = []
     for r in runs:

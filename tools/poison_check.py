@@ -5,10 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from msmd_amd import ops
-from msmd_amd.config import default_args
+from msmd_amd.config import synthetic_args
 from msmd_amd.model import get_diffusion_model
 dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
-model = get_diffusion_model(default_args(compute_dtype=dt), "cuda").eval()
+model = get_diffusion_model(synthetic_args(compute_dtype=dt), "cuda").eval()
 b = bench.synth_batch(32, 0, "cuda")
 ref = [x.clone() for x in bench.step(model, b)]
 torch.cuda.synchronize()

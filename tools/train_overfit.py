@@ -3,13 +3,13 @@ hipGraph mode by default): the loss must fall and stay finite."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from msmd_amd.config import default_args
+from msmd_amd.config import synthetic_args
 from msmd_amd.model import get_diffusion_model
 from msmd_amd.style_encoder import get_style_encoder
 from msmd_amd.training_script import Trainer, synthetic_batch
 dev = torch.device("cuda:0")
 steps = int(os.environ.get("STEPS", "200"))
-args = default_args(compute_dtype="bf16", lr=float(os.environ.get("LR", "1e-4")), warm_iter=20)
+args = synthetic_args(compute_dtype="bf16", lr=float(os.environ.get("LR", "1e-4")), warm_iter=20)
 model = get_diffusion_model(args, dev); se = get_style_encoder(args, "vae2").to(dev)
 model.train(); se.train()
 tr = Trainer(args, model, se, use_graph=os.environ.get("GRAPH", "1") == "1")

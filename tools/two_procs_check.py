@@ -5,13 +5,13 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
-from msmd_amd.config import default_args
+from msmd_amd.config import synthetic_args
 from msmd_amd.model import get_diffusion_model
 who = sys.argv[1]
 flag = lambda n: f"/tmp/two_procs_{n}"
 if who == "B":
     while not os.path.exists(flag("A_ref")): time.sleep(0.05)
-model = get_diffusion_model(default_args(compute_dtype="bf16"), "cuda").eval()
+model = get_diffusion_model(synthetic_args(compute_dtype="bf16"), "cuda").eval()
 b = bench.synth_batch(32, 0 if who == "A" else 1, "cuda")
 enc = model.audio_encoder
 fn = lambda: enc.encode(b["audio"], 25, frame_num=200, dtype=torch.bfloat16, pad=True).float()

@@ -3,10 +3,10 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
-from msmd_amd.config import default_args
+from msmd_amd.config import synthetic_args
 from msmd_amd.model import get_diffusion_model
 dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
-args = default_args(compute_dtype=dt)
+args = synthetic_args(compute_dtype=dt)
 model = get_diffusion_model(args, "cuda").eval()
 NS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 bs = [bench.synth_batch(32, r, "cuda") for r in range(NS)]

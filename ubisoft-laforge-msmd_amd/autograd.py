@@ -32,10 +32,12 @@ class WeightCache:
 
     def get(self, w: torch.Tensor, dtype):
         key = (id(w), dtype)
+        ver = w._version
         e = self.persistent.get(key)
         if e is not None:
             if e[0]() is w and e[1] == (w.data_ptr(), tuple(w.shape)):
-                if e[4][0] == w._version:
+                ver = e[5]()        # an alias view answers with its owner parameters' counters (FusedAlias.version)
+                if e[4][0] == ver:
                     return e[2], e[3]
                 # written in place behind the arena's back (load_state_dict, manual edits): cast afresh below until
                 # the owner's next refresh() picks the new values up
@@ -44,13 +46,13 @@ class WeightCache:
         e = self.store.get(key)
         # id() values are recycled once a tensor dies: an entry is valid only for the SAME live tensor object (weak
         # reference), at the same version and storage address
-        if e is None or e[0]() is not w or e[1] != (w._version, w.data_ptr(), tuple(w.shape)):
+        if e is None or e[0]() is not w or e[1] != (ver, w.data_ptr(), tuple(w.shape)):
             w2 = w.detach().reshape(w.shape[0], -1)
             K = w2.shape[1]
             Kp = (K + 7) // 8 * 8
             wc = ops.pad_cols(w2.float().contiguous(), Kp, dtype)     # (N, Kp)
             wct = ops.transpose2d(wc[:, :K] if Kp != K else wc, 8)     # (K, Np)
-            e = self.store[key] = (weakref.ref(w), (w._version, w.data_ptr(), tuple(w.shape)), wc, wct)
+            e = self.store[key] = (weakref.ref(w), (ver, w.data_ptr(), tuple(w.shape)), wc, wct)
         return e[2], e[3]
 
 
@@ -66,6 +68,16 @@ class FusedAlias:
 
     def __init__(self, w, b, wgrad, bgrad, owners):
         self.w, self.b, self.wgrad, self.bgrad, self.owners = w, b, wgrad, bgrad, list(owners)
+        # `w` / `b` carry no autograd history: without an input that requires grad the node's output would not either and its
+        # backward -- the only place the owners' gradients are written -- would silently never run.  The token is a leaf that
+        # always requires grad and rides along as an extra input of the node (its own gradient is None).
+        self.token = torch.zeros((), device=w.device, requires_grad=True)
+
+    def version(self):
+        """In-place writes to the OWNER parameters (load_state_dict, p.copy_(), a finite-difference probe) move THEIR version
+        counters, not the arena view's (parameters got their own counter through `p.data = view`): the cached casts of the
+        alias are valid for this number only."""
+        return self.w._version + sum(o._version for o in self.owners)
 
 
 FUSED = {}   # (kind, id(module), layer index) -> FusedAlias; filled by the Trainer (direct-gradient mode only)
@@ -77,13 +89,20 @@ class WeightArena:
     LinearFn finds them through CACHE.persistent, so an iteration issues no per-weight cast / transpose launches."""
 
     def __init__(self, flat_param, params, aliases=(), skip=()):
-        """aliases: plain 2-D views of the arena (FusedAlias.w) that get their own cast / transpose; skip: parameters
-        that are only ever used through an alias."""
+        """aliases: FusedAlias objects (or plain 2-D views of the arena) whose `w` gets its own cast / transpose; skip:
+        parameters that are only ever used through an alias."""
         self.flat = flat_param
         rows, self.views = [], []
         off = tiles = 0
         base = flat_param.data_ptr()
         skip = {id(p) for p in skip}
+        vfn = {}     # id(tensor) -> its version getter (an alias answers with its owners' counters)
+        alias_w = []
+        for a in aliases:
+            t = a.w if isinstance(a, FusedAlias) else a
+            alias_w.append(t)
+            vfn[id(t)] = a.version if isinstance(a, FusedAlias) else (lambda t=t: t._version)
+        aliases = alias_w
         alias_ids = {id(t) for t in aliases}
         for p in list(params) + list(aliases):
             if id(p) in skip:
@@ -107,18 +126,19 @@ class WeightArena:
         self.tr = torch.empty(off, device=dev, dtype=torch.bfloat16)
         self.versions = []
         for p, o, N, K in self.views:
-            box = [p._version]
-            self.versions.append(box)
+            get = vfn.get(id(p)) or (lambda r=weakref.ref(p): r()._version)
+            box = [get()]
+            self.versions.append((box, get))
             CACHE.persistent[(id(p), torch.bfloat16)] = (weakref.ref(p), (p.data_ptr(), tuple(p.shape)),
                                                          self.cast[o:o + N * K].view(N, K), self.tr[o:o + N * K].view(K, N),
-                                                         box)
+                                                         box, get)
         self.refresh()
 
     def refresh(self):
         if self.n:
             ops.cast_transpose_multi(self.flat, self.meta, self.n, self.tiles, self.cast, self.tr)
-            for (p, _, _, _), box in zip(self.views, self.versions):
-                box[0] = p._version
+            for box, get in self.versions:
+                box[0] = get()
 
     def release(self):
         """Drop this arena's views from the cache (the bf16 arenas are freed with them)."""
@@ -158,7 +178,10 @@ def _mask_u8(mask):
     e = _MASKS.get(key)
     if e is None or e[0]() is not mask or e[1] != (mask._version, mask.data_ptr()):
         if len(_MASKS) > 64:
-            _MASKS.clear()
+            # drop entries of masks that died; a LIVE mask's uint8 copy may be baked into a captured hipGraph as a raw
+            # pointer (the denoiser's alignment mask in graph-mode training) and must never be freed behind it
+            for k in [k for k, v in _MASKS.items() if v[0]() is None]:
+                del _MASKS[k]
         e = _MASKS[key] = (weakref.ref(mask), (mask._version, mask.data_ptr()), mask.to(torch.uint8).contiguous())
     return e[2]
 
@@ -174,7 +197,13 @@ def _param_grads(dz2, xin, w, b_ref, has_b, K, need_w, need_b, alias):
     want_b = has_b and need_b
     if alias is not None:
         fa = alias
-        ops.gemm_tn(dz2, xin.reshape(M, Kp), out=fa.wgrad.view(N, Kp), colsum_out=fa.bgrad, accumulate=True)
+        if dtype == torch.bfloat16 and USE_GEMM_TN and N % 8 == 0 and Kp == K:
+            ops.gemm_tn(dz2, xin.reshape(M, Kp), out=fa.wgrad.view(N, Kp), colsum_out=fa.bgrad, accumulate=True)
+        else:       # the forms the TN kernel does not take (fp32 operands, USE_GEMM_TN off): the generic products, then added
+            dwa, dba = _param_grads(dz2, xin, w, None, has_b, K, True, True, None)
+            fa.wgrad.add_(dwa.reshape(fa.wgrad.shape))
+            if has_b:
+                fa.bgrad.add_(dba.reshape(fa.bgrad.shape))
         if GRAD_WRITTEN is not None:
             for o in fa.owners:
                 GRAD_WRITTEN(o)
@@ -252,18 +281,18 @@ class Junction:
     with a Junction the jout node hands its residual gradient over instead of returning it, and the jin node passes it to
     its data-gradient GEMM as the epilogue's residual operand.  Legal only when the jout node's input depends on the jin
     node's output (then its backward runs first); the jin node raises if that was not so.  One Junction per block and pass."""
-    __slots__ = ("armed", "paired", "pending", "shape")
+    __slots__ = ("armed", "paired", "pending", "shape", "ident")
 
     def __init__(self):
         self.armed = self.paired = False
-        self.pending = self.shape = None
+        self.pending = self.shape = self.ident = None
 
 
 class LinearFn(torch.autograd.Function):
     """y = act(x @ w.T + b) + residual   (x: (..., K) compute dtype; w (N, K), b (N) fp32 master parameters)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, residual, act, p_drop=0.0, site=0, alias=None, jin=None, jout=None):
+    def forward(ctx, x, w, b, residual, act, p_drop=0.0, site=0, alias=None, jin=None, jout=None, token=None):
         """y = dropout_p(act(x W^T + b)) + residual in ONE GEMM launch: the epilogue also writes the pre-activation z
         (needed by the backward) when there is an activation, and applies the Philox keep mask.  alias (FusedAlias):
         w / b are arena views without autograd history; the backward adds dW / db into alias.wgrad / alias.bgrad.
@@ -276,8 +305,12 @@ class LinearFn(torch.autograd.Function):
         ctx.jin = ctx.jout = None
         if jin is not None and ctx.needs_input_grad[0] and wc.shape[1] == K and x.dtype in (torch.bfloat16, torch.float16):
             ctx.jin, jin.armed, jin.shape = jin, True, tuple(x.shape)
+            jin.ident = (x.data_ptr(), x._version, x.dtype)
+        # the residual must BE the tensor the jin node consumed (same storage, same version), not merely look like it: a
+        # same-shaped neighbour (h_in vs h after a refactor) would get its gradient routed into the wrong dx without an error
         if (jout is not None and jout.armed and residual is not None and ctx.needs_input_grad[3]
-                and tuple(residual.shape) == jout.shape and residual.dtype == x.dtype):
+                and tuple(residual.shape) == jout.shape and (residual.data_ptr(), residual._version, residual.dtype) == jout.ident
+                and residual.dtype == x.dtype):
             ctx.jout, jout.paired = jout, True
         xin = x if wc.shape[1] == K else ops.pad_cols(x.contiguous(), wc.shape[1], dtype)
         xin = xin.contiguous()
@@ -318,16 +351,17 @@ class LinearFn(torch.autograd.Function):
             dzp = dz2 if wct.shape[1] == N else ops.pad_cols(dz2, wct.shape[1], dtype)
             jres = None
             if ctx.jin is not None and ctx.jin.paired:
-                if ctx.jin.pending is None:   # the provider is downstream of this node in every legal use: it has run
+                pend, ctx.jin.pending = ctx.jin.pending, None
+                if pend is None:   # the provider is downstream of this node in every legal use: it has run
                     raise RuntimeError("Junction: the residual node's backward has not handed its gradient over")
-                jres, ctx.jin.pending = ctx.jin.pending.reshape(M, -1), None
+                jres = pend.reshape(M, -1)
             dx = ops.gemm(dzp, wct, residual=jres).reshape(*xin.shape[:-1], wct.shape[0])
         dw, db = _param_grads(dz2, xin, w, ctx.b_ref, ctx.has_b, ctx.K, ctx.needs_input_grad[1], ctx.needs_input_grad[2],
                               ctx.alias)
         dres = dy if ctx.has_r and ctx.needs_input_grad[3] else None
         if ctx.jout is not None and dres is not None:
             ctx.jout.pending, dres = dres, None
-        return dx, dw, db, dres, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None
 
 
 class FFNFn(torch.autograd.Function):
@@ -696,7 +730,7 @@ def linear(x, w, b=None, act=ACT_NONE, residual=None, junction_in=None, junction
 
 def linear_alias(x, fa, act=ACT_NONE, residual=None, junction_in=None):
     """linear() on a FusedAlias operand (arena views; gradients go straight into the gradient arena)."""
-    return _apply(LinearFn, x, fa.w, fa.b, residual, act, 0.0, 0, fa, junction_in if USE_JUNCTIONS else None, None)
+    return _apply(LinearFn, x, fa.w, fa.b, residual, act, 0.0, 0, fa, junction_in if USE_JUNCTIONS else None, None, fa.token)
 
 
 def layer_norm(x, gamma, beta, post_add=None, sole_consumer=True):

@@ -31,6 +31,9 @@ DEFAULTS = dict(
     # engine (new in this build)
     compute_dtype="bf16",       # "bf16" speed mode | "fp32" parity mode
     encoder_layers=None,        # override HF num_hidden_layers (tests use 1-2)
+    # pretrained audio encoder (reference model.py:95 / :100 hard-code the hub id and /code/models/Huggingface/hub2):
+    audio_encoder_weights=None,  # None: the hub id's local checkpoint, else RAISE | a checkpoint directory | "synthetic"
+    hf_cache_dir=None,           # hub-cache root searched first (then HF_HUB_CACHE, HF_HOME, ~/.cache, the reference's)
 )
 
 
@@ -38,3 +41,10 @@ def default_args(**overrides) -> argparse.Namespace:
     cfg = dict(DEFAULTS)
     cfg.update(overrides)
     return argparse.Namespace(**cfg)
+
+
+def synthetic_args(**overrides) -> argparse.Namespace:
+    """default_args with the audio encoder on the closed-form synthetic weights of msmd_amd.synth, said out loud:
+    benchmarks, smoke() and the developer tools have no pretrained asset (no network)."""
+    overrides.setdefault("audio_encoder_weights", "synthetic")
+    return default_args(**overrides)

@@ -44,46 +44,40 @@ def window_plan(n_samples: int, fps, n_motions: int, audio_unit: float):
 def infer_coeffs(model, args, audio, shape_coef, audio_unit, style_feats=None, n_repetitions: int = 1, cfg_mode=None,
                  cfg_cond=None, cfg_scale: float = 1.15, include_shape: bool = False, dynamic_threshold=(0, 1, 4),
                  noise=None):
-    """reference inference.py:34-75.  ``noise`` (optional): {'xT': tensor, 'z': [dict per window]} for replay."""
-    _, _, n_subdivision, n_pad_samples, n_padding_frames = window_plan(len(audio), args.fps, args.n_motions, audio_unit)
-    stride = args.n_motions
-    if n_pad_samples > 0:
-        audio = F.pad(audio, (0, n_pad_samples), value=0)
-    audio_feat = model.extract_audio_feature(audio.unsqueeze(0), args.n_motions * n_subdivision)
-    coef_list = []
-    prev_motion_feat = prev_audio_feat = noise_T = None
-    for i in range(n_subdivision):
-        start_idx = i * stride
-        end_idx = start_idx + args.n_motions
-        indicator = torch.ones((n_repetitions, args.n_motions)).to(model.device) if args.use_indicator else None
-        if indicator is not None and i == n_subdivision - 1 and n_padding_frames > 0:
-            indicator[:, -n_padding_frames:] = 0
-        audio_in = audio_feat[:, start_idx:end_idx].expand(n_repetitions, -1, -1)
-        style_feat = style_feats[i] if isinstance(style_feats, list) else style_feats
-        zi = noise["z"][i] if noise is not None else None
-        if i == 0:
-            motion_feat, noise_T, prev_audio_feat = model.sample(
-                audio_in, shape_coef, style_feat, motion_at_T=noise["xT"] if noise is not None else None,
-                indicator=indicator, cfg_mode=cfg_mode, cfg_cond=cfg_cond, cfg_scale=cfg_scale,
-                dynamic_threshold=dynamic_threshold, noise=zi)
-        else:
-            motion_feat, noise_T, prev_audio_feat = model.sample(
-                audio_in, shape_coef, style_feat, prev_motion_feat, prev_audio_feat, noise_T, indicator=indicator,
-                cfg_mode=cfg_mode, cfg_cond=cfg_cond, cfg_scale=cfg_scale, dynamic_threshold=dynamic_threshold,
-                noise=zi)
-        prev_motion_feat = motion_feat[:, -args.n_prev_motions:].clone()
-        prev_audio_feat = prev_audio_feat[:, -args.n_prev_motions:]
-        motion_coef = motion_feat
-        if i == n_subdivision - 1 and n_padding_frames > 0:
-            motion_coef = motion_coef[:, :-n_padding_frames]
-        coef_list.append(motion_coef)
-    return torch.cat(coef_list, dim=1)
+    """Coefficients for one clip of any length (reference inference.py:34-75; same signature, window arithmetic and hand-off
+    rules).  The clip is zero-padded to a whole number of n_motions-frame windows and encoded ONCE; each window is one
+    `model.sample` call conditioned on the previous window's last n_prev_motions motion / audio-feature frames, every
+    window after the first starts from window 0's x_T, and the frames that only cover the padding are cut from the result.
+    ``noise`` (optional, replay): {'xT': tensor, 'z': [per-window dict of per-step draws]}."""
+    L, keep = args.n_motions, args.n_prev_motions
+    _, _, n_windows, pad_samples, pad_frames = window_plan(len(audio), args.fps, L, audio_unit)
+    tail = max(pad_frames, 0)                       # frames of the last window that lie entirely in the zero padding
+    wave = F.pad(audio, (0, pad_samples), value=0) if pad_samples > 0 else audio
+    per_window = model.extract_audio_feature(wave.unsqueeze(0), L * n_windows).split(L, dim=1)
+    guidance = dict(cfg_mode=cfg_mode, cfg_cond=cfg_cond, cfg_scale=cfg_scale, dynamic_threshold=dynamic_threshold)
+    history = (None, None, None if noise is None else noise["xT"])      # (prev motion, prev audio features, x_T)
+    pieces = []
+    for w, feat in enumerate(per_window):
+        cut = tail if w == n_windows - 1 else 0
+        indicator = None
+        if args.use_indicator:
+            indicator = torch.ones((n_repetitions, L), device=model.device)
+            if cut:
+                indicator[:, L - cut:] = 0
+        style = style_feats[w] if isinstance(style_feats, list) else style_feats
+        x0, x_T, feat_used = model.sample(feat.expand(n_repetitions, -1, -1), shape_coef, style, *history, indicator=indicator,
+                                          noise=None if noise is None else noise["z"][w], **guidance)
+        history = (x0[:, -keep:].clone(), feat_used[:, -keep:], x_T)
+        pieces.append(x0[:, :L - cut] if cut else x0)
+    return torch.cat(pieces, dim=1)
 
 
 def load_model(model_root: str, model_name: str, iter_num: str, device: torch.device):
     """reference inference.py:85-103 (same directory layout and checkpoint keys)."""
     import os
     model_args = load_args(Path(os.path.join(model_root, "DPT", model_name)))
+    # the checkpoint holds every audio-encoder tensor (strict load below): no Hugging Face copy is needed to rebuild the model
+    model_args.audio_encoder_weights = "checkpoint"
     model = get_diffusion_model(model_args, device)
     ckpt = Path(model_root) / "DPT" / model_name / "checkpoints" / f"iter_{iter_num}.pt"
     data = torch.load(ckpt, map_location=device, weights_only=False)  # reference checkpoints pickle their args Namespace

@@ -527,14 +527,22 @@ class MSMD(nn.Module):
         if self.use_style:
             self.style_feat_dim = args.d_style
         self.audio_model = args.audio_model
-        enc_cfg = dict(num_hidden_layers=getattr(args, "encoder_layers", None) or 12)
+        enc_cfg = dict(num_hidden_layers=getattr(args, "encoder_layers", None))
+        # reference model.py:95 / :100: the pretrained encoder, from a LOCAL Hugging Face checkpoint.  args.audio_encoder_weights:
+        # None = the reference's hub id (raises when no local copy exists), a directory = that checkpoint, "synthetic" = the
+        # closed-form weights (benchmarks / tests), "checkpoint" = bare architecture, a full state_dict follows (inference.load_model);
+        # args.hf_cache_dir = hub-cache root (the reference hard-codes its own)
+        src = getattr(args, "audio_encoder_weights", None)
+        pre = dict(cache_dir=getattr(args, "hf_cache_dir", None),
+                   synthetic=True if src == "synthetic" else ("checkpoint" if src == "checkpoint" else None))
+        hub = lambda default: default if src in (None, "synthetic", "checkpoint") else src
         if self.audio_model == "wav2vec2":
             from .utils.wav2vec2 import Wav2Vec2Model
-            self.audio_encoder = Wav2Vec2Model.from_pretrained("facebook/wav2vec2-base-960h", config=enc_cfg)
+            self.audio_encoder = Wav2Vec2Model.from_pretrained(hub("facebook/wav2vec2-base-960h"), config=enc_cfg, **pre)
             frozen = ("feature_extractor",)
         elif self.audio_model == "hubert":
             from .utils.hubert import HubertModel
-            self.audio_encoder = HubertModel.from_pretrained("facebook/hubert-base-ls960", config=enc_cfg)
+            self.audio_encoder = HubertModel.from_pretrained(hub("facebook/hubert-base-ls960"), config=enc_cfg, **pre)
             frozen = ("feature_extractor", "feature_projection", "encoder.layers.0.", "encoder.layers.1.")
         elif self.audio_model == "hubert_large":
             # BASELINE.json configs[3] "HuBERT-large encoder swap": not reachable in the reference (model.py:100
@@ -544,7 +552,7 @@ class MSMD(nn.Module):
             cfg = dict(LARGE_CONFIG)
             if getattr(args, "encoder_layers", None):
                 cfg["num_hidden_layers"] = args.encoder_layers
-            self.audio_encoder = HubertModel.from_pretrained("facebook/hubert-large-ls960-ft", config=cfg)
+            self.audio_encoder = HubertModel.from_pretrained(hub("facebook/hubert-large-ls960-ft"), config=cfg, **pre)
             frozen = ("feature_extractor", "feature_projection", "encoder.layers.0.", "encoder.layers.1.")
         else:
             raise ValueError(f"Unknown audio model {self.audio_model}!")

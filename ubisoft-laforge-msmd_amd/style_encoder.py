@@ -11,9 +11,10 @@ from .model import _cd, _is_split
 from .utils.model_common import ParamTree, sinusoid_table
 
 
-def get_style_encoder(args, model_style="vae2"):
-    """reference style_encoder.py:7-12 (returns None for anything but 'vae2', as the reference does)."""
-    if model_style == "vae2":
+def get_style_encoder(args, style_encoder_model_style="diffposetalk"):
+    """reference style_encoder.py:7-12: returns None for anything but 'vae2' -- its own default included -- as the reference
+    does (every caller passes args.style_enc_model_style = "vae2": training_script.py:527, inference.py:97)."""
+    if style_encoder_model_style == "vae2":
         return StyleEncoder_VAE2(args)
     return None
 

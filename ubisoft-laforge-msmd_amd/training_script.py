@@ -200,7 +200,7 @@ class Trainer:
                                  if self.direct_grad and model.compute_dtype == torch.bfloat16 else ([], []))
         self._aliases = aliases     # keeps the alias tensors (and with them their cache keys) alive
         if model.compute_dtype == torch.bfloat16:
-            self.weight_arena = ag.WeightArena(self.flat_param, params, aliases=[a.w for a in aliases], skip=only_aliased)
+            self.weight_arena = ag.WeightArena(self.flat_param, params, aliases=aliases, skip=only_aliased)
         # Philox (seed, step) for dropout masks: device memory, advanced once per iteration
         self.noise_state = torch.tensor([0x5EED0000 + 7919 * dp.env_rank()[0], 0], dtype=torch.int64, device=self.device)
 
@@ -765,6 +765,10 @@ def build_parser():
     ap.add_argument("--compute_dtype", type=str, default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--hip_graph", action="store_true", help="replay forward+backward as one hipGraph per truncation pattern")
     ap.add_argument("--exp_root", type=str, default="experiments")
+    ap.add_argument("--audio_encoder_weights", type=str, default=None,
+                    help="Hugging Face checkpoint directory of the pretrained audio encoder (default: the reference's hub id, looked up "
+                         "locally; the run stops if none is found), or 'synthetic' for closed-form test weights")
+    ap.add_argument("--hf_cache_dir", type=str, default=None, help="hub-cache root searched first (reference: /code/models/Huggingface/hub2)")
     return ap
 
 
@@ -795,6 +799,8 @@ def main(argv=None):
     val_set = ResidentDataset(raw, names[:n_val], coef_stats=train_set.coef_stats, coef_fps=args.fps,
                               original_fps=getattr(args, "original_fps", 30), n_motions=args.n_motions,
                               clip_len=args.n_motions, device=device, random_crop=False)
+    if cli.continue_from and args.audio_encoder_weights is None:
+        args.audio_encoder_weights = "checkpoint"      # every encoder tensor comes from the checkpoint loaded below
     model = get_diffusion_model(args, device)
     style_enc = get_style_encoder(args, args.style_enc_model_style).to(device)
     trainer = Trainer(args, model, style_enc, use_graph=cli.hip_graph)

@@ -108,6 +108,15 @@ class FLAME(nn.Module):
         self._packed = None
         return super()._apply(fn, *a, **k)
 
+    def _find_dynamic_lmk_idx_and_bcoords(self, pose, dynamic_lmk_faces_idx, dynamic_lmk_b_coords, neck_kin_chain,
+                                          dtype=torch.float32, pose2rot=True):
+        """reference utils/flame.py:126-172: the contour's face ids and barycentric weights for each frame's yaw -- the
+        neck chain's relative rotation, its yaw in degrees rounded, clamped to <= 39 and negative angles folded to 39..78,
+        is the row of both tables (one kernel: msmd_dynamic_lmk_row; forward() above uses the same launch)."""
+        chain = torch.as_tensor(neck_kin_chain, device=pose.device).to(torch.int32).contiguous()
+        row = ops.dynamic_lmk_row(pose.float().contiguous(), chain, pose_is_matrix=not pose2rot).long()
+        return torch.index_select(dynamic_lmk_faces_idx, 0, row), torch.index_select(dynamic_lmk_b_coords, 0, row)
+
     def seletec_3d68(self, vertices):
         p = self._pack()
         return ops.landmarks(vertices.float().contiguous(), p["faces"], p["full_idx"], self.full_lmk_bary_coords)

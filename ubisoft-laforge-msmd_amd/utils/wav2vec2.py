@@ -104,6 +104,55 @@ def linear_interpolation(features, input_fps, output_fps, output_len=None):
     return ops.interp_linear(features, output_len)
 
 
+def _hub_roots(cache_dir=None):
+    """Directories searched for a hub-cache layout, in order (the last one is the reference's own, model.py:95)."""
+    import os
+    roots = [cache_dir, os.environ.get("HF_HUB_CACHE"),
+             os.path.join(os.environ["HF_HOME"], "hub") if os.environ.get("HF_HOME") else None,
+             os.path.join(os.path.expanduser("~"), ".cache", "huggingface", "hub"), "/code/models/Huggingface/hub2"]
+    return [str(r) for r in roots if r]
+
+
+def _is_checkpoint_dir(d):
+    import os
+    return os.path.isfile(os.path.join(d, "config.json")) and any(
+        os.path.isfile(os.path.join(d, f)) for f in ("model.safetensors", "pytorch_model.bin"))
+
+
+def find_pretrained(name, cache_dir=None):
+    """Local directory of checkpoint `name` (a path, or a hub id resolved in the hub-cache layout), or None."""
+    import glob
+    import os
+    name = str(name)
+    if os.path.isdir(name) and _is_checkpoint_dir(name):
+        return name
+    for root in _hub_roots(cache_dir):
+        direct = os.path.join(root, name)
+        if os.path.isdir(direct) and _is_checkpoint_dir(direct):
+            return direct
+        repo = os.path.join(root, "models--" + name.replace("/", "--"))
+        ref = os.path.join(repo, "refs", "main")
+        if os.path.isfile(ref):
+            snap = os.path.join(repo, "snapshots", open(ref).read().strip())
+            if _is_checkpoint_dir(snap):
+                return snap
+        for snap in sorted(glob.glob(os.path.join(repo, "snapshots", "*"))):
+            if _is_checkpoint_dir(snap):
+                return snap
+    return None
+
+
+def load_hf_state_dict(directory):
+    """name -> tensor of a Hugging Face checkpoint directory (safetensors preferred, as transformers does)."""
+    import os
+    st = os.path.join(directory, "model.safetensors")
+    if os.path.isfile(st):
+        from safetensors.torch import load_file
+        return load_file(st, device="cpu")
+    sd = torch.load(os.path.join(directory, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+    return sd.get("state_dict", sd) if isinstance(sd, dict) else sd
+
+
 class Wav2Vec2Model(nn.Module):
     """HF-key-compatible parameter tree + HIP forward.  ``config`` carries num_hidden_layers etc."""
 
@@ -120,7 +169,7 @@ class Wav2Vec2Model(nn.Module):
                    layerdrop=0.1, apply_spec_augment=True, mask_time_prob=0.05, mask_time_length=10,
                    mask_time_min_masks=2)
         if config is not None:
-            cfg.update(config if isinstance(config, dict) else vars(config))
+            cfg.update({k: v for k, v in (config if isinstance(config, dict) else vars(config)).items() if v is not None})
         self.config = SimpleNamespace(**cfg)
         c = self.config
         if isinstance(c.conv_dim, (tuple, list)):   # HF configs carry one entry per conv layer (all 512)
@@ -143,11 +192,72 @@ class Wav2Vec2Model(nn.Module):
         self.split_mode = False   # set by MSMD for compute_dtype "f16x2" (contractions on MSMD_F16X2 split pairs)
 
     @classmethod
-    def from_pretrained(cls, name=None, cache_dir=None, **kw):
-        """No network and no HF cache in this environment: returns the architecture with the
-        deterministic synthetic weights (msmd_amd.synth); real weights arrive via load_state_dict."""
-        m = cls(kw.get("config"))
-        synth.load_synthetic(m, prefix="audio_encoder.")
+    def from_pretrained(cls, name=None, cache_dir=None, *, config=None, synthetic=None, **kw):
+        """reference model.py:95 / :100 -- ``Wav2Vec2Model.from_pretrained('facebook/wav2vec2-base-960h', cache_dir=...)``.
+
+        Loads a LOCAL Hugging Face checkpoint (there is no network here and no `transformers` on the path):
+        ``name`` may be a directory holding ``config.json`` + ``model.safetensors`` / ``pytorch_model.bin``, or a hub id
+        that is looked up in the hub cache layout (``<cache_dir>/models--org--name/snapshots/<rev>/``) under
+        ``cache_dir``, ``$HF_HUB_CACHE``, ``$HF_HOME/hub``, ``~/.cache/huggingface/hub`` and the reference's hard-coded
+        ``/code/models/Huggingface/hub2``.  ``config`` entries override those of ``config.json`` (tests cut
+        ``num_hidden_layers``).  Task-head checkpoints (``wav2vec2.*`` / ``hubert.*`` prefixes, ``lm_head``) and both
+        weight-norm spellings load; a missing encoder tensor raises.
+
+        When no checkpoint is found this RAISES, as the reference would, unless synthetic weights were asked for:
+        ``synthetic=True`` or ``MSMD_SYNTHETIC_WEIGHTS=1`` in the environment (tests, bench.py and smoke() set it: they
+        run on the closed-form weights of msmd_amd.synth).  A run never trains on a noise-initialised encoder silently.
+        ``synthetic="checkpoint"`` builds the bare architecture for callers that load a full state_dict right after."""
+        import os
+        if synthetic == "checkpoint":      # the caller loads a complete state_dict next (inference.load_model, Trainer.load_checkpoint)
+            m = cls(config)
+            m.weights_source = "checkpoint"
+            return m
+        found = find_pretrained(name, cache_dir) if name is not None else None
+        if found is None:
+            if synthetic is None:
+                synthetic = os.environ.get("MSMD_SYNTHETIC_WEIGHTS", "0") not in ("", "0")
+            if not synthetic:
+                raise FileNotFoundError(
+                    f"{cls.__name__}.from_pretrained({name!r}): no local Hugging Face checkpoint (config.json + "
+                    f"model.safetensors | pytorch_model.bin) under {_hub_roots(cache_dir)}; pass a checkpoint directory, "
+                    f"set cache_dir / HF_HOME, or ask for synthetic weights explicitly (synthetic=True, "
+                    f"args.audio_encoder_weights='synthetic' or MSMD_SYNTHETIC_WEIGHTS=1)")
+            m = cls(config)
+            synth.load_synthetic(m, prefix="audio_encoder.")
+            m.weights_source = "synthetic"
+            return m
+        import json
+        with open(os.path.join(found, "config.json")) as f:
+            hf = json.load(f)
+        cfg = {k: hf[k] for k in ("num_hidden_layers", "hidden_size", "intermediate_size", "num_attention_heads", "conv_dim",
+                                  "num_conv_pos_embeddings", "num_conv_pos_embedding_groups", "layer_norm_eps",
+                                  "feat_extract_norm", "conv_bias", "do_stable_layer_norm", "hidden_dropout",
+                                  "attention_dropout", "activation_dropout", "feat_proj_dropout", "layerdrop",
+                                  "apply_spec_augment", "mask_time_prob", "mask_time_length", "mask_time_min_masks") if k in hf}
+        if tuple(hf.get("conv_kernel", CONV_KERNEL)) != CONV_KERNEL or tuple(hf.get("conv_stride", CONV_STRIDE)) != CONV_STRIDE:
+            raise ValueError(f"{found}: conv_kernel / conv_stride {hf.get('conv_kernel')} / {hf.get('conv_stride')} are not the "
+                             f"wav2vec2 / HuBERT feature extractor this path implements ({CONV_KERNEL} / {CONV_STRIDE})")
+        if len(set(hf.get("conv_dim", [512]))) != 1:
+            raise ValueError(f"{found}: conv_dim {hf['conv_dim']} varies per layer; the path's feature extractor is uniform")
+        if config is not None:     # e.g. fewer layers than the checkpoint holds (tests): the rest of the checkpoint is dropped
+            over = dict(config if isinstance(config, dict) else vars(config))
+            cfg.update({k: v for k, v in over.items() if v is not None})
+        m = cls(cfg)
+        sd = load_hf_state_dict(found)
+        want = m.state_dict()
+        clean = {}
+        for k, v in sd.items():
+            for head in ("wav2vec2.", "hubert."):      # task-head checkpoints (Wav2Vec2ForCTC: the 960h model) nest the encoder
+                if k.startswith(head):
+                    k = k[len(head):]
+            k = synth.canonical_name(k)
+            if k in want:
+                clean[k] = v
+        missing = [k for k in want if k not in clean and k != "masked_spec_embed"]
+        if missing:
+            raise KeyError(f"{found}: checkpoint lacks {len(missing)} encoder tensors, e.g. {missing[:4]}")
+        m.load_state_dict(clean, strict=False)
+        m.weights_source = found
         return m
 
     def _load_from_state_dict(self, state_dict, prefix, *a, **k):
