@@ -524,9 +524,11 @@ def test_gemm_store_flags_and_variants_are_bit_identical(dtype):
     b = torch.randn(N, generator=g).to(DEV)
     r = torch.randn(M, N, generator=g).to(DEV, dtype)
     ref = o.gemm(a, w, b, r, act=o.ACT_GELU, variant=17, flags=0)
-    variants = (0, 9, 12, 14, 15, 17) + ((13,) if dtype == torch.bfloat16 else ())
+    # 60-64: the v4 kernels (fragment reads pipelined inside the wave, 256 x 128 / 128 x 128 tiles; bf16 instantiations)
+    variants = (0, 9, 12, 14, 15, 17) + ((13, 60, 61, 62, 63, 64) if dtype == torch.bfloat16 else ())
     for v in variants:
-        for fl in (0, o.GEMM_WRITE_THROUGH, o.GEMM_PAIRED_STORES, o.GEMM_WRITE_THROUGH | o.GEMM_PAIRED_STORES):
+        for fl in (0, o.GEMM_WRITE_THROUGH, o.GEMM_PAIRED_STORES, o.GEMM_WRITE_THROUGH | o.GEMM_PAIRED_STORES,
+                   o.GEMM_PAIRED_STORES | o.GEMM_STAGGER):
             c = o.gemm(a, w, b, r, act=o.ACT_GELU, variant=v, flags=fl)
             assert torch.equal(c, ref), (v, fl, float((c.float() - ref.float()).abs().max()))
 

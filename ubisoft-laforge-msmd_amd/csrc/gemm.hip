@@ -38,6 +38,8 @@ struct GemmArgs {
   const float* a_stats = nullptr; int a_nt = 0; const float* w_colsum = nullptr;
   const float* r_stats = nullptr; int r_nt = 0; const float* r_gamma = nullptr; const float* r_beta = nullptr;
   float* stats_out = nullptr; float ln_eps = 1e-5f;
+  // flags bit 2 (MSMD_GEMM_STAGGER): the workgroups dispatched second onto their CU start `stagger_ticks` (100 MHz) late
+  int stagger_ticks = 0;
 };
 
 template <typename T> struct Mfma;
@@ -110,7 +112,10 @@ template <typename TO> __device__ __forceinline__ void store4_out(TO* p, const f
 // Interior tiles (fully inside M x N, vector-aligned): straight-line code, no per-element bounds checks.
 // AB: the kernel also serves msmd_gemm_actbwd (flags bit 3).  Only the LDS-DMA 16-bit kernels carry that code: in the v1 /
 // fp32 kernels it cost 272 bytes of scratch (fp32 mode 23.8 -> 34 ms).
-template <typename TO, int FM, int FN, bool AB = false>
+// LEAN: the inference epilogue only (no pre-activation copy, no dropout, no activation backward): the launcher sends calls that
+// carry those to the kernels that compile them in.  On the 16-fragment wave tiles of gemm4_kernel the full epilogue is
+// tens of thousands of instructions and pushed the accumulators into scratch.
+template <typename TO, int FM, int FN, bool AB = false, bool LEAN = false>
 __device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int z, int m_base,
                                                        int n_base, int fr, int fq) {
   TO* __restrict__ C = (TO*)p.C + (z / p.batch_inner) * p.strideC + (z % p.batch_inner) * p.strideC2 +
@@ -146,11 +151,11 @@ __device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const 
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= act_grad_fast((float)z4[e], p.act);
     } else {
-      if (p.Z) store4_out<TO>((TO*)p.Z + (crow + i * 16 - (TO*)p.C), v, wt);
+      if (!LEAN && p.Z) store4_out<TO>((TO*)p.Z + (crow + i * 16 - (TO*)p.C), v, wt);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = act_out<TO>(v[e], p.act);
     }
-    if (p.p_drop > 0.f) {
+    if (!LEAN && p.p_drop > 0.f) {
       const long idx = (long)(m_base + j * 16 + fr) * p.N + (n_base + i * 16 + fq * 4);
       const Philox4 rb = dropout_bits(p.rng, p.site, (unsigned long)(idx >> 2));
       const unsigned thr = dropout_threshold(p.p_drop);
@@ -205,11 +210,11 @@ __device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const 
   }
 }
 
-template <typename TO, int FM, int FN, bool AB = false>
+template <typename TO, int FM, int FN, bool AB = false, bool LEAN = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int z, int m_base,
                                               int n_base, int fr, int fq) {
   if (p.vec_ok && m_base + FM * 16 <= p.M && n_base + FN * 16 <= p.N) {
-    gemm_epilogue_interior<TO, FM, FN, AB>(p, acc, z, m_base, n_base, fr, fq);
+    gemm_epilogue_interior<TO, FM, FN, AB, LEAN>(p, acc, z, m_base, n_base, fr, fq);
     return;
   }
   TO* __restrict__ C = (TO*)p.C + (z / p.batch_inner) * p.strideC + (z % p.batch_inner) * p.strideC2;
@@ -238,7 +243,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
         for (int e = 0; e < 4; ++e)
           if (n + e < p.N) v[e] *= act_grad_fast((float)zp[e], p.act);
       } else {
-        if (p.Z) {
+        if (!LEAN && p.Z) {
           TO* zp = (TO*)p.Z + (cp - (TO*)p.C);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -247,7 +252,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_out<TO>(v[e], p.act);
       }
-      if (p.p_drop > 0.f) {   // launcher guarantees N % 4 == 0 and ldc == N here
+      if (!LEAN && p.p_drop > 0.f) {   // launcher guarantees N % 4 == 0 and ldc == N here
         const Philox4 rb = dropout_bits(p.rng, p.site, (unsigned long)(((long)m * p.N + n) >> 2));
         const unsigned thr = dropout_threshold(p.p_drop);
         const float c = 1.0f / (1.0f - p.p_drop);
@@ -329,7 +334,7 @@ __device__ __forceinline__ void ln_finish(const float* stats, int nt, int M, int
 template <typename TO, int FM, int FN, int MODE>
 __device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int m_base, int n_base,
                                                  int fr, int fq, const f32x2 (&raw)[FM][4]) {
-  static_assert((FN == 4 || FN == 2) && (FM == 2 || FM == 3), "one wave = one statistics slab of 16 FN columns, 2 or 3 fragment rows");
+  static_assert((FN == 4 || FN == 2) && (FM >= 2 && FM <= 4), "one wave = one statistics slab of 16 FN columns, 2 to 4 fragment rows");
   constexpr int SLAB = FN * 16;
   // fragment columns whose operands are requested together: all of them for the two-row tiles; two at a time for the
   // 192-row tile, whose kernel has 128 registers for everything (all four would need 166: one workgroup per CU)
@@ -394,17 +399,20 @@ __device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& p, const f32x4 
       bool stored = false;
       if constexpr (sizeof(TO) == 2) {
         if (pair) {     // lanes l and l ^ 16 swap one fragment row: one 16-byte store each (see gemm_epilogue_interior)
-          const u32x2 a = __builtin_bit_cast(u32x2, o[0]), b = __builtin_bit_cast(u32x2, o[1]);
-          const u32x2 send = odd ? a : b;
-          u32x2 recv;
-          recv[0] = __shfl_xor(send[0], 16, 64);
-          recv[1] = __shfl_xor(send[1], 16, 64);
-          const u32x4 w = odd ? u32x4{recv[0], recv[1], b[0], b[1]} : u32x4{a[0], a[1], recv[0], recv[1]};
-          const int m = m_base + (odd ? 16 : 0) + fr;
-          if (m < p.M) *(u32x4*)((TO*)p.C + (long)m * p.ldc + n + i * 16 - (odd ? 4 : 0)) = w;
-          if constexpr (FM == 3) {   // the third fragment row of the 192-row tile has no partner: plain 8-byte stores
-            const int m2 = m_base + 32 + fr;
-            if (m2 < p.M) *(V4*)((TO*)p.C + (long)m2 * p.ldc + n + i * 16) = o[2];
+#pragma unroll
+          for (int jp = 0; jp + 1 < FM; jp += 2) {
+            const u32x2 a = __builtin_bit_cast(u32x2, o[jp]), b = __builtin_bit_cast(u32x2, o[jp + 1]);
+            const u32x2 send = odd ? a : b;
+            u32x2 recv;
+            recv[0] = __shfl_xor(send[0], 16, 64);
+            recv[1] = __shfl_xor(send[1], 16, 64);
+            const u32x4 w = odd ? u32x4{recv[0], recv[1], b[0], b[1]} : u32x4{a[0], a[1], recv[0], recv[1]};
+            const int m = m_base + jp * 16 + (odd ? 16 : 0) + fr;
+            if (m < p.M) *(u32x4*)((TO*)p.C + (long)m * p.ldc + n + i * 16 - (odd ? 4 : 0)) = w;
+          }
+          if constexpr (FM % 2 == 1) {   // the last fragment row of the 192-row tile has no partner: plain 8-byte stores
+            const int m2 = m_base + (FM - 1) * 16 + fr;
+            if (m2 < p.M) *(V4*)((TO*)p.C + (long)m2 * p.ldc + n + i * 16) = o[FM - 1];
           }
           stored = true;
         }
@@ -594,6 +602,14 @@ __global__ __launch_bounds__(WM * WN * 64, STAG ? 4 : 1) void gemm2_kernel(const
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s, s);
+  if (p.stagger_ticks > 0 && ((pid >> 8) & 1) && pid < 512) {
+    // Two co-resident workgroups that start together stay in lockstep for the whole launch (both multiply, then both run
+    // their epilogues, then their two successors start together): the second one of each CU waits half a tile period once,
+    // with its first stage already in flight, so that from then on one workgroup's prologue / epilogue runs beside the
+    // other's K loop
+    const unsigned long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((long)(__builtin_amdgcn_s_memrealtime() - t0) < p.stagger_ticks) __builtin_amdgcn_s_sleep(16);
+  }
   // LayerNorm-folding mode (msmd_gemm_ln; the 4 x 2-wave 128 x 128 tile only): the row statistics' loads go out now, consumed in the epilogue
   constexpr bool LNK = (BN == 128 || BN == 64) && WN == 2 && (FM == 2 || FM == 3) && !STAG && sizeof(TO) == 2;   // slab = BN / 2
   // the 192-row tile has no registers to spare during the K loop (124 of 128): its statistics are loaded in the epilogue instead
@@ -842,6 +858,185 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2s_kernel(const GemmArgs p) 
   else gemm_epilogue_split<FM, FN>(p, acc0, z, m0 + wm, n0 + wn, fr, fq);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// bf16 / f16 kernel v4 (round 4): the same LDS image, LDS-DMA ring and epilogues as gemm2_kernel, with the fragment reads
+// software-pipelined INSIDE each wave and one workgroup barrier per K tile placed between its two 32-deep k-steps.
+//
+// Why (tools/lds_share_probe.hip, tools/intake_probe.hip): with LDS-DMA writes, fragment reads and MFMAs
+// running free in the 128 x 128 tile's per-K-tile ratio one CU sustains 0.37 us per K tile (1 460 TFLOP/s chip-wide);
+// gemm2_kernel takes 0.52 us hot and 0.68 us in the step.  Its waves run  wait / barrier / 4 DMA / 12 reads / lgkmcnt(0) /
+// 16 MFMA  back to back: nothing inside a wave overlaps, and a 128 x 128 K tile needs all of the CU's 64 B/clk vector-memory
+// path for as long as its MFMAs take (32 KB staged per 512 MFMA cycles), so every bubble is lost.  Here:
+//   * a wave holds TWO fragment sets; while the 16-32 MFMAs of one k-step issue, the reads of the next k-step are in flight
+//     (also across the K-tile boundary), so the matrix pipe never waits for LDS latency;
+//   * the barrier sits between the k-steps: before it  reads(g1) + MFMA(g0),  after it  DMA(tile + NSTAGE) + reads(next g0) +
+//     MFMA(g1) -- the stage a wave refills is the one whose last reads the barrier has just retired, and the DMA has
+//     NSTAGE - 1 whole K tiles to land;
+//   * bigger tiles at ONE workgroup per CU (256 x 128: 48 KB per 1024 MFMA cycles = 3/4 of the bytes per FLOP; 256 VGPRs):
+//     8 waves of 64 x 64.  Same products in the same order per output element as gemm2_kernel: bit-identical results.
+constexpr int waitcnt_lgkm0() { return 0xC07F; }                                              // lgkmcnt(0), vmcnt / expcnt untouched
+constexpr int waitcnt_vm(int n) { return (n & 0xF) | 0x70 | 0xF00 | ((n >> 4) << 14); }        // vmcnt(n), lgkmcnt / expcnt untouched
+
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, typename TI = bf16_t, bool ILV = false>
+__global__ __launch_bounds__(WM * WN * 64)
+__attribute__((amdgpu_waves_per_eu(NSTAGE * (BM + BN) * 128 > 80 * 1024 ? WM * WN / 4 : WM * WN / 2, NSTAGE * (BM + BN) * 128 > 80 * 1024 ? WM * WN / 4 : WM * WN / 2)))
+void gemm4_kernel(const GemmArgs p) {
+  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int LPT = (BM + BN) * 8 / NT;  // LDS-DMA instructions per thread per K tile
+  constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+  static_assert((BM + BN) * 8 % NT == 0, "tile chunks must divide over the threads");
+  static_assert(NSTAGE == 2 || NSTAGE == 3, "ring of 2 or 3 stages");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int pid = blockIdx.x;
+  const int xcd = pid & 7, slot = pid >> 3;
+  const int xm_n = 8 / p.xn, ntx = (p.nt + p.xn - 1) / p.xn;
+  const int m_tile = (slot / ntx) * xm_n + (xcd % xm_n), n_tile = (slot % ntx) * p.xn + xcd / xm_n;
+  if (m_tile >= p.mt || n_tile >= p.nt) return;
+  const int z = blockIdx.z;
+  const int zo = z / p.batch_inner, zi = z % p.batch_inner;
+  const bf16_t* __restrict__ A = (const bf16_t*)p.A + zo * p.strideA + zi * p.strideA2;
+  const bf16_t* __restrict__ W = (const bf16_t*)p.W + zo * p.strideW + zi * p.strideW2;
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+  const bf16_t* src[LPT];
+#pragma unroll
+  for (int i = 0; i < LPT; ++i) {
+    const int id = (i * NW + wid) * 64 + lane;  // 16-B slot of the tile image
+    const int row = id >> 3, phys = id & 7;
+    const int c = phys ^ ((row >> 1) & 7);      // logical chunk stored at this physical slot
+    if (row < BM) src[i] = A + a_row_offset(p, min(m0 + row, p.M - 1)) + c * 8;
+    else src[i] = W + (long)min(n0 + row - BM, p.N - 1) * p.ldw + c * 8;
+  }
+  auto issue_piece = [&](int i, int kt, int stage) {
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[i] + kt * 64), (lds_void_t*)(smem + stage * STAGE + (i * NW + wid) * 1024), 16, 0, 0);
+  };
+  auto issue = [&](int kt, int stage) {
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) issue_piece(i, kt, stage);
+  };
+
+  const int wm = (wid / WN) * (BM / WM), wn = (wid % WN) * (BN / WN);
+  const int fr = lane & 15, fq = lane >> 4;
+  // fragment addresses inside a stage: rows wm + 16 j + fr (A) / BM + wn + 16 i + fr (W); the swizzle (row >> 1) & 7 only
+  // depends on fr because the row bases are multiples of 16
+  const int sw = (fr >> 1) & 7;
+  const unsigned offA = (wm + fr) * 128, offW = (BM + wn + fr) * 128;
+  const unsigned ch[2] = {(unsigned)((fq ^ sw) << 4), (unsigned)(((4 + fq) ^ sw) << 4)};
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 fx[2][FM], fw[2][FN];     // two fragment sets: k-step g of the tile being multiplied lives in set g
+  auto read0 = [&](unsigned sbase) {
+#pragma unroll
+    for (int j = 0; j < FM; ++j) fx[0][j] = *(const u32x4*)(smem + sbase + offA + ch[0] + j * 2048);
+#pragma unroll
+    for (int i = 0; i < FN; ++i) fw[0][i] = *(const u32x4*)(smem + sbase + offW + ch[0] + i * 2048);
+  };
+  auto read1 = [&](unsigned sbase) {
+#pragma unroll
+    for (int j = 0; j < FM; ++j) fx[1][j] = *(const u32x4*)(smem + sbase + offA + ch[1] + j * 2048);
+#pragma unroll
+    for (int i = 0; i < FN; ++i) fw[1][i] = *(const u32x4*)(smem + sbase + offW + ch[1] + i * 2048);
+  };
+
+  const int nk = p.K / 64;
+  // LayerNorm-folding mode: the row statistics' loads go out before the K loop, consumed in the epilogue (as gemm2_kernel)
+  constexpr bool LNK = (BN / WN == 64 || BN / WN == 32) && (FM >= 2 && FM <= 4) && sizeof(TO) == 2;
+  f32x2 lnraw[LNK ? FM : 1][4];
+  if constexpr (LNK) {
+    if (p.a_stats) ln_issue<FM>(p.a_stats, p.a_nt, p.M, m0 + wm, fr, fq, lnraw);
+    else if (p.r_stats) ln_issue<FM>(p.r_stats, p.r_nt, p.M, m0 + wm, fr, fq, lnraw);
+  }
+  // prologue: NSTAGE - 1 tiles in flight, tile 0 landed, the last stage filled, fragment set 0 of tile 0 read
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) issue(s, s);
+  if (NSTAGE - 1 <= nk) __builtin_amdgcn_s_waitcnt(waitcnt_vm((NSTAGE - 2) * LPT));
+  else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+  __builtin_amdgcn_s_barrier();
+  if (NSTAGE - 1 < nk) issue(NSTAGE - 1, NSTAGE - 1);
+  read0(0);
+  __builtin_amdgcn_s_waitcnt(waitcnt_lgkm0());
+  int st = 0;
+  if constexpr (ILV) {
+    // Branch-free body, instruction stream interleaved by hand: every fragment read and every DMA piece sits BETWEEN two
+    // MFMAs (pinned with sched_barrier: sched_group_barrier left the DMA pieces -- chained through M0 -- in one burst).  With one workgroup per CU the
+    // eight waves move in lockstep from barrier to barrier; bursts (48 DMA pieces, then 64 fragment reads, then the MFMAs)
+    // serialise the vector-memory queue, the LDS and the matrix pipe one after the other -- measured 2.1 x the free-running
+    // time per K tile.  Past the last K tile the reads and the refill are repeated on clamped indices (the stage they
+    // touch is never read again) instead of being branched around: one basic block per half.
+    static_assert(FM * FN >= FM + FN + LPT, "one MFMA slot per fragment read and DMA piece");
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned char* sa = smem + st * STAGE;
+      // half 1: MFMAs of k-step 0; the 8 fragment reads of k-step 1 go out one per MFMA slot
+#pragma unroll
+      for (int q = 0; q < FM * FN; ++q) {
+        Mfma<TI>::run(fw[0][q / FM], fx[0][q % FM], acc[q / FM][q % FM]);
+        if (q < FM) fx[1][q] = *(const u32x4*)(sa + offA + ch[1] + q * 2048);
+        else if (q < FM + FN) fw[1][q - FM] = *(const u32x4*)(sa + offW + ch[1] + (q - FM) * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_waitcnt(waitcnt_vm((NSTAGE - 2) * LPT));
+      __builtin_amdgcn_s_waitcnt(waitcnt_lgkm0());
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const int sn = st + 1 == NSTAGE ? 0 : st + 1;
+      const unsigned char* sna = smem + sn * STAGE;
+      const int kr = min(kt + NSTAGE, nk - 1);
+      // half 2: MFMAs of k-step 1; the next tile's k-step-0 reads first (they are needed first), then the refill's DMA pieces
+#pragma unroll
+      for (int q = 0; q < FM * FN; ++q) {
+        Mfma<TI>::run(fw[1][q / FM], fx[1][q % FM], acc[q / FM][q % FM]);
+        if (q < FM) fx[0][q] = *(const u32x4*)(sna + offA + ch[0] + q * 2048);
+        else if (q < FM + FN) fw[0][q - FM] = *(const u32x4*)(sna + offW + ch[0] + (q - FM) * 2048);
+        else if (q - FM - FN < LPT) issue_piece(q - FM - FN, kr, st);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_waitcnt(waitcnt_lgkm0());
+      st = sn;
+    }
+    __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));     // the clamped refills of the last iterations must not outlive the workgroup's LDS
+  } else {
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned sb = st * STAGE;
+    read1(sb);                                   // k-step 1 of this tile: in flight under the MFMAs of k-step 0
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) Mfma<TI>::run(fw[0][i], fx[0][j], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+    // tile kt + 1 has landed (this wave's share; the barrier makes it everyone's); the newer tile may stay in flight
+    if (kt + NSTAGE - 1 < nk) __builtin_amdgcn_s_waitcnt(waitcnt_vm((NSTAGE - 2) * LPT));
+    else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    __builtin_amdgcn_s_waitcnt(waitcnt_lgkm0());  // set 1 is in registers: this wave has finished reading stage st
+    __builtin_amdgcn_s_barrier();
+    const int sn = st + 1 == NSTAGE ? 0 : st + 1;
+    if (kt + NSTAGE < nk) issue(kt + NSTAGE, st);   // stage st is free: every wave has its fragments of tile kt in registers
+    if (kt + 1 < nk) read0(sn * STAGE);          // k-step 0 of the next tile: in flight under the MFMAs of k-step 1
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) Mfma<TI>::run(fw[1][i], fx[1][j], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(waitcnt_lgkm0());
+    st = sn;
+  }
+  }
+  if constexpr (LNK) {
+    if (p.a_stats) { gemm_epilogue_ln<TO, FM, FN, 1>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
+    if (p.r_stats || p.stats_out) { gemm_epilogue_ln<TO, FM, FN, 2>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
+  }
+  // the 16-fragment wave tiles carry the inference epilogue only (launch_gemm4 refuses Z / dropout / actbwd calls for them)
+  gemm_epilogue<TO, FM, FN, sizeof(TO) == 2 && FM * FN <= 8, (FM * FN > 8)>(p, acc, z, m0 + wm, n0 + wn, fr, fq);
+}
+
 #ifdef MSMD_EXPERIMENTAL
 // Developer knobs exist ONLY in the experimental build (make EXP=1 -> libmsmd_hip_exp.so): the product library has no
 // process-global state -- kernel variant and epilogue flags travel per call in `act` (include/msmd_hip.h).
@@ -870,6 +1065,38 @@ static int launch_gemm2(GemmArgs& p, int batch, hipStream_t st) {
   // (the 0.7 fitted on the qkv shape, where 2 x 4 ties with 8 x 1 and both trail 4 x 2).  Forward step, same-graph A/B
   // in both orders: 8 x 1 4.96 ms, 4 x 2 everywhere 4.89, this rule 4.88.  tuning key 7 forces xn = 1 / 2 / 4.
   int want_xn = 1;
+  if (MSMD_TUNE(7) == 1 || MSMD_TUNE(7) == 2 || MSMD_TUNE(7) == 4) {
+    want_xn = MSMD_TUNE(7);
+  } else {
+    const double a_bytes = 2.0 * p.M * (double)(p.rows_per_batch < p.M ? p.lda : p.K), w_bytes = 2.0 * p.N * (double)p.K;
+    double best = 1e30;
+    for (int xn = 1; xn <= 4; xn *= 2) {
+      const double c = 0.7 * xn * a_bytes + (8.0 / xn) * w_bytes;
+      if (c < best && p.nt >= xn) { best = c; want_xn = xn; }
+    }
+  }
+  p.xn = p.nt >= want_xn ? want_xn : 1;
+  const int xm_n = 8 / p.xn;
+  dim3 grid(((p.mt + xm_n - 1) / xm_n) * ((p.nt + p.xn - 1) / p.xn) * 8, 1, batch);
+  // stagger (flags bit 2): only where the launch runs more than one round of two workgroups per CU
+  p.stagger_ticks = ((p.flags & 4) && batch == 1 && NSTAGE * (BM + BN) * 128 <= 80 * 1024 && (long)p.mt * p.nt > 640)
+                        ? (int)(100.0 * 0.5 * ((p.K / 64) * 0.5 + 3.0)) : 0;
+  hipLaunchKernelGGL(kfn, grid, dim3(WM * WN * 64), lds, st, p);
+  MSMD_RETURN_LAST();
+}
+
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, typename TI = bf16_t, bool ILV = false>
+static int launch_gemm4(GemmArgs& p, int batch, hipStream_t st) {
+  constexpr int lds = NSTAGE * (BM + BN) * 128;
+  static bool attr_done = false;
+  auto kfn = gemm4_kernel<TO, BM, BN, WM, WN, NSTAGE, TI, ILV>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  if ((BM / WM / 16) * (BN / WN / 16) > 8 && (p.Z || p.p_drop > 0.f || (p.flags & 8))) return -1;   // lean epilogue: not a training call
+  p.mt = (p.M + BM - 1) / BM; p.nt = (p.N + BN - 1) / BN;
+  int want_xn = 1;     // XCD grid over (M, N) tiles: the cost model of launch_gemm2
   if (MSMD_TUNE(7) == 1 || MSMD_TUNE(7) == 2 || MSMD_TUNE(7) == 4) {
     want_xn = MSMD_TUNE(7);
   } else {
@@ -952,6 +1179,12 @@ static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
     case 14: return launch_gemm2<TO, 256, 64, 8, 1, 2, true>(p, batch, st);   // narrow outputs (N <= 64): 8 waves of 32 x 64
     case 15: return launch_gemm2<TO, 192, 128, 4, 2, 2, true>(p, batch, st);  // tall grids (M >= 16 k): 80 KB, still 2 workgroups / CU
     case 17: return launch_gemm2<TO, 128, 128, 4, 2, 2, true>(p, batch, st);
+    // v4 kernels (fragment reads pipelined inside the wave, barrier between the k-steps):
+    case 60: return launch_gemm4<TO, 256, 128, 4, 2, 3>(p, batch, st);                   // 144 KB, 1 workgroup / CU, 8 waves of 64 x 64
+    case 61: return launch_gemm4<TO, 256, 128, 4, 2, 2>(p, batch, st);                   // 96 KB
+    case 62: return launch_gemm4<TO, 128, 128, 4, 2, 2>(p, batch, st);                   // 64 KB, 2 workgroups / CU: variant 17's tile
+    case 63: return launch_gemm4<TO, 256, 128, 4, 2, 3, bf16_t, true>(p, batch, st);     // 60 with the refill's DMA between the MFMAs
+    case 64: return launch_gemm4<TO, 256, 128, 4, 2, 2, bf16_t, true>(p, batch, st);     // 63 with a 2-stage ring (96 KB)
 #ifdef MSMD_EXPERIMENTAL
     case 41: return launch_gemm2<TO, 128, 128, 4, 2, 2, true, bf16_t, true>(p, batch, st);   // 17 with waves 4-7 staggered: -25 % (5c)
     case 40: return launch_gemm8p<TO>(p, batch, st);   // 256 x 256, 8-phase schedule, one workgroup per CU (round 3: slower, see exp/)

@@ -167,7 +167,7 @@ _TUNED = {}
 # Per-call GEMM knobs (include/msmd_hip.h: MSMD_GEMM_VARIANT / _WRITE_THROUGH / _PAIRED_STORES).  The C library has no
 # global state; these module-level defaults are what `gemm()` passes when the caller gives none (`gemm_defaults`
 # scopes a change, e.g. while a hipGraph is captured -- the choice is then baked into that graph).
-GEMM_WRITE_THROUGH, GEMM_PAIRED_STORES = 1 << 16, 1 << 17
+GEMM_WRITE_THROUGH, GEMM_PAIRED_STORES, GEMM_STAGGER = 1 << 16, 1 << 17, 1 << 18
 # attention launches also pull the layer's remaining weights through the memory-side cache (msmd_attention_prefetch)
 PREFETCH_WEIGHTS = os.environ.get("MSMD_PREFETCH", "1") != "0"
 # transformer blocks: LayerNorm folded into the neighbouring GEMMs (gemm_ln); False (MSMD_FOLD_LN=0) = LayerNorm kernels
