@@ -701,7 +701,11 @@ def run_train(a, rank, world, device):
     args = synthetic_args(compute_dtype="bf16", lr=2e-5, warm_iter=5000)
     model = get_diffusion_model(args, device).train()
     se = get_style_encoder(args, "vae2").to(device).train()
-    tr = Trainer(args, model, se, use_graph=not a.eager)
+    # MSMD_NATIVE_RCCL=1: the buckets' all-reduce through the C ABI (msmd_allreduce_bucket, csrc/comm.hip) instead of
+    # torch.distributed; --bucket-dtype bf16: 16-bit staging of every bucket (half the bytes over xGMI)
+    native = os.environ.get("MSMD_NATIVE_RCCL") == "1" and world > 1
+    bdt = {"fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}[a.bucket_dtype]
+    tr = Trainer(args, model, se, use_graph=not a.eager, comm=dp.RcclComm(device) if native else None, bucket_dtype=bdt if world > 1 else None)
     batch = synthetic_batch(a.batch, rank, device)
     if tr.use_graph:
         tr.capture_all(batch)
@@ -750,6 +754,55 @@ def run_train(a, rank, world, device):
         out["roofline"] = roof
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_train_baseline()
+    if world == 1 and not a.no_exchange_rehearsal:
+        del tr, model, se
+        torch.cuda.empty_cache()
+        out["exchange_rehearsal_world1"] = exchange_rehearsal(a, device, bdt)
+    return out
+
+
+def exchange_rehearsal(a, device, bucket_dtype):
+    """The data-parallel step's exchange with the REAL library on one GPU: a one-rank RCCL communicator through the C ABI
+    (msmd_comm_init / msmd_allreduce_bucket), the iteration captured as one hipGraph per gradient bucket, every bucket's
+    all-reduce enqueued on the side stream under the rest of backward.  The sum over one rank moves no bytes between GPUs:
+    what this leg establishes is that librccl loads and executes inside the step, what the segmented-graph form costs, and
+    that the gradients are unchanged; xGMI time is unmeasured until a multi-GPU node runs `--gpus N`."""
+    from msmd_amd import dp
+    from msmd_amd.config import synthetic_args
+    from msmd_amd.model import get_diffusion_model
+    from msmd_amd.style_encoder import get_style_encoder
+    from msmd_amd.training_script import Trainer, synthetic_batch
+    args = synthetic_args(compute_dtype="bf16", lr=2e-5, warm_iter=5000)
+    model = get_diffusion_model(args, device).train()
+    se = get_style_encoder(args, "vae2").to(device).train()
+    comm = dp.RcclComm(device)
+    tr = Trainer(args, model, se, use_graph=not a.eager, comm=comm, exchange_at_world_1=True, bucket_dtype=bucket_dtype)
+    batch = synthetic_batch(a.batch, 0, device)
+    if tr.use_graph:
+        tr.capture_all(batch)
+    run = lambda: tr.step(batch, it=1)
+    calls = [0]
+    real = comm.all_reduce
+
+    def counted(t, stream=None):
+        calls[0] += 1
+        return real(t, stream)
+    comm.all_reduce = counted
+    with_x = dp.timed_steps(run, a.steps, 2, sync=torch.cuda.synchronize, device=device) / a.steps
+    per_step = calls[0] / (a.steps + 2)
+    comm.all_reduce = real
+    ar = dp.timed_steps(tr.reducer.exchange_only, 5, 2, sync=torch.cuda.synchronize, device=device) / 5
+    tr.reducer.mute = True
+    solo = dp.timed_steps(run, a.steps, 1, sync=torch.cuda.synchronize, device=device) / a.steps
+    tr.reducer.mute = False
+    lib = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln})
+    out = dict(ms_per_step_with_exchange=round(with_x * 1e3, 3), ms_per_step_exchange_muted=round(solo * 1e3, 3),
+               allreduce_alone_ms=round(ar * 1e3, 3), allreduce_calls_per_step=round(per_step, 1), buckets=len(tr.reducer.buckets),
+               gradient_bytes=int(tr.reducer.arena.numel() * 4), bucket_dtype=a.bucket_dtype, librccl_mapped=lib,
+               launch=tr.launch_description(),
+               note="one-rank communicator: RCCL executes on every bucket, no bytes cross xGMI; multi-GPU time unmeasured here")
+    del tr
+    comm.destroy()
     return out
 
 
@@ -793,6 +846,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the f16x2 / fp32 parity-mode timings")
+    ap.add_argument("--bucket-dtype", default="fp32", choices=["fp32", "bf16", "fp16"],
+                    help="train mode: dtype the gradient buckets are summed in over RCCL (16-bit = staged copy, half the bytes)")
+    ap.add_argument("--no-exchange-rehearsal", action="store_true",
+                    help="train mode, one GPU: skip the leg that runs the step with a one-rank RCCL communicator on every bucket")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of hipGraph replays")
     ap.add_argument("--no-two-streams-leg", dest="two_streams_leg", action="store_false",
                     help="skip the extra leg that times two steps in flight (verified per step)")

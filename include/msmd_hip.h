@@ -487,6 +487,22 @@ int msmd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    float beta1, float beta2, float eps, int step, float grad_scale, msmd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Gradient exchange over RCCL / xGMI: the one exchange step on the path (SURVEY.md 8b "msmd_allreduce_bucket (RCCL)", 8e;
+ * the reference steps one process, training_script.py:190-199 -- its data-parallel form sums the gradient of every
+ * parameter over the ranks before optimizer.step()).  One process per GPU, one communicator per process; librccl is
+ * resolved with dlopen at first use (csrc/comm.hip), so nothing here costs a process that never exchanges.
+ *   msmd_comm_unique_id: rank 0 fills 128 bytes that every rank passes to msmd_comm_init (sent over any side channel);
+ *   msmd_comm_init: collective over the job; the calling thread's current HIP device is the rank's GPU;
+ *   msmd_allreduce_bucket: buf[0 .. n) <- SUM over ranks, in place, enqueued on `stream` (the reducer's side stream, behind
+ *     an event of the compute stream: overlapped with the rest of backward); dtype MSMD_F32 (a bucket of the flat gradient
+ *     arena), MSMD_BF16 / MSMD_F16 (its 16-bit staging copy: half the bytes over xGMI).
+ * Return codes: 0, an ncclResult_t, or 1000 + n when librccl could not be loaded (1) / lacks a symbol (2). */
+int msmd_comm_unique_id(void* id_out_128_bytes);
+int msmd_comm_init(void** comm_out, int world, int rank, const void* id_128_bytes);
+int msmd_comm_destroy(void* comm);
+int msmd_allreduce_bucket(void* comm, void* buf, long n, int dtype, msmd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Backward-pass building blocks (training; reference training_script.py:195).  dgrad / wgrad are msmd_gemm calls on
  * transposed operands: dX = dZ . W (W^T as the (K, N) operand), dW = dZ^T . X (both operands transposed).
  */

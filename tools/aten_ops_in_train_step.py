@@ -25,6 +25,9 @@ torch.cuda.synchronize()
 counts = collections.Counter()
 bytes_ = collections.Counter()
 by_line = collections.Counter()
+REDUCE = ("sum", "mean", "var", "var_mean", "std", "norm", "linalg_vector_norm", "amax", "amin", "max", "min", "all", "any", "prod",
+          "logsumexp", "_softmax", "count_nonzero", "cumsum", "argmax")
+reductions = collections.Counter()   # (op, input shape, outputs, elements reduced per output, calling line)
 slow = collections.Counter()      # ops with a non-contiguous (s) or broadcast operand: the generic strided elementwise kernels
 
 
@@ -38,6 +41,17 @@ class Count(TorchDispatchMode):
             return out
         shp = next((tuple(a.shape) for a in args if torch.is_tensor(a)), ())
         t = out if torch.is_tensor(out) else None
+        if name.split(".")[0] in REDUCE and t is not None and shp:
+            n_in = 1
+            for d_ in shp:
+                n_in *= d_
+            n_out = max(1, t.numel())
+            wr = "autograd engine"
+            for fr in reversed(traceback.extract_stack()[:-1]):
+                if "msmd_amd" in fr.filename:
+                    wr = f"{os.path.basename(fr.filename)}:{fr.lineno}"
+                    break
+            reductions[(name, shp, n_out, n_in // n_out, wr)] += 1
         counts[(name, shp)] += 1
         where = "autograd engine (backward of a torch op)"
         for fr in reversed(traceback.extract_stack()[:-1]):
@@ -68,6 +82,12 @@ for (w, n), c in by_line.most_common(60):
 print(f"ops with a strided (s) or broadcast operand: {sum(slow.values())}")
 for (w, n, shp), c in slow.most_common(70):
     print(f"  {w:44s} {n:24s} x{c:3d}  {shp[:90]}")
+# The host library runs a reduction over MANY elements into FEW outputs as a multi-block kernel (partial sums in a staging
+# buffer + a semaphore zeroed by a memset node): inside the step's hipGraphs two of those returned wrong sums.
+# Everything with >= 256 elements per output and fewer than ~2048 outputs is a candidate and must not sit inside a capture.
+print("reductions by the host library (op, input shape, outputs, elements per output, calling line):")
+for (n, shp, n_out, per, wr), c in sorted(reductions.items(), key=lambda kv: -kv[0][3]):
+    print(f"  {'CANDIDATE ' if per >= 256 and n_out < 2048 else '          '}{n:22s} {str(shp):26s} -> {n_out:8d} outputs, {per:8d} per output  x{c:3d}  {wr}")
 print("largest by bytes written:")
 for (n, s), b in bytes_.most_common(40):
     print(f"  {n:28s} {str(s):28s} x{counts[(n, s)]:4d}  {b / 1e6:9.1f} MB")

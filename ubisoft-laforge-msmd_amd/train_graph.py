@@ -158,6 +158,37 @@ class LayerDropSelectFn(torch.autograd.Function):
         return None, torch.where(flag, g, z), torch.where(flag, z, g)
 
 
+class NullTokenSelectFn(torch.autograd.Function):
+    """Classifier-free-guidance masking of reference model.py:205-218: out[b] = mask[b] ? token : x[b] for a (1, 1, C) learned null
+    token and x (B, T, C).  Written as torch.where on the expanded token, autograd sums the token's gradient over (B, T) with
+    the host library's reduction: 800 x 512 for null_audio_feat, which that library runs as a MULTI-BLOCK reduction (partial
+    sums in a staging buffer, a semaphore word zeroed by a memset node in front of the kernel).  Inside the hipGraphs of the
+    training step that launch returned a wrong sum on the first replay after another graph of the shared pool had run (round
+    4: tools/dp_rccl_debug.py -- the eager backward and every further replay agreed; only this gradient was off, by O(1)),
+    the same family as round 3's NaN weight-norm reduction.  The token's gradient is a column sum of the masked rows by
+    msmd_colsum here (deterministic, one launch, its workspace written before it is read)."""
+
+    @staticmethod
+    def forward(ctx, mask, token, x):
+        """mask: bool (B,) [per sequence: the CFG tokens] or (B, T) [per frame: SpecAugment's masked_spec_embed,
+        utils/wav2vec2.py:99-105]; token: (C,) or (1, 1, C), any float dtype; x: (B, T, C)."""
+        m = mask.reshape(mask.shape + (1,) * (x.ndim - mask.ndim))
+        ctx.save_for_backward(m)
+        ctx.token_shape, ctx.token_dtype = token.shape, token.dtype
+        return torch.where(m, token.reshape(-1).to(x.dtype), x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (m,) = ctx.saved_tensors
+        mf = m.to(g.dtype)
+        gm = (g * mf).reshape(-1, g.shape[-1]).contiguous()
+        if gm.is_cuda and gm.dtype in (torch.float32, torch.bfloat16):
+            d_token = ops.colsum(gm)
+        else:
+            d_token = gm.float().sum(0)
+        return None, d_token.reshape(ctx.token_shape).to(ctx.token_dtype), g * (1 - mf)
+
+
 def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
     """Differentiable counterpart of Wav2Vec2Model.encode (utils/wav2vec2.py): (B, L) audio -> (B, frame_num, 768)."""
     c = enc.config
@@ -180,7 +211,7 @@ def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
             fn = compute_mask_indices_hf if enc.model_type == "hubert" else compute_mask_indices
             m = torch.from_numpy(fn((h.shape[0], h.shape[1]), c.mask_time_prob, c.mask_time_length,
                                     c.mask_time_min_masks, noise.host_rng)).to(h.device)
-        h = torch.where(m.unsqueeze(-1), g("masked_spec_embed").to(h.dtype), h)
+        h = NullTokenSelectFn.apply(m, g("masked_spec_embed"), h)
     w = _fold_weight_norm(g("encoder.pos_conv_embed.conv.weight_g"), g("encoder.pos_conv_embed.conv.weight_v"))
     z = PosConvFn.apply(h, w, g("encoder.pos_conv_embed.conv.bias"))
     h = h + ag_act(z, ops.ACT_GELU)
@@ -508,10 +539,9 @@ def msmd_forward_train(model, motion_feat, audio_or_feat, shape_feat, style_feat
     if prev_audio_feat is None:
         prev_audio_feat = model.start_audio_feat.expand(B, -1, -1)
     if null_style_mask is not None:
-        style_feat = torch.where(null_style_mask.view(-1, 1, 1), model.null_style_feat.expand(B, -1, -1), style_feat)
+        style_feat = NullTokenSelectFn.apply(null_style_mask, model.null_style_feat, style_feat)
     if null_audio_mask is not None:
-        audio_feat = torch.where(null_audio_mask.view(-1, 1, 1),
-                                 model.null_audio_feat.expand(B, model.n_motions, -1), audio_feat)
+        audio_feat = NullTokenSelectFn.apply(null_audio_mask, model.null_audio_feat, audio_feat)
     person_feat = torch.cat([shape_feat, style_feat], dim=-1)
     ts = torch.as_tensor(time_step, device=model.device, dtype=torch.long)
     ab = model.diffusion_sched.alpha_bars[ts]
@@ -722,4 +752,6 @@ def loss_vert_train(args, is_starting_sample, shape_coef, motion_coef_gt, target
 
 def kl_train(mu, logvar):
     """reference utils/common.py:443-454."""
-    return -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp())
+    # summed per row, then over the rows: ONE sum over all 8 192 elements is a multi-block reduction of the host library (a
+    # semaphore-and-staging-buffer kernel), which does not belong inside the step's hipGraphs (NullTokenSelectFn above)
+    return -0.5 * (1 + logvar - mu.pow(2) - logvar.exp()).sum(dim=1).sum()

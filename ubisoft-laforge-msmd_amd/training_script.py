@@ -148,7 +148,7 @@ def batch_from_loader(item):
 
 class Trainer:
     def __init__(self, args, model, style_enc, process_group=None, bucket_mb=32.0, use_graph=False, flame=None,
-                 coef_stats=None):
+                 coef_stats=None, comm=None, bucket_dtype=None, exchange_at_world_1=False):
         self.args, self.model, self.style_enc = args, model, style_enc
         self.device = model.device
         # vertex-space training branch (reference training_script.py:167-170: use_vertex_space on the legacy FLAME
@@ -166,7 +166,8 @@ class Trainer:
         dp.ADJACENT = tg.adjacent_parameter_groups(model)
         try:
             self.flat_param = dp.flatten_parameters(params)
-            self.reducer = dp.GradBucketReducer(params, bucket_mb=bucket_mb, process_group=process_group)
+            self.reducer = dp.GradBucketReducer(params, bucket_mb=bucket_mb, process_group=process_group, comm=comm,
+                                                bucket_dtype=bucket_dtype, exchange_at_world_1=exchange_at_world_1)
         finally:
             dp.ADJACENT = []
         self.weight_arena = None
@@ -189,7 +190,8 @@ class Trainer:
         self._graphs, self._graph_pool, self._flag_table = {}, None, None
         # hipGraph mode with more than one rank: capture the iteration as bucket-aligned SEGMENTS so every bucket's
         # all-reduce starts as soon as its gradients are final (MSMD_SEGMENT_GRAPHS=1 forces it on one rank: tests)
-        self.segment_graphs = self.use_graph and (self.reducer.world > 1 or os.environ.get("MSMD_SEGMENT_GRAPHS") == "1")
+        self.segment_graphs = self.use_graph and (self.reducer.world > 1 or os.environ.get("MSMD_SEGMENT_GRAPHS") == "1"
+                                                  or self.reducer.exchange_at_world_1)
         self._stepping = True
         # weight gradients are added straight into the arena by the wgrad GEMM when bucket launches do not hang
         # on per-parameter autograd hooks (graph mode launches them from finish(); world 1 launches nothing)
