@@ -408,6 +408,53 @@ def leg_lbs(device, frames_list=(6400, 25600)):
     return out
 
 
+def leg_rotations_landmarks(device, N=1 << 22, frames=25600):
+    """The small HBM-bound kernels north_star names beside the skinning: rotation conversions (utils/rotation_conversions.py:
+    one item per thread, 12-64 B per item) and the 68 landmarks + dynamic-contour LUT row (utils/lbs.py:102-138,
+    utils/flame.py:126-172) -- HIP-event time per launch against algorithmic bytes (items x (bytes in + bytes out))."""
+    from types import SimpleNamespace
+    from msmd_amd import ops, synth
+    from msmd_amd.utils import rotation_conversions as rc
+    from msmd_amd.utils.flame import FLAME, FLAMEConfig
+    g = torch.Generator(device="cpu").manual_seed(0)
+    aa = torch.randn(N, 3, generator=g).to(device)
+    R = rc.axis_angle_to_matrix(aa)
+    q = rc.matrix_to_quaternion(R)
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    out = {}
+    for name, fn, nbytes in (("axis_angle_to_matrix", lambda: rc.axis_angle_to_matrix(aa), 12 + 36),
+                             ("matrix_to_quaternion", lambda: rc.matrix_to_quaternion(R), 36 + 16),
+                             ("quaternion_to_matrix", lambda: rc.quaternion_to_matrix(q), 16 + 36),
+                             ("matrix_to_rotation_6d", lambda: rc.matrix_to_rotation_6d(R), 36 + 24)):
+        ms = timed(fn)          # includes the output allocation of the Python wrapper (caching allocator: no device call)
+        gbs = N * nbytes / ms / 1e6
+        out[name] = dict(items=N, us=round(ms * 1e3, 1), bytes_per_item=nbytes, gb_per_s=round(gbs, 1), hbm_frac=round(gbs / PEAK_HBM_GBS, 4))
+    cfg = SimpleNamespace(**vars(FLAMEConfig))
+    cfg.asset = synth.flame_asset()
+    fl = FLAME(cfg).to(device)
+    exp, pose = (0.5 * torch.randn(frames, 50, generator=g)).to(device), (0.2 * torch.randn(frames, 6, generator=g)).to(device)
+    verts, _, _ = fl(torch.zeros(frames, 100, device=device), exp, pose, return_lm2d=False, return_lm3d=False)
+    p = fl._pack()
+    ms = timed(lambda: ops.landmarks(verts, p["faces"], p["full_idx"], fl.full_lmk_bary_coords))
+    nbytes = 68 * (3 * 12 + 12)       # 3 gathered vertices + the written landmark (+ the per-call 68-entry tables, cache-resident)
+    gbs = frames * nbytes / ms / 1e6
+    out["landmarks_68"] = dict(frames=frames, us=round(ms * 1e3, 1), bytes_per_frame=nbytes, gb_per_s=round(gbs, 1), hbm_frac=round(gbs / PEAK_HBM_GBS, 4),
+                               note="gathers 204 vertices of 5023 per frame: 36-byte pieces of 60 KB rows, sector-granular traffic is ~5x the algorithmic bytes")
+    return {"rotations_landmarks": out}
+
+
 def leg_train(device, B=32, steps=5):
     from msmd_amd.config import synthetic_args
     from msmd_amd.model import get_diffusion_model
@@ -473,13 +520,13 @@ def leg_hubert_large(device, B=32, steps=5):
 def run_legs(device, which="all"):
     """`which`: "all" or a comma-separated subset of sampler,lbs,train,hubert (profiling runs time one leg at a time)."""
     legs = {}
-    for name, fn in (("sampler_b64_t500", leg_sampler), ("lbs", leg_lbs), ("train_step_b32", leg_train),
-                     ("hubert_large_10s_b32", leg_hubert_large)):
+    for name, fn in (("sampler_b64_t500", leg_sampler), ("lbs", leg_lbs), ("rotations_landmarks", leg_rotations_landmarks),
+                     ("train_step_b32", leg_train), ("hubert_large_10s_b32", leg_hubert_large)):
         if which != "all" and not any(name.startswith(w) for w in which.split(",")):
             continue
         try:
             r = fn(device)
-            if name == "lbs":
+            if name in ("lbs", "rotations_landmarks"):
                 legs.update(r)
             else:
                 legs[name] = r
