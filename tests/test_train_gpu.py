@@ -680,3 +680,52 @@ def test_first_graph_replay_after_another_variant_equals_the_eager_backward():
             os.environ.pop("MSMD_SEGMENT_GRAPHS", None)
         else:
             os.environ["MSMD_SEGMENT_GRAPHS"] = old
+
+
+def test_checkpoint_moments_land_on_their_parameters_across_arena_layouts(tmp_path):
+    """Trainer.load_checkpoint remaps the flat Adam moments parameter by parameter from the WRITER's arena order to this
+    trainer's: (1) a checkpoint written by this build (arena_order recorded: the encoder's Q / K / V pulled together),
+    (2) one written before round 3 (no arena_order: plain reverse registration order, ALIGN-rounded offsets).  Each parameter's
+    slice of exp_avg / exp_avg_sq carries a recognisable per-parameter pattern; a wrong offset would only show up as slightly
+    wrong optimizer state after a resume.  A moments tensor whose length does not match the order is refused."""
+    from msmd_amd import dp
+    from msmd_amd.model import get_diffusion_model
+    from msmd_amd.style_encoder import get_style_encoder
+    from msmd_amd.training_script import Trainer
+    args = default_args(compute_dtype="bf16", encoder_layers=2, n_layers=1, lr=1e-4, warm_iter=0)
+    tr = Trainer(args, get_diffusion_model(args, DEV).eval(), get_style_encoder(args, "vae2").to(DEV).eval())
+    named = tr._named_trainable()
+    code = {n: float(i + 1) for i, (n, _) in enumerate(named)}
+    al = lambda k: (k + dp.ALIGN - 1) // dp.ALIGN * dp.ALIGN
+
+    def moments(order):
+        m = torch.zeros(sum(al(p.numel()) for _, p in named))
+        off = 0
+        for n in order:
+            k = dict(named)[n].numel()
+            m[off:off + k] = code[n] + torch.arange(k) * 1e-7
+            off += al(k)
+        return m
+
+    base = tr.flat_param.data_ptr()
+    for tag, order, record in (("this build", tr._arena_names(), True),
+                               ("before round 3", [n for n, _ in named][::-1], False)):
+        assert (order == tr._arena_names()) == record      # the two layouts really differ (Q / K / V adjacency)
+        opt = {"exp_avg": moments(order), "exp_avg_sq": moments(order) * 2, "step": 7,
+               "layout": [(n, int(p.numel())) for n, p in named]}
+        if record:
+            opt["arena_order"] = order
+        ck = {"args": args, "model": tr.model.state_dict(), "style_enc": tr.style_enc.state_dict(), "iter": 3, "optimizer": opt}
+        path = tmp_path / f"ck_{record}.pt"
+        torch.save(ck, path)
+        tr.exp_avg.zero_(); tr.exp_avg_sq.zero_()
+        assert tr.load_checkpoint(path) == 3 and tr.opt_step == 7
+        for n, p in named:
+            dst, k = (p.data_ptr() - base) // 4, p.numel()
+            want = code[n] + torch.arange(k) * 1e-7
+            assert torch.equal(tr.exp_avg[dst:dst + k].cpu(), want), (tag, n)
+            assert torch.equal(tr.exp_avg_sq[dst:dst + k].cpu(), want * 2), (tag, n)
+    bad = dict(ck)
+    bad["optimizer"] = dict(opt, exp_avg=opt["exp_avg"][:-dp.ALIGN])
+    with pytest.raises(ValueError, match="optimizer moments hold"):
+        tr.load_checkpoint(bad)

@@ -733,8 +733,9 @@ class MSMD(nn.Module):
             call()
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = call()
+        with ops.capture_guard():
+            with torch.cuda.graph(graph):
+                out = call()
         if verify:
             keep = {k: v.clone() for k, v in static.items()}
             static["audio"].copy_(keep["audio"].flip(0))

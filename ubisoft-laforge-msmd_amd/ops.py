@@ -168,6 +168,27 @@ _TUNED = {}
 # global state; these module-level defaults are what `gemm()` passes when the caller gives none (`gemm_defaults`
 # scopes a change, e.g. while a hipGraph is captured -- the choice is then baked into that graph).
 GEMM_WRITE_THROUGH, GEMM_PAIRED_STORES, GEMM_STAGGER = 1 << 16, 1 << 17, 1 << 18
+
+
+class capture_guard:
+    """Around every hipGraph stream capture of this package: collect garbage first and keep Python's cyclic collector off for
+    the duration.  A collection that starts INSIDE a capture runs the destructors of whatever earlier code left in reference
+    cycles -- captured graphs, events, communicators: device-runtime calls that are not permitted while a stream is capturing --
+    and the process aborts (seen as a rare `Fatal Python error: Aborted ... Garbage-collecting` under the segmented training
+    capture, round 4).  torch.cuda.graph() collects at entry too, but does not hold the collector off."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+        return False
 # attention launches also pull the layer's remaining weights through the memory-side cache (msmd_attention_prefetch)
 PREFETCH_WEIGHTS = os.environ.get("MSMD_PREFETCH", "1") != "0"
 # transformer blocks: LayerNorm folded into the neighbouring GEMMs (gemm_ln); False (MSMD_FOLD_LN=0) = LayerNorm kernels

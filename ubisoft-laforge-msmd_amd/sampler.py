@@ -246,8 +246,9 @@ class _StepGraph:
             body()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            body()
+        with ops.capture_guard():
+            with torch.cuda.graph(self.graph):
+                body()
 
     def run(self, T, motion_at_T, ops_in, coefficients):
         self.x.copy_(motion_at_T)

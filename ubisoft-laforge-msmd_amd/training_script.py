@@ -252,6 +252,10 @@ class Trainer:
             names = dict((n, p) for n, p in self._named_trainable())
             saved_order = opt.get("arena_order") or [n for n, _ in self._named_trainable()][::-1]
             base = self.flat_param.data_ptr()
+            need = sum((names[n].numel() + dp.ALIGN - 1) // dp.ALIGN * dp.ALIGN for n in saved_order)
+            if need != int(opt["exp_avg"].numel()) or need != int(opt["exp_avg_sq"].numel()):
+                raise ValueError(f"optimizer moments hold {int(opt['exp_avg'].numel())} elements, the checkpoint's arena order "
+                                 f"accounts for {need}")
             off = 0
             for n in saved_order:
                 p = names[n]
@@ -551,6 +555,11 @@ class Trainer:
                     self._capture(key, batch, {}, [t0, t1])
 
     def _capture(self, key, batch, draws, trunc):
+        from . import ops
+        with ops.capture_guard():      # no cyclic garbage collection while a stream is capturing
+            return self._capture_guarded(key, batch, draws, trunc)
+
+    def _capture_guarded(self, key, batch, draws, trunc):
         audio_pair, motion_pair, shape = batch
         dev = self.device
         sb = ([a.clone() for a in audio_pair], [m.clone() for m in motion_pair], shape.clone())
