@@ -40,6 +40,8 @@ struct GemmArgs {
   float* stats_out = nullptr; float ln_eps = 1e-5f;
   // flags bit 2 (MSMD_GEMM_STAGGER): the workgroups dispatched second onto their CU start `stagger_ticks` (100 MHz) late
   int stagger_ticks = 0;
+  // developer build only (msmd_exp_set_stamps): per-workgroup time stamps of the plain-epilogue path, 8 longs per workgroup
+  long* stamps = nullptr;
 };
 
 template <typename T> struct Mfma;
@@ -547,7 +549,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t, bool STAG = false>
+// EPI: which epilogues this instantiation carries.  0 = all of them behind run-time tests (training: pre-activation copy,
+// dropout, activation backward, both LayerNorm forms); 1 = the plain inference epilogue only (bias, activation, residual);
+// 2 / 3 = the LayerNorm-operand / LayerNorm-residual form only.  One instantiation with everything is 127 KB of code of which a
+// launch executes a few KB scattered among the branches it does not take: per-workgroup stamps (tools/gemm_stamps.py) put the
+// epilogue of a 128 x 128 tile at 3.0 us for 32 outputs per lane (bias only), most of it instruction fetch.
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t, bool STAG = false, int EPI = 0>
 __global__ __launch_bounds__(WM * WN * 64, STAG ? 4 : 1) void gemm2_kernel(const GemmArgs p) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int STAGE = (BM + BN) * 128;
@@ -568,6 +575,10 @@ __global__ __launch_bounds__(WM * WN * 64, STAG ? 4 : 1) void gemm2_kernel(const
   const bf16_t* __restrict__ W = (const bf16_t*)p.W + zo * p.strideW + zi * p.strideW2;
   const int m0 = m_tile * BM, n0 = n_tile * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+#ifdef MSMD_EXPERIMENTAL
+  long stamp[5] = {0, 0, 0, 0, 0};
+  if (p.stamps) stamp[0] = (long)__builtin_amdgcn_s_memrealtime();
+#endif
 
   const bf16_t* src[LPT];
 #pragma unroll
@@ -616,8 +627,8 @@ __global__ __launch_bounds__(WM * WN * 64, STAG ? 4 : 1) void gemm2_kernel(const
   // (one batched round trip; with two workgroups per CU and grids of many rounds it hides under the neighbour's K loop)
   constexpr bool LN_LATE = FM == 3;
   f32x2 lnraw[(LNK && !LN_LATE) ? FM : 1][4];
-  if constexpr (LNK && !LN_LATE) {
-    if (p.a_stats) ln_issue<FM>(p.a_stats, p.a_nt, p.M, m0 + wm, fr, fq, lnraw);
+  if constexpr (LNK && !LN_LATE && EPI != 1) {
+    if (EPI == 2 || (EPI == 0 && p.a_stats)) ln_issue<FM>(p.a_stats, p.a_nt, p.M, m0 + wm, fr, fq, lnraw);
     else if (p.r_stats) ln_issue<FM>(p.r_stats, p.r_nt, p.M, m0 + wm, fr, fq, lnraw);
   }
   int stage = 0;
@@ -675,6 +686,9 @@ __global__ __launch_bounds__(WM * WN * 64, STAG ? 4 : 1) void gemm2_kernel(const
     if (kt + NSTAGE - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LPT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#ifdef MSMD_EXPERIMENTAL
+    if (p.stamps && kt == 0) stamp[1] = (long)__builtin_amdgcn_s_memrealtime();
+#endif
     if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, (stage + NSTAGE - 1) % NSTAGE);
     const unsigned char* sa = smem + stage * STAGE;
     const unsigned char* sw = sa + BM * 128;
@@ -715,21 +729,44 @@ __global__ __launch_bounds__(WM * WN * 64, STAG ? 4 : 1) void gemm2_kernel(const
     }
     stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
   }
-  if constexpr (LNK && !LN_LATE) {
-    if (p.a_stats) { gemm_epilogue_ln<TO, FM, FN, 1>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
-    if (p.r_stats || p.stats_out) { gemm_epilogue_ln<TO, FM, FN, 2>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
-  }
-  if constexpr (LNK && LN_LATE) {
-    if (p.a_stats || p.r_stats || p.stats_out) {
-      f32x2 late[FM][4];
-      if (p.a_stats) ln_issue<FM>(p.a_stats, p.a_nt, p.M, m0 + wm, fr, fq, late);
-      else if (p.r_stats) ln_issue<FM>(p.r_stats, p.r_nt, p.M, m0 + wm, fr, fq, late);
-      if (p.a_stats) gemm_epilogue_ln<TO, FM, FN, 1>(p, acc, m0 + wm, n0 + wn, fr, fq, late);
-      else gemm_epilogue_ln<TO, FM, FN, 2>(p, acc, m0 + wm, n0 + wn, fr, fq, late);
-      return;
+#ifdef MSMD_EXPERIMENTAL
+  if (p.stamps) stamp[2] = (long)__builtin_amdgcn_s_memrealtime();
+#endif
+  auto run_epilogue = [&]() {
+    if constexpr (EPI == 1) { gemm_epilogue<TO, FM, FN, false, true>(p, acc, z, m0 + wm, n0 + wn, fr, fq); return; }
+    if constexpr (LNK && !LN_LATE && EPI == 2) { gemm_epilogue_ln<TO, FM, FN, 1>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
+    if constexpr (LNK && !LN_LATE && EPI == 3) { gemm_epilogue_ln<TO, FM, FN, 2>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
+    if constexpr (LNK && !LN_LATE) {
+      if (p.a_stats) { gemm_epilogue_ln<TO, FM, FN, 1>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
+      if (p.r_stats || p.stats_out) { gemm_epilogue_ln<TO, FM, FN, 2>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
+    }
+    if constexpr (LNK && LN_LATE) {
+      if (p.a_stats || p.r_stats || p.stats_out) {
+        f32x2 late[FM][4];
+        if (p.a_stats) ln_issue<FM>(p.a_stats, p.a_nt, p.M, m0 + wm, fr, fq, late);
+        else if (p.r_stats) ln_issue<FM>(p.r_stats, p.r_nt, p.M, m0 + wm, fr, fq, late);
+        if (p.a_stats) gemm_epilogue_ln<TO, FM, FN, 1>(p, acc, m0 + wm, n0 + wn, fr, fq, late);
+        else gemm_epilogue_ln<TO, FM, FN, 2>(p, acc, m0 + wm, n0 + wn, fr, fq, late);
+        return;
+      }
+    }
+    gemm_epilogue<TO, FM, FN, sizeof(TO) == 2>(p, acc, z, m0 + wm, n0 + wn, fr, fq);
+  };
+  run_epilogue();
+#ifdef MSMD_EXPERIMENTAL
+  if (p.stamps) {      // per-workgroup stamps (tools/gemm_stamps.py): entry, first tile landed, K loop done, stores issued, stores drained
+    stamp[3] = (long)__builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp[4] = (long)__builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+      long* o = p.stamps + (long)pid * 8;
+      unsigned hw = 0, xcc = 0;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      o[0] = stamp[0]; o[1] = stamp[1]; o[2] = stamp[2]; o[3] = stamp[3]; o[4] = stamp[4]; o[5] = hw; o[6] = xcc; o[7] = m_tile * 1000 + n_tile;
     }
   }
-  gemm_epilogue<TO, FM, FN, sizeof(TO) == 2>(p, acc, z, m0 + wm, n0 + wn, fr, fq);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1041,6 +1078,8 @@ void gemm4_kernel(const GemmArgs p) {
 // Developer knobs exist ONLY in the experimental build (make EXP=1 -> libmsmd_hip_exp.so): the product library has no
 // process-global state -- kernel variant and epilogue flags travel per call in `act` (include/msmd_hip.h).
 int g_tuning[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+long* g_gemm_stamps = nullptr;
+extern "C" int msmd_exp_set_stamps(long* p) { g_gemm_stamps = p; return 0; }
 extern "C" int msmd_exp_set_tuning(int key, int value) {
   if (key < 0 || key >= 16) return 1;
   g_tuning[key] = value;
@@ -1049,11 +1088,11 @@ extern "C" int msmd_exp_set_tuning(int key, int value) {
 #include "exp/gemm_variants.inc"
 #endif
 
-template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t, bool STAG = false>
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t, bool STAG = false, int EPI = 0>
 static int launch_gemm2(GemmArgs& p, int batch, hipStream_t st) {
   constexpr int lds = NSTAGE * (BM + BN) * 128;
   static bool attr_done = false;
-  auto kfn = gemm2_kernel<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, STAG>;
+  auto kfn = gemm2_kernel<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, STAG, EPI>;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
@@ -1081,8 +1120,26 @@ static int launch_gemm2(GemmArgs& p, int batch, hipStream_t st) {
   // stagger (flags bit 2): only where the launch runs more than one round of two workgroups per CU
   p.stagger_ticks = ((p.flags & 4) && batch == 1 && NSTAGE * (BM + BN) * 128 <= 80 * 1024 && (long)p.mt * p.nt > 640)
                         ? (int)(100.0 * 0.5 * ((p.K / 64) * 0.5 + 3.0)) : 0;
+#ifdef MSMD_EXPERIMENTAL
+  p.stamps = g_gemm_stamps;
+#endif
   hipLaunchKernelGGL(kfn, grid, dim3(WM * WN * 64), lds, st, p);
   MSMD_RETURN_LAST();
+}
+
+// One instantiation per epilogue family, picked per call (see gemm2_kernel's EPI): the plain inference epilogue, the two
+// LayerNorm forms, and the everything-kernel for training calls (pre-activation copy / dropout / activation backward).
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t>
+static int launch_gemm2_epi(GemmArgs& p, int batch, hipStream_t st) {
+  constexpr bool LNK = (BN == 128 || BN == 64) && WN == 2 && (BM / WM / 16 == 2 || BM / WM / 16 == 3) && sizeof(TO) == 2;
+  constexpr bool LATE = BM / WM / 16 == 3;
+  if constexpr (LNK && !LATE) {
+    if (p.a_stats) return launch_gemm2<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, false, 2>(p, batch, st);
+    if (p.r_stats || p.stats_out) return launch_gemm2<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, false, 3>(p, batch, st);
+  }
+  const bool plain = !p.a_stats && !p.r_stats && !p.stats_out && !p.Z && !(p.p_drop > 0.f) && !(p.flags & 8);
+  if (plain) return launch_gemm2<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, false, 1>(p, batch, st);
+  return launch_gemm2<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, false, 0>(p, batch, st);
 }
 
 template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, typename TI = bf16_t, bool ILV = false>
@@ -1173,12 +1230,13 @@ static int dispatch_gemm2s(GemmArgs& p, int batch, hipStream_t st, int variant) 
 template <typename TO>
 static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
   switch (variant) {
-    case 9: return launch_gemm2<TO, 64, 64, 2, 2, 4>(p, batch, st);
-    case 12: return launch_gemm2<TO, 64, 64, 2, 2, 2>(p, batch, st);
+    case 9: return launch_gemm2_epi<TO, 64, 64, 2, 2, 4>(p, batch, st);
+    case 12: return launch_gemm2_epi<TO, 64, 64, 2, 2, 2>(p, batch, st);
     case 13: return launch_gemm2<TO, 128, 128, 4, 2, 2>(p, batch, st);
-    case 14: return launch_gemm2<TO, 256, 64, 8, 1, 2, true>(p, batch, st);   // narrow outputs (N <= 64): 8 waves of 32 x 64
-    case 15: return launch_gemm2<TO, 192, 128, 4, 2, 2, true>(p, batch, st);  // tall grids (M >= 16 k): 80 KB, still 2 workgroups / CU
-    case 17: return launch_gemm2<TO, 128, 128, 4, 2, 2, true>(p, batch, st);
+    case 14: return launch_gemm2_epi<TO, 256, 64, 8, 1, 2, true>(p, batch, st);   // narrow outputs (N <= 64): 8 waves of 32 x 64
+    case 15: return launch_gemm2_epi<TO, 192, 128, 4, 2, 2, true>(p, batch, st);  // tall grids (M >= 16 k): 80 KB, still 2 workgroups / CU
+    case 17: return launch_gemm2_epi<TO, 128, 128, 4, 2, 2, true>(p, batch, st);
+    case 66: return launch_gemm2<TO, 128, 128, 4, 2, 2, true>(p, batch, st);       // 17 as ONE kernel with every epilogue (round 3's form)
     // v4 kernels (fragment reads pipelined inside the wave, barrier between the k-steps):
     case 60: return launch_gemm4<TO, 256, 128, 4, 2, 3>(p, batch, st);                   // 144 KB, 1 workgroup / CU, 8 waves of 64 x 64
     case 61: return launch_gemm4<TO, 256, 128, 4, 2, 2>(p, batch, st);                   // 96 KB
@@ -1255,11 +1313,11 @@ static int launch_gemm(GemmArgs& p, int batch, hipStream_t st) {
 template <typename TO>
 static int dispatch_gemm2_f16(GemmArgs& p, int batch, hipStream_t st, int variant) {
   switch (variant) {
-    case 9: return launch_gemm2<TO, 64, 64, 2, 2, 4, false, f16_t>(p, batch, st);
-    case 12: return launch_gemm2<TO, 64, 64, 2, 2, 2, false, f16_t>(p, batch, st);
-    case 14: return launch_gemm2<TO, 256, 64, 8, 1, 2, true, f16_t>(p, batch, st);
-    case 15: return launch_gemm2<TO, 192, 128, 4, 2, 2, true, f16_t>(p, batch, st);
-    case 17: return launch_gemm2<TO, 128, 128, 4, 2, 2, true, f16_t>(p, batch, st);
+    case 9: return launch_gemm2_epi<TO, 64, 64, 2, 2, 4, false, f16_t>(p, batch, st);
+    case 12: return launch_gemm2_epi<TO, 64, 64, 2, 2, 2, false, f16_t>(p, batch, st);
+    case 14: return launch_gemm2_epi<TO, 256, 64, 8, 1, 2, true, f16_t>(p, batch, st);
+    case 15: return launch_gemm2_epi<TO, 192, 128, 4, 2, 2, true, f16_t>(p, batch, st);
+    case 17: return launch_gemm2_epi<TO, 128, 128, 4, 2, 2, true, f16_t>(p, batch, st);
     default: return -1;
   }
 }
@@ -1427,6 +1485,7 @@ extern "C" int msmd_gemm_ln(const void* A, const void* W, const float* bias, con
   hipStream_t st = (hipStream_t)stream;
   int variant = big ? 17 : (K >= 1024 ? 9 : 12);
   if (big && M >= 16000 && (long)((M + 191) / 192) * (N / 128) >= 400) variant = 15;    // tall grids: the 192 x 128 tile (same 64-column slabs)
+  if (variant == 17 && ((act >> 8) & 0xff) == 66) variant = 66;    // A/B hook: the one-kernel-with-every-epilogue form of variant 17
   const int r = in_dtype == MSMD_BF16 ? dispatch_gemm2<bf16_t>(p, 1, st, variant) : dispatch_gemm2_f16<f16_t>(p, 1, st, variant);
   return r >= 0 ? r : 1;
 }
