@@ -1485,7 +1485,10 @@ extern "C" int msmd_gemm_ln(const void* A, const void* W, const float* bias, con
   hipStream_t st = (hipStream_t)stream;
   int variant = big ? 17 : (K >= 1024 ? 9 : 12);
   if (big && M >= 16000 && (long)((M + 191) / 192) * (N / 128) >= 400) variant = 15;    // tall grids: the 192 x 128 tile (same 64-column slabs)
-  if (variant == 17 && ((act >> 8) & 0xff) == 66) variant = 66;    // A/B hook: the one-kernel-with-every-epilogue form of variant 17
+  {   // caller's tile hint for the big-tile family (same 64-column statistics slabs): 15 = 192 x 128, 17 = 128 x 128, 66 = A/B form of 17
+    const int hint = (act >> 8) & 0xff;
+    if (big && (hint == 15 || hint == 17 || hint == 66)) variant = hint;
+  }
   const int r = in_dtype == MSMD_BF16 ? dispatch_gemm2<bf16_t>(p, 1, st, variant) : dispatch_gemm2_f16<f16_t>(p, 1, st, variant);
   return r >= 0 ? r : 1;
 }
