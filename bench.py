@@ -171,7 +171,7 @@ def pmc_traffic(mode):
     """HBM bytes per launch of the dominant kernel from this round's committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE in SEPARATE runs; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC counters
     cannot be read from inside this process: the figure is a constant from profiles/ (null when absent), not this run."""
-    for name in ("r03_pmc_hbm_fetch_write_per_kernel.json", "r02_pmc_hbm_fetch_write_per_kernel.json"):
+    for name in ("r04_pmc_hbm_fetch_write_per_kernel.json", "r03_pmc_hbm_fetch_write_per_kernel.json", "r02_pmc_hbm_fetch_write_per_kernel.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -181,8 +181,9 @@ def pmc_traffic(mode):
             ks = [v for n, v in d.items() if want + "I" in n.replace("<", "I") and "128ELi128E" in n.replace(", ", "ELi").replace("<", "I")]
             ks = ks or [v for n, v in d.items() if want in n and "128" in n and ("gemm2s" in n) == (mode == "f16x2")]
             if ks:
-                k = max(ks, key=lambda v: v.get("launches", 0))
-                return round((2.0 * k["fetch_kb_avg"] + k["write_kb_avg"]) * 1024.0)
+                # since round 4 the 128 x 128 kernel is one symbol per epilogue family: launch-weighted mean over them
+                n = sum(v.get("launches", 0) for v in ks) or 1
+                return round(sum(v.get("launches", 0) * (2.0 * v["fetch_kb_avg"] + v["write_kb_avg"]) for v in ks) / n * 1024.0)
         except Exception:
             pass
     return None
