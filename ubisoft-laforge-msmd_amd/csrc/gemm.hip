@@ -555,7 +555,9 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 // launch executes a few KB scattered among the branches it does not take: per-workgroup stamps (tools/gemm_stamps.py) put the
 // epilogue of a 128 x 128 tile at 3.0 us for 32 outputs per lane (bias only), most of it instruction fetch.
 template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t, bool STAG = false, int EPI = 0>
-__global__ __launch_bounds__(WM * WN * 64, STAG ? 4 : 1) void gemm2_kernel(const GemmArgs p) {
+// 8-wave workgroups whose ring fits twice into a CU's LDS are MEANT to run two per CU: 4 waves per SIMD = 128 registers
+// (the 192-row tile's everything-epilogue instantiation drifted to 145 once, i.e. to one workgroup per CU: HuBERT-large 18.7 -> 21.4 ms)
+__global__ __launch_bounds__(WM * WN * 64, (STAG || (WM * WN == 8 && NSTAGE * (BM + BN) * 128 <= 80 * 1024)) ? 4 : 1) void gemm2_kernel(const GemmArgs p) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int LPT = (BM + BN) * 8 / NT;  // LDS-DMA instructions per thread per K tile
@@ -736,6 +738,13 @@ __global__ __launch_bounds__(WM * WN * 64, STAG ? 4 : 1) void gemm2_kernel(const
     if constexpr (EPI == 1) { gemm_epilogue<TO, FM, FN, false, true>(p, acc, z, m0 + wm, n0 + wn, fr, fq); return; }
     if constexpr (LNK && !LN_LATE && EPI == 2) { gemm_epilogue_ln<TO, FM, FN, 1>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
     if constexpr (LNK && !LN_LATE && EPI == 3) { gemm_epilogue_ln<TO, FM, FN, 2>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
+    if constexpr (LNK && LN_LATE && (EPI == 2 || EPI == 3)) {      // the 192-row tile: statistics loaded here (no registers to spare in the K loop)
+      f32x2 late[FM][4];
+      if constexpr (EPI == 2) ln_issue<FM>(p.a_stats, p.a_nt, p.M, m0 + wm, fr, fq, late);
+      else if (p.r_stats) ln_issue<FM>(p.r_stats, p.r_nt, p.M, m0 + wm, fr, fq, late);
+      gemm_epilogue_ln<TO, FM, FN, EPI - 1>(p, acc, m0 + wm, n0 + wn, fr, fq, late);
+      return;
+    }
     if constexpr (LNK && !LN_LATE) {
       if (p.a_stats) { gemm_epilogue_ln<TO, FM, FN, 1>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
       if (p.r_stats || p.stats_out) { gemm_epilogue_ln<TO, FM, FN, 2>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
@@ -1132,8 +1141,7 @@ static int launch_gemm2(GemmArgs& p, int batch, hipStream_t st) {
 template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t>
 static int launch_gemm2_epi(GemmArgs& p, int batch, hipStream_t st) {
   constexpr bool LNK = (BN == 128 || BN == 64) && WN == 2 && (BM / WM / 16 == 2 || BM / WM / 16 == 3) && sizeof(TO) == 2;
-  constexpr bool LATE = BM / WM / 16 == 3;
-  if constexpr (LNK && !LATE) {
+  if constexpr (LNK) {
     if (p.a_stats) return launch_gemm2<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, false, 2>(p, batch, st);
     if (p.r_stats || p.stats_out) return launch_gemm2<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, false, 3>(p, batch, st);
   }

@@ -733,6 +733,10 @@ def train(args, model, style_enc, train_loader, val_loader, optimizer, save_dir,
         log.append(out["loss"])
         if rank == 0 and it % args.log_iter == 0 and it != start_iter:
             val = torch.stack(log[-args.log_smooth_win:]).mean().item()   # the only host sync, once per log interval
+            if val != val or abs(val) == float("inf"):
+                # a non-finite loss must stop the run here, not train on: both reduction incidents of rounds 3 / 4 (the host
+                # library's multi-block sums inside hipGraphs) would have surfaced at this check
+                raise FloatingPointError(f"non-finite training loss at iteration {it} (hipGraph mode: {trainer.use_graph})")
             if writer is not None:
                 writer.add_scalar("train/loss", val, it)
                 writer.add_scalar("opt/lr", trainer.current_lr(), it)
