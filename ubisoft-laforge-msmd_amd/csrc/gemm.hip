@@ -556,8 +556,10 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 // epilogue of a 128 x 128 tile at 3.0 us for 32 outputs per lane (bias only), most of it instruction fetch.
 template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t, bool STAG = false, int EPI = 0>
 // 8-wave workgroups whose ring fits twice into a CU's LDS are MEANT to run two per CU: 4 waves per SIMD = 128 registers
-// (the 192-row tile's everything-epilogue instantiation drifted to 145 once, i.e. to one workgroup per CU: HuBERT-large 18.7 -> 21.4 ms)
-__global__ __launch_bounds__(WM * WN * 64, (STAG || (WM * WN == 8 && NSTAGE * (BM + BN) * 128 <= 80 * 1024)) ? 4 : 1) void gemm2_kernel(const GemmArgs p) {
+// (the 192-row tile's LayerNorm epilogues drifted to 145 once, i.e. to one workgroup per CU: HuBERT-large 18.7 -> 21.4 ms).
+// Its everything-epilogue instantiation (EPI 0: dropout / pre-activation copies on a tall grid, no caller on the path) does not
+// fit 128 without spilling and keeps the register count the compiler picks.
+__global__ __launch_bounds__(WM * WN * 64, (STAG || (WM * WN == 8 && NSTAGE * (BM + BN) * 128 <= 80 * 1024 && (EPI != 0 || BM * BN <= 128 * 128))) ? 4 : 1) void gemm2_kernel(const GemmArgs p) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int LPT = (BM + BN) * 8 / NT;  // LDS-DMA instructions per thread per K tile
