@@ -89,6 +89,16 @@ template <typename TO> __device__ __forceinline__ float act_out(float x, int act
   if (act == MSMD_ACT_ELU) return elu1(x);
   return x;
 }
+// ACT >= 0: the activation is a compile-time constant of the KERNEL (the launcher picks the instantiation from p.act).  With
+// the run-time code tested per ELEMENT the compiler keeps a scalar compare-and-branch around each of a lane's 32 outputs
+// (737 branches in the 128 x 128 kernel; per-workgroup stamps put its bias-only epilogue at 2.7-3.0 us of a 15 us tile, almost
+// all of it taken branches and instruction fetch); three copies behind ONE test inside the kernel spill.  ACT < 0: run-time.
+template <typename TO, int ACT> __device__ __forceinline__ float act_out_c(float x, int act) {
+  if constexpr (ACT == MSMD_ACT_GELU) return sizeof(TO) == 2 ? gelu_poly16(x) : gelu_erf(x);
+  else if constexpr (ACT == MSMD_ACT_ELU) return elu1(x);
+  else if constexpr (ACT == MSMD_ACT_NONE) return x;
+  else return act_out<TO>(x, act);
+}
 
 // Output stores.  wt = write-through (`sc1`): the bytes leave the XCD's L2 for memory as they are stored instead of
 // waiting dirty for the end-of-kernel write-back (MI355X_MICROARCH.md, "stores of each flavour"), so a consumer kernel
@@ -117,9 +127,9 @@ template <typename TO> __device__ __forceinline__ void store4_out(TO* p, const f
 // LEAN: the inference epilogue only (no pre-activation copy, no dropout, no activation backward): the launcher sends calls that
 // carry those to the kernels that compile them in.  On the 16-fragment wave tiles of gemm4_kernel the full epilogue is
 // tens of thousands of instructions and pushed the accumulators into scratch.
-template <typename TO, int FM, int FN, bool AB = false, bool LEAN = false>
-__device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int z, int m_base,
-                                                       int n_base, int fr, int fq) {
+template <typename TO, int FM, int FN, bool AB, bool LEAN, int ACT>
+__device__ __forceinline__ void gemm_epilogue_interior_a(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int z, int m_base,
+                                                         int n_base, int fr, int fq) {
   TO* __restrict__ C = (TO*)p.C + (z / p.batch_inner) * p.strideC + (z % p.batch_inner) * p.strideC2 +
                        (long)(m_base + fr) * p.ldc + n_base + fq * 4;
   const TO* __restrict__ R = p.R ? (const TO*)p.R + z * p.strideR + (long)(m_base + fr) * p.ldr + n_base + fq * 4 : nullptr;
@@ -151,11 +161,11 @@ __device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const 
     if (AB && (p.flags & 8)) {    // the backward of y = dropout(act(z)) applied to this data gradient: z read where C goes
       const V4 z4 = *(const V4*)((const TO*)p.Z + (crow + i * 16 - (TO*)p.C));
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= act_grad_fast((float)z4[e], p.act);
+      for (int e = 0; e < 4; ++e) v[e] *= act_grad_fast((float)z4[e], ACT >= 0 ? ACT : p.act);
     } else {
       if (!LEAN && p.Z) store4_out<TO>((TO*)p.Z + (crow + i * 16 - (TO*)p.C), v, wt);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = act_out<TO>(v[e], p.act);
+      for (int e = 0; e < 4; ++e) v[e] = act_out_c<TO, ACT>(v[e], p.act);
     }
     if (!LEAN && p.p_drop > 0.f) {
       const long idx = (long)(m_base + j * 16 + fr) * p.N + (n_base + i * 16 + fq * 4);
@@ -212,11 +222,11 @@ __device__ __forceinline__ void gemm_epilogue_interior(const GemmArgs& p, const 
   }
 }
 
-template <typename TO, int FM, int FN, bool AB = false, bool LEAN = false>
+template <typename TO, int FM, int FN, bool AB = false, bool LEAN = false, int ACT = -1>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int z, int m_base,
                                               int n_base, int fr, int fq) {
   if (p.vec_ok && m_base + FM * 16 <= p.M && n_base + FN * 16 <= p.N) {
-    gemm_epilogue_interior<TO, FM, FN, AB, LEAN>(p, acc, z, m_base, n_base, fr, fq);
+    gemm_epilogue_interior_a<TO, FM, FN, AB, LEAN, ACT>(p, acc, z, m_base, n_base, fr, fq);
     return;
   }
   TO* __restrict__ C = (TO*)p.C + (z / p.batch_inner) * p.strideC + (z % p.batch_inner) * p.strideC2;
@@ -243,7 +253,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
         const TO* zp = (const TO*)p.Z + (cp - (TO*)p.C);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (n + e < p.N) v[e] *= act_grad_fast((float)zp[e], p.act);
+          if (n + e < p.N) v[e] *= act_grad_fast((float)zp[e], ACT >= 0 ? ACT : p.act);
       } else {
         if (!LEAN && p.Z) {
           TO* zp = (TO*)p.Z + (cp - (TO*)p.C);
@@ -252,7 +262,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
             if (n + e < p.N) zp[e] = (TO)v[e];
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_out<TO>(v[e], p.act);
+        for (int e = 0; e < 4; ++e) v[e] = act_out_c<TO, ACT>(v[e], p.act);
       }
       if (!LEAN && p.p_drop > 0.f) {   // launcher guarantees N % 4 == 0 and ldc == N here
         const Philox4 rb = dropout_bits(p.rng, p.site, (unsigned long)(((long)m * p.N + n) >> 2));
@@ -333,9 +343,9 @@ __device__ __forceinline__ void ln_finish(const float* stats, int nt, int M, int
 // the statistics of the stored rows written when stats_out is given.  Every load of the epilogue (bias, column sums or
 // gamma / beta, the residual fragments) is issued up front, unconditionally: with run-time "is this pointer set" tests
 // inside the fragment loops the compiler serialises them into one L2 round trip per fragment column (+4 us per launch).
-template <typename TO, int FM, int FN, int MODE>
-__device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int m_base, int n_base,
-                                                 int fr, int fq, const f32x2 (&raw)[FM][4]) {
+template <typename TO, int FM, int FN, int MODE, int ACT>
+__device__ __forceinline__ void gemm_epilogue_ln_a(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int m_base, int n_base,
+                                                   int fr, int fq, const f32x2 (&raw)[FM][4]) {
   static_assert((FN == 4 || FN == 2) && (FM >= 2 && FM <= 4), "one wave = one statistics slab of 16 FN columns, 2 to 4 fragment rows");
   constexpr int SLAB = FN * 16;
   // fragment columns whose operands are requested together: all of them for the two-row tiles; two at a time for the
@@ -388,7 +398,7 @@ __device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& p, const f32x4 
         for (int e = 0; e < 4; ++e) {
           float x = acc[i][j][e];
           if constexpr (MODE == 1) x = rs[j] * (x - mu[j] * xv[ii][e]);
-          v[e] = act_out<TO>(x + bv[ii][e], p.act);
+          v[e] = act_out_c<TO, ACT>(x + bv[ii][e], p.act);
           if constexpr (MODE == 2) v[e] += fmaf(((float)rr[j][ii][e] - mu[j]) * rs[j], xv[ii][e], yv[ii][e]);
         }
         if constexpr (sizeof(TO) == 4) o[j] = V4{v[0], v[1], v[2], v[3]};
@@ -440,6 +450,12 @@ __device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& p, const f32x4 
       }
     }
   }
+}
+
+template <typename TO, int FM, int FN, int MODE, int ACT = -1>
+__device__ __forceinline__ void gemm_epilogue_ln(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int m_base, int n_base,
+                                                 int fr, int fq, const f32x2 (&raw)[FM][4]) {
+  gemm_epilogue_ln_a<TO, FM, FN, MODE, ACT>(p, acc, m_base, n_base, fr, fq, raw);
 }
 
 template <typename T, typename TO, int BM, int BN>
@@ -554,12 +570,15 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 // 2 / 3 = the LayerNorm-operand / LayerNorm-residual form only.  One instantiation with everything is 127 KB of code of which a
 // launch executes a few KB scattered among the branches it does not take: per-workgroup stamps (tools/gemm_stamps.py) put the
 // epilogue of a 128 x 128 tile at 3.0 us for 32 outputs per lane (bias only), most of it instruction fetch.
-template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t, bool STAG = false, int EPI = 0>
+// EPIA = EPI + 10 * (1 + activation) when the activation is compiled in as well (11 / 21 plain with none / GELU, 12 / 22
+// LayerNorm-operand with none / GELU, 13 LayerNorm-residual with none): see act_out_c.
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t, bool STAG = false, int EPIA = 0>
 // 8-wave workgroups whose ring fits twice into a CU's LDS are MEANT to run two per CU: 4 waves per SIMD = 128 registers
 // (the 192-row tile's LayerNorm epilogues drifted to 145 once, i.e. to one workgroup per CU: HuBERT-large 18.7 -> 21.4 ms).
 // Its everything-epilogue instantiation (EPI 0: dropout / pre-activation copies on a tall grid, no caller on the path) does not
 // fit 128 without spilling and keeps the register count the compiler picks.
-__global__ __launch_bounds__(WM * WN * 64, (STAG || (WM * WN == 8 && NSTAGE * (BM + BN) * 128 <= 80 * 1024 && (EPI != 0 || BM * BN <= 128 * 128))) ? 4 : 1) void gemm2_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, (STAG || (WM * WN == 8 && NSTAGE * (BM + BN) * 128 <= 80 * 1024 && (EPIA % 10 != 0 || BM * BN <= 128 * 128))) ? 4 : 1) void gemm2_kernel(const GemmArgs p) {
+  constexpr int EPI = EPIA % 10, ACTK = EPIA / 10 - 1;
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int LPT = (BM + BN) * 8 / NT;  // LDS-DMA instructions per thread per K tile
@@ -736,32 +755,38 @@ __global__ __launch_bounds__(WM * WN * 64, (STAG || (WM * WN == 8 && NSTAGE * (B
 #ifdef MSMD_EXPERIMENTAL
   if (p.stamps) stamp[2] = (long)__builtin_amdgcn_s_memrealtime();
 #endif
+  // the 192-row tile has no register to spare: the lane's fragment coordinates are derived again here instead of living
+  // through the K loop (one of them went to scratch otherwise)
+  int tid_e = tid;
+  if constexpr (LN_LATE) asm volatile("" : "+v"(tid_e));
+  const int wm_e = ((tid_e >> 6) / WN) * (BM / WM), wn_e = ((tid_e >> 6) % WN) * (BN / WN);
+  const int fr_e = tid_e & 15, fq_e = (tid_e & 63) >> 4;
   auto run_epilogue = [&]() {
-    if constexpr (EPI == 1) { gemm_epilogue<TO, FM, FN, false, true>(p, acc, z, m0 + wm, n0 + wn, fr, fq); return; }
-    if constexpr (LNK && !LN_LATE && EPI == 2) { gemm_epilogue_ln<TO, FM, FN, 1>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
-    if constexpr (LNK && !LN_LATE && EPI == 3) { gemm_epilogue_ln<TO, FM, FN, 2>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
+    if constexpr (EPI == 1) { gemm_epilogue<TO, FM, FN, false, true, ACTK>(p, acc, z, m0 + wm_e, n0 + wn_e, fr_e, fq_e); return; }
+    if constexpr (LNK && !LN_LATE && EPI == 2) { gemm_epilogue_ln<TO, FM, FN, 1, ACTK>(p, acc, m0 + wm_e, n0 + wn_e, fr_e, fq_e, lnraw); return; }
+    if constexpr (LNK && !LN_LATE && EPI == 3) { gemm_epilogue_ln<TO, FM, FN, 2, ACTK>(p, acc, m0 + wm_e, n0 + wn_e, fr_e, fq_e, lnraw); return; }
     if constexpr (LNK && LN_LATE && (EPI == 2 || EPI == 3)) {      // the 192-row tile: statistics loaded here (no registers to spare in the K loop)
       f32x2 late[FM][4];
-      if constexpr (EPI == 2) ln_issue<FM>(p.a_stats, p.a_nt, p.M, m0 + wm, fr, fq, late);
-      else if (p.r_stats) ln_issue<FM>(p.r_stats, p.r_nt, p.M, m0 + wm, fr, fq, late);
-      gemm_epilogue_ln<TO, FM, FN, EPI - 1>(p, acc, m0 + wm, n0 + wn, fr, fq, late);
+      if constexpr (EPI == 2) ln_issue<FM>(p.a_stats, p.a_nt, p.M, m0 + wm_e, fr_e, fq_e, late);
+      else if (p.r_stats) ln_issue<FM>(p.r_stats, p.r_nt, p.M, m0 + wm_e, fr_e, fq_e, late);
+      gemm_epilogue_ln<TO, FM, FN, EPI - 1, ACTK>(p, acc, m0 + wm_e, n0 + wn_e, fr_e, fq_e, late);
       return;
     }
     if constexpr (LNK && !LN_LATE) {
-      if (p.a_stats) { gemm_epilogue_ln<TO, FM, FN, 1>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
-      if (p.r_stats || p.stats_out) { gemm_epilogue_ln<TO, FM, FN, 2>(p, acc, m0 + wm, n0 + wn, fr, fq, lnraw); return; }
+      if (p.a_stats) { gemm_epilogue_ln<TO, FM, FN, 1, ACTK>(p, acc, m0 + wm_e, n0 + wn_e, fr_e, fq_e, lnraw); return; }
+      if (p.r_stats || p.stats_out) { gemm_epilogue_ln<TO, FM, FN, 2, ACTK>(p, acc, m0 + wm_e, n0 + wn_e, fr_e, fq_e, lnraw); return; }
     }
     if constexpr (LNK && LN_LATE) {
       if (p.a_stats || p.r_stats || p.stats_out) {
         f32x2 late[FM][4];
-        if (p.a_stats) ln_issue<FM>(p.a_stats, p.a_nt, p.M, m0 + wm, fr, fq, late);
-        else if (p.r_stats) ln_issue<FM>(p.r_stats, p.r_nt, p.M, m0 + wm, fr, fq, late);
-        if (p.a_stats) gemm_epilogue_ln<TO, FM, FN, 1>(p, acc, m0 + wm, n0 + wn, fr, fq, late);
-        else gemm_epilogue_ln<TO, FM, FN, 2>(p, acc, m0 + wm, n0 + wn, fr, fq, late);
+        if (p.a_stats) ln_issue<FM>(p.a_stats, p.a_nt, p.M, m0 + wm_e, fr_e, fq_e, late);
+        else if (p.r_stats) ln_issue<FM>(p.r_stats, p.r_nt, p.M, m0 + wm_e, fr_e, fq_e, late);
+        if (p.a_stats) gemm_epilogue_ln<TO, FM, FN, 1, ACTK>(p, acc, m0 + wm_e, n0 + wn_e, fr_e, fq_e, late);
+        else gemm_epilogue_ln<TO, FM, FN, 2, ACTK>(p, acc, m0 + wm_e, n0 + wn_e, fr_e, fq_e, late);
         return;
       }
     }
-    gemm_epilogue<TO, FM, FN, sizeof(TO) == 2>(p, acc, z, m0 + wm, n0 + wn, fr, fq);
+    gemm_epilogue<TO, FM, FN, sizeof(TO) == 2, false, ACTK>(p, acc, z, m0 + wm_e, n0 + wn_e, fr_e, fq_e);
   };
   run_epilogue();
 #ifdef MSMD_EXPERIMENTAL
@@ -787,12 +812,58 @@ __global__ __launch_bounds__(WM * WN * 64, (STAG || (WM * WN == 8 && NSTAGE * (B
 // k-step and fragment pair: acc0 += Wh.Ah, acc1 += Wh.Al + Wl.Ah (three v_mfma_f32_16x16x32_f16), result
 // acc0 + acc1 / 2048.  The launcher passes lda / ldw / strides of A and W already doubled (fp16 units); K stays logical.
 // TO = float (fp32 C and residual) or f16_t (C and residual in split storage).
-template <int FM, int FN>
+// ACT: see act_out_c (>= 0: a constant of the kernel).  GELU through the 12-instruction erf (|abs err| <= 1.5e-7, i.e.
+// <= 0.5 |x| 1.5e-7 on the output: the size of an fp32 rounding error at these magnitudes); libm's erff would be ~15 % of an
+// FFN1 launch.
+template <int ACT> __device__ __forceinline__ float act_split(float x, int act) {
+  if constexpr (ACT == MSMD_ACT_GELU) return gelu_fast(x);
+  else if constexpr (ACT == MSMD_ACT_NONE) return x;
+  else return act == MSMD_ACT_GELU ? gelu_fast(x) : apply_act(x, act);
+}
+
+template <int FM, int FN, int ACT = -1>
 __device__ __forceinline__ void gemm_epilogue_split(const GemmArgs& p, const f32x4 (&acc)[FN][FM], int z, int m_base,
                                                     int n_base, int fr, int fq) {
   f16_t* __restrict__ C = (f16_t*)p.C + 2 * ((z / p.batch_inner) * p.strideC + (z % p.batch_inner) * p.strideC2);
   const f16_t* __restrict__ R = p.R ? (const f16_t*)p.R + 2 * (z * p.strideR) : nullptr;
   const float* __restrict__ bias = p.bias ? p.bias + z * p.strideBias : nullptr;
+  if (m_base + FM * 16 <= p.M && n_base + FN * 16 <= p.N) {
+    // interior tiles: straight-line code, every load (bias, both halves of every residual fragment) requested before the
+    // first store -- between the stores they are serialised into one L2 round trip per fragment (see gemm_epilogue_interior)
+    const int n = n_base + fq * 4;
+    f32x4 bv[FN];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) bv[i] = bias ? *(const f32x4*)(bias + n + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f16x4 rh[FM][FN], rl[FM][FN];
+    if (R) {
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const f16_t* rrow = R + (long)(m_base + j * 16 + fr) * 2 * p.ldr;
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          const f16_t* q = rrow + split_col(n + i * 16);
+          rh[j][i] = *(const f16x4*)q;
+          rl[j][i] = *(const f16x4*)(q + 32);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      f16_t* crow = C + (long)(m_base + j * 16 + fr) * 2 * p.ldc;
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_split<ACT>(acc[i][j][e] + bv[i][e], p.act);
+        if (R) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += unsplit_f16x2(rh[j][i][e], rl[j][i][e]);
+        }
+        store4_split(crow, n + i * 16, v);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < FN; ++i) {
     const int n = n_base + i * 16 + fq * 4;
@@ -804,9 +875,7 @@ __device__ __forceinline__ void gemm_epilogue_split(const GemmArgs& p, const f32
       if (m >= p.M) continue;
       float v[4];
 #pragma unroll
-      // GELU through the 12-instruction erf (|abs err| <= 1.5e-7, i.e. <= 0.5 |x| 1.5e-7 on the output: the size of an
-      // fp32 rounding error at these magnitudes); libm's erff would be ~15 % of an FFN1 launch
-      for (int e = 0; e < 4; ++e) { const float x_ = acc[i][j][e] + bv[e]; v[e] = p.act == MSMD_ACT_GELU ? gelu_fast(x_) : apply_act(x_, p.act); }
+      for (int e = 0; e < 4; ++e) v[e] = act_split<ACT>(acc[i][j][e] + bv[e], p.act);
       if (R) {
         float r[4];
         load4_split(R + (long)m * 2 * p.ldr, n, r);
@@ -818,7 +887,7 @@ __device__ __forceinline__ void gemm_epilogue_split(const GemmArgs& p, const f32
   }
 }
 
-template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE>
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, int ACTK = -1>
 __global__ __launch_bounds__(WM * WN * 64) void gemm2s_kernel(const GemmArgs p) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int STAGE = (BM + BN) * 128;
@@ -902,8 +971,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2s_kernel(const GemmArgs p) 
     for (int j = 0; j < FM; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc0[i][j][e] = fmaf(acc1[i][j][e], MSMD_SPLIT_INV, acc0[i][j][e]);
-  if constexpr (sizeof(TO) == 4) gemm_epilogue<float, FM, FN>(p, acc0, z, m0 + wm, n0 + wn, fr, fq);
-  else gemm_epilogue_split<FM, FN>(p, acc0, z, m0 + wm, n0 + wn, fr, fq);
+  if constexpr (sizeof(TO) == 4) gemm_epilogue<float, FM, FN, false, false, ACTK>(p, acc0, z, m0 + wm, n0 + wn, fr, fq);
+  else gemm_epilogue_split<FM, FN, ACTK>(p, acc0, z, m0 + wm, n0 + wn, fr, fq);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1143,12 +1212,19 @@ static int launch_gemm2(GemmArgs& p, int batch, hipStream_t st) {
 template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t>
 static int launch_gemm2_epi(GemmArgs& p, int batch, hipStream_t st) {
   constexpr bool LNK = (BN == 128 || BN == 64) && WN == 2 && (BM / WM / 16 == 2 || BM / WM / 16 == 3) && sizeof(TO) == 2;
+  // every family also with the activation as a constant of the kernel (none / GELU: what the path launches; ELU and the
+  // LayerNorm-residual form with an activation stay run-time)
+  int epi = 0;
+  if (LNK && p.a_stats) epi = 2;
+  else if (LNK && (p.r_stats || p.stats_out)) epi = 3;
+  else if (!p.a_stats && !p.r_stats && !p.stats_out && !p.Z && !(p.p_drop > 0.f) && !(p.flags & 8)) epi = 1;
+  const int a = p.act == MSMD_ACT_NONE ? 10 : (p.act == MSMD_ACT_GELU && epi != 3) ? 20 : 0;
+#define MSMD_EPI_CASE(E) case E: return launch_gemm2<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, false, E>(p, batch, st)
   if constexpr (LNK) {
-    if (p.a_stats) return launch_gemm2<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, false, 2>(p, batch, st);
-    if (p.r_stats || p.stats_out) return launch_gemm2<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, false, 3>(p, batch, st);
+    switch (epi + a) { MSMD_EPI_CASE(2); MSMD_EPI_CASE(12); MSMD_EPI_CASE(22); MSMD_EPI_CASE(3); MSMD_EPI_CASE(13); default: break; }
   }
-  const bool plain = !p.a_stats && !p.r_stats && !p.stats_out && !p.Z && !(p.p_drop > 0.f) && !(p.flags & 8);
-  if (plain) return launch_gemm2<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, false, 1>(p, batch, st);
+  switch (epi + a) { MSMD_EPI_CASE(1); MSMD_EPI_CASE(11); MSMD_EPI_CASE(21); MSMD_EPI_CASE(10); MSMD_EPI_CASE(20); default: break; }
+#undef MSMD_EPI_CASE
   return launch_gemm2<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, false, 0>(p, batch, st);
 }
 
@@ -1181,11 +1257,15 @@ static int launch_gemm4(GemmArgs& p, int batch, hipStream_t st) {
   MSMD_RETURN_LAST();
 }
 
-template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE>
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, int ACTK = -1>
 static int launch_gemm2s(GemmArgs& p, int batch, hipStream_t st) {
+  if constexpr (ACTK == -1 && NSTAGE * (BM + BN) * 128 <= 80 * 1024) {      // the routed tiles: the activation as a constant of the kernel
+    if (p.act == MSMD_ACT_NONE) return launch_gemm2s<TO, BM, BN, WM, WN, NSTAGE, MSMD_ACT_NONE>(p, batch, st);
+    if (p.act == MSMD_ACT_GELU) return launch_gemm2s<TO, BM, BN, WM, WN, NSTAGE, MSMD_ACT_GELU>(p, batch, st);
+  }
   constexpr int lds = NSTAGE * (BM + BN) * 128;
   static bool attr_done = false;
-  auto kfn = gemm2s_kernel<TO, BM, BN, WM, WN, NSTAGE>;
+  auto kfn = gemm2s_kernel<TO, BM, BN, WM, WN, NSTAGE, ACTK>;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
