@@ -1223,7 +1223,10 @@ static int launch_gemm2_epi(GemmArgs& p, int batch, hipStream_t st) {
   if constexpr (LNK) {
     switch (epi + a) { MSMD_EPI_CASE(2); MSMD_EPI_CASE(12); MSMD_EPI_CASE(22); MSMD_EPI_CASE(3); MSMD_EPI_CASE(13); default: break; }
   }
-  switch (epi + a) { MSMD_EPI_CASE(1); MSMD_EPI_CASE(11); MSMD_EPI_CASE(21); MSMD_EPI_CASE(10); MSMD_EPI_CASE(20); default: break; }
+  switch (epi + a) { MSMD_EPI_CASE(1); MSMD_EPI_CASE(11); MSMD_EPI_CASE(21); default: break; }
+  if constexpr (sizeof(TI) == 2 && !__is_same(TI, f16_t)) {     // the everything-epilogue is the training step's: bf16 only
+    switch (epi + a) { MSMD_EPI_CASE(10); MSMD_EPI_CASE(20); default: break; }
+  }
 #undef MSMD_EPI_CASE
   return launch_gemm2<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, false, 0>(p, batch, st);
 }
