@@ -178,7 +178,9 @@ def pmc_traffic(mode):
         try:
             d = json.load(open(path))
             want = {"bf16": "gemm2_kernel", "fp16": "gemm2_kernel", "f16x2": "gemm2s_kernel", "fp32": "gemm_kernel"}[mode]
-            ks = [v for n, v in d.items() if want + "I" in n.replace("<", "I") and "128ELi128E" in n.replace(", ", "ELi").replace("<", "I")]
+            # (the multi-round launches of the same tile run as gemm2p_kernel, its persistent form)
+            ks = [v for n, v in d.items() if any(w + "I" in n.replace("<", "I") for w in (want, want.replace("gemm2_", "gemm2p_")))
+                  and "128ELi128E" in n.replace(", ", "ELi").replace("<", "I")]
             ks = ks or [v for n, v in d.items() if want in n and "128" in n and ("gemm2s" in n) == (mode == "f16x2")]
             if ks:
                 # since round 4 the 128 x 128 kernel is one symbol per epilogue family: launch-weighted mean over them

@@ -50,6 +50,7 @@ int msmd_abi_version(void);
 #define MSMD_GEMM_WRITE_THROUGH (1 << 16) /* output stores carry `sc1`: the bytes leave the XCD's L2 as they are stored */
 #define MSMD_GEMM_PAIRED_STORES (1 << 17) /* 16-bit outputs: lane pairs swap a fragment row, one 16-byte store each */
 #define MSMD_GEMM_STAGGER (1 << 18)       /* multi-round launches: the second workgroup of every CU starts half a tile period late */
+#define MSMD_GEMM_ONE_TILE_PER_WORKGROUP (1 << 19) /* opt out of the persistent form of multi-round launches (A/B; same bits) */
 
 /* Measurement aid: one wavefront that spins for `us` microseconds of the 100 MHz constant clock (s_memrealtime) and
  * optionally stores the ticks it actually spun.  bench.py times it at two lengths to calibrate the overhead of a HIP

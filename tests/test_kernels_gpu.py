@@ -533,6 +533,53 @@ def test_gemm_store_flags_and_variants_are_bit_identical(dtype):
             assert torch.equal(c, ref), (v, fl, float((c.float() - ref.float()).abs().max()))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_persistent_multi_round_form_is_bit_identical(dtype):
+    """Launches of more than 512 tiles of the 128 x 128 kernel run as 512 persistent workgroups (gemm2p_kernel: the next tile's
+    first operand stage is issued by the last K tile of the current one).  Same products in the same order per tile: the
+    outputs and the LayerNorm statistics equal the one-tile-per-workgroup form (MSMD_GEMM_ONE_TILE_PER_WORKGROUP) bit for
+    bit, on a grid with ragged edges in M (6500 rows = 51 tiles x 18 / 24 / 6 column tiles), for every epilogue family."""
+    from msmd_amd import ops as O
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(19)
+    M, D, F = 6500, 768, 3072
+    a = torch.randn(M, D, generator=g).to(DEV, dtype)
+    w_qkv = (torch.randn(3 * D, D, generator=g) / math.sqrt(D)).to(DEV, dtype)
+    b_qkv = torch.randn(3 * D, generator=g).to(DEV)
+    r_qkv = torch.randn(M, 3 * D, generator=g).to(DEV, dtype)
+    one = o.GEMM_ONE_TILE_PER_WORKGROUP
+    for act in (o.ACT_NONE, o.ACT_GELU):          # plain epilogue, with and without residual
+        for r in (None, r_qkv):
+            c0 = o.gemm(a, w_qkv, b_qkv, r, act=act, variant=17, flags=o.GEMM_PAIRED_STORES | one)
+            c1 = o.gemm(a, w_qkv, b_qkv, r, act=act, variant=17, flags=o.GEMM_PAIRED_STORES)
+            assert torch.equal(c0, c1), (act, r is not None)
+    # LayerNorm-residual form (statistics out, 64-column slabs) and LayerNorm-operand form, tall enough for two rounds
+    M2 = 12900                                    # 101 x 6 = 606 tiles of 128 x 128
+    u0 = (torch.randn(M2, D, generator=g) * 2 + 0.3).to(DEV, dtype)
+    a2 = torch.randn(M2, D, generator=g).to(DEV, dtype)
+    w1 = (torch.randn(D, D, generator=g) / math.sqrt(D)).to(DEV, dtype)
+    b1 = torch.randn(D, generator=g).to(DEV)
+    g0, be0 = (torch.rand(D, generator=g) + 0.5).to(DEV), (torch.randn(D, generator=g) * 0.1).to(DEV)
+    x = u0.double().reshape(M2, -1, 64)
+    st0 = torch.stack([x.sum(-1), (x * x).sum(-1)], -1).transpose(0, 1).float().contiguous()
+    w2f, cs2, b2f = o.fold_layernorm(torch.randn(F, D, generator=g).to(DEV) / math.sqrt(D), torch.randn(F, generator=g).to(DEV),
+                                     (torch.rand(D, generator=g) + 0.5).to(DEV), (torch.randn(D, generator=g) * 0.1).to(DEV), dtype)
+    outs = []
+    for fl in (one, 0):
+        O.GEMM_LN_FLAGS = fl
+        try:
+            c1, s1 = o.gemm_ln(a2, w1, b1, u0, r_stats=st0, r_gamma=g0, r_beta=be0, stats_out=True)
+            c1p, s1p = o.gemm_ln(a2, w1, b1, u0, stats_out=True)
+            f = o.gemm_ln(c1, w2f, b2f, act=o.ACT_GELU, a_stats=s1, w_colsum=cs2)
+            q = o.gemm_ln(c1, w2f, b2f, a_stats=s1, w_colsum=cs2)
+        finally:
+            O.GEMM_LN_FLAGS = 0
+        outs.append((c1, s1, c1p, s1p, f, q))
+    assert s1.shape[0] == D // 64
+    for x0, x1 in zip(*outs):
+        assert torch.equal(x0, x1)
+
+
 @pytest.mark.parametrize("M", [1000, 6500, 16100])     # 64 x 64 tiles / 32-column slabs; 128 x 128 and (tall grids) 192 x 128 tiles / 64-column slabs; ragged M
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_gemm_ln_folds_layernorm_into_producer_and_consumer(dtype, M):

@@ -806,6 +806,140 @@ __global__ __launch_bounds__(WM * WN * 64, (STAG || (WM * WN == 8 && NSTAGE * (B
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Persistent form of gemm2_kernel<.., 2 stages, pipelined> for launches of MORE THAN ONE ROUND (more tiles than the 512
+// workgroups the chip holds at two per CU).  The grid is 512 workgroups; workgroup b multiplies the tiles gemm2_kernel's blocks
+// b, b + 512, b + 1024, ... would (same XCD: 512 % 8 == 0) -- and the operand stream never drains between them: the LAST K
+// tile of a tile issues the FIRST stage of the next one, so the next tile's prologue (addresses, the first operand round
+// trip: 1.2-1.9 us per workgroup on the stamps of DESIGN.md 5d) runs under this tile's last multiply and its epilogue, and
+// there is no workgroup retirement / dispatch between rounds (0.8 us on the same stamps).  Per tile the products, their
+// order and the epilogue are gemm2_kernel's: results are bit-identical.
+template <typename TO, int BM, int BN, int WM, int WN, typename TI, int EPIA>
+__global__ __launch_bounds__(WM * WN * 64, 4) void gemm2p_kernel(const GemmArgs p) {
+  constexpr int EPI = EPIA % 10, ACTK = EPIA / 10 - 1;
+  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int LPT = (BM + BN) * 8 / NT;
+  constexpr int FM = BM / WM / 16, FN = BN / WN / 16;
+  static_assert(EPI >= 1 && EPI <= 3 && sizeof(TO) == 2 && NW == 8 && WN == 2 && BN == 128 && (FM == 2 || FM == 3), "the hot 8-wave tiles, inference epilogues");
+  static_assert((BM + BN) * 8 % NT == 0, "tile chunks must divide over the threads");
+  constexpr bool LN_LATE = FM == 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int xm_n = 8 / p.xn, ntx = (p.nt + p.xn - 1) / p.xn;
+  const int vgrid = ((p.mt + xm_n - 1) / xm_n) * ntx * 8;      // gemm2_kernel's grid
+  const TI* __restrict__ A = (const TI*)p.A;
+  const TI* __restrict__ W = (const TI*)p.W;
+  // first block id >= vb of this workgroup's sequence that maps to a tile (the XCD grid pads), or -1
+  auto next_tile = [&](int vb, int& m0, int& n0) -> int {
+    for (; vb < vgrid; vb += gridDim.x) {
+      const int xcd = vb & 7, slot = vb >> 3;
+      const int m_tile = (slot / ntx) * xm_n + (xcd % xm_n), n_tile = (slot % ntx) * p.xn + xcd / xm_n;
+      if (m_tile < p.mt && n_tile < p.nt) { m0 = m_tile * BM; n0 = n_tile * BN; return vb; }
+    }
+    return -1;
+  };
+  // Everything derived from the lane id is derived AGAIN per tile and per phase (t_k for the K loop, t_e for the epilogue) from
+  // copies the compiler cannot match: kept across the tile loop, the K loop's fragment / staging offsets would be live in
+  // the epilogue and the epilogue's in the K loop (+30 registers: 90-250 bytes of scratch in every LayerNorm form)
+  const TI* src[LPT];
+  auto set_src = [&](int m0, int n0, int t) {
+    const int lane = t & 63, wid = t >> 6;
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      const int id = (i * NW + wid) * 64 + lane;  // 16-B slot of the tile image
+      const int row = id >> 3, phys = id & 7;
+      const int c = phys ^ ((row >> 1) & 7);      // logical chunk stored at this physical slot
+      if (row < BM) src[i] = A + a_row_offset(p, min(m0 + row, p.M - 1)) + c * 8;
+      else src[i] = W + (long)min(n0 + row - BM, p.N - 1) * p.ldw + c * 8;
+    }
+  };
+  auto issue = [&](int kt, int stage, int t) {
+    const int wid = t >> 6;
+#pragma unroll
+    for (int i = 0; i < LPT; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[i] + kt * 64),
+                                       (lds_void_t*)(smem + stage * STAGE + (i * NW + wid) * 1024), 16, 0, 0);
+  };
+  int m0 = 0, n0 = 0;
+  int vb = next_tile(blockIdx.x, m0, n0);
+  if (vb < 0) return;
+  const int nk = p.K / 64;
+  set_src(m0, n0, tid);
+  int stage = 0;
+  issue(0, 0, tid);
+  for (;;) {
+    int t_k = tid;
+    asm volatile("" : "+v"(t_k));
+    const int wm = ((t_k >> 6) / WN) * (BM / WM), wn = ((t_k >> 6) % WN) * (BN / WN);
+    const int fr = t_k & 15, fq = (t_k & 63) >> 4;
+    f32x2 lnraw[LN_LATE ? 1 : FM][4];
+    if constexpr (!LN_LATE && EPI != 1) {
+      if constexpr (EPI == 2) ln_issue<FM>(p.a_stats, p.a_nt, p.M, m0 + wm, fr, fq, lnraw);
+      else if (p.r_stats) ln_issue<FM>(p.r_stats, p.r_nt, p.M, m0 + wm, fr, fq, lnraw);
+    }
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int m0n = 0, n0n = 0, vbn = -1;
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) {
+        issue(kt + 1, stage ^ 1, t_k);
+      } else {
+        // the other stage is free (every wave is past this barrier, i.e. done reading it): the next tile's first stage
+        vbn = next_tile(vb + (int)gridDim.x, m0n, n0n);
+        if (vbn >= 0) { set_src(m0n, n0n, t_k); issue(0, stage ^ 1, t_k); }
+      }
+      const unsigned char* sa = smem + stage * STAGE;
+      const unsigned char* sw = sa + BM * 128;
+      u32x4 fx[2][FM], fw[2][FN];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int j = 0; j < FM; ++j) fx[g][j] = *(const u32x4*)(sa + lds_off(wm + j * 16 + fr, g * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < FN; ++i) fw[g][i] = *(const u32x4*)(sw + lds_off(wn + i * 16 + fr, g * 4 + fq));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+          for (int j = 0; j < FM; ++j) Mfma<TI>::run(fw[g][i], fx[g][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      stage ^= 1;
+    }
+    int t_e = tid;
+    asm volatile("" : "+v"(t_e));
+    const int wm_e = ((t_e >> 6) / WN) * (BM / WM), wn_e = ((t_e >> 6) % WN) * (BN / WN);
+    const int fr_e = t_e & 15, fq_e = (t_e & 63) >> 4;
+    if constexpr (EPI == 1) {
+      gemm_epilogue<TO, FM, FN, false, true, ACTK>(p, acc, 0, m0 + wm_e, n0 + wn_e, fr_e, fq_e);
+    } else if constexpr (!LN_LATE) {
+      gemm_epilogue_ln<TO, FM, FN, EPI - 1, ACTK>(p, acc, m0 + wm_e, n0 + wn_e, fr_e, fq_e, lnraw);
+    } else {      // the 192-row tile: statistics loaded here (no registers to spare in the K loop)
+      f32x2 late[FM][4];
+      if constexpr (EPI == 2) ln_issue<FM>(p.a_stats, p.a_nt, p.M, m0 + wm_e, fr_e, fq_e, late);
+      else if (p.r_stats) ln_issue<FM>(p.r_stats, p.r_nt, p.M, m0 + wm_e, fr_e, fq_e, late);
+      gemm_epilogue_ln<TO, FM, FN, EPI - 1, ACTK>(p, acc, m0 + wm_e, n0 + wn_e, fr_e, fq_e, late);
+    }
+    if (vbn < 0) break;
+    vb = vbn; m0 = m0n; n0 = n0n;
+    // the operand addresses again, from values the compiler cannot match with the ones above: they are NOT kept in
+    // registers across the epilogue (8 registers the LayerNorm epilogues do not have)
+    asm volatile("" : "+s"(m0), "+s"(n0));
+    int t_s = tid;
+    asm volatile("" : "+v"(t_s));
+    set_src(m0, n0, t_s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // MSMD_F16X2 ("split pair", common.h) kernel: the parity-grade speed mode.  Operands are rows of 2K fp16 numbers in
 // 32-element blocks [hi x 32 | lo x 32], so ONE 128-byte line = one 32-deep k-step of both planes and the LDS-DMA
 // ring, LDS image, swizzle and fragment reads are those of gemm2_kernel (chunks 0-3 of a row = hi, 4-7 = lo).  Per
@@ -1168,21 +1302,13 @@ extern "C" int msmd_exp_set_tuning(int key, int value) {
 #include "exp/gemm_variants.inc"
 #endif
 
-template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t, bool STAG = false, int EPI = 0>
-static int launch_gemm2(GemmArgs& p, int batch, hipStream_t st) {
-  constexpr int lds = NSTAGE * (BM + BN) * 128;
-  static bool attr_done = false;
-  auto kfn = gemm2_kernel<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, STAG, EPI>;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
-  }
-  p.mt = (p.M + BM - 1) / BM; p.nt = (p.N + BN - 1) / BN;
-  // XCD grid over (M, N) tiles.  With all 8 XCDs striped along M every L2 streams its own copy of the whole weight
-  // matrix from HBM, while the activation rows (the previous kernel's output) are still warm: an XCD of an
-  // (8 / xn) x xn grid reads 1 / xn of W and xn / 8 of A, so xn is picked per problem from  0.7 xn |A| + (8 / xn) |W|
-  // (the 0.7 fitted on the qkv shape, where 2 x 4 ties with 8 x 1 and both trail 4 x 2).  Forward step, same-graph A/B
-  // in both orders: 8 x 1 4.96 ms, 4 x 2 everywhere 4.89, this rule 4.88.  tuning key 7 forces xn = 1 / 2 / 4.
+// XCD grid over (M, N) tiles (p.mt, p.nt set).  With all 8 XCDs striped along M every L2 streams its own copy of the whole weight
+// matrix from HBM, while the activation rows (the previous kernel's output) are still warm: an XCD of an
+// (8 / xn) x xn grid reads 1 / xn of W and xn / 8 of A, so xn is picked per problem from  0.7 xn |A| + (8 / xn) |W|
+// (the 0.7 fitted on the qkv shape, where 2 x 4 ties with 8 x 1 and both trail 4 x 2).  Forward step, same-graph A/B
+// in both orders: 8 x 1 4.96 ms, 4 x 2 everywhere 4.89, this rule 4.88.  tuning key 7 forces xn = 1 / 2 / 4.
+template <int BM, int BN>
+static void gemm2_xcd_grid(GemmArgs& p) {
   int want_xn = 1;
   if (MSMD_TUNE(7) == 1 || MSMD_TUNE(7) == 2 || MSMD_TUNE(7) == 4) {
     want_xn = MSMD_TUNE(7);
@@ -1195,6 +1321,37 @@ static int launch_gemm2(GemmArgs& p, int batch, hipStream_t st) {
     }
   }
   p.xn = p.nt >= want_xn ? want_xn : 1;
+}
+
+// gemm2p_kernel: 512 persistent workgroups (two per CU) over a grid of more than 512 tiles
+template <typename TO, int BM, int BN, int WM, int WN, typename TI, int EPIA>
+static int launch_gemm2p(GemmArgs& p, hipStream_t st) {
+  constexpr int lds = 2 * (BM + BN) * 128;
+  static bool attr_done = false;
+  auto kfn = gemm2p_kernel<TO, BM, BN, WM, WN, TI, EPIA>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  p.stagger_ticks = 0;
+#ifdef MSMD_EXPERIMENTAL
+  p.stamps = nullptr;
+#endif
+  hipLaunchKernelGGL(kfn, dim3(512, 1, 1), dim3(WM * WN * 64), lds, st, p);
+  MSMD_RETURN_LAST();
+}
+
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, bool PIPE = false, typename TI = bf16_t, bool STAG = false, int EPI = 0>
+static int launch_gemm2(GemmArgs& p, int batch, hipStream_t st) {
+  constexpr int lds = NSTAGE * (BM + BN) * 128;
+  static bool attr_done = false;
+  auto kfn = gemm2_kernel<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, STAG, EPI>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  p.mt = (p.M + BM - 1) / BM; p.nt = (p.N + BN - 1) / BN;
+  gemm2_xcd_grid<BM, BN>(p);
   const int xm_n = 8 / p.xn;
   dim3 grid(((p.mt + xm_n - 1) / xm_n) * ((p.nt + p.xn - 1) / p.xn) * 8, 1, batch);
   // stagger (flags bit 2): only where the launch runs more than one round of two workgroups per CU
@@ -1219,6 +1376,21 @@ static int launch_gemm2_epi(GemmArgs& p, int batch, hipStream_t st) {
   else if (LNK && (p.r_stats || p.stats_out)) epi = 3;
   else if (!p.a_stats && !p.r_stats && !p.stats_out && !p.Z && !(p.p_drop > 0.f) && !(p.flags & 8)) epi = 1;
   const int a = p.act == MSMD_ACT_NONE ? 10 : (p.act == MSMD_ACT_GELU && epi != 3) ? 20 : 0;
+  if constexpr (LNK && PIPE && NSTAGE == 2 && WM * WN == 8 && BN == 128 && BM == 128) {
+    // more than one round of two workgroups per CU: the persistent form (gemm2p_kernel); flags bit 4 = caller opts out (A/B).
+    // The 128 x 128 tile's plain and LayerNorm-operand epilogues: the LayerNorm-residual one (its launches on the path are
+    // single-round) and the 192-row tile do not fit 128 registers in this form (20-128 bytes of scratch).
+    if (batch == 1 && epi >= 1 && a && !(p.flags & 16)) {
+      p.mt = (p.M + BM - 1) / BM; p.nt = (p.N + BN - 1) / BN;
+      gemm2_xcd_grid<BM, BN>(p);
+      const int xm_n = 8 / p.xn;
+      if (((p.mt + xm_n - 1) / xm_n) * ((p.nt + p.xn - 1) / p.xn) * 8 > 512) {
+#define MSMD_EPI_CASE(E) case E: return launch_gemm2p<TO, BM, BN, WM, WN, TI, E>(p, st)
+        switch (epi + a) { MSMD_EPI_CASE(11); MSMD_EPI_CASE(21); MSMD_EPI_CASE(12); MSMD_EPI_CASE(22); default: break; }
+#undef MSMD_EPI_CASE
+      }
+    }
+  }
 #define MSMD_EPI_CASE(E) case E: return launch_gemm2<TO, BM, BN, WM, WN, NSTAGE, PIPE, TI, false, E>(p, batch, st)
   if constexpr (LNK) {
     switch (epi + a) { MSMD_EPI_CASE(2); MSMD_EPI_CASE(12); MSMD_EPI_CASE(22); MSMD_EPI_CASE(3); MSMD_EPI_CASE(13); default: break; }
@@ -1423,7 +1595,7 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
                      int internal_flags = 0) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch_inner <= 0 || !A || !W || !C) return 1;
   const int hint = (act >> 8) & 0xff;  // caller-chosen kernel variant (host-side autotune), 0 = heuristic below
-  const int flags = ((act >> 16) & 0x7) | internal_flags;  // MSMD_GEMM_WRITE_THROUGH / MSMD_GEMM_PAIRED_STORES (include/msmd_hip.h)
+  const int flags = ((act >> 16) & 0x7) | (((act >> 19) & 1) << 4) | internal_flags;  // MSMD_GEMM_WRITE_THROUGH / MSMD_GEMM_PAIRED_STORES (include/msmd_hip.h)
   act &= 0xff;
   if (in_dtype == MSMD_F16X2) {
     // split-pair operands: logical sizes in, fp16 strides (x 2) into the kernel; 32-element blocks must stay whole
@@ -1571,7 +1743,7 @@ extern "C" int msmd_gemm_ln(const void* A, const void* W, const float* bias, con
   p.strideA = p.strideW = p.strideC = p.strideBias = p.strideR = 0;
   p.batch_inner = 1; p.strideA2 = p.strideW2 = p.strideC2 = 0;
   p.Z = nullptr; p.p_drop = 0.f; p.rng = nullptr; p.site = 0; p.xn = 1;
-  p.flags = (ldc % 8) == 0 ? 2 : 0;   // paired 16-byte stores
+  p.flags = ((ldc % 8) == 0 ? 2 : 0) | (((act >> 19) & 1) << 4);   // paired 16-byte stores; MSMD_GEMM_ONE_TILE_PER_WORKGROUP
   p.a_stats = a_stats; p.a_nt = a_stats ? K / slab_in : 0; p.w_colsum = w_colsum;
   p.r_stats = r_stats; p.r_nt = r_stats ? N / slab_in : 0; p.r_gamma = r_gamma; p.r_beta = r_beta;
   p.stats_out = stats_out; p.ln_eps = eps;

@@ -168,6 +168,8 @@ _TUNED = {}
 # global state; these module-level defaults are what `gemm()` passes when the caller gives none (`gemm_defaults`
 # scopes a change, e.g. while a hipGraph is captured -- the choice is then baked into that graph).
 GEMM_WRITE_THROUGH, GEMM_PAIRED_STORES, GEMM_STAGGER = 1 << 16, 1 << 17, 1 << 18
+GEMM_ONE_TILE_PER_WORKGROUP = 1 << 19      # opt out of the persistent form of multi-round launches (A/B; same bits)
+GEMM_LN_FLAGS = 0              # extra `act` bits msmd_gemm_ln calls carry (A/B hook: GEMM_ONE_TILE_PER_WORKGROUP)
 GEMM_LN_ROUTER = None          # optional (M, N, K) -> 15 | 17 | None: tile hint for msmd_gemm_ln's big-tile family
 GEMM_LN_ALL_IN_ONE = False     # A/B hook (tools/ab_forward.py): msmd_gemm_ln on the one-kernel-with-every-epilogue form (variant 66)
 
@@ -197,6 +199,9 @@ PREFETCH_WEIGHTS = os.environ.get("MSMD_PREFETCH", "1") != "0"
 FOLD_LN = os.environ.get("MSMD_FOLD_LN", "1") != "0"
 GEMM_ROUTER = None   # developer hook (tools/ab_forward.py): callable (M, N, K, batch) -> variant or None, consulted per call
 _GEMM_DEFAULT = {"variant": 0, "flags": GEMM_PAIRED_STORES, "split_variant": 0}   # paired 16-byte stores: -1 % on the forward step
+if os.environ.get("MSMD_GEMM_ONE_TILE", "0") == "1":      # developers' A/B switch (tools/ab_env.sh): every launch in the one-tile-per-workgroup form
+    _GEMM_DEFAULT["flags"] |= GEMM_ONE_TILE_PER_WORKGROUP
+    GEMM_LN_FLAGS = GEMM_ONE_TILE_PER_WORKGROUP
 
 
 class gemm_defaults:
@@ -343,7 +348,7 @@ def gemm_ln(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=No
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.check(lib.msmd_gemm_ln(_p(a), _p(w), _p(bias), _p(residual), _p(out), M, N, K, _dt(a), _dt(out), a.stride(-2) if a.dim() >= 2 else K,
-                                w.stride(0), N, ldr, act | (((66 if GEMM_LN_ALL_IN_ONE else (GEMM_LN_ROUTER(M, N, K) or 0) if GEMM_LN_ROUTER is not None else 0)) << 8), _p(a_stats), _p(w_colsum), _p(r_stats), _p(r_gamma),
+                                w.stride(0), N, ldr, act | GEMM_LN_FLAGS | (((66 if GEMM_LN_ALL_IN_ONE else (GEMM_LN_ROUTER(M, N, K) or 0) if GEMM_LN_ROUTER is not None else 0)) << 8), _p(a_stats), _p(w_colsum), _p(r_stats), _p(r_gamma),
                                 _p(r_beta), _p(st), slab_in, slab_out, float(eps), _stream()), "msmd_gemm_ln")
     if GEMM_TRACE is not None:
         e1.record()
