@@ -9,6 +9,8 @@ traj[t] to the CPU every step, model.py:433); per-step scalars come from host co
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -204,8 +206,11 @@ def sample(model, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=N
     return x, motion_at_T, audio_feat
 
 
+STEPS_PER_GRAPH = int(os.environ.get("MSMD_SAMPLER_STEPS_PER_GRAPH", "10"))
+
+
 class _StepGraph:
-    """One captured denoise step (hipGraph): device-side step counter, static operand buffers."""
+    """k captured denoise steps (one hipGraph): device-side step counter, static operand buffers."""
 
     def __init__(self, model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, like, dyn=None):
         B = N // n_entries
@@ -245,10 +250,15 @@ class _StepGraph:
         with torch.cuda.stream(side):
             body()
         torch.cuda.current_stream().wait_stream(side)
+        # STEPS_PER_GRAPH consecutive denoising steps per captured graph (the step counter lives on the device, so the body is
+        # simply recorded that many times): T / k replays instead of T.  k = the largest divisor of T up to the cap, so one
+        # graph serves the whole loop.
+        self.k = max(d for d in range(1, min(STEPS_PER_GRAPH, T) + 1) if T % d == 0)
         self.graph = torch.cuda.CUDAGraph()
         with ops.capture_guard():
             with torch.cuda.graph(self.graph):
-                body()
+                for _ in range(self.k):
+                    body()
 
     def run(self, T, motion_at_T, ops_in, coefficients):
         self.x.copy_(motion_at_T)
@@ -270,7 +280,7 @@ class _StepGraph:
             tab[t, 0], tab[t, 1], tab[t, 2] = c0, c1, (sg if t > 1 else 0.0)
         self.coef_table.copy_(tab)
         self.t_dev.fill_(T)
-        for _ in range(T):
+        for _ in range(T // self.k):
             self.graph.replay()
         return self.x.clone()
 
@@ -279,7 +289,7 @@ def _graph_loop(model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, ta
                 mem, kv_list, stat, tok_person, emb_all, scales, coefficients, dyn=None, cross_list=None):
     like = dict(prev_m=prev_m, ind_in=ind_in, mem=mem, kv_list=kv_list, cross_list=cross_list, stat=stat, tok_person=tok_person,
                 emb_all=emb_all, scales=scales)
-    key = (T, N, n_entries, Lp, L, mode, target, dtype, ind_in is not None, getattr(net, "_pack_gen", 0), dyn, cross_list is not None)
+    key = (T, N, n_entries, Lp, L, mode, target, dtype, ind_in is not None, getattr(net, "_pack_gen", 0), dyn, cross_list is not None, STEPS_PER_GRAPH)
     cache = model.__dict__.setdefault("_step_graphs", {})
     g = cache.get(key)
     if g is None:
