@@ -257,6 +257,43 @@ def test_trainer_hipgraph_step_matches_eager():
     assert len(trg._graphs) >= 2
 
 
+@pytest.mark.parametrize("truncate_first", [False, True])
+def test_two_windows_as_one_batch_equals_window_after_window(truncate_first):
+    """Trainer(batch_windows=True) runs the style encoder, the audio encoder and the denoiser once on [window 0 | window 1]
+    rows; batch_windows=False is the reference's order (training_script.py:99-195).  Eval mode, every draw injected: the same
+    per-key losses (1e-5 relative) and the same gradient arena -- fp32 sums of 2 B rows in one weight-gradient product
+    instead of two accumulated ones: 2e-4 of the arena's largest entry, per-element mismatches above 1e-5 relative rare --
+    with window 0 whole (hand-off = its own last frames) and truncated (hand-off from the complete clip's extra pass)."""
+    from msmd_amd.model import get_diffusion_model
+    from msmd_amd.style_encoder import get_style_encoder
+    from msmd_amd.training_script import Trainer, synthetic_batch
+    args = default_args(compute_dtype="fp32", encoder_layers=2, n_layers=2, lr=1e-3, warm_iter=0, gradient_accumulation_steps=1)
+    B = 2
+    batch = synthetic_batch(B, 0, DEV)
+    draws = dict(cross=[False, True], end_idx=[torch.tensor([60, 100], device=DEV) if truncate_first else None,
+                                               torch.tensor([100, 33], device=DEV)], t=[[5, 400], [250, 20]],
+                 eps=[dev(synth.normalish(f"bw/eps{i}", (B, 100, 67))) for i in range(2)],
+                 style_eps=[dev(synth.normalish(f"bw/se{i}", (B, 256))) for i in range(2)],
+                 cfg_flag=[dev(np.array([0.1, 0.7], np.float32)), dev(np.array([0.95, 0.3], np.float32))])
+    res = []
+    for bw in (False, True):
+        torch.manual_seed(0)
+        model = get_diffusion_model(args, DEV).eval()
+        se = get_style_encoder(args, "vae2").to(DEV).eval()
+        tr = Trainer(args, model, se, batch_windows=bw)
+        tr.reducer.begin_backward()
+        tr.reducer.arena.zero_()
+        out = tr._fwd_bwd(batch, draws, [truncate_first, True], draws["cross"])
+        torch.cuda.synchronize()
+        res.append((out, tr.reducer.arena.clone()))
+    (o0, g0), (o1, g1) = res
+    for k in o0:
+        assert abs(float(o0[k]) - float(o1[k])) <= 1e-5 * max(1.0, abs(float(o0[k]))), (k, float(o0[k]), float(o1[k]))
+    scale = float(g0.abs().max())
+    assert scale > 0 and float((g0 - g1).abs().max()) <= 2e-4 * scale, (float((g0 - g1).abs().max()), scale)
+    assert float(((g0 - g1).abs() > 1e-5 * scale).float().mean()) < 1e-3
+
+
 def test_trainer_segmented_hipgraph_matches_single_graph(monkeypatch):
     """hipGraph mode for more than one rank (forced here on one): the iteration is captured as SEGMENTS that end where a
     gradient bucket receives its last write of the backward (autograd accumulations AND the wgrad GEMM's direct arena

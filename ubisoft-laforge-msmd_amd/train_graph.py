@@ -189,8 +189,11 @@ class NullTokenSelectFn(torch.autograd.Function):
         return None, d_token.reshape(ctx.token_shape).to(ctx.token_dtype), g * (1 - mf)
 
 
-def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
-    """Differentiable counterpart of Wav2Vec2Model.encode (utils/wav2vec2.py): (B, L) audio -> (B, frame_num, 768)."""
+def audio_encoder_train(enc, audio, output_fps, frame_num, dtype, groups=1):
+    """Differentiable counterpart of Wav2Vec2Model.encode (utils/wav2vec2.py): (B, L) audio -> (B, frame_num, 768).
+    groups > 1: the batch is `groups` equal blocks of rows that the reference would have encoded in separate calls (the two
+    windows of a training iteration): SpecAugment consumes one injected mask per block and LayerDrop draws one coin per
+    block and layer, as separate calls would."""
     c = enc.config
     with torch.no_grad():
         r, rep = pad_audio_plan(audio.shape[1])
@@ -207,6 +210,8 @@ def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
     if noise.active and c.apply_spec_augment and c.mask_time_prob > 0:
         # SpecAugment (utils/wav2vec2.py:99-105 / HF _mask_hidden_states): masked frames <- masked_spec_embed
         m = noise.next_spec_mask()
+        if m is not None and groups > 1 and m.shape[0] * groups == h.shape[0]:
+            m = torch.cat([m] + [noise.next_spec_mask() for _ in range(groups - 1)], 0)
         if m is None:
             fn = compute_mask_indices_hf if enc.model_type == "hubert" else compute_mask_indices
             m = torch.from_numpy(fn((h.shape[0], h.shape[1]), c.mask_time_prob, c.mask_time_length,
@@ -226,9 +231,15 @@ def audio_encoder_train(enc, audio, output_fps, frame_num, dtype):
         skip_flag = None
         if noise.active and c.layerdrop > 0:
             if noise.graph_safe:
-                skip_flag = torch.rand((), device=h.device) < c.layerdrop
-            elif (noise.host_rng if noise.host_rng is not None else np.random).rand() < c.layerdrop:
-                continue
+                skip_flag = torch.rand((), device=h.device) < c.layerdrop if groups == 1 else \
+                    (torch.rand((groups, 1, 1), device=h.device) < c.layerdrop).repeat_interleave(h.shape[0] // groups, 0)
+            else:
+                rng = noise.host_rng if noise.host_rng is not None else np.random
+                coins = [rng.rand() < c.layerdrop for _ in range(groups)]
+                if all(coins):
+                    continue
+                if any(coins):      # some blocks skip this layer: compute it and select per block
+                    skip_flag = torch.tensor(coins, device=h.device).view(groups, 1, 1).repeat_interleave(h.shape[0] // groups, 0)
         h_in = h
         p = f"encoder.layers.{n}."
         wq, wk, wv = (g(p + f"attention.{k}_proj.weight") for k in "qkv")
@@ -367,9 +378,9 @@ def ag_act(z, act):
     return ActFn.apply(z, act)
 
 
-def audio_feat_train(model, audio, frame_num, dtype):
+def audio_feat_train(model, audio, frame_num, dtype, groups=1):
     """reference model.py:250-264 (differentiable): encoder at 2L -> pairwise mean -> audio_feature_map."""
-    h = audio_encoder_train(model.audio_encoder, audio, model.fps, frame_num * 2, dtype)
+    h = audio_encoder_train(model.audio_encoder, audio, model.fps, frame_num * 2, dtype, groups)
     h = 0.5 * (h[:, 0::2] + h[:, 1::2])  # exact 2:1 linear resample (SURVEY.md Appendix A)
     return ag.linear(h.contiguous(), model.audio_feature_map.weight, model.audio_feature_map.bias)
 

@@ -148,8 +148,11 @@ def batch_from_loader(item):
 
 class Trainer:
     def __init__(self, args, model, style_enc, process_group=None, bucket_mb=32.0, use_graph=False, flame=None,
-                 coef_stats=None, comm=None, bucket_dtype=None, exchange_at_world_1=False):
+                 coef_stats=None, comm=None, bucket_dtype=None, exchange_at_world_1=False, batch_windows=None):
         self.args, self.model, self.style_enc = args, model, style_enc
+        # both windows of an iteration through each network as one batch of 2 B rows (_two_windows_batched); False or
+        # MSMD_TRAIN_BATCH_WINDOWS=0: window 0, then window 1 (the reference's order)
+        self.batch_windows = (os.environ.get("MSMD_TRAIN_BATCH_WINDOWS", "1") != "0") if batch_windows is None else bool(batch_windows)
         self.device = model.device
         # vertex-space training branch (reference training_script.py:167-170: use_vertex_space on the legacy FLAME
         # dataset types): the loss runs through FLAME, differentiably (train_graph.loss_vert_train)
@@ -325,73 +328,184 @@ class Trainer:
         noise.state, noise.host_rng = self.noise_state, self.rng
         noise.begin()
         with torch.enable_grad():
-            styles, mus, logvars = [], [], []
-            for i in range(2):
-                mu, logvar = tg.style_encoder_train(se, motion_pair[i], dtype)
-                e = draws["style_eps"][i] if "style_eps" in draws else torch.randn_like(mu)
-                styles.append(mu + e * torch.exp(0.5 * logvar))
-                mus.append(mu)
-                logvars.append(logvar)
-            terms = {k: [] for k in lw}     # every loss term of both windows, summed per key and weighted in ONE pass below
-            prev_motion = prev_audio = None
-            for i in range(2):
-                audio, motion = audio_pair[i], motion_pair[i]
-                if torch.is_tensor(cross[i]):
-                    style = torch.where(cross[i], styles[1 - i], styles[i])
-                else:
-                    style = styles[1 - i] if cross[i] else styles[i]
-                if "end_idx" in draws:
-                    end_idx = draws["end_idx"][i]
-                else:
-                    end_idx = torch.randint(1, args.n_motions, (B,), device=self.device) if trunc[i] else None
-                if end_idx is not None:
-                    # reference utils/common.py:816-832: audio is cut at (end_idx * audio_unit).long() with the DATASET's
-                    # audio_unit = 16000 / fps (a float: 533.33 at 30 fps) and both tensors padded per args.pad_mode
-                    e32 = end_idx.to(torch.int32).contiguous()
-                    a32 = (end_idx.to(torch.float32) * self.audio_unit).long().to(torch.int32).contiguous()
-                    audio_in = ops.truncate_rows_(audio.float().clone().contiguous(), a32, 1, self.pad_replicate)
-                    motion_in = ops.truncate_rows_(motion.float().clone().contiguous(), e32, 1, self.pad_replicate)
-                    indicator = (torch.arange(args.n_motions, device=self.device).expand(B, -1) < end_idx.unsqueeze(1)).float()
-                else:
-                    audio_in, motion_in = audio, motion
-                    indicator = torch.ones(B, args.n_motions, device=self.device)
-                ts = draws["t"][i] if "t" in draws else model.diffusion_sched.uniform_sample_t_device(B)
-                eps = draws["eps"][i] if "eps" in draws else torch.randn_like(motion_in)
-                ns, na = self._cfg_masks(draws, i, B)
-                shape_in = torch.zeros_like(shape) if getattr(args, "do_ignore_shape", False) else shape
-                _, target, _, audio_feat = tg.msmd_forward_train(model, motion_in, audio_in, shape_in, style, prev_motion,
-                                                                 prev_audio, ts, indicator, eps, ns, na)
-                if i == 0:
-                    if end_idx is not None:  # truncated: hand over the COMPLETE clip's features (training_script.py:152-155)
-                        prev_motion = motion[:, -n_prev:]
-                        with torch.no_grad():
-                            if noise.active:   # the reference's extra pass also runs under model.train()
-                                prev_audio = tg.audio_feat_train(model, audio, model.n_motions, dtype).float()[:, -n_prev:]
-                            else:
-                                prev_audio = model.extract_audio_feature(audio)[:, -n_prev:]
-                    else:
-                        prev_motion = motion_in[:, -n_prev:].detach()
-                        prev_audio = audio_feat[:, -n_prev:]
-                if self.vertex_space:
-                    ld = tg.loss_vert_train(args, i == 0, shape, motion_in, target, prev_motion if i == 1 else None,
-                                            self.coef_stats, self.flame, end_idx)
-                    pairs = ld.items()
-                else:
-                    tup = tg.loss_no_vert_train(args, i == 0, motion_in, target, prev_motion if i == 1 else None, end_idx,
-                                                halve=False)     # the / 2 of the first six terms rides in _combine_losses
-                    pairs = zip(("noise", "vel", "smooth", "head_angle", "head_vel", "head_smooth", "head_trans"),
-                                [(v, 0.5) for v in tup[:6]] + [(tup[6], 1.0)])
-                for key, val in pairs:
-                    val, sc = val if isinstance(val, tuple) else (val, 1.0)
-                    if val is not None and torch.is_tensor(val) and lw.get(key, 0) > 0:
-                        terms[key].append((val, sc))
-                terms["kl_div"].append((tg.kl_train(mus[i], logvars[i]), 1.0))
+            if self.batch_windows:
+                terms = self._two_windows_batched(batch, draws, trunc, cross, lw, dtype)
+            else:
+                terms = self._two_windows_in_turn(batch, draws, trunc, cross, lw, dtype)
             losses, loss = self._combine_losses(terms, lw)
             loss.backward()
         noise.active = False    # module-level switch: never leak train-mode noise into other callers of the graph
         out = {k: v.detach() for k, v in losses.items()}
         out["loss"] = loss.detach()
         return out
+
+    def _two_windows_in_turn(self, batch, draws, trunc, cross, lw, dtype):
+        """The reference's order (training_script.py:99-195): window 0 through the whole model, then window 1.  Kept as the
+        comparison form of _two_windows_batched (MSMD_TRAIN_BATCH_WINDOWS=0)."""
+        args, model, se = self.args, self.model, self.style_enc
+        audio_pair, motion_pair, shape = batch
+        B = audio_pair[0].shape[0]
+        n_prev = args.n_prev_motions
+        noise = ag.TrainNoise
+        styles, mus, logvars = [], [], []
+        for i in range(2):
+            mu, logvar = tg.style_encoder_train(se, motion_pair[i], dtype)
+            e = draws["style_eps"][i] if "style_eps" in draws else torch.randn_like(mu)
+            styles.append(mu + e * torch.exp(0.5 * logvar))
+            mus.append(mu)
+            logvars.append(logvar)
+        terms = {k: [] for k in lw}     # every loss term of both windows, summed per key and weighted in ONE pass below
+        prev_motion = prev_audio = None
+        for i in range(2):
+            audio, motion = audio_pair[i], motion_pair[i]
+            if torch.is_tensor(cross[i]):
+                style = torch.where(cross[i], styles[1 - i], styles[i])
+            else:
+                style = styles[1 - i] if cross[i] else styles[i]
+            if "end_idx" in draws:
+                end_idx = draws["end_idx"][i]
+            else:
+                end_idx = torch.randint(1, args.n_motions, (B,), device=self.device) if trunc[i] else None
+            if end_idx is not None:
+                # reference utils/common.py:816-832: audio is cut at (end_idx * audio_unit).long() with the DATASET's
+                # audio_unit = 16000 / fps (a float: 533.33 at 30 fps) and both tensors padded per args.pad_mode
+                e32 = end_idx.to(torch.int32).contiguous()
+                a32 = (end_idx.to(torch.float32) * self.audio_unit).long().to(torch.int32).contiguous()
+                audio_in = ops.truncate_rows_(audio.float().clone().contiguous(), a32, 1, self.pad_replicate)
+                motion_in = ops.truncate_rows_(motion.float().clone().contiguous(), e32, 1, self.pad_replicate)
+                indicator = (torch.arange(args.n_motions, device=self.device).expand(B, -1) < end_idx.unsqueeze(1)).float()
+            else:
+                audio_in, motion_in = audio, motion
+                indicator = torch.ones(B, args.n_motions, device=self.device)
+            ts = draws["t"][i] if "t" in draws else model.diffusion_sched.uniform_sample_t_device(B)
+            eps = draws["eps"][i] if "eps" in draws else torch.randn_like(motion_in)
+            ns, na = self._cfg_masks(draws, i, B)
+            shape_in = torch.zeros_like(shape) if getattr(args, "do_ignore_shape", False) else shape
+            _, target, _, audio_feat = tg.msmd_forward_train(model, motion_in, audio_in, shape_in, style, prev_motion,
+                                                             prev_audio, ts, indicator, eps, ns, na)
+            if i == 0:
+                if end_idx is not None:  # truncated: hand over the COMPLETE clip's features (training_script.py:152-155)
+                    prev_motion = motion[:, -n_prev:]
+                    with torch.no_grad():
+                        if noise.active:   # the reference's extra pass also runs under model.train()
+                            prev_audio = tg.audio_feat_train(model, audio, model.n_motions, dtype).float()[:, -n_prev:]
+                        else:
+                            prev_audio = model.extract_audio_feature(audio)[:, -n_prev:]
+                else:
+                    prev_motion = motion_in[:, -n_prev:].detach()
+                    prev_audio = audio_feat[:, -n_prev:]
+            if self.vertex_space:
+                ld = tg.loss_vert_train(args, i == 0, shape, motion_in, target, prev_motion if i == 1 else None,
+                                        self.coef_stats, self.flame, end_idx)
+                pairs = ld.items()
+            else:
+                tup = tg.loss_no_vert_train(args, i == 0, motion_in, target, prev_motion if i == 1 else None, end_idx,
+                                            halve=False)     # the / 2 of the first six terms rides in _combine_losses
+                pairs = zip(("noise", "vel", "smooth", "head_angle", "head_vel", "head_smooth", "head_trans"),
+                            [(v, 0.5) for v in tup[:6]] + [(tup[6], 1.0)])
+            for key, val in pairs:
+                val, sc = val if isinstance(val, tuple) else (val, 1.0)
+                if val is not None and torch.is_tensor(val) and lw.get(key, 0) > 0:
+                    terms[key].append((val, sc))
+            terms["kl_div"].append((tg.kl_train(mus[i], logvars[i]), 1.0))
+        return terms
+
+    def _window_inputs(self, i, batch, draws, trunc, cross, styles):
+        """What window i feeds the model, drawn / derived exactly as the in-turn form does (reference training_script.py
+        :120-150, utils/common.py:816-832 for the truncation)."""
+        args, model = self.args, self.model
+        audio_pair, motion_pair, shape = batch
+        B = audio_pair[0].shape[0]
+        audio, motion = audio_pair[i], motion_pair[i]
+        if torch.is_tensor(cross[i]):
+            style = torch.where(cross[i], styles[1 - i], styles[i])
+        else:
+            style = styles[1 - i] if cross[i] else styles[i]
+        if "end_idx" in draws:
+            end_idx = draws["end_idx"][i]
+        else:
+            end_idx = torch.randint(1, args.n_motions, (B,), device=self.device) if trunc[i] else None
+        if end_idx is not None:
+            e32 = end_idx.to(torch.int32).contiguous()
+            a32 = (end_idx.to(torch.float32) * self.audio_unit).long().to(torch.int32).contiguous()
+            audio_in = ops.truncate_rows_(audio.float().clone().contiguous(), a32, 1, self.pad_replicate)
+            motion_in = ops.truncate_rows_(motion.float().clone().contiguous(), e32, 1, self.pad_replicate)
+            indicator = (torch.arange(args.n_motions, device=self.device).expand(B, -1) < end_idx.unsqueeze(1)).float()
+        else:
+            audio_in, motion_in = audio, motion
+            indicator = torch.ones(B, args.n_motions, device=self.device)
+        ts = draws["t"][i] if "t" in draws else model.diffusion_sched.uniform_sample_t_device(B)
+        eps = draws["eps"][i] if "eps" in draws else torch.randn_like(motion_in)
+        ns, na = self._cfg_masks(draws, i, B)
+        shape_in = torch.zeros_like(shape) if getattr(args, "do_ignore_shape", False) else shape
+        return dict(style=style, end_idx=end_idx, audio_in=audio_in, motion_in=motion_in, indicator=indicator,
+                    ts=torch.as_tensor(ts, device=self.device, dtype=torch.long), eps=eps, ns=ns, na=na, shape_in=shape_in)
+
+    def _two_windows_batched(self, batch, draws, trunc, cross, lw, dtype):
+        """Both windows through every network as ONE batch of 2 B rows.  Window 1 takes from window 0 only the last
+        n_prev frames of its ground-truth motion and of its (detached) audio features (reference training_script.py:152-160):
+        nothing a window's denoiser pass computes reaches the other window, and the audio features of both windows depend on the
+        audio alone -- so the style encoder, the audio encoder and the denoiser each run once on [window 0 rows | window 1
+        rows], window 1's hand-off read from the encoder's output in between.  Per row the arithmetic is the in-turn form's
+        (GEMM rows are independent); weight gradients sum 2 B rows in one product instead of two accumulated ones.  Train-mode
+        noise keeps the reference's granularity: one SpecAugment mask and one LayerDrop coin per window and layer."""
+        args, model, se = self.args, self.model, self.style_enc
+        audio_pair, motion_pair, shape = batch
+        B = audio_pair[0].shape[0]
+        n_prev = args.n_prev_motions
+        noise = ag.TrainNoise
+        mu2, logvar2 = tg.style_encoder_train(se, torch.cat([motion_pair[0], motion_pair[1]], 0), dtype)
+        styles, mus, logvars = [], [], []
+        for i in range(2):
+            mu, logvar = mu2[i * B:(i + 1) * B], logvar2[i * B:(i + 1) * B]
+            e = draws["style_eps"][i] if "style_eps" in draws else torch.randn_like(mu)
+            styles.append(mu + e * torch.exp(0.5 * logvar))
+            mus.append(mu)
+            logvars.append(logvar)
+        terms = {k: [] for k in lw}
+        W = [self._window_inputs(i, batch, draws, trunc, cross, styles) for i in range(2)]
+        feat2 = tg.audio_feat_train(model, torch.cat([W[0]["audio_in"].float(), W[1]["audio_in"].float()], 0), model.n_motions, dtype,
+                                    groups=2).float()
+        if W[0]["end_idx"] is not None:  # truncated: hand over the COMPLETE clip's features (training_script.py:152-155)
+            prev_motion = motion_pair[0][:, -n_prev:]
+            with torch.no_grad():
+                if noise.active:   # the reference's extra pass also runs under model.train()
+                    prev_audio = tg.audio_feat_train(model, audio_pair[0], model.n_motions, dtype).float()[:, -n_prev:]
+                else:
+                    prev_audio = model.extract_audio_feature(audio_pair[0])[:, -n_prev:]
+        else:
+            prev_motion = W[0]["motion_in"][:, -n_prev:].detach()
+            prev_audio = feat2[:B, -n_prev:].detach()
+        cat = lambda k: torch.cat([W[0][k], W[1][k]], 0)
+        masks = []
+        for k in ("ns", "na"):
+            m0, m1 = W[0][k], W[1][k]
+            if m0 is None and m1 is None:
+                masks.append(None)
+            else:
+                z = torch.zeros(B, dtype=torch.bool, device=self.device)
+                masks.append(torch.cat([m0 if m0 is not None else z, m1 if m1 is not None else z], 0))
+        prev_m2 = torch.cat([model.start_motion_feat.expand(B, -1, -1), prev_motion.to(model.start_motion_feat.dtype)], 0)
+        prev_a2 = torch.cat([model.start_audio_feat.expand(B, -1, -1), prev_audio.to(model.start_audio_feat.dtype)], 0)
+        _, target2, _, _ = tg.msmd_forward_train(model, cat("motion_in"), feat2, cat("shape_in"), cat("style"), prev_m2, prev_a2,
+                                                 cat("ts"), cat("indicator"), cat("eps"), masks[0], masks[1])
+        for i in range(2):
+            motion_in, end_idx, target = W[i]["motion_in"], W[i]["end_idx"], target2[i * B:(i + 1) * B]
+            if self.vertex_space:
+                ld = tg.loss_vert_train(args, i == 0, shape, motion_in, target, prev_motion if i == 1 else None,
+                                        self.coef_stats, self.flame, end_idx)
+                pairs = ld.items()
+            else:
+                tup = tg.loss_no_vert_train(args, i == 0, motion_in, target, prev_motion if i == 1 else None, end_idx,
+                                            halve=False)     # the / 2 of the first six terms rides in _combine_losses
+                pairs = zip(("noise", "vel", "smooth", "head_angle", "head_vel", "head_smooth", "head_trans"),
+                            [(v, 0.5) for v in tup[:6]] + [(tup[6], 1.0)])
+            for key, val in pairs:
+                val, sc = val if isinstance(val, tuple) else (val, 1.0)
+                if val is not None and torch.is_tensor(val) and lw.get(key, 0) > 0:
+                    terms[key].append((val, sc))
+            terms["kl_div"].append((tg.kl_train(mus[i], logvars[i]), 1.0))
+        return terms
 
     def _combine_losses(self, terms, lw):
         """per-key sums (for the log) and the weighted total of all loss terms: stack + two masked reductions instead of a zero
