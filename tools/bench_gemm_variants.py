@@ -22,6 +22,9 @@ if os.environ.get("SHAPES") == "sampler":      # the sampler's decoder layers: M
 if os.environ.get("SHAPES") == "denoiser":     # the forward step's decoder layers: M = 32 x 111 rows
     shapes = [("sa_out", 3552, 512, 512), ("ffn2", 3552, 512, 2048), ("ffn1", 3552, 2048, 512), ("qkv", 3552, 1536, 512),
               ("kv_all", 3520, 8192, 512), ("md0", 3520, 256, 512)]
+if os.environ.get("SHAPES") == "train":        # the training step's encoder layers with both windows in one batch: M = 64 x 200 rows
+    shapes = [("out", 12800, 768, 768), ("ffn2", 12800, 768, 3072), ("ffn1", 12800, 3072, 768), ("qkv", 12800, 2304, 768),
+              ("dec_out", 7104, 512, 512), ("dec_ffn1", 7104, 2048, 512), ("dec_ffn2", 7104, 512, 2048), ("dec_qkv", 7104, 1536, 512)]
 g = torch.Generator(device="cuda").manual_seed(0)
 for name, M, N, K in shapes:
     a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)

@@ -1587,6 +1587,18 @@ static int dispatch_gemm2_f16(GemmArgs& p, int batch, hipStream_t st, int varian
   }
 }
 
+// Between 9 600 and 16 000 rows (the training step's M = 12 800: both windows in one batch) the tile follows how full the
+// LAST round of 512 workgroups is: 12800 x 768 is 600 tiles of 128 x 128 (one full round + 88 stragglers) but 402 of
+// 192 x 128 (one round).  Measured (tools/bench_gemm_variants.py, SHAPES=train): x 768 x 3072 78.9 -> 68.0 us, x 2304 x 768
+// 66.1 -> 60.7, x 768 x 768 a tie, x 3072 x 768 79.6 -> 82.4 (kept on 128 x 128 by this rule); 1.2 = the 192-row tile's
+// advantage per round-slot on those shapes.
+static bool tall_rounds_favour_192(int M, long tiles128, long tiles192) {
+  if (M < 9600 || tiles192 < 256) return false;
+  const double fill128 = (double)tiles128 / (512.0 * (double)((tiles128 + 511) / 512));
+  const double fill192 = (double)tiles192 / (512.0 * (double)((tiles192 + 511) / 512));
+  return 1.2 * fill192 > 1.03 * fill128;
+}
+
 static int gemm_impl(const void* A, const void* W, const float* bias, const void* residual, void* C, int M, int N, int K,
                      int in_dtype, int out_dtype, long lda, int rows_per_batch, long a_batch_stride, long ldw, long ldc,
                      long ldr, int act, int batch, long strideA, long strideW, long strideC, long strideBias,
@@ -1669,6 +1681,8 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
         // the 128 x 128 tile: conv1 454 -> 379 us, 21312 x 512 x 2048 58.7 -> 49.6, 21312 x 2048 x 512 76.6 -> 64.7; worse
         // below ~16 k rows (12800 x 512 x 1024: 22 -> 28 us) and mixed at M = 6400
         variant = 15;
+      } else if (N > 64 && tall_rounds_favour_192(M, tiles128, tiles192) && !z_out && !(p_drop > 0.f) && !(flags & 8) && out_dtype == MSMD_BF16) {
+        variant = 15;      // inference epilogues only: the 192-row tile's everything-epilogue runs one workgroup per CU
       } else if (N > 64 && tiles128 >= 192) {
         variant = MSMD_TUNE(4) ? 13 : 17;  // 128x128, 8 waves (4x2), 2-stage ring, 2 workgroups/CU, fragment reads pipelined
         // experiment knobs (tools/ab_graph.py): 5 = variant for M >= 20000 (conv stack), 6 = variant for the rest
@@ -1688,6 +1702,9 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
     int variant = hint ? hint : ((N > 64 && tiles128 >= 192) ? 17 : ((K >= 1024) ? 9 : 12));
     if (!hint && N <= 64 && (long)((M + 255) / 256) * nz >= 256) variant = 14;
     if (!hint && N > 64 && M >= 16000 && (long)((M + 191) / 192) * ((N + 127) / 128) * nz >= 400) variant = 15;
+    if (!hint && N > 64 && out_dtype == MSMD_F16 && !z_out && !(p_drop > 0.f) && !(flags & 8) &&
+        tall_rounds_favour_192(M, tiles128, (long)((M + 191) / 192) * ((N + 127) / 128) * nz))
+      variant = 15;
     const int r = out_dtype == MSMD_F16 ? dispatch_gemm2_f16<f16_t>(p, nz, st, variant)
                                         : dispatch_gemm2_f16<float>(p, nz, st, variant);
     if (r >= 0) return r;
@@ -1750,6 +1767,7 @@ extern "C" int msmd_gemm_ln(const void* A, const void* W, const float* bias, con
   hipStream_t st = (hipStream_t)stream;
   int variant = big ? 17 : (K >= 1024 ? 9 : 12);
   if (big && M >= 16000 && (long)((M + 191) / 192) * (N / 128) >= 400) variant = 15;    // tall grids: the 192 x 128 tile (same 64-column slabs)
+  if (big && tall_rounds_favour_192(M, tiles128, (long)((M + 191) / 192) * (N / 128))) variant = 15;
   {   // caller's tile hint for the big-tile family (same 64-column statistics slabs): 15 = 192 x 128, 17 = 128 x 128, 66 = A/B form of 17
     const int hint = (act >> 8) & 0xff;
     if (big && (hint == 15 || hint == 17 || hint == 66)) variant = hint;
