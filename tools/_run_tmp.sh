@@ -1,2 +1,3 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-SHAPES=encoder MSMD_LIB=ubisoft-laforge-msmd_amd/csrc/libmsmd_hip_exp.so python tools/bench_gemm_variants.py 17,56,11,50,7,47,49 20 2>&1 | grep -v amdgpu | cut -c1-330
+timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "persistent or gemm_ln or bit_identical" 2>&1 | grep -E "passed|failed|Error|assert" | tail -3
+AB_ARGS="--legs hubert" bash tools/ab_env.sh MSMD_GEMM_ONE_TILE=1 bf16
