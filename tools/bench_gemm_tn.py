@@ -12,6 +12,9 @@ lib = _lib.load()
 p = lambda t: t.data_ptr() if t is not None else None
 SHAPES = [(6400, 768, 768), (6400, 2304, 768), (6400, 3072, 768), (6400, 768, 3072), (3520, 512, 512), (3520, 1536, 512),
           (3520, 1024, 512), (3520, 512, 1024), (3520, 2048, 512), (3200, 512, 512)]
+if os.environ.get("SHAPES") == "train2":     # both windows in one batch: M = 64 x 200 encoder rows, 64 x 110 / 111 decoder rows
+    SHAPES = [(12800, 768, 768), (12800, 2304, 768), (12800, 3072, 768), (12800, 768, 3072), (7040, 512, 512), (7040, 1536, 512),
+              (7040, 1024, 512), (7040, 2048, 512), (7040, 512, 2048), (6400, 512, 512)]
 ws = torch.empty(1 << 28, device="cuda", dtype=torch.uint8)
 st = torch.cuda.current_stream().cuda_stream
 for (M, N, K) in SHAPES:
