@@ -52,6 +52,54 @@ __global__ __launch_bounds__(512) void k(float* __restrict__ out, int B, int V, 
   }
 }
 
+// W adjacent 128-vertex slices per workgroup visit: 16 rows x (1536 W) B as whole-row dwordx4 (pattern 2 is W = 1); ALIGN = 1:
+// every run starts on the 64-byte boundary at or below its first byte and ends on the one at or above its last (the extra bytes
+// are the neighbours': only the rate matters here) -- what would the edges' partial lines cost?
+template <int W, int ALIGN>
+__global__ __launch_bounds__(512) void kw(float* __restrict__ out, int B, int V, int fpb, int vgn) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int vg8 = (vgn + 7) >> 3, L = blockIdx.x;
+  const int v_grp = (L & 7) * vg8 + ((L >> 3) % vg8);
+  if (v_grp >= vgn) return;
+  const int f_begin = ((L >> 3) / vg8) * fpb;
+  if (f_begin >= B) return;
+  const int f_end = min(B, f_begin + fpb), ntiles = (f_end - f_begin + 15) >> 4;
+  const int vbase = min(v_grp * 128 * W, V - 128 * W);
+  float val = (float)tid;
+  for (int t = 0; t < ntiles; ++t) {
+    const int f0 = f_begin + 16 * t;
+    val += 1.0f;
+#pragma unroll
+    for (int s = 0; s < 3 * W; ++s) {
+      const int p = s * 64 + lane, r = 2 * wid + p / (96 * W), c = p % (96 * W);
+      const int f = min(f0 + r, B - 1);
+      char* d = (char*)(out + ((long)f * V + vbase) * 3) + c * 16;
+      if (ALIGN) d = (char*)((unsigned long)d & ~63ul) + (c & 3) * 16;
+      *(f32x4u*)d = f32x4{val, val + s, val, val};
+    }
+  }
+}
+
+template <int W, int ALIGN> float runw(float* out, int B, int V, int reps) {
+  const int vg = (V + 128 * W - 1) / (128 * W);
+  int splits = (1024 + vg - 1) / vg;
+  int fpb = (((B + splits - 1) / splits) + 15) / 16 * 16;
+  splits = (B + fpb - 1) / fpb;
+  dim3 grid(((vg + 7) / 8) * 8 * splits);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((kw<W, ALIGN>), grid, dim3(512), 0, 0, out, B, V, fpb, vg);
+  hipEventRecord(e0);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((kw<W, ALIGN>), grid, dim3(512), 0, 0, out, B, V, fpb, vg);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  return ms / reps;
+}
+
+// plain linear stream of the same bytes (16 B per lane, grid-stride)
+__global__ __launch_bounds__(512) void klin(f32x4* __restrict__ out, long n16) {
+  for (long i = blockIdx.x * 512l + threadIdx.x; i < n16; i += gridDim.x * 512l) out[i] = f32x4{1.f, 2.f, 3.f, (float)i};
+}
+
 template <int P> float run(float* out, int B, int V, int reps) {
   const int vt = (V + 127) / 128;
   int splits = (1024 + vt - 1) / vt;
@@ -77,5 +125,20 @@ int main(int argc, char** argv) {
   t = run<2>(out, B, V, 10); printf("pattern 2 (whole 1536-B rows, dwordx4)      %8.1f us  %7.0f GB/s\n", t * 1e3, gb / t * 1e3);
   t = run<3>(out, B, V, 10); printf("pattern 3 (whole rows, nontemporal)         %8.1f us  %7.0f GB/s\n", t * 1e3, gb / t * 1e3);
   t = run<4>(out, B, V, 10); printf("pattern 4 (dword x 3 nontemporal)           %8.1f us  %7.0f GB/s\n", t * 1e3, gb / t * 1e3);
+  t = runw<1, 0>(out, B, V, 10); printf("W = 1 (1536-B runs)                          %8.1f us  %7.0f GB/s\n", t * 1e3, gb / t * 1e3);
+  t = runw<2, 0>(out, B, V, 10); printf("W = 2 (3072-B runs)                          %8.1f us  %7.0f GB/s\n", t * 1e3, gb / t * 1e3);
+  t = runw<4, 0>(out, B, V, 10); printf("W = 4 (6144-B runs)                          %8.1f us  %7.0f GB/s\n", t * 1e3, gb / t * 1e3);
+  t = runw<1, 1>(out, B, V, 10); printf("W = 1, 64-B aligned pieces                   %8.1f us  %7.0f GB/s\n", t * 1e3, gb / t * 1e3);
+  t = runw<4, 1>(out, B, V, 10); printf("W = 4, 64-B aligned pieces                   %8.1f us  %7.0f GB/s\n", t * 1e3, gb / t * 1e3);
+  {
+    const long n16 = (long)B * V * 12 / 16;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(klin, dim3(2048), dim3(512), 0, 0, (f32x4*)out, n16);
+    hipEventRecord(e0);
+    for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(klin, dim3(2048), dim3(512), 0, 0, (f32x4*)out, n16);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); t = ms / 10;
+    printf("linear stream, 16 B per lane                 %8.1f us  %7.0f GB/s\n", t * 1e3, gb / t * 1e3);
+  }
   return 0;
 }
