@@ -22,8 +22,9 @@ out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 act = ops.ACT_GELU if os.environ.get("ACT", "none") == "gelu" else ops.ACT_NONE
 FLAGS = {"paired": ops.GEMM_PAIRED_STORES, "plain": 0, "wt": ops.GEMM_WRITE_THROUGH | ops.GEMM_PAIRED_STORES}[os.environ.get("FLAGS", "paired")]
 BIAS = os.environ.get("BIAS", "1") == "1"
+VARIANT = int(os.environ.get("VARIANT", "17"))      # 12 / 9: the 64 x 64 tiles of the decoder-sized GEMMs
 for _ in range(5):
-    ops.gemm(a, w, b if BIAS else None, None, act, out=out, variant=17, flags=FLAGS)
+    ops.gemm(a, w, b if BIAS else None, None, act, out=out, variant=VARIANT, flags=FLAGS)
 stamps = torch.zeros(4096 * 8, device="cuda", dtype=torch.int64)
 lib.msmd_exp_set_stamps.argtypes = [__import__("ctypes").c_void_p]
 lib.msmd_exp_set_stamps(stamps.data_ptr())
@@ -31,7 +32,7 @@ runs = []
 for _ in range(5):
     stamps.zero_()
     torch.cuda.synchronize()
-    ops.gemm(a, w, b if BIAS else None, None, act, out=out, variant=17, flags=FLAGS)
+    ops.gemm(a, w, b if BIAS else None, None, act, out=out, variant=VARIANT, flags=FLAGS)
     torch.cuda.synchronize()
     s = stamps.view(-1, 8).cpu().numpy()
     runs.append(s[s[:, 0] > 0].copy())
