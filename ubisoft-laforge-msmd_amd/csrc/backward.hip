@@ -53,8 +53,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= cols) return;
   const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  float s = 0.f;
-  for (long r = r0; r < r1; ++r) s += to_f32(x[r * ld + c]);
+  // four interleaved running sums (rows r0 + 4 i + u), added in a fixed order: the loop is a chain of loads, not bandwidth
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  long r = r0;
+  for (; r + 3 < r1; r += 4) {
+    a0 += to_f32(x[r * ld + c]);
+    a1 += to_f32(x[(r + 1) * ld + c]);
+    a2 += to_f32(x[(r + 2) * ld + c]);
+    a3 += to_f32(x[(r + 3) * ld + c]);
+  }
+  for (; r < r1; ++r) a0 += to_f32(x[r * ld + c]);
+  const float s = (a0 + a1) + (a2 + a3);
   if (partial) partial[(long)blockIdx.y * cols + c] = s;
   else atomicAdd(&out[c], s);
 }
@@ -65,8 +74,18 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
   const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
   float s = 0.f;
-  if (c < cols)
-    for (int b = g; b < nblocks; b += 4) s += partial[(long)b * cols + c];
+  if (c < cols) {
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    int b = g;
+    for (; b + 12 < nblocks; b += 16) {
+      b0 += partial[(long)b * cols + c];
+      b1 += partial[(long)(b + 4) * cols + c];
+      b2 += partial[(long)(b + 8) * cols + c];
+      b3 += partial[(long)(b + 12) * cols + c];
+    }
+    for (; b < nblocks; b += 4) b0 += partial[(long)b * cols + c];
+    s = (b0 + b1) + (b2 + b3);
+  }
   red[g][cx] = s;
   __syncthreads();
   if (g == 0 && c < cols) out[c] = (accumulate ? out[c] : 0.f) + ((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
