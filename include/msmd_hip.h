@@ -497,7 +497,11 @@ int msmd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  *   msmd_allreduce_bucket: buf[0 .. n) <- SUM over ranks, in place, enqueued on `stream` (the reducer's side stream, behind
  *     an event of the compute stream: overlapped with the rest of backward); dtype MSMD_F32 (a bucket of the flat gradient
  *     arena), MSMD_BF16 / MSMD_F16 (its 16-bit staging copy: half the bytes over xGMI).
- * Return codes: 0, an ncclResult_t, or 1000 + n when librccl could not be loaded (1) / lacks a symbol (2). */
+ *   msmd_comm_version: ncclGetVersion of the librccl in use (a copy the process already mapped -- torch's -- is adopted
+ *     before anything is loaded), or -(1000 + n).
+ * Return codes: 0, an ncclResult_t, or 1000 + n when librccl could not be loaded (1) / lacks a symbol (2) / reports a
+ * major version other than the 2.x whose rccl.h slice csrc/comm.hip restates (3). */
+int msmd_comm_version(void);
 int msmd_comm_unique_id(void* id_out_128_bytes);
 int msmd_comm_init(void** comm_out, int world, int rank, const void* id_128_bytes);
 int msmd_comm_destroy(void* comm);

@@ -980,7 +980,58 @@ def g9_signatures(M, SE, mc):
     print(f"wrote {path}  ({len(rec)} callables)")
 
 
-ALL = dict(g9_signatures=g9_signatures, g1_specaug=g1_specaug, g7_dataset=g7_dataset, g2_lr_schedule=g2_lr_schedule, g3_audio_large=g3_audio_large, g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
+# --------------------------------------------------------------------------- G10 fresh-parameter initialisation
+INIT_CASES = (("default", {}),
+              ("variant", dict(no_use_learnable_pe=True, guiding_conditions="audio", num_of_basis=2, use_indicator=False,
+                               n_layers=3, d_style=128, dataset_type="flame_mead_ravdess")))
+
+
+def _tensor_record(v):
+    import zlib
+    a = np.ascontiguousarray(v.detach().float().numpy())
+    d = a.astype(np.float64).ravel()
+    return (np.array([d.mean(), d.std(), d.min(), d.max()]), np.uint32(zlib.crc32(a.tobytes())),
+            a.ravel()[:8].copy())
+
+
+def g10_init(M, SE, mc):
+    """What the reference's CONSTRUCTORS leave in every parameter they create themselves (everything but the pretrained
+    audio encoder): reference model.py:115-138, 856-908 and style_encoder.py:133-176, i.e. the defaults of the torch.nn
+    layers they instantiate, drawn from the CPU generator.  The generator is seeded at the moment `from_pretrained` returns
+    (model) / right before the constructor (style encoder), so the record is (a) per-tensor mean / std / min / max and
+    (b) the exact draw (crc32 of the bytes + the first 8 values) a product constructor must reproduce from the same state."""
+    import utils.wav2vec2 as w2
+    from transformers import Wav2Vec2Config
+    saved = w2.Wav2Vec2Model.__dict__["from_pretrained"]
+    out = {}
+    try:
+        for case, kw in INIT_CASES:
+            for seed in (0, 1):
+                def seeded(cls, name, seed=seed, **_kw):
+                    m = cls(Wav2Vec2Config(attn_implementation="eager", num_hidden_layers=1))
+                    torch.manual_seed(seed)
+                    return m
+                w2.Wav2Vec2Model.from_pretrained = classmethod(seeded)
+                args = ref_args(**kw)
+                model = M.get_diffusion_model(args, device="cpu")
+                torch.manual_seed(seed)
+                se = SE.get_style_encoder(args, "vae2")
+                for prefix, mod in (("model", model), ("style", se)):
+                    keys = [k for k, _ in mod.named_parameters() if not k.startswith("audio_encoder.")]
+                    out[f"{case}/{seed}/{prefix}/keys"] = np.array(keys)
+                    recs = [_tensor_record(dict(mod.named_parameters())[k]) for k in keys]
+                    out[f"{case}/{seed}/{prefix}/stats"] = np.stack([r[0] for r in recs])
+                    out[f"{case}/{seed}/{prefix}/crc"] = np.array([r[1] for r in recs], dtype=np.uint32)
+                    out[f"{case}/{seed}/{prefix}/head"] = np.stack([np.pad(r[2], (0, 8 - len(r[2]))) for r in recs])
+                    out[f"{case}/{seed}/{prefix}/numel"] = np.array([dict(mod.named_parameters())[k].numel() for k in keys])
+    finally:
+        w2.Wav2Vec2Model.from_pretrained = saved
+    import json
+    out["cases"] = np.array(json.dumps(dict(INIT_CASES)))
+    save("g10_init", **out)
+
+
+ALL = dict(g10_init=g10_init, g9_signatures=g9_signatures, g1_specaug=g1_specaug, g7_dataset=g7_dataset, g2_lr_schedule=g2_lr_schedule, g3_audio_large=g3_audio_large, g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
            g3_forward=g3_forward, g3_style=g3_style, g3_sample=g3_sample, g3_infer=g3_infer,
            g4_flame=g4_flame, g4_rotations=g4_rotations, g5_losses=g5_losses, g6_train=g6_train,
            g5_losses_no_constrain_prev=g5_losses_no_constrain_prev, g3_denoiser_options=g3_denoiser_options, g4_lbs_blocks=g4_lbs_blocks,

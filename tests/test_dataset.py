@@ -298,3 +298,58 @@ def test_dataset_pickle_adapter_keeps_reference_constructor(tmp_path):
                         batch_overfit_size=1)
     assert len(one) == 1
     assert len(list(DatasetPickle.load_dict_in_chunks_static(pkl))) == 2
+
+
+@pytest.mark.gpu
+def test_training_cli_from_a_local_pretrained_encoder_keeps_it(tmp_path, monkeypatch):
+    """reference training_script.py:527-528 + model.py:95-101: a fresh run builds the model around the PRETRAINED audio
+    encoder.  training_script.main on a local Hugging Face checkpoint directory (real widths, one transformer layer; no
+    synthetic switch anywhere): after two iterations the frozen feature extractor in the written checkpoint still equals the
+    file bit for bit, the trainable encoder tensors are the file's plus two small Adam steps, the other parameters came from
+    the reference's initialisation (not the closed-form fill)."""
+    import json
+    import os
+    import pickle
+    import torch
+    from safetensors.torch import save_file
+    from msmd_amd import shapes
+    from msmd_amd.training_script import main
+    monkeypatch.delenv("MSMD_SYNTHETIC_WEIGHTS", raising=False)
+    ck = tmp_path / "w2v"
+    os.makedirs(ck)
+    cfg = dict(model_type="wav2vec2", num_hidden_layers=1, hidden_size=768, intermediate_size=3072, num_attention_heads=12,
+               conv_dim=[512] * 7, conv_kernel=[10, 3, 3, 3, 3, 2, 2], conv_stride=[5, 2, 2, 2, 2, 2, 2],
+               num_conv_pos_embeddings=128, num_conv_pos_embedding_groups=16, layer_norm_eps=1e-5, feat_extract_norm="group",
+               conv_bias=False, do_stable_layer_norm=False, architectures=["Wav2Vec2ForCTC"])
+    with open(ck / "config.json", "w") as f:
+        json.dump(cfg, f)
+    file_sd = {"wav2vec2." + k: torch.from_numpy(synth.fill_tensor("pretrained." + k, s)).contiguous()
+               for k, s in shapes.audio_encoder_shapes(1).items()}
+    save_file(file_sd, str(ck / "model.safetensors"))
+    raw = raw_clips()
+    path = tmp_path / "corpus.pkl"
+    with open(path, "wb") as f:
+        pickle.dump(raw, f)
+    torch.manual_seed(11)
+    tr = main(["--exp_name", "pre", "--data_root", str(path), "--exp_root", str(tmp_path), "--n_motions", "100",
+               "--n_prev_motions", "10", "--fps", "25", "--audio_model", "wav2vec2", "--rot_repr", "aa", "--use_indicator",
+               "--batch_size", "2", "--log_iter", "1", "--warm_iter", "0", "--lr", "1e-5", "--max_iter", "1", "--save_iter", "1",
+               "--val_iter", "100", "--audio_encoder_weights", str(ck)])
+    torch.cuda.synchronize()
+    assert tr.model.audio_encoder.weights_source == str(ck) and tr.opt_step == 2
+    saved = torch.load(tmp_path / "pre" / "checkpoints" / "iter_0000001.pt", weights_only=False)["model"]
+    n_frozen = n_trained = 0
+    for k, want in file_sd.items():
+        k = "audio_encoder." + k[len("wav2vec2."):]
+        got = saved[k].cpu().float()
+        if k.startswith("audio_encoder.feature_extractor."):
+            assert torch.equal(got, want), k
+            n_frozen += 1
+        elif "masked_spec_embed" not in k:
+            assert float((got - want).abs().max()) <= 2 * 1e-5 * 1.01 + 1e-7, k     # two Adam steps of at most lr each
+            n_trained += 1
+    assert n_frozen == 9 and n_trained >= 20
+    # the rest is the reference's initialisation, not the closed-form fill, and follows the caller's generator
+    w = saved["denoising_net.person_proj.weight"].cpu().float()
+    assert not torch.allclose(w, torch.from_numpy(synth.fill_tensor("denoising_net.person_proj.weight", w.shape)), atol=1e-3)
+    assert abs(float(w.std()) - (1.0 / 356 ** 0.5) / 3 ** 0.5) < 0.05 * float(w.std())      # U(+-1/sqrt fan_in)

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in protos:
         assert hasattr(lib, name), f"{name} declared in include/msmd_hip.h but not exported"
-    assert _lib.load().msmd_abi_version() == 1  # host-only call, no GPU needed
+    assert _lib.load().msmd_abi_version() == 2  # host-only call, no GPU needed
 
 
 def test_library_is_stateless_and_has_no_packed_fp32_math(tmp_path):
@@ -251,6 +251,98 @@ def test_from_pretrained_loads_a_local_hf_checkpoint_or_fails_loudly(tmp_path, m
     torch.save(sd, d3 / "pytorch_model.bin")
     with pytest.raises(KeyError, match="lacks 1 encoder tensors"):
         Wav2Vec2Model.from_pretrained(str(d3))
+
+
+def test_constructor_keeps_the_pretrained_encoder_and_initialises_the_rest_as_the_reference(tmp_path, monkeypatch):
+    """reference model.py:95-101 loads the Hugging Face encoder and only freezes parameters of it; model.py:115-138,
+    856-908 and style_encoder.py:133-176 leave every other parameter at the defaults of the torch.nn layers they
+    instantiate, drawn from the caller's generator.  (a) get_diffusion_model on a local checkpoint: every encoder tensor
+    still equals the file AFTER construction (also with MSMD_SYNTHETIC_WEIGHTS=1 in the environment: a named checkpoint
+    wins); (b) the non-encoder parameters follow the reference's distributions: tests/golden/g10_init.npz holds, per
+    tensor, mean / std / min / max and the exact draw (crc32 + first values) of the reference's own constructors seeded at
+    the moment from_pretrained returns -- the product reproduces the draw bit for bit from the same generator state and a
+    different seed gives a different, equally distributed draw; the closed-form synthetic fill appears only when named."""
+    import zlib
+    from msmd_amd.model import get_diffusion_model
+    from msmd_amd.style_encoder import get_style_encoder
+    import json
+    g = load_golden("g10_init")
+    # ---- (a) the loaded encoder survives construction
+    d1 = tmp_path / "ckpt"
+    sh = _tiny_hf_checkpoint(str(d1), "wav2vec2", "safetensors", "weight_g")
+    for env in ("1", None):
+        if env is None:
+            monkeypatch.delenv("MSMD_SYNTHETIC_WEIGHTS", raising=False)
+        else:
+            monkeypatch.setenv("MSMD_SYNTHETIC_WEIGHTS", env)
+        m = get_diffusion_model(default_args(n_layers=1, audio_encoder_weights=str(d1)), "cpu")
+        assert m.audio_encoder.weights_source == str(d1)
+        got = m.audio_encoder.state_dict()
+        for i, (k, shape) in enumerate(sh.items()):
+            if k == "masked_spec_embed":
+                continue
+            assert torch.equal(got[k], torch.from_numpy(synth.uniform("hf." + k, shape)) + float(i)), k
+        # ... and nothing outside it is the synthetic fill or left at the allocation's zeros
+        own = dict(m.named_parameters())
+        assert not torch.equal(own["denoising_net.person_proj.weight"],
+                               torch.from_numpy(synth.fill_tensor("denoising_net.person_proj.weight", own["denoising_net.person_proj.weight"].shape)))
+        for k, v in own.items():
+            if k.startswith("audio_encoder.") or k.endswith(("in_proj_bias", "out_proj.bias")) or (".norm" in k and k.endswith("bias")):
+                continue
+            assert float(v.detach().abs().sum()) > 0, k
+        assert m.audio_feature_map.weight.shape == (512, 64)
+    monkeypatch.delenv("MSMD_SYNTHETIC_WEIGHTS", raising=False)
+    # ---- (b) the reference's draw, bit for bit and in distribution
+    cases = json.loads(str(g["cases"]))
+    same_torch = f"torch={torch.__version__};" in str(g["_versions"])
+
+    def record(v):
+        a = np.ascontiguousarray(v.detach().float().numpy())
+        d = a.astype(np.float64).ravel()
+        return np.array([d.mean(), d.std(), d.min(), d.max()]), zlib.crc32(a.tobytes())
+
+    for case, kw in cases.items():
+        args = default_args(encoder_layers=1, audio_encoder_weights="checkpoint", **kw)   # bare encoder, no generator use
+        built = {}
+        for seed in (0, 1, 7):
+            torch.manual_seed(seed)
+            model = get_diffusion_model(args, "cpu")
+            torch.manual_seed(seed)
+            se = get_style_encoder(args, "vae2")
+            built[seed] = (model, se)
+            if seed == 7:
+                continue
+            for prefix, mod in (("model", model), ("style", se)):
+                own = {k: v for k, v in mod.named_parameters() if not k.startswith("audio_encoder.")}
+                keys = [str(k) for k in g[f"{case}/{seed}/{prefix}/keys"]]
+                assert list(own) == keys, (case, prefix)                      # same parameters, same registration order
+                for i, k in enumerate(keys):
+                    st, crc = record(own[k])
+                    want = g[f"{case}/{seed}/{prefix}/stats"][i]
+                    n = int(g[f"{case}/{seed}/{prefix}/numel"][i])
+                    if same_torch:
+                        assert crc == int(g[f"{case}/{seed}/{prefix}/crc"][i]), (case, seed, k)
+                        assert np.array_equal(own[k].detach().numpy().ravel()[:8], g[f"{case}/{seed}/{prefix}/head"][i][:min(8, n)])
+                    # distribution: the reference's spread, whatever the generator (a draw of n values: 6 sigma on the mean)
+                    assert abs(st[1] - want[1]) <= 0.2 * want[1] + 1e-12, (case, seed, k, st, want)
+                    assert abs(st[0] - want[0]) <= 6.0 * max(want[1], 1e-12) / np.sqrt(n) + 1e-7, (case, seed, k, st, want)
+                    assert st[2] >= want[2] - 0.75 * abs(want[2]) - 1e-12 and st[3] <= want[3] + 0.75 * abs(want[3]) + 1e-12, (case, k)
+        # torch.manual_seed moves the draw; the statistics stay (seed 7 against the reference's seed-0 record)
+        m0, m7 = built[0][0], built[7][0]
+        w0, w7 = m0.denoising_net.person_proj.weight.detach(), m7.denoising_net.person_proj.weight.detach()
+        assert not torch.equal(w0, w7) and abs(float(w0.std()) - float(w7.std())) < 0.02 * float(w0.std())
+        assert not torch.equal(built[0][1].state_dict()["encoder.linear1.weight"], built[7][1].state_dict()["encoder.linear1.weight"])
+        # nn.TransformerDecoder deep-copies its layer: all decoder layers start from one draw, in the reference and here
+        sd = m0.denoising_net.state_dict()
+        for k in [k for k in sd if k.startswith("transformer.layers.0.")]:
+            assert torch.equal(sd[k], sd[k.replace("layers.0.", f"layers.{args.n_layers - 1}.")]), k
+    # ---- the closed-form fill appears only when asked for by name
+    syn = get_diffusion_model(default_args(encoder_layers=1, n_layers=1, audio_encoder_weights="synthetic"), "cpu")
+    w = syn.denoising_net.person_proj.weight
+    assert torch.equal(w, torch.from_numpy(synth.fill_tensor("denoising_net.person_proj.weight", w.shape)))
+    se = get_style_encoder(default_args(audio_encoder_weights="synthetic"), "vae2")
+    w = se.state_dict()["encoder.linear1.weight"]
+    assert torch.equal(w, torch.from_numpy(synth.fill_tensor("encoder.linear1.weight", w.shape)))
 
 
 def test_public_signatures_match_the_reference():

@@ -2,8 +2,10 @@
 // a single process, its DDP analogue sums gradients over ranks).  C-ABI entries of include/msmd_hip.h:
 //   msmd_comm_unique_id / msmd_comm_init / msmd_comm_destroy    one communicator per process (one process per GPU)
 //   msmd_allreduce_bucket                                        in-place SUM of one gradient bucket on the caller's stream
-// librccl is resolved at FIRST USE with dlopen("librccl.so.1"): a process that never exchanges (inference, one-GPU
-// training) does not load it, and a process that has torch's copy mapped (same soname) shares that one.
+// librccl is resolved at FIRST USE: a process that never exchanges (inference, one-GPU training) does not load it.  A copy the
+// process has ALREADY mapped (torch's bundled librccl, by soname) is adopted first with RTLD_NOLOAD so that one process never
+// holds two RCCL runtimes; only then is the soname / the ROCm path loaded.  The library's major version is checked against the
+// slice of rccl.h restated below (ncclGetVersion: 2.x), anything else is refused with 1003.
 #include "common.h"
 #include <dlfcn.h>
 #include <cstring>
@@ -18,6 +20,7 @@ typedef int (*comm_destroy_t)(void*);
 typedef int (*all_reduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef const char* (*get_error_string_t)(int);
 typedef int (*comm_count_t)(void*, int*);
+typedef int (*get_version_t)(int*);
 
 struct Rccl {
   void* handle = nullptr;
@@ -26,7 +29,8 @@ struct Rccl {
   comm_destroy_t comm_destroy = nullptr;
   all_reduce_t all_reduce = nullptr;
   comm_count_t comm_count = nullptr;
-  int status = -1;   // 0 = resolved
+  int version = 0;   // ncclGetVersion: major * 10000 + minor * 100 + patch
+  int status = -1;   // 0 = resolved, 1 = not found, 2 = symbols missing, 3 = unknown major version
 };
 Rccl g_rccl;
 std::once_flag g_once;
@@ -34,11 +38,19 @@ std::once_flag g_once;
 const Rccl& rccl() {
   std::call_once(g_once, [] {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-      g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    for (const char* n : names) {          // a copy that is already mapped (torch's) wins: never two runtimes in one process
+      g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
       if (g_rccl.handle) break;
     }
+    for (const char* n : names) {
+      if (g_rccl.handle) break;
+      g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    }
     if (!g_rccl.handle) { g_rccl.status = 1; return; }
+    get_version_t get_version = (get_version_t)dlsym(g_rccl.handle, "ncclGetVersion");
+    int version = 0;
+    if (!get_version || get_version(&version) != 0 || version / 10000 != 2) { g_rccl.status = 3; return; }
+    g_rccl.version = version;
     g_rccl.get_unique_id = (get_unique_id_t)dlsym(g_rccl.handle, "ncclGetUniqueId");
     g_rccl.comm_init_rank = (comm_init_rank_t)dlsym(g_rccl.handle, "ncclCommInitRank");
     g_rccl.comm_destroy = (comm_destroy_t)dlsym(g_rccl.handle, "ncclCommDestroy");
@@ -69,6 +81,12 @@ extern "C" int msmd_comm_init(void** comm_out, int world, int rank, const void* 
   UniqueId u;
   std::memcpy(&u, id, sizeof(u));
   return r.comm_init_rank(comm_out, world, u, rank);
+}
+
+// ncclGetVersion of the library in use (major * 10000 + minor * 100 + patch), or -(1000 + n) when it could not be resolved.
+extern "C" int msmd_comm_version(void) {
+  const Rccl& r = rccl();
+  return r.status ? -(1000 + r.status) : r.version;
 }
 
 extern "C" int msmd_comm_destroy(void* comm) {

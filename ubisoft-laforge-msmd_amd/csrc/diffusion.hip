@@ -268,7 +268,7 @@ extern "C" int msmd_cast(const void* x, void* y, long n, int in_dtype, int out_d
   return msmd_pad_cols(x, y, 1, (int)n, (int)n, in_dtype, out_dtype, stream);
 }
 
-extern "C" int msmd_abi_version(void) { return 1; }
+extern "C" int msmd_abi_version(void) { return 2; }   // 2: + msmd_comm_* / msmd_allreduce_bucket (round 4), msmd_comm_version
 
 // ---------------------------------------------------------------------------------------------------
 // Dynamic thresholding of the denoiser output (reference model.py:396-402, 578-584):

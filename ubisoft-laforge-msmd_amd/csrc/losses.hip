@@ -138,10 +138,11 @@ extern "C" int msmd_masked_seq_loss(const float* gt, const float* pred, const in
 //   d loss / d pred[n, tau, c] = - scale up / (cnt nc) * sum_k s_k crit'(d[n, tau - k, c])   over the valid rows tau - k.
 // cnt is read from the forward's workspace (acc_ws[1]); `upstream` is the incoming 0-dim gradient on the device.
 __global__ __launch_bounds__(256) void masked_seq_loss_bwd_kernel(const LossArgs p, float* __restrict__ grad,
-                                                                  const float* __restrict__ upstream, float scale) {
-  // narrow rows (blockDim 256, launched when nc <= 256): one wave per (n, tau) row, four rows per workgroup -- 3 520 workgroups of
-  // one wave each were dispatch-bound (18 us for 235 k elements)
-  const int rows_per_wg = blockDim.x >> 6;
+                                                                  const float* __restrict__ upstream, float scale,
+                                                                  int rows_per_wg) {
+  // narrow rows (rows_per_wg = 4, launched when nc <= 256): one wave per (n, tau) row, four rows per workgroup -- 3 520 workgroups
+  // of one wave each were dispatch-bound (18 us for 235 k elements); wide rows (vertex space, nc = 15 069): rows_per_wg = 1,
+  // all 256 threads stride one row
   const int n = blockIdx.y, tau = blockIdx.x * rows_per_wg + (threadIdx.x >> 6);
   if (tau >= p.T) return;
   const int c_first = rows_per_wg > 1 ? (threadIdx.x & 63) : threadIdx.x, c_step = rows_per_wg > 1 ? 64 : blockDim.x;
@@ -196,10 +197,10 @@ extern "C" int msmd_masked_seq_loss_bwd(const float* gt, const float* pred, cons
   LossArgs p{gt, pred, end_idx, (double*)acc_ws, N, T, C, c_lo, c_hi, order, prefix, criterion, 0, mode};
   if (c_hi - c_lo <= 256)
     hipLaunchKernelGGL(masked_seq_loss_bwd_kernel, dim3((T + 3) / 4, N), dim3(256), 0, (hipStream_t)stream, p, grad_pred, upstream,
-                       scale);
+                       scale, 4);
   else
-    hipLaunchKernelGGL(masked_seq_loss_bwd_kernel, dim3(T, N), dim3(64), 0, (hipStream_t)stream, p, grad_pred, upstream,
-                       scale);
+    hipLaunchKernelGGL(masked_seq_loss_bwd_kernel, dim3(T, N), dim3((c_hi - c_lo) >= 1024 ? 256 : 64), 0, (hipStream_t)stream, p,
+                       grad_pred, upstream, scale, 1);
   MSMD_RETURN_LAST();
 }
 

@@ -101,11 +101,22 @@ class RcclComm:
         self._lib.check(self.lib.msmd_allreduce_bucket(self.comm, t.data_ptr(), t.numel(), self._DT[t.dtype], st.cuda_stream),
                         "msmd_allreduce_bucket")
 
+    @property
+    def version(self):
+        """ncclGetVersion of the librccl behind the C ABI (a copy torch already mapped is adopted, csrc/comm.hip)."""
+        return int(self.lib.msmd_comm_version())
+
     def destroy(self):
-        if self.comm is not None and self.comm.value:
+        if getattr(self, "comm", None) is not None and self.comm.value:
             torch.cuda.synchronize(self.device)
             self._lib.check(self.lib.msmd_comm_destroy(self.comm), "msmd_comm_destroy")
         self.comm = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:      # interpreter teardown: the runtime may be gone already
+            pass
 
 
 ALIGN = 64  # elements: every tensor starts on a 256-byte boundary of its arena (kernels need 16-byte operands)
@@ -315,7 +326,13 @@ class GradBucketReducer:
         buf = view
         if self.stage is not None:
             buf = self.stage[start:end]
-            buf.copy_(view)                      # fp32 -> 16 bit (one rounding of this rank's contribution)
+            if buf.dtype == torch.float16 and self.world > 1:
+                # fp16 has no headroom for a sum over ranks (max 65 504, no loss scaling on this path): stage contribution / world,
+                # so the SUM is the mean and cannot exceed the largest single contribution; scaled back after the exchange.
+                # bf16 staging (fp32's exponent range) needs no such guard and is the recommended 16-bit bucket type.
+                buf.copy_(view * (1.0 / self.world))
+            else:
+                buf.copy_(view)                  # fp32 -> 16 bit (one rounding of this rank's contribution)
         if self.comm is not None:
             self.comm.all_reduce(buf, self.side if self.cuda else None)
         elif self.world > 1:
@@ -326,6 +343,8 @@ class GradBucketReducer:
                 w.wait()     # NCCL: this (side) stream waits for the collective, no host block; gloo: host wait -- then the copy back
         if self.stage is not None:
             view.copy_(buf)
+            if buf.dtype == torch.float16 and self.world > 1:
+                view.mul_(float(self.world))
 
     def _launch(self, b):
         exchanging = self.world > 1 or (self.exchange_at_world_1 and self.comm is not None)

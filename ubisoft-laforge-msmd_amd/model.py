@@ -15,7 +15,7 @@ from types import SimpleNamespace
 import torch
 import torch.nn as nn
 
-from . import ops, shapes, synth
+from . import init, ops, shapes, synth
 from .utils.model_common import ParamTree, PositionalEncoding, enc_dec_mask, sinusoid_table  # noqa: F401  (enc_dec_mask re-exported)
 
 
@@ -131,7 +131,8 @@ class _TE(nn.Module):
 class DenoisingNetwork_MSMD(nn.Module):
     """reference model.py:820-996 (architecture='decoder')."""
 
-    def __init__(self, args, device="cuda", motion_feat_dim=50, use_head_alpha=True, regularize_alpha="None"):
+    def __init__(self, args, device="cuda", motion_feat_dim=50, use_head_alpha=True, regularize_alpha="None",
+                 init_parameters=True):
         super().__init__()
         self.regularize_alpha = regularize_alpha
         self.use_head_alpha = use_head_alpha
@@ -194,6 +195,8 @@ class DenoisingNetwork_MSMD(nn.Module):
             self._diag_mask = False
         self._packed = None
         self._packed_dtype = None
+        if init_parameters:     # the torch.nn defaults of the layers reference model.py:856-908 instantiates, caller's RNG
+            init.denoiser_(self, args)
         self.to(device)
 
     @property
@@ -559,6 +562,11 @@ class MSMD(nn.Module):
         for name, p in self.audio_encoder.named_parameters():  # model.py:97,101-110
             if name.startswith(frozen):
                 p.requires_grad = False
+        # The encoder is what from_pretrained returned and is never written again here.  Everything else starts from the
+        # reference's initialisation (msmd_amd.init: the torch.nn defaults, drawn from the caller's torch RNG in the
+        # reference's construction order) -- unless the closed-form synthetic weights were asked for by name, which then fill
+        # the WHOLE model (tests / bench / smoke: the goldens are recorded on them).
+        synthetic = getattr(self.audio_encoder, "weights_source", None) == "synthetic"
         if args.architecture == "decoder":
             self.audio_feature_map = ParamTree({"weight": (args.feature_dim, self.audio_encoder.config.hidden_size),
                                                 "bias": (args.feature_dim,)})
@@ -566,9 +574,11 @@ class MSMD(nn.Module):
         else:
             raise ValueError(f"Unknown architecture {args.architecture}!")
         self.start_motion_feat = nn.Parameter(torch.zeros(1, self.n_prev_motions, self.motion_feat_dim))
+        if not synthetic:
+            init.msmd_front_(self, args)
         self.denoising_net = DenoisingNetwork_MSMD(args, "cpu", motion_feat_dim=self.motion_feat_dim,
                                                    use_head_alpha=self.use_head_alpha,
-                                                   regularize_alpha=self.regularize_alpha)
+                                                   regularize_alpha=self.regularize_alpha, init_parameters=not synthetic)
         self.diffusion_sched = DiffusionSchedule(args.n_diff_steps, args.diff_schedule)
         self.cfg_mode = args.cfg_mode
         guiding_conditions = args.guiding_conditions.split(",") if args.guiding_conditions else []
@@ -579,7 +589,10 @@ class MSMD(nn.Module):
             self.null_style_feat = nn.Parameter(torch.zeros(1, 1, self.style_feat_dim))
         if "audio" in self.guiding_conditions:
             self.null_audio_feat = nn.Parameter(torch.zeros(1, 1, args.feature_dim))
-        synth.load_synthetic(self)  # deterministic init (no pretrained assets offline); checkpoints overwrite it
+        if synthetic:
+            synth.load_synthetic(self)   # closed-form fill of every parameter, the (already synthetic) encoder included
+        else:
+            init.msmd_back_(self, args)
         self.audio_encoder.split_mode = self.split_mode
         self._afm = None
         self.to(device)

@@ -206,7 +206,9 @@ def sample(model, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=N
     return x, motion_at_T, audio_feat
 
 
-STEPS_PER_GRAPH = int(os.environ.get("MSMD_SAMPLER_STEPS_PER_GRAPH", "10"))
+# clamped to [1, 50]: k bodies in one graph keep k steps of intermediates alive in the graph's private pool (about 0.2 GB per
+# step at B = 64, fp16: 2 GB at the default 10 of the 288 GB)
+STEPS_PER_GRAPH = min(50, max(1, int(os.environ.get("MSMD_SAMPLER_STEPS_PER_GRAPH", "10"))))
 
 
 class _StepGraph:

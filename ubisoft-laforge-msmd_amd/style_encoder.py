@@ -6,7 +6,7 @@ from types import SimpleNamespace
 import torch
 import torch.nn as nn
 
-from . import ops, shapes, synth
+from . import init, ops, shapes, synth
 from .model import _cd, _is_split
 from .utils.model_common import ParamTree, sinusoid_table
 
@@ -46,7 +46,10 @@ class StyleEncoder_VAE2(nn.Module):
         for name, m in tree._modules.items():
             self.add_module(name, m)
         self.PE = _PE(self.conv_feature_dim)
-        synth.load_synthetic(self)
+        if init.synthetic_requested(args):   # closed-form weights, asked for by name (tests / bench / smoke)
+            synth.load_synthetic(self)
+        else:                                # the reference's torch.nn defaults under the caller's RNG (style_encoder.py:133-176)
+            init.style_encoder_(self, args)
         self._packed = None
         self._packed_dtype = None
 

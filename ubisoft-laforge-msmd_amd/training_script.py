@@ -173,6 +173,11 @@ class Trainer:
                                                 bucket_dtype=bucket_dtype, exchange_at_world_1=exchange_at_world_1)
         finally:
             dp.ADJACENT = []
+        if self.reducer.world > 1:
+            # replicas start from rank 0's parameters whatever each rank's generator drew at construction (a fresh run draws
+            # the non-encoder parameters from torch's RNG, msmd_amd.init); frozen tensors come from the checkpoint on every rank
+            self.reducer.td.broadcast(self.flat_param, src=self.reducer.td.get_global_rank(process_group, 0)
+                                      if process_group is not None else 0, group=process_group)
         self.weight_arena = None
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
@@ -845,18 +850,26 @@ def train(args, model, style_enc, train_loader, val_loader, optimizer, save_dir,
         batch = batch_from_loader(item) if isinstance(item[0], (list, tuple)) and isinstance(item[1][0], dict) else item
         out = trainer.step(batch, it=it)
         log.append(out["loss"])
+        if it % args.log_iter == 0 and it != start_iter:
+            # EVERY rank looks at its own smoothed loss (the only host sync, once per log interval) and the ranks agree on the
+            # verdict with a one-element MAX all-reduce, so a non-finite loss stops all of them together -- a lone rank 0
+            # raising would leave the others blocked in the next bucket all-reduce.  Both reduction incidents of rounds 3 / 4
+            # (the host library's multi-block sums inside hipGraphs) would have surfaced at this check.
+            val_t = torch.stack(log[-args.log_smooth_win:]).mean()
+            bad = (~torch.isfinite(val_t)).float()
+            if trainer.reducer.world > 1:
+                trainer.reducer.td.all_reduce(bad, op=trainer.reducer.td.ReduceOp.MAX, group=trainer.reducer.group)
+            val = val_t.item()
+            if float(bad.item()) != 0.0:
+                raise FloatingPointError(f"non-finite training loss at iteration {it} on some rank (this rank {rank}: {val}; "
+                                         f"hipGraph mode: {trainer.use_graph})")
+            log = log[-args.log_smooth_win:]
         if rank == 0 and it % args.log_iter == 0 and it != start_iter:
-            val = torch.stack(log[-args.log_smooth_win:]).mean().item()   # the only host sync, once per log interval
-            if val != val or abs(val) == float("inf"):
-                # a non-finite loss must stop the run here, not train on: both reduction incidents of rounds 3 / 4 (the host
-                # library's multi-block sums inside hipGraphs) would have surfaced at this check
-                raise FloatingPointError(f"non-finite training loss at iteration {it} (hipGraph mode: {trainer.use_graph})")
             if writer is not None:
                 writer.add_scalar("train/loss", val, it)
                 writer.add_scalar("opt/lr", trainer.current_lr(), it)
             print(f"iter {it}: loss {val:.5f}  lr {trainer.current_lr():.3e}  "
                   f"{(time.time() - t0) / max(1, it - start_iter) * 1e3:.1f} ms/it")
-            log = log[-args.log_smooth_win:]
         if rank == 0 and ((it % args.save_iter == 0 and it not in (0, start_iter)) or it == args.max_iter):
             trainer.save_checkpoint(save_dir / f"iter_{it:07}.pt", it)
         if val_loader is not None and ((it % args.val_iter == 0 and it not in (0, start_iter)) or it == args.max_iter):
