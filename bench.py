@@ -706,7 +706,7 @@ def run_forward(a, rank, world, device):
         out["roofline"] = roofline_leg(model, b, a.dtype)
     if not a.no_parity:
         pm = []
-        for mode in [m for m in ("f16x2", "fp32") if m != a.dtype]:
+        for mode in [m for m in ("f16x2", "fp32", "fp16") if m != a.dtype]:   # fp16: the other 16-bit storage mode (error / time Pareto)
             el, _, tg, sm = timed(mode)
             ent = dict(dtype=mode, ms_per_step=round(el / a.steps * 1e3, 3), single_stream_ms_per_step=None if sm is None else round(sm, 3),
                        frames_per_s=round(a.batch * 100 * a.steps / el, 1),

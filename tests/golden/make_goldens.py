@@ -514,6 +514,44 @@ def g3_infer(M, SE, mc):
     save("g3_infer", **out)
 
 
+# --------------------------------------------------------------------------- G3 style-clip ingestion
+INGEST_CASES = ((90, 30, "tensor"), (131, 30, "numpy"), (77, 24, "tensor"), (50, 25, "numpy"), (400, 30, "tensor"))
+
+
+def ingest_inputs(n, tag="ingest"):
+    """Synthetic style clip + corpus statistics (shared with tests/test_host_cpu.py / test_model_gpu.py)."""
+    e = (synth.normalish(f"{tag}/{n}/exp", (n, 50)) * 1.5 + 0.2).astype(np.float32)
+    h = (synth.normalish(f"{tag}/{n}/head", (n, 3)) * 0.3).astype(np.float32)
+    st = {"exp_mean": synth.normalish(f"{tag}/exp_mean", (50,)) * 0.1, "exp_std": np.abs(synth.normalish(f"{tag}/exp_std", (50,))) + 0.5,
+          "pose_mean": synth.normalish(f"{tag}/pose_mean", (3,)) * 0.1, "pose_std": np.abs(synth.normalish(f"{tag}/pose_std", (3,))) + 0.5}
+    return e, h, {k: v.astype(np.float32) for k, v in st.items()}
+
+
+def g3_ingest(M, SE, mc):
+    """reference inference.py:109-183 `query_for_motion_coeff` itself (function object built from the file's AST: the script
+    cannot be imported here), fed pickle files as its caller does: corpus statistics, expression code (a tensor) and head
+    rotation (tensor or array), original fps 30 / 24 / 25 -> 25."""
+    import pickle as pkl
+    from scipy.interpolate import interp1d
+    tree = ast.parse(open(os.path.join(REF, "inference.py")).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "query_for_motion_coeff"][0]
+    ns = dict(torch=torch, np=np, pkl=pkl, interp1d=interp1d, argparse=argparse)
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "<reference inference.py:query_for_motion_coeff>", "exec"), ns)
+    out = {"cases": np.array([f"{n},{fps},{kind}" for n, fps, kind in INGEST_CASES])}
+    with tempfile.TemporaryDirectory() as d:
+        for n, fps, kind in INGEST_CASES:
+            e, h, st = ingest_inputs(n)
+            paths = {k: os.path.join(d, f"{k}_{n}.pkl") for k in ("stats", "exp", "head")}
+            for k, obj in (("stats", {a: t(b) for a, b in st.items()}), ("exp", t(e)), ("head", t(h) if kind == "tensor" else h)):
+                with open(paths[k], "wb") as f:
+                    pkl.dump(obj, f)
+            args = argparse.Namespace(coef_dict_path=paths["stats"])
+            motion, shape = ns["query_for_motion_coeff"](args, paths["exp"], paths["head"], device="cpu", original_fps=fps, target_fps=25)
+            out[f"motion_{n}_{fps}"] = motion.numpy()
+            out[f"shape_{n}_{fps}"] = shape.numpy()
+    save("g3_ingest", **out)
+
+
 # --------------------------------------------------------------------------- G4 FLAME / rotations
 def write_flame_asset(tmpdir):
     a = synth.flame_asset()
@@ -1031,7 +1069,7 @@ def g10_init(M, SE, mc):
     save("g10_init", **out)
 
 
-ALL = dict(g10_init=g10_init, g9_signatures=g9_signatures, g1_specaug=g1_specaug, g7_dataset=g7_dataset, g2_lr_schedule=g2_lr_schedule, g3_audio_large=g3_audio_large, g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
+ALL = dict(g10_init=g10_init, g3_ingest=g3_ingest, g9_signatures=g9_signatures, g1_specaug=g1_specaug, g7_dataset=g7_dataset, g2_lr_schedule=g2_lr_schedule, g3_audio_large=g3_audio_large, g1_index=g1_index, g2_schedule=g2_schedule, g3_audio=g3_audio, g3_denoiser=g3_denoiser,
            g3_forward=g3_forward, g3_style=g3_style, g3_sample=g3_sample, g3_infer=g3_infer,
            g4_flame=g4_flame, g4_rotations=g4_rotations, g5_losses=g5_losses, g6_train=g6_train,
            g5_losses_no_constrain_prev=g5_losses_no_constrain_prev, g3_denoiser_options=g3_denoiser_options, g4_lbs_blocks=g4_lbs_blocks,

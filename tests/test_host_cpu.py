@@ -525,6 +525,99 @@ def test_grad_bucket_reducer_ranks_skip_different_layers_world_2_gloo(tmp_path):
     assert out["err"] < 1e-6, out
 
 
+def test_grad_bucket_reducer_world_8_gloo_bucket_order_kl_weight_and_accumulation(tmp_path):
+    """The 8-rank control flow of BASELINE configs[2] (8 x local batch = global batch) on CPU, so that the first real 8-GPU
+    run is not also the first 8-rank run (SURVEY.md 8e caveats 1-3): (1) every rank launches the SAME bucket sequence although
+    each skips a different layer (LayerDrop) and so completes its buckets in a different order; (2) the KL term is a batch
+    SUM (reference utils/common.py:454): weighted by `kl_weight_scale` = world on every rank, all-reduce(sum) / world equals
+    the gradient of ONE process on the global batch -- mean terms and the sum term both; (3) with
+    gradient_accumulation_steps = 2 nothing is exchanged on the first micro-step (reference training_script.py:199) and the
+    stepping micro-step reduces the accumulated gradients once."""
+    script = tmp_path / "w8.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, json
+        sys.path.insert(0, {ROOT!r})
+        import torch, torch.distributed as td
+        from msmd_amd import dp
+        torch.set_num_threads(1)
+        rank, world = dp.init("gloo")
+        assert world == 8
+        torch.manual_seed(0)
+        layers = [torch.nn.Linear(16, 16) for _ in range(9)]
+        head_mu, head_lv = torch.nn.Linear(16, 4), torch.nn.Linear(16, 4)
+        params = [p for l in layers for p in l.parameters()] + list(head_mu.parameters()) + list(head_lv.parameters())
+        red = dp.GradBucketReducer(params, bucket_mb=0.0005)
+        assert len(red.buckets) >= 9 and red.kl_weight_scale == 8.0
+        order = []
+        orig = red._launch
+        def spy(b):
+            if not red.launched[b]:
+                order.append((phase[0], b))
+            return orig(b)
+        red._launch = spy
+        KLW, B = 1e-2, 4                                  # local batch 4, global 32
+        X = torch.randn(2, world * B, 16)                 # two micro-batches of the global batch
+
+        def loss(x, skip, kl_scale):
+            h = x
+            for i, l in enumerate(layers):
+                if i != skip:
+                    h = h + torch.tanh(l(h))
+            mu, lv = head_mu(h), head_lv(h)
+            kl = -0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp())          # batch SUM, as the reference
+            return h.pow(2).mean() + KLW * kl_scale * kl
+
+        phase = ["m1"]
+        red.zero_grad()
+        red.enabled = False; red.begin_backward()
+        loss(X[0, rank * B:(rank + 1) * B], 1 + rank, red.kl_weight_scale).backward()        # micro-step 1: no exchange
+        phase[0] = "m2"
+        red.enabled = True; red.begin_backward()
+        loss(X[1, rank * B:(rank + 1) * B], 8 - rank, red.kl_weight_scale).backward()        # stepping micro-step
+        phase[0] = "finish"
+        flat, scale = red.finish()
+        got = [(p.grad * scale).clone() for p in params]
+        # ONE process on the global batch: per-rank layer skips reproduced shard by shard; mean terms average over ranks,
+        # the KL sum adds over ranks (weight NOT scaled)
+        ref = [torch.zeros_like(p) for p in params]
+        for m, skips in ((0, [1 + r for r in range(world)]), (1, [8 - r for r in range(world)])):
+            for r in range(world):
+                for p in params: p.grad = None
+                x = X[m, r * B:(r + 1) * B]
+                h = x
+                for i, l in enumerate(layers):
+                    if i != skips[r]:
+                        h = h + torch.tanh(l(h))
+                mu, lv = head_mu(h), head_lv(h)
+                kl = -0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp())
+                (h.pow(2).mean() / world + KLW * kl).backward()
+                for t, p in zip(ref, params):
+                    if p.grad is not None: t += p.grad
+        err = max(float((g - t).abs().max()) for g, t in zip(got, ref))
+        scale_ref = max(float(t.abs().max()) for t in ref)
+        orders = [None] * world
+        td.all_gather_object(orders, order)
+        if rank == 0:
+            print(json.dumps(dict(err=err, scale=scale_ref, same_order=all([b for _, b in o] == [b for _, b in orders[0]] for o in orders),
+                                  early_any=[e for o in orders for e in o if e[0] == "m1"], hooked=sum(1 for o in orders for e in o if e[0] == "m2"),
+                                  early=[e for e in orders[0] if e[0] == "m1"], n_launch=len(orders[0]),
+                                  buckets=len(red.buckets), in_order=[b for _, b in orders[0]] == sorted(b for _, b in orders[0]))))
+        td.destroy_process_group()
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["err"] < 1e-5 * max(1.0, out["scale"]), out
+    # the collective SEQUENCE (bucket indices) is identical on all ranks; which of them a rank launches from a hook and which
+    # from finish() differs by rank (each skips another layer), and some did go out from hooks during backward
+    assert out["same_order"] and out["in_order"] and out["early_any"] == [] and out["n_launch"] == out["buckets"], out
+    assert out["hooked"] > 0, out
+
+
 def test_grad_bucket_reducer_accumulation_rearm_and_write_sequence_world_2_gloo(tmp_path):
     """(1) Gradient accumulation with a parameter that is unused in micro-step 1: the arrival counters are re-armed
     per backward (`begin_backward`), so no bucket is reduced before the stepping micro-step's backward has finished
@@ -648,6 +741,13 @@ def test_style_clip_ingestion_and_denormalisation():
         ex, hr = denormalize_coeffs(m, stats)
         if fps == 25:
             assert np.abs(ex.numpy() - e).max() < 1e-5 and np.abs(hr.numpy() - h).max() < 1e-5
+
+
+def test_style_clip_ingestion_matches_the_reference_function(tmp_path):
+    """reference inference.py:109-183 on pickle inputs (g3_ingest, recorded from the reference's own
+    function object), host path with device="cpu"; tests/test_model_gpu.py runs the same check with device="cuda"."""
+    from helpers import check_ingestion_against_reference
+    check_ingestion_against_reference(tmp_path, "cpu")
 
 
 def test_common_script_plumbing():

@@ -712,3 +712,11 @@ def test_layernorm_fold_in_the_denoiser_trunk_and_sampler(dtype):
         s_f, s_p = maxabs(res[True, "s"], ref_s), maxabs(res[False, "s"], ref_s)
         print(f"sampler fp16 (500 steps): folded err {s_f:.4f}, LayerNorm kernels err {s_p:.4f}")
         assert s_f <= 1.5 * s_p + 0.01
+
+
+@pytest.mark.gpu
+def test_style_clip_ingestion_on_device_matches_the_reference_function(tmp_path):
+    """SURVEY.md 8(f) n3 with device="cuda": the tensors `query_for_motion_coeff` puts on the GPU equal the outputs of the
+    reference's own function (g3_ingest: reference inference.py:109-183, built from its AST at generation time)."""
+    from helpers import check_ingestion_against_reference
+    check_ingestion_against_reference(tmp_path, "cuda")

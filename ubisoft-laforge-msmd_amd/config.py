@@ -42,9 +42,11 @@ DEFAULTS = dict(
 # HuBERT-large hidden states (LayerNorm-ed, |x| <= ~6) and the B = 64 sampler.  fp32 / f16x2 meet the north_star's 1e-4.
 # The 16-bit storage modes are throughput modes: their error is the operands' own rounding (tools/bf16_error_budget.py: with
 # bf16 WEIGHTS ALONE a 12-layer post-LN encoder is already 0.024 off; an fp32 residual stream buys 0.037 -> 0.032), measured
-# 0.05-0.09 (bf16) and 0.006-0.011 (fp16) over boxes, batches and seeds; the bounds are the next power of two above that.
+# 0.05-0.088 (bf16) and 0.006-0.011 (fp16) over boxes, batches and seeds (rounds 2-4); the bounds are the worst measurement
+# plus a margin of about 1/8 (a last-bit change upstream moves the maximum over 214 k outputs by a few per cent), so a regression
+# of the 16-bit arithmetic shows up here instead of hiding under a power of two.
 # tests/test_model_gpu.py asserts them on the bench workloads and bench.py exits non-zero when its own batch exceeds them.
-PARITY_BOUNDS = {"fp32": 1e-4, "f16x2": 1e-4, "fp16": 2.0 ** -6, "bf16": 2.0 ** -3}
+PARITY_BOUNDS = {"fp32": 1e-4, "f16x2": 1e-4, "fp16": 2.0 ** -6, "bf16": 0.1}
 
 
 def default_args(**overrides) -> argparse.Namespace:

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void masked_seq_loss_bwd_kernel(const LossArgs
   // narrow rows (rows_per_wg = 4, launched when nc <= 256): one wave per (n, tau) row, four rows per workgroup -- 3 520 workgroups
   // of one wave each were dispatch-bound (18 us for 235 k elements); wide rows (vertex space, nc = 15 069): rows_per_wg = 1,
   // all 256 threads stride one row
-  const int n = blockIdx.y, tau = blockIdx.x * rows_per_wg + (threadIdx.x >> 6);
+  const int n = blockIdx.y, tau = blockIdx.x * rows_per_wg + (rows_per_wg > 1 ? (int)(threadIdx.x >> 6) : 0);
   if (tau >= p.T) return;
   const int c_first = rows_per_wg > 1 ? (threadIdx.x & 63) : threadIdx.x, c_step = rows_per_wg > 1 ? 64 : blockDim.x;
   const int nc = p.c_hi - p.c_lo, Td = p.T - p.order;

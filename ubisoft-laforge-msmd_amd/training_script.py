@@ -649,7 +649,8 @@ class Trainer:
         flags.copy_(self._flag_table[int(cross[0]) * 2 + int(cross[1])], non_blocking=True)
         stepping = self._stepping
         for gseg, buckets in g:
-            gseg.replay()
+            if gseg is not None:     # a stretch in which nothing was recorded (e.g. after the last gradient write) has no graph
+                gseg.replay()
             if stepping:
                 for b in buckets:        # final for this backward: reduce it under the segments that follow
                     self.reducer._launch(b)
@@ -743,16 +744,27 @@ class Trainer:
                     else:
                         gr.capture_begin(pool=self._graph_pool)
 
+                def end(gr):
+                    """capture_end; returns None instead of the graph when NOTHING was recorded in the stretch (the host
+                    library says so with a warning): such a segment keeps its bucket list and is never replayed."""
+                    import warnings
+                    with warnings.catch_warnings(record=True) as caught:
+                        warnings.simplefilter("always")
+                        gr.capture_end()
+                    for w in caught:
+                        if "Graph is empty" not in str(w.message):
+                            warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+                    if self._graph_pool is None:
+                        self._graph_pool = gr.pool()
+                    return None if any("Graph is empty" in str(w.message) for w in caught) else gr
+
                 def cut(bucket):
                     if getattr(red, "_last_cut_count", None) == red.write_count:
                         segs[-1][1].append(bucket)   # several buckets final at the same write: one cut, and they all
                         return                       # belong to the segment that just closed
                     cur[1].append(bucket)
                     red._last_cut_count = red.write_count
-                    cur[0].capture_end()
-                    if self._graph_pool is None:
-                        self._graph_pool = cur[0].pool()
-                    segs.append((cur[0], cur[1]))
+                    segs.append((end(cur[0]), cur[1]))
                     cur[0], cur[1] = torch.cuda.CUDAGraph(), []
                     begin(cur[0])
                 red.final_pos, red.write_count, red._last_cut_count = final_pos, 0, None
@@ -761,10 +773,9 @@ class Trainer:
                     with torch.cuda.stream(cs):
                         begin(cur[0])
                         out = self._fwd_bwd(sb, sd, trunc, cross)
-                        cur[0].capture_end()
-                        if self._graph_pool is None:
-                            self._graph_pool = cur[0].pool()
-                        segs.append((cur[0], cur[1]))
+                        tail = end(cur[0])
+                        if tail is not None or cur[1]:      # nothing after the last cut and no bucket left: no segment
+                            segs.append((tail, cur[1]))
                 finally:
                     red.on_bucket_final, red.final_pos = None, None
                     ag.GRAD_WRITTEN = None
@@ -774,6 +785,9 @@ class Trainer:
         self._invalidate_caches()             # cached casts now live in the graph's pool: eager code must re-make them
         self.reducer.arena.copy_(saved)
         self.reducer.begin_backward()
+        # (segments with a graph, segments that recorded nothing): asserted by tests/test_train_gpu.py
+        self.graph_segments = getattr(self, "graph_segments", {})
+        self.graph_segments[key] = (sum(1 for g_, _ in segs if g_ is not None), sum(1 for g_, _ in segs if g_ is None))
         ent = (sb, sd, flags, segs, out, spec)
         self._graphs[key] = ent
         return ent
