@@ -326,6 +326,21 @@ def test_sampler_hip_graph_matches_eager():
                                            dev(x["prev_motion"]), dev(x["prev_audio"]), motion_at_T=xT,
                                            indicator=dev(x["indicator"]), **kw)
             assert torch.equal(eager, graph), kw
+            # two LANES (each clip's chain of steps on a HIP stream of its own, forked / joined inside the captured graph;
+            # the default from 48 sequences per lane up): the same bits again
+            from msmd_amd import sampler as smp
+            model.__dict__.pop("_step_graphs", None)
+            with mock.patch.object(smp, "MIN_LANE_SEQS", 1), mock.patch.object(smp, "LANES", 2), \
+                    mock.patch("torch.randn_like", side_effect=lambda t: torch.zeros_like(t)):
+                laned, _, _ = model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]),
+                                           dev(x["prev_motion"]), dev(x["prev_audio"]), motion_at_T=xT,
+                                           indicator=dev(x["indicator"]), **kw)
+                assert next(iter(model._step_graphs.values())).lanes == 2
+            assert torch.equal(eager, laned), kw
+            model.__dict__.pop("_step_graphs", None)
+            with mock.patch("torch.randn_like", side_effect=lambda t: torch.zeros_like(t)):     # back to the one-lane graph
+                model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]), dev(x["prev_motion"]), dev(x["prev_audio"]),
+                             motion_at_T=xT, indicator=dev(x["indicator"]), **kw)
         # second call re-uses the cached graph with new operands
         with mock.patch("torch.randn_like", side_effect=lambda t: torch.zeros_like(t)):
             again, _, _ = model.sample(dev(x["audio_feat"]) * 0.5, dev(x["shape"]), dev(x["style"]), dev(x["prev_motion"]),

@@ -417,6 +417,16 @@ def test_trainer_segmented_hipgraph_matches_single_graph(monkeypatch):
     (segs,) = [ent[3] for ent in tr2._graphs.values()]
     nb = len(tr2.reducer.buckets)
     assert len(segs) >= 3 and nb >= 4
+    # segment accounting: one segment per distinct "bucket became final" write position; a stretch in which nothing was
+    # recorded (after the LAST gradient write there is nothing left to capture) holds no graph and is not replayed -- the
+    # host library's "The CUDA Graph is empty" warning of earlier rounds was exactly that stretch
+    (n_graphs, n_empty), = tr2.graph_segments.values()
+    assert n_graphs == sum(1 for g_, _ in segs if g_ is not None) and n_graphs >= 3
+    assert n_empty == sum(1 for g_, _ in segs if g_ is None) <= 1
+    assert all(bks for g_, bks in segs if g_ is None)                 # a graph-less segment exists only to carry buckets
+    assert sum(len(bks) for _, bks in segs) == nb                      # every bucket belongs to exactly one segment
+    (n1, e1), = tr1.graph_segments.values()
+    assert (n1, e1) == (1, 0)                                          # one-graph mode: one non-empty graph
     per_step = l2[: len(l2) // 2]
     assert sorted(set(per_step)) == list(range(nb))            # every bucket handed over (finish() re-visits are no-ops)
     early = [b for _, bks in segs[:-1] for b in bks]

@@ -724,22 +724,49 @@ class MSMD(nn.Module):
     # ------------------------------------------------------------------ static-shape replay
     @torch.no_grad()
     def capture_forward(self, motion_feat, audio, shape_feat, style_feat, time_step, indicator, eps,
-                        train_with_CFG=False, verify=True):
+                        train_with_CFG=False, verify=True, lanes=1):
         """Capture `forward` for these (static) shapes as ONE hipGraph and return `run(**new_inputs) -> outputs`.
         The ~300 launches of a forward are then re-issued by the GPU's command processor: host-side launch jitter
         disappears (it matters when several ranks share a host).  `run` copies any tensors it is given into the
         captured input buffers (device-to-device) and replays; the returned tensors are the graph's output buffers
         (valid until the next replay).  time_step must be a device LongTensor.  With `verify` the first replay is
-        checked bit for bit against the eager forward on perturbed inputs (a replay can never serve stale results)."""
+        checked bit for bit against the eager forward on perturbed inputs (a replay can never serve stale results).
+
+        ``lanes`` > 1: the batch is cut into that many contiguous groups of clips and every group runs the WHOLE forward on a
+        HIP stream of its own, forked and joined inside the one captured graph.  Clips are independent in every operator of
+        the path, so the results are those of the one-lane step, bit for bit (checked by `verify` against
+        the eager one-lane forward); what changes is the schedule: the under-filled phases of one lane's launches (300-tile
+        GEMM grids, the decoder's small grids, attention, every launch's tail and epilogue burst) run beside another
+        lane's K loops instead of beside nothing.  lanes must divide the batch."""
+        lanes = max(1, int(lanes))
+        if motion_feat.shape[0] % lanes:
+            raise ValueError(f"capture_forward: lanes={lanes} does not divide the batch of {motion_feat.shape[0]}")
         static = dict(motion_feat=motion_feat.clone(), audio=audio.clone(), shape_feat=shape_feat.clone(),
                       style_feat=style_feat.clone(), time_step=torch.as_tensor(time_step, device=self.device).long().clone(),
                       indicator=indicator.clone(), eps=eps.clone())
 
+        def one(sl=slice(None)):
+            return self.forward(static["motion_feat"][sl], static["audio"][sl], static["shape_feat"][sl], static["style_feat"][sl],
+                                time_step=static["time_step"][sl], indicator=static["indicator"][sl],
+                                train_with_CFG=train_with_CFG, eps=static["eps"][sl])
+        lane_streams = [torch.cuda.Stream() for _ in range(lanes)] if lanes > 1 else []
+
         def call():
-            return self.forward(static["motion_feat"], static["audio"], static["shape_feat"], static["style_feat"],
-                                time_step=static["time_step"], indicator=static["indicator"],
-                                train_with_CFG=train_with_CFG, eps=static["eps"])
-        call()                                       # lazy packing before any capture
+            if lanes == 1:
+                return one()
+            if train_with_CFG:
+                raise ValueError("capture_forward: lanes > 1 draws nothing inside the graph (train_with_CFG=False, eps given)")
+            cur = torch.cuda.current_stream()
+            per = static["motion_feat"].shape[0] // lanes
+            parts = []
+            for i, st in enumerate(lane_streams):        # fork: every lane starts behind the caller's stream ...
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    parts.append(one(slice(i * per, (i + 1) * per)))
+            for st in lane_streams:                      # ... and the caller's stream continues behind all of them
+                cur.wait_stream(st)
+            return tuple(torch.cat([p[k] for p in parts], dim=0) for k in range(len(parts[0])))
+        one()                                        # lazy packing before any capture
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -756,7 +783,7 @@ class MSMD(nn.Module):
             graph.replay()
             torch.cuda.synchronize()
             got = out[1].clone()
-            if not torch.equal(call()[1], got):
+            if not torch.equal(one()[1], got):       # the eager ONE-lane forward on the whole batch
                 raise RuntimeError("hipGraph replay of MSMD.forward differs from the eager forward")
             for k, v in keep.items():
                 static[k].copy_(v)

@@ -211,30 +211,39 @@ def sample(model, audio_or_feat, shape_feat, style_feat=None, prev_motion_feat=N
 STEPS_PER_GRAPH = min(50, max(1, int(os.environ.get("MSMD_SAMPLER_STEPS_PER_GRAPH", "10"))))
 
 
-class _StepGraph:
-    """k captured denoise steps (one hipGraph): device-side step counter, static operand buffers."""
+# Lanes: the batch of a hipGraph loop is cut into LANES contiguous groups of clips; every group runs its own chain of denoising
+# steps on a HIP stream of its own, forked and joined inside each captured graph.  Sequences are independent, so
+# every lane computes exactly what it would compute alone; the lanes drift against each other, and one lane's launch tails,
+# epilogue store bursts and small grids (person-token attention, heads, CFG / DDPM update) run under another lane's K loops.
+# Used from MIN_LANE_SEQS sequences per lane up (a lane must still fill the chip on its own); MSMD_SAMPLER_LANES=1 turns it off.
+LANES = min(4, max(1, int(os.environ.get("MSMD_SAMPLER_LANES", "2"))))
+MIN_LANE_SEQS = 48
 
-    def __init__(self, model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, like, dyn=None):
-        B = N // n_entries
-        self.x = torch.zeros(B, L, dm, device=dev, dtype=torch.float32)
-        self.prev_m = torch.zeros_like(like["prev_m"])
-        self.ind = torch.zeros_like(like["ind_in"]) if like["ind_in"] is not None else None
-        self.mem = torch.zeros_like(like["mem"])
-        self.kv = [torch.zeros_like(k) for k in like["kv_list"]]
-        self.cross = [torch.zeros_like(r) for r in like["cross_list"]] if like.get("cross_list") is not None else None
-        self.stat = torch.zeros_like(like["stat"])
-        self.tok = torch.zeros_like(like["tok_person"])
-        self.emb_all = torch.zeros_like(like["emb_all"])
-        self.scales = torch.zeros_like(like["scales"]) if like["scales"] is not None else None
-        self.coef_table = torch.zeros(T + 1, 3, device=dev, dtype=torch.float32)
+
+class _Lane:
+    """Static operand buffers + the step body of one lane (Bl clips x n_entries CFG entries, entry-major rows)."""
+
+    def __init__(self, net, dtype, dev, T, Bl, n_entries, Lp, L, dm, nb, mode, target, P, like, shared, rows, clips, dyn):
+        Nl = Bl * n_entries
+        take = lambda t: torch.zeros((len(rows),) + tuple(t.shape[1:]), device=dev, dtype=t.dtype)
+        self.rows, self.clips = rows, clips          # index tensors into the N-row / B-row operands of the whole batch
+        self.x = torch.zeros(Bl, L, dm, device=dev, dtype=torch.float32)
+        self.prev_m = take(like["prev_m"])
+        self.ind = take(like["ind_in"]) if like["ind_in"] is not None else None
+        self.mem = take(like["mem"])
+        self.kv = [take(k) for k in like["kv_list"]]
+        self.cross = [take(r) for r in like["cross_list"]] if like.get("cross_list") is not None else None
+        self.stat_per_clip = like["stat"].shape[0] == clips.numel() * shared["lanes"]
+        self.stat = (torch.zeros((Bl,) + tuple(like["stat"].shape[1:]), device=dev, dtype=like["stat"].dtype)
+                     if self.stat_per_clip else shared["stat"])
+        self.tok = take(like["tok_person"])
         self.t_dev = torch.zeros(1, device=dev, dtype=torch.int32)
-        self.emb_row = torch.zeros(self.emb_all.shape[-1], device=dev, dtype=self.emb_all.dtype)
+        self.emb_row = torch.zeros(shared["emb_all"].shape[-1], device=dev, dtype=shared["emb_all"].dtype)
         self.coefs = torch.zeros(3, device=dev, dtype=torch.float32)
-        self.feats = torch.zeros(N, 1 + Lp + L, P.kp_feat, device=dev, dtype=dtype)
-        self.T = T
+        self.feats = torch.zeros(Nl, 1 + Lp + L, P.kp_feat, device=dev, dtype=dtype)
 
         def body():
-            ops.sampler_step_select(self.emb_all, self.coef_table, self.t_dev, self.emb_row, self.coefs)
+            ops.sampler_step_select(shared["emb_all"], shared["coef_table"], self.t_dev, self.emb_row, self.coefs)
             ops.denoiser_pack_input(self.x, self.prev_m, self.ind, self.feats)
             dec = net.trunk(self.feats, self.tok, self.mem, dtype, kv_list=self.kv, row0_add=self.emb_row,
                             cross_list=self.cross)
@@ -243,14 +252,64 @@ class _StepGraph:
             if dyn:
                 res = ops.dynamic_threshold_(res.float().contiguous(), L, *dyn)
             z = torch.randn_like(self.x)  # graph-safe philox stream; sigma_1 = 0 reproduces z = 0 at t = 1
-            ops.cfg_ddpm_step_dev(self.x, res, z, self.scales, self.coefs, n_entries, Lp, mode, target)
+            ops.cfg_ddpm_step_dev(self.x, res, z, shared["scales"], self.coefs, n_entries, Lp, mode, target)
         self.body = body
+
+    def load(self, motion_at_T, ops_in):
+        self.x.copy_(motion_at_T[self.clips])
+        for name in ("prev_m", "mem"):
+            getattr(self, name).copy_(ops_in[name][self.rows])
+        if self.stat_per_clip:
+            self.stat.copy_(ops_in["stat"][self.clips])
+        self.tok.copy_(ops_in["tok_person"][self.rows])
+        if self.ind is not None:
+            self.ind.copy_(ops_in["ind_in"][self.rows])
+        for dst, src in zip(self.kv, ops_in["kv_list"]):
+            dst.copy_(src[self.rows])
+        if self.cross is not None:
+            for dst, src in zip(self.cross, ops_in["cross_list"]):
+                dst.copy_(src[self.rows])
+
+
+class _StepGraph:
+    """k captured denoise steps per lane (one hipGraph): device-side step counters, static operand buffers."""
+
+    def __init__(self, model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, like, dyn=None, lanes=1):
+        B = N // n_entries
+        self.lanes = lanes
+        self.shared = dict(lanes=lanes, emb_all=torch.zeros_like(like["emb_all"]), stat=torch.zeros_like(like["stat"]),
+                           scales=torch.zeros_like(like["scales"]) if like["scales"] is not None else None,
+                           coef_table=torch.zeros(T + 1, 3, device=dev, dtype=torch.float32))
+        Bl = B // lanes
+        self.lane = []
+        for l in range(lanes):
+            clips = torch.arange(l * Bl, (l + 1) * Bl, device=dev)
+            rows = torch.cat([clips + e * B for e in range(n_entries)])
+            self.lane.append(_Lane(net, dtype, dev, T, Bl, n_entries, Lp, L, dm, nb, mode, target, P, like, self.shared,
+                                   rows, clips, dyn))
+        self.T = T
+        self.streams = [torch.cuda.Stream() for _ in range(lanes)] if lanes > 1 else [None]
+
+        def bodies(k):
+            if lanes == 1:
+                for _ in range(k):
+                    self.lane[0].body()
+                return
+            cur = torch.cuda.current_stream()
+            for ln, st in zip(self.lane, self.streams):     # fork ... every lane records its k steps back to back ...
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    for _ in range(k):
+                        ln.body()
+            for st in self.streams:                         # ... join
+                cur.wait_stream(st)
         # warm-up on a side stream (allocator + lazy kernel loading), then capture
-        self.t_dev.fill_(1)
+        for ln in self.lane:
+            ln.t_dev.fill_(1)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            body()
+            bodies(1)
         torch.cuda.current_stream().wait_stream(side)
         # STEPS_PER_GRAPH consecutive denoising steps per captured graph (the step counter lives on the device, so the body is
         # simply recorded that many times): T / k replays instead of T.  k = the largest divisor of T up to the cap, so one
@@ -259,42 +318,40 @@ class _StepGraph:
         self.graph = torch.cuda.CUDAGraph()
         with ops.capture_guard():
             with torch.cuda.graph(self.graph):
-                for _ in range(self.k):
-                    body()
+                bodies(self.k)
 
     def run(self, T, motion_at_T, ops_in, coefficients):
-        self.x.copy_(motion_at_T)
-        for name in ("prev_m", "mem", "stat", "emb_all"):
-            getattr(self, name).copy_(ops_in[name])
-        self.tok.copy_(ops_in["tok_person"])
-        if self.ind is not None:
-            self.ind.copy_(ops_in["ind_in"])
-        if self.scales is not None:
-            self.scales.copy_(ops_in["scales"])
-        for dst, src in zip(self.kv, ops_in["kv_list"]):
-            dst.copy_(src)
-        if self.cross is not None:
-            for dst, src in zip(self.cross, ops_in["cross_list"]):
-                dst.copy_(src)
+        for ln in self.lane:
+            ln.load(motion_at_T, ops_in)
+        self.shared["emb_all"].copy_(ops_in["emb_all"])
+        self.shared["stat"].copy_(ops_in["stat"])
+        if self.shared["scales"] is not None:
+            self.shared["scales"].copy_(ops_in["scales"])
         tab = torch.zeros(T + 1, 3)
         for t in range(1, T + 1):
             c0, c1, sg = coefficients(t)
             tab[t, 0], tab[t, 1], tab[t, 2] = c0, c1, (sg if t > 1 else 0.0)
-        self.coef_table.copy_(tab)
-        self.t_dev.fill_(T)
+        self.shared["coef_table"].copy_(tab)
+        for ln in self.lane:
+            ln.t_dev.fill_(T)
         for _ in range(T // self.k):
             self.graph.replay()
-        return self.x.clone()
+        return torch.cat([ln.x for ln in self.lane], dim=0) if self.lanes > 1 else self.lane[0].x.clone()
 
 
 def _graph_loop(model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, motion_at_T, prev_m, ind_in,
                 mem, kv_list, stat, tok_person, emb_all, scales, coefficients, dyn=None, cross_list=None):
     like = dict(prev_m=prev_m, ind_in=ind_in, mem=mem, kv_list=kv_list, cross_list=cross_list, stat=stat, tok_person=tok_person,
                 emb_all=emb_all, scales=scales)
-    key = (T, N, n_entries, Lp, L, mode, target, dtype, ind_in is not None, getattr(net, "_pack_gen", 0), dyn, cross_list is not None, STEPS_PER_GRAPH)
+    B = N // n_entries
+    lanes = getattr(model, "sampler_lanes", LANES)
+    while lanes > 1 and (B % lanes or N // lanes < MIN_LANE_SEQS):
+        lanes -= 1
+    key = (T, N, n_entries, Lp, L, mode, target, dtype, ind_in is not None, getattr(net, "_pack_gen", 0), dyn, cross_list is not None,
+           STEPS_PER_GRAPH, lanes)
     cache = model.__dict__.setdefault("_step_graphs", {})
     g = cache.get(key)
     if g is None:
         cache.clear()  # one resident graph (its private memory pool holds all step intermediates)
-        g = cache[key] = _StepGraph(model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, like, dyn)
+        g = cache[key] = _StepGraph(model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, like, dyn, lanes)
     return g.run(T, motion_at_T.float(), like, coefficients)
