@@ -37,4 +37,4 @@ for rep in range(7):
 base = outs[lanes[0]]
 for n in runs:
     r = sorted(res[n])
-    print(f"lanes {n}: median {r[len(r) // 2]:.3f} ms/step  min {r[0]:.3f}   output {'== lanes ' + str(lanes[0]) if torch.equal(outs[n], base) else 'differs: max %.3g' % float((outs[n].float() - base.float()).abs().max())}")
+    print(f"lanes {n}: drift vs one lane {runs[n].lane_drift:.3g}  median {r[len(r) // 2]:.3f} ms/step  min {r[0]:.3f}   output {'== lanes ' + str(lanes[0]) if torch.equal(outs[n], base) else 'differs: max %.3g' % float((outs[n].float() - base.float()).abs().max())}")

@@ -12,24 +12,27 @@ from msmd_amd.config import synthetic_args
 from msmd_amd.model import DiffusionSchedule, get_diffusion_model
 
 T, B = int(os.environ.get("T", "200")), int(os.environ.get("B", "64"))
-lanes = [int(x) for x in os.environ.get("LANES", "1,2,4").split(",")]
+lanes = [int(x) for x in os.environ.get("LANES", "1,2").split(",")]
+fused = [bool(int(x)) for x in os.environ.get("FUSED", "0,1").split(",")]      # msmd_cross_row0_ln on / off
+lanes = [(n, f) for f in fused for n in lanes]
 model = get_diffusion_model(synthetic_args(compute_dtype=os.environ.get("DTYPE", "fp16")), "cuda").eval()
 model.diffusion_sched = DiffusionSchedule(T, "cosine").to("cuda")
 af = torch.randn(B, 100, 512, device="cuda"); shape = torch.zeros(B, 100, device="cuda"); style = torch.randn(B, 256, device="cuda")
 ind = torch.ones(B, 100, device="cuda")
 res = {n: [] for n in lanes}
 for rep in range(3):
-    for n in lanes:
+    for n, f in lanes:
         model.sampler_lanes = n
+        model.denoising_net.fused_cross_row0 = f
         model.__dict__.pop("_step_graphs", None)
         x, _, _ = model.sample(af, shape, style, indicator=ind, cfg_scale=1.15)  # capture + warm-up
         torch.cuda.synchronize(); t0 = time.perf_counter()
         x, _, _ = model.sample(af, shape, style, indicator=ind, cfg_scale=1.15)
-        torch.cuda.synchronize(); res[n].append((time.perf_counter() - t0) / T * 1e3)
+        torch.cuda.synchronize(); res[n, f].append((time.perf_counter() - t0) / T * 1e3)
         assert bool(torch.isfinite(x).all())
         used = next(iter(model._step_graphs.values())).lanes
         if rep == 0:
             print(f"lanes asked {n}, used {used}")
-for n in lanes:
-    r = sorted(res[n])
-    print(f"lanes {n}: {r[len(r) // 2]:.3f} ms/step (min {r[0]:.3f}) B={B} T={T}")
+for n, f in lanes:
+    r = sorted(res[n, f])
+    print(f"lanes {n} cross_row0_ln {int(f)}: {r[len(r) // 2]:.3f} ms/step (min {r[0]:.3f}) B={B} T={T}")

@@ -65,9 +65,52 @@ __global__ void add_pe_token_kernel(T* __restrict__ x, const float* __restrict__
   }
 }
 
+// the same on 16-bit rows with d % 8 == 0: 8 elements (one 16-byte access) per thread, the same arithmetic per element
+template <typename T>
+__global__ __launch_bounds__(256) void add_pe_token_v8_kernel(T* __restrict__ x, const float* __restrict__ pe,
+                                                              const T* __restrict__ tok0, const T* __restrict__ row0_add,
+                                                              int Tn, int d) {
+  typedef typename Vec8T<T>::type V8;
+  const int n = blockIdx.y, per_row = d >> 3;
+  const int i8 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i8 >= Tn * per_row) return;
+  const int t = i8 / per_row, c = (i8 - t * per_row) << 3;
+  T* xp = x + ((long)n * Tn + t) * d + c;
+  float base[8];
+  if (t == 0) {
+    const V8 tk = *(const V8*)(tok0 + (long)n * d + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) base[e] = (float)tk[e];
+    if (row0_add) {
+      const V8 ra = *(const V8*)(row0_add + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) base[e] += (float)ra[e];
+    }
+  } else {
+    const V8 xv = *(const V8*)xp;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) base[e] = (float)xv[e];
+  }
+  const f32x4 p0 = *(const f32x4*)(pe + (long)t * d + c), p1 = *(const f32x4*)(pe + (long)t * d + c + 4);
+  V8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = (T)(base[e] + p0[e]); o[4 + e] = (T)(base[4 + e] + p1[e]); }
+  *(V8*)xp = o;
+}
+
 extern "C" int msmd_add_pe_token(void* x, const float* pe, const void* tok0, const void* row0_add, int N, int T, int d,
                                  int dtype, msmd_stream_t stream) {
   if (N <= 0 || T <= 0 || d <= 0 || !tok0) return 1;
+  if (dtype != MSMD_F32 && (d & 7) == 0 && !(((uintptr_t)x | (uintptr_t)pe | (uintptr_t)tok0 | (uintptr_t)row0_add) & 15)) {
+    dim3 grid8((T * (d >> 3) + 255) / 256, N);
+    if (dtype == MSMD_F16)
+      hipLaunchKernelGGL(add_pe_token_v8_kernel<f16_t>, grid8, dim3(256), 0, (hipStream_t)stream, (f16_t*)x, pe,
+                         (const f16_t*)tok0, (const f16_t*)row0_add, T, d);
+    else
+      hipLaunchKernelGGL(add_pe_token_v8_kernel<bf16_t>, grid8, dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, pe,
+                         (const bf16_t*)tok0, (const bf16_t*)row0_add, T, d);
+    MSMD_RETURN_LAST();
+  }
   dim3 grid((T * d + 255) / 256, N), block(256);
   if (dtype == MSMD_F32)
     hipLaunchKernelGGL(add_pe_token_kernel<float>, grid, block, 0, (hipStream_t)stream, (float*)x, pe,

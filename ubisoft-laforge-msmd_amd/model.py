@@ -404,7 +404,12 @@ class DenoisingNetwork_MSMD(nn.Module):
             if not fold_n1:
                 x = ops.layernorm(u1, *L.n1)
             kv = kv_list[li] if kv_list is not None else ops.gemm(mem, L.ca_kvw, L.ca_kvb)
-            if diag:
+            if diag and fold_n1 and d == 512 and H == 8 and kv.shape[1] <= 128 and getattr(self, "fused_cross_row0", True):
+                # norm1 -> person-token cross-attention + out-projection -> norm2 in ONE launch (rows t >= 1 stream through
+                # the same launch beside the 192 person-token chains): three launches of the step less per layer
+                x = ops.cross_row0_ln(u1, L.f_caq[0], L.f_caq[2], L.f_caq[1], kv, L.ca_ow, L.ca_ob, cross_list[li],
+                                      *L.n1, *L.n2, H, scale)
+            elif diag:
                 # only the person token (row 0) has a real softmax; rows t >= 1 come from the precomputed R
                 R = cross_list[li]
                 # same-box A/B in the sampler graph: fused -1 % at N = 192 sequences, +1.5 % at N = 3 (a longer serial
@@ -734,10 +739,12 @@ class MSMD(nn.Module):
 
         ``lanes`` > 1: the batch is cut into that many contiguous groups of clips and every group runs the WHOLE forward on a
         HIP stream of its own, forked and joined inside the one captured graph.  Clips are independent in every operator of
-        the path, so the results are those of the one-lane step, bit for bit (checked by `verify` against
-        the eager one-lane forward); what changes is the schedule: the under-filled phases of one lane's launches (300-tile
-        GEMM grids, the decoder's small grids, attention, every launch's tail and epilogue burst) run beside another
-        lane's K loops instead of beside nothing.  lanes must divide the batch."""
+        the path, so every lane's result IS `forward` of its group of clips, bit for bit (checked by `verify`
+        against the eager per-group forwards); against the one-lane forward of the whole batch the 16-bit modes differ in
+        last bits only (row-statistics slabs and tile shapes follow the row count of a launch), which `run.lane_drift`
+        reports.  What changes is the schedule: the under-filled phases of one lane's launches (300-tile GEMM grids, the
+        decoder's small grids, attention, every launch's tail and epilogue burst) run beside another lane's K loops
+        instead of beside nothing.  lanes must divide the batch."""
         lanes = max(1, int(lanes))
         if motion_feat.shape[0] % lanes:
             raise ValueError(f"capture_forward: lanes={lanes} does not divide the batch of {motion_feat.shape[0]}")
@@ -783,8 +790,9 @@ class MSMD(nn.Module):
             graph.replay()
             torch.cuda.synchronize()
             got = out[1].clone()
-            if not torch.equal(one()[1], got):       # the eager ONE-lane forward on the whole batch
+            if not torch.equal(call()[1], got):      # the eager forward(s) of the same group(s) of clips
                 raise RuntimeError("hipGraph replay of MSMD.forward differs from the eager forward")
+            drift = float((one()[1].float() - got.float()).abs().max()) if lanes > 1 else 0.0
             for k, v in keep.items():
                 static[k].copy_(v)
 
@@ -794,6 +802,7 @@ class MSMD(nn.Module):
             graph.replay()
             return out
         run.graph, run.static = graph, static
+        run.lanes, run.lane_drift = lanes, (drift if verify else None)   # max |lanes - one-lane| on the verification inputs
         return run
 
     # ------------------------------------------------------------------ sampler
