@@ -225,20 +225,6 @@ int msmd_person_query_attention_ln(const void* x, long x_seq_stride, const void*
                                    long kv_tstride, void* out, int N, int H, int Tk, int d, float scale, int dtype,
                                    msmd_stream_t stream);
 
-/* norm1 -> cross-attention branch -> norm2 of a post-LN decoder layer in ONE launch under the diagonal alignment mask
- * (reference model.py:874-878 nn.TransformerDecoderLayer; utils/model_common.py:103-107 mask of width 1):
- *   x[n, t] = LN2(LN1(u[n, t]) + R[n, t])  for t >= 1  (R = V[t - 1] Wo^T + bo: step-invariant, precomputed),
- *   x[n, 0] = LN2(LN1(u[n, 0]) + softmax(scale q K^T) V Wo^T + bo),  q = LN1(u[n, 0]) Wq^T + bq  (the person token).
- * u, R, x: (N, Tn, 512) rows of `dtype` (MSMD_F16 | MSMD_BF16; x aliases neither); [K | V] rows (1024 elements) at
- * KV + n*kv_bstride + t*kv_tstride, Tk <= 128;
- * Wq / bq / wq_colsum: the norm1-folded query projection (msmd_gemm_ln's operand form); Wo (512, 512) / bo; g1 / b1 / g2 / b2:
- * norm1 / norm2 (fp32).  d = 512, H = 8 only.  Replaces msmd_person_query_attention_ln + a 1-row-per-sequence msmd_gemm +
- * msmd_layernorm_pre of the sampler's step. */
-int msmd_cross_row0_ln(const void* u, const void* Wq, const float* bq, const float* wq_colsum, const void* KV, const void* Wo,
-                       const float* bo, const void* R, const float* g1, const float* b1, const float* g2, const float* b2,
-                       void* x, int N, int Tn, int Tk, long kv_bstride, long kv_tstride, int d, int H, float scale, float eps,
-                       int dtype, msmd_stream_t stream);
-
 /* Training-mode attention forward: as msmd_attention with attention-probability dropout p_drop (HF
  * attention_dropout, nn.MultiheadAttention(dropout=0.1) inside the decoder / encoder layers).  The keep mask is
  * Philox4x32-10(seed = rng_state[0], step = rng_state[1], site, counter = ((b H + h) Tq + q) * 128 + 4 * (key / 32) + (key / 4) % 4):

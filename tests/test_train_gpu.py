@@ -422,7 +422,7 @@ def test_trainer_segmented_hipgraph_matches_single_graph(monkeypatch):
     # host library's "The CUDA Graph is empty" warning of earlier rounds was exactly that stretch
     (n_graphs, n_empty), = tr2.graph_segments.values()
     assert n_graphs == sum(1 for g_, _ in segs if g_ is not None) and n_graphs >= 3
-    assert n_empty == sum(1 for g_, _ in segs if g_ is None) <= 1
+    assert n_empty == sum(1 for g_, _ in segs if g_ is None) < n_graphs      # consecutive final writes with no launch between them
     assert all(bks for g_, bks in segs if g_ is None)                 # a graph-less segment exists only to carry buckets
     assert sum(len(bks) for _, bks in segs) == nb                      # every bucket belongs to exactly one segment
     (n1, e1), = tr1.graph_segments.values()

@@ -13,7 +13,7 @@ from msmd_amd.model import DiffusionSchedule, get_diffusion_model
 
 T, B = int(os.environ.get("T", "200")), int(os.environ.get("B", "64"))
 lanes = [int(x) for x in os.environ.get("LANES", "1,2").split(",")]
-fused = [bool(int(x)) for x in os.environ.get("FUSED", "0,1").split(",")]      # msmd_cross_row0_ln on / off
+fused = [False]
 lanes = [(n, f) for f in fused for n in lanes]
 model = get_diffusion_model(synthetic_args(compute_dtype=os.environ.get("DTYPE", "fp16")), "cuda").eval()
 model.diffusion_sched = DiffusionSchedule(T, "cosine").to("cuda")

@@ -964,6 +964,128 @@ __global__ __launch_bounds__(256) void person_query_attention_kernel(const T* __
   }
 }
 
+
+// Weight-stationary form for many sequences (the sampler's N = 96 .. 192): the kernel above reads a head's 64 x d slice of Wq
+// once per (sequence, head) wave -- N x d x d x 2 B = 100 MB through the L2s at N = 192, which is what its 22 us are.  Here a
+// workgroup owns ONE head and 8 sequences (a wave each): the slice is staged into LDS once (64 KB, 16-byte linear copies, rows
+// XOR-swizzled by (row & 7) x 16 B so the projection's 8-row x 128-byte reads spread over all banks), then every wave runs
+// the projection out of LDS and the Tq = 1 attention as above.  L2 traffic: N / 8 x d x d x 2 B = 12.6 MB.  d = 512, 16-bit.
+template <typename T>
+__global__ __launch_bounds__(512) void person_query_attention_ws_kernel(const T* __restrict__ x, long x_seq_stride,
+                                                                        const T* __restrict__ Wq, const float* __restrict__ bq,
+                                                                        const T* __restrict__ K, const T* __restrict__ V,
+                                                                        long kv_bstride, long kv_tstride, T* __restrict__ out,
+                                                                        int N, int Tk, float scale,
+                                                                        const float* __restrict__ wq_colsum, float ln_eps) {
+  constexpr int D = 512, NIT = 16;
+  typedef typename Vec8T<T>::type V8;
+  __shared__ __attribute__((aligned(16))) T s_w[64 * D];      // 64 KB: row r, 16-byte chunk j at chunk index r*64 + (j ^ (r & 7))
+  __shared__ float sq[8][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int g = lane >> 3, c = lane & 7;
+  const int h = blockIdx.x, n = blockIdx.y * 8 + wid;
+  const bool live = n < N;
+  const int nn = live ? n : N - 1;
+  // the K stream and the token row do not depend on the weights: requested before the slice is staged
+  const T* kbase = K + (long)nn * kv_bstride + h * 64 + c * 8;
+  const T* vbase = V + (long)nn * kv_bstride + h * 64 + c * 8;
+  u32x4 kraw[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+    if (it * 8 < Tk) kraw[it] = *(const u32x4*)(kbase + (long)min(it * 8 + g, Tk - 1) * kv_tstride);
+  const T* x0 = x + (long)nn * x_seq_stride;
+  {
+    const u32x4* src = (const u32x4*)(Wq + (long)h * 64 * D);
+    u32x4* dst = (u32x4*)s_w;
+    u32x4 tmp[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tmp[k] = src[k * 512 + threadIdx.x];      // 4096 chunks of 16 B, linear
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ch = k * 512 + threadIdx.x, r = ch >> 6, j = ch & 63;
+      dst[r * 64 + (j ^ (r & 7))] = tmp[k];
+    }
+  }
+  __syncthreads();
+  float qv[8];
+#pragma unroll
+  for (int rb = 0; rb < 8; ++rb) qv[rb] = 0.f;
+  float xs1 = 0.f, xs2 = 0.f;
+#pragma unroll 2
+  for (int i = 0; i < 8; ++i) {      // (not fully unrolled: 64 LDS reads in flight at once would not fit the registers)
+    float xv[8];
+    const V8 xr = *(const V8*)(x0 + (c + 8 * i) * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { xv[e] = (float)xr[e]; xs1 += xv[e]; xs2 = fmaf(xv[e], xv[e], xs2); }
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb) {
+      const int r = rb * 8 + g, j = c + 8 * i;
+      const V8 wv = *(const V8*)(s_w + ((long)r * 64 + (j ^ (r & 7))) * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[rb] = fmaf(xv[e], (float)wv[e], qv[rb]);
+    }
+  }
+  float ln_mu = 0.f, ln_rs = 1.f;
+  if (wq_colsum) {
+    ln_mu = group8_sum(xs1) * (1.0f / D);
+    ln_rs = rsqrtf(fmaxf(group8_sum(xs2) * (1.0f / D) - ln_mu * ln_mu, 0.f) + ln_eps);
+  }
+#pragma unroll
+  for (int rb = 0; rb < 8; ++rb) {
+    float t = group8_sum(qv[rb]);
+    const int r = h * 64 + rb * 8 + g;
+    if (wq_colsum) t = ln_rs * (t - ln_mu * wq_colsum[r]);
+    if (c == 0) sq[wid][rb * 8 + g] = (t + (bq ? bq[r] : 0.f)) * scale;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float q8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) q8[e] = sq[wid][c * 8 + e];
+  float sc[NIT];
+  float m = -INFINITY;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int key = it * 8 + g;
+    sc[it] = -INFINITY;
+    if (it * 8 < Tk) {
+      const V8 v8 = __builtin_bit_cast(V8, kraw[it]);
+      float a = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a = fmaf(q8[e], (float)v8[e], a);
+      a = group8_sum(a);
+      if (key < Tk) { sc[it] = a; m = fmaxf(m, a); }
+    }
+  }
+  m = wave_max(m);
+  float l = 0.f, o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int key = it * 8 + g;
+    if (it * 8 < Tk) {
+      const float pv = key < Tk ? __expf(sc[it] - m) : 0.f;
+      l += pv;
+      const V8 v8 = *(const V8*)(vbase + (long)min(key, Tk - 1) * kv_tstride);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = fmaf(pv, (float)v8[e], o[e]);
+    }
+  }
+  l = wave_sum(l) * 0.125f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float t = o[e];
+    t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+    o[e] = t / l;
+  }
+  if (g == 0 && live) {
+    V8 ov;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ov[e] = (T)o[e];
+    *(V8*)(out + (long)n * D + h * 64 + c * 8) = ov;
+  }
+}
+
 static int person_query_impl(const void* x, long x_seq_stride, const void* Wq, const float* bq, const void* K,
                              const void* V, long kv_bstride, long kv_tstride, void* out, int N, int H, int Tk, int d,
                              float scale, int dtype, msmd_stream_t stream, const float* wq_colsum, float ln_eps) {
@@ -972,8 +1094,20 @@ static int person_query_impl(const void* x, long x_seq_stride, const void* Wq, c
   if (x_seq_stride % E || kv_bstride % E || kv_tstride % E || ((uintptr_t)x & 15) || ((uintptr_t)Wq & 15) ||
       ((uintptr_t)K & 15) || ((uintptr_t)V & 15))
     return 1;
-  const dim3 grid((N * H + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
+  if (d == 512 && Tk <= 128 && N >= 32 && dtype != MSMD_F32) {      // many sequences: a head's weight slice staged once per 8 of them
+    const dim3 gws(H, (N + 7) / 8);
+    if (dtype == MSMD_F16)
+      hipLaunchKernelGGL(person_query_attention_ws_kernel<f16_t>, gws, dim3(512), 0, st, (const f16_t*)x, x_seq_stride,
+                         (const f16_t*)Wq, bq, (const f16_t*)K, (const f16_t*)V, kv_bstride, kv_tstride, (f16_t*)out, N, Tk, scale,
+                         wq_colsum, ln_eps);
+    else
+      hipLaunchKernelGGL(person_query_attention_ws_kernel<bf16_t>, gws, dim3(512), 0, st, (const bf16_t*)x, x_seq_stride,
+                         (const bf16_t*)Wq, bq, (const bf16_t*)K, (const bf16_t*)V, kv_bstride, kv_tstride, (bf16_t*)out, N, Tk,
+                         scale, wq_colsum, ln_eps);
+    MSMD_RETURN_LAST();
+  }
+  const dim3 grid((N * H + 3) / 4), block(256);
 #define LAUNCH_PQA(T)                                                                                                  \
   do {                                                                                                                 \
     if (Tk <= 128)                                                                                                     \
@@ -1009,241 +1143,3 @@ extern "C" int msmd_person_query_attention_ln(const void* x, long x_seq_stride, 
                            wq_colsum, ln_eps);
 }
 
-
-// ---------------------------------------------------------------------------------------------------
-// norm1 -> cross-attention branch -> norm2 of a post-LN decoder layer in ONE launch, for the diagonal alignment mask
-// (reference model.py:874-878 nn.TransformerDecoderLayer; utils/model_common.py:103-107 mask of width 1):
-//   x[n, t] = LN2( LN1(u[n, t]) + R[n, t] )                                  rows t >= 1: R = V[t - 1] Wo^T + bo, step-invariant
-//   x[n, 0] = LN2( LN1(u[n, 0]) + softmax(q K^T) V Wo^T + bo ),  q = LN1(u[n, 0]) Wq^T + bq   the person token, the one real softmax
-// u = the un-normalised rows the self-attention out-projection stored.  It replaces three launches of the sampler's step
-// (person_query_attention 22 us, a 192-row out-projection GEMM 10 us, layernorm_pre 21 us: two latency chains and an HBM
-// pass one after the other) by one whose workgroups 0 .. N-1 run the person-token chain of one sequence each (8 waves = 8
-// heads; query projection through the LayerNorm-folded weights, scores, softmax, P V, then the out-projection and both
-// LayerNorms of that one row inside the workgroup) while the remaining workgroups stream the N x (Tn - 1) other rows (a wave
-// per row, 16-byte accesses) on the rest of the chip.  d = 512, H = 8 (the decoder's geometry), 16-bit rows.
-template <typename T>
-__global__ __launch_bounds__(512, 4) void cross_row0_ln_kernel(const T* __restrict__ u, const T* __restrict__ Wq,
-                                                            const float* __restrict__ bq, const float* __restrict__ wq_colsum,
-                                                            const T* __restrict__ KV, const T* __restrict__ Wo,
-                                                            const float* __restrict__ bo, const T* __restrict__ R,
-                                                            const float* __restrict__ g1, const float* __restrict__ b1,
-                                                            const float* __restrict__ g2, const float* __restrict__ b2,
-                                                            T* __restrict__ x, int N, int Tn, int Tk, float scale, float eps,
-                                                            long kv_bs, long kv_ts) {
-  constexpr int D = 512, H = 8;
-  typedef typename Vec8T<T>::type V8;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if ((int)blockIdx.x >= N) {
-    // ---- rows t >= 1: two rows per wave (all four 16-byte loads in flight before the first use: this path shares its register
-    // allocation with the person-token path, so few waves fit a SIMD), a whole 1 KiB row per access
-    const long total = (long)N * (Tn - 1);
-    const long r0 = ((long)(blockIdx.x - N) * 8 + wid) * 2;
-    if (r0 >= total) return;
-    const bool two = r0 + 1 < total;
-    long off[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const long r = min(r0 + k, total - 1);
-      off[k] = ((r / (Tn - 1)) * Tn + 1 + r % (Tn - 1)) * D + lane * 8;
-    }
-    V8 uv[2], rv[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) { uv[k] = *(const V8*)(u + off[k]); rv[k] = *(const V8*)(R + off[k]); }
-    float ga1[8], be1[8], ga2[8], be2[8];
-    *(f32x4*)ga1 = *(const f32x4*)(g1 + lane * 8); *(f32x4*)(ga1 + 4) = *(const f32x4*)(g1 + lane * 8 + 4);
-    *(f32x4*)be1 = *(const f32x4*)(b1 + lane * 8); *(f32x4*)(be1 + 4) = *(const f32x4*)(b1 + lane * 8 + 4);
-    *(f32x4*)ga2 = *(const f32x4*)(g2 + lane * 8); *(f32x4*)(ga2 + 4) = *(const f32x4*)(g2 + lane * 8 + 4);
-    *(f32x4*)be2 = *(const f32x4*)(b2 + lane * 8); *(f32x4*)(be2 + 4) = *(const f32x4*)(b2 + lane * 8 + 4);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (k == 1 && !two) break;
-      float v[8], s = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { v[e] = (float)uv[k][e]; s += v[e]; }
-      const float mean0 = wave_sum(s) * (1.0f / D);
-      float q0 = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const float dd = v[e] - mean0; q0 = fmaf(dd, dd, q0); }
-      const float rstd0 = 1.0f / sqrtf(wave_sum(q0) * (1.0f / D) + eps);
-      s = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {     // norm1 rounded to the storage type (what a separate LayerNorm launch would have stored)
-        v[e] = (float)(T)((v[e] - mean0) * rstd0 * ga1[e] + be1[e]) + (float)rv[k][e];
-        s += v[e];
-      }
-      const float mean = wave_sum(s) * (1.0f / D);
-      float q = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const float dd = v[e] - mean; q = fmaf(dd, dd, q); }
-      const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
-      V8 ov;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) ov[e] = (T)((v[e] - mean) * rstd * ga2[e] + be2[e]);
-      *(V8*)(x + off[k]) = ov;
-    }
-    return;
-  }
-  // ---- the person token of sequence n: wave = head
-  __shared__ float s_q[H][64];
-  __shared__ float s_a0[D];
-  __shared__ float s_y[D];
-  __shared__ float s_red[2][H];
-  const int n = blockIdx.x, h = wid;
-  const int g = lane >> 3, c = lane & 7;
-  const T* u0 = u + (long)n * Tn * D;
-  const T* kbase = KV + (long)n * kv_bs + h * 64 + c * 8;
-  const T* vbase = kbase + D;
-  constexpr int NIT = 16;                      // Tk <= 128 keys, 8 per iteration
-  // 4 waves per SIMD (<= 128 registers): a streaming workgroup of the rows t >= 1 must fit a CU beside a person-token one, or
-  // the 192 CUs these chains occupy for ~25 us would stream nothing.  So only K is requested before the projection (it does
-  // not depend on the query); V is read after the scores, all 16 pieces at once.
-  u32x4 kraw[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it)
-    if (it * 8 < Tk) kraw[it] = *(const u32x4*)(kbase + (long)min(it * 8 + g, Tk - 1) * kv_ts);
-  float qv[8];
-#pragma unroll
-  for (int rb = 0; rb < 8; ++rb) qv[rb] = 0.f;
-  float xs1 = 0.f, xs2 = 0.f;
-  for (int i = 0; i < D / 64; ++i) {
-    float xv[8];
-    load8<T>(u0 + (c + 8 * i) * 8, xv);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { xs1 += xv[e]; xs2 = fmaf(xv[e], xv[e], xs2); }
-#pragma unroll
-    for (int rb = 0; rb < 8; ++rb) {
-      float wv[8];
-      load8<T>(Wq + (long)(h * 64 + rb * 8 + g) * D + (c + 8 * i) * 8, wv);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) qv[rb] = fmaf(xv[e], wv[e], qv[rb]);
-    }
-  }
-  const float ln_mu = group8_sum(xs1) * (1.0f / D);
-  const float ln_rs = rsqrtf(fmaxf(group8_sum(xs2) * (1.0f / D) - ln_mu * ln_mu, 0.f) + eps);
-#pragma unroll
-  for (int rb = 0; rb < 8; ++rb) {
-    float t = group8_sum(qv[rb]);
-    const int r = h * 64 + rb * 8 + g;
-    t = ln_rs * (t - ln_mu * wq_colsum[r]);
-    if (c == 0) s_q[h][rb * 8 + g] = (t + bq[r]) * scale;
-  }
-  __builtin_amdgcn_wave_barrier();
-  float q8[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) q8[e] = s_q[h][c * 8 + e];
-  float sc[NIT];
-  float m = -INFINITY;
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int key = it * 8 + g;
-    sc[it] = -INFINITY;
-    if (it * 8 < Tk) {
-      const V8 v8 = __builtin_bit_cast(V8, kraw[it]);
-      float a = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) a = fmaf(q8[e], (float)v8[e], a);
-      a = group8_sum(a);
-      if (key < Tk) { sc[it] = a; m = fmaxf(m, a); }
-    }
-  }
-  m = wave_max(m);
-  float l = 0.f, o[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = 0.f;
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int key = it * 8 + g;
-    if (it * 8 < Tk) {
-      const float pv = key < Tk ? __expf(sc[it] - m) : 0.f;
-      l += pv;
-      const V8 v8 = *(const V8*)(vbase + (long)min(key, Tk - 1) * kv_ts);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = fmaf(pv, (float)v8[e], o[e]);
-    }
-  }
-  l = wave_sum(l) * 0.125f;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float t = o[e];
-    t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
-    o[e] = t / l;
-  }
-  if (g == 0) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s_a0[h * 64 + c * 8 + e] = (float)(T)o[e];   // rounded as the attention output a GEMM would read
-  }
-  __syncthreads();
-  // ---- out-projection of the one row: wave h owns outputs h*64 .. h*64+63, same lane geometry as the query projection
-  float rv[8];
-#pragma unroll
-  for (int rb = 0; rb < 8; ++rb) rv[rb] = 0.f;
-  for (int i = 0; i < D / 64; ++i) {
-    float av[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) av[e] = s_a0[(c + 8 * i) * 8 + e];
-#pragma unroll
-    for (int rb = 0; rb < 8; ++rb) {
-      float wv[8];
-      load8<T>(Wo + (long)(h * 64 + rb * 8 + g) * D + (c + 8 * i) * 8, wv);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) rv[rb] = fmaf(av[e], wv[e], rv[rb]);
-    }
-  }
-#pragma unroll
-  for (int rb = 0; rb < 8; ++rb) {
-    const float t = group8_sum(rv[rb]);
-    const int j = h * 64 + rb * 8 + g;
-    if (c == 0) {
-      // y = LN1(u0)[j] (rounded to storage, as rows t >= 1) + the branch (rounded as the R rows are)
-      const float y1 = (float)(T)(((float)u0[j] - ln_mu) * ln_rs * g1[j] + b1[j]);
-      s_y[j] = y1 + (float)(T)(t + bo[j]);
-    }
-  }
-  __syncthreads();
-  // ---- norm2 of the row: one element per thread
-  const int j = threadIdx.x;
-  const float y = s_y[j];
-  float s = wave_sum(y);
-  if (lane == 0) s_red[0][wid] = s;
-  __syncthreads();
-  float tot = 0.f;
-#pragma unroll
-  for (int w = 0; w < H; ++w) tot += s_red[0][w];
-  const float mean = tot * (1.0f / D);
-  const float dd = y - mean;
-  s = wave_sum(dd * dd);
-  if (lane == 0) s_red[1][wid] = s;
-  __syncthreads();
-  tot = 0.f;
-#pragma unroll
-  for (int w = 0; w < H; ++w) tot += s_red[1][w];
-  const float rstd = 1.0f / sqrtf(tot * (1.0f / D) + eps);
-  x[(long)n * Tn * D + j] = (T)(dd * rstd * g2[j] + b2[j]);
-}
-
-// see cross_row0_ln_kernel.  u / R / x: (N, Tn, 512) 16-bit rows (x may alias neither); KV: [K | V] rows of the audio memory
-// at KV + n kv_bstride + t kv_tstride (1024 elements each, Tk <= 128); Wq / bq / wq_colsum: the norm1-folded query projection (msmd_gemm_ln's operand form); Wo / bo:
-// the cross-attention out-projection; g1 / b1 / g2 / b2: norm1 / norm2.  H = 8 heads of 64.
-extern "C" int msmd_cross_row0_ln(const void* u, const void* Wq, const float* bq, const float* wq_colsum, const void* KV,
-                                  const void* Wo, const float* bo, const void* R, const float* g1, const float* b1,
-                                  const float* g2, const float* b2, void* x, int N, int Tn, int Tk, long kv_bstride,
-                                  long kv_tstride, int d, int H, float scale, float eps, int dtype, msmd_stream_t stream) {
-  if (N <= 0 || Tn < 2 || Tk <= 0 || Tk > 128 || d != 512 || H != 8 || kv_tstride < 2 * d || (kv_tstride & 7) || (kv_bstride & 7) || !u || !Wq || !bq || !wq_colsum || !KV || !Wo || !bo ||
-      !R || !g1 || !b1 || !g2 || !b2 || !x || x == u || x == R)
-    return 1;
-  if (((uintptr_t)u | (uintptr_t)Wq | (uintptr_t)KV | (uintptr_t)Wo | (uintptr_t)R | (uintptr_t)x | (uintptr_t)g1 | (uintptr_t)b1 |
-       (uintptr_t)g2 | (uintptr_t)b2) & 15)
-    return 1;
-  const long rows = (long)N * (Tn - 1);
-  dim3 grid((unsigned)(N + (rows + 15) / 16)), block(512);   // N person-token workgroups first, then 16 rows per workgroup
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == MSMD_F16)
-    hipLaunchKernelGGL(cross_row0_ln_kernel<f16_t>, grid, block, 0, st, (const f16_t*)u, (const f16_t*)Wq, bq, wq_colsum,
-                       (const f16_t*)KV, (const f16_t*)Wo, bo, (const f16_t*)R, g1, b1, g2, b2, (f16_t*)x, N, Tn, Tk, scale, eps, kv_bstride, kv_tstride);
-  else if (dtype == MSMD_BF16)
-    hipLaunchKernelGGL(cross_row0_ln_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)u, (const bf16_t*)Wq, bq, wq_colsum,
-                       (const bf16_t*)KV, (const bf16_t*)Wo, bo, (const bf16_t*)R, g1, b1, g2, b2, (bf16_t*)x, N, Tn, Tk, scale, eps, kv_bstride, kv_tstride);
-  else
-    return 1;
-  MSMD_RETURN_LAST();
-}

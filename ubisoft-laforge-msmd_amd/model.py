@@ -404,12 +404,7 @@ class DenoisingNetwork_MSMD(nn.Module):
             if not fold_n1:
                 x = ops.layernorm(u1, *L.n1)
             kv = kv_list[li] if kv_list is not None else ops.gemm(mem, L.ca_kvw, L.ca_kvb)
-            if diag and fold_n1 and d == 512 and H == 8 and kv.shape[1] <= 128 and getattr(self, "fused_cross_row0", True):
-                # norm1 -> person-token cross-attention + out-projection -> norm2 in ONE launch (rows t >= 1 stream through
-                # the same launch beside the 192 person-token chains): three launches of the step less per layer
-                x = ops.cross_row0_ln(u1, L.f_caq[0], L.f_caq[2], L.f_caq[1], kv, L.ca_ow, L.ca_ob, cross_list[li],
-                                      *L.n1, *L.n2, H, scale)
-            elif diag:
+            if diag:
                 # only the person token (row 0) has a real softmax; rows t >= 1 come from the precomputed R
                 R = cross_list[li]
                 # same-box A/B in the sampler graph: fused -1 % at N = 192 sequences, +1.5 % at N = 3 (a longer serial

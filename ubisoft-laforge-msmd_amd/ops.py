@@ -1009,26 +1009,6 @@ def person_query_attention(x, wq, bq, kv, n_heads, scale, wq_colsum=None, eps=1e
     return out
 
 
-def cross_row0_ln(u, wq, bq, wq_colsum, kv, wo, bo, R, g1, b1, g2, b2, n_heads, scale, eps=1e-5):
-    """x = LN2(LN1(u) + branch) for a post-LN decoder layer under the diagonal alignment mask, ONE launch
-    (msmd_cross_row0_ln): rows t >= 1 take their branch from R (precomputed V[t-1] Wo^T + bo), row 0 (the person token) runs
-    the real cross-attention against kv (N, Tk, 2d) = [K | V] -- query projection through the norm1-folded (wq, bq, wq_colsum),
-    softmax, P V, out-projection (wo, bo) -- inside the launch.  u, R: (N, Tn, 512) 16-bit; returns x like u."""
-    _need_cuda(u, wq, kv, wo, R)
-    N, Tn, d = u.shape
-    Tk = kv.shape[1]
-    if not (u.is_contiguous() and R.is_contiguous() and R.shape == u.shape and kv.shape[2] == 2 * d and kv.stride(2) == 1
-            and wq.is_contiguous() and wo.is_contiguous() and wq.shape == (d, d) and wo.shape == (d, d)):
-        raise ValueError("cross_row0_ln: shapes / layout")
-    if not (u.dtype == wq.dtype == kv.dtype == wo.dtype == R.dtype):
-        raise TypeError("cross_row0_ln: u, wq, kv, wo, R must share a dtype")
-    x = torch.empty_like(u)
-    _lib.check(_lib.load().msmd_cross_row0_ln(_p(u), _p(wq), _p(bq), _p(wq_colsum), _p(kv), _p(wo), _p(bo), _p(R), _p(g1), _p(b1),
-                                              _p(g2), _p(b2), _p(x), N, Tn, Tk, kv.stride(0), kv.stride(1), d, n_heads,
-                                              float(scale), float(eps), _dt(u), _stream()), "msmd_cross_row0_ln")
-    return x
-
-
 def cast_transpose_multi(flat, meta, n, tiles, cast_arena, t_arena):
     """One launch: bf16 cast + bf16 transpose of n (N, K) matrices of the flat fp32 arena (meta: see msmd_hip.h)."""
     _need_cuda(flat, meta, cast_arena, t_arena)
