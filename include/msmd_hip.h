@@ -144,14 +144,6 @@ int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsum, int M, i
                  long ldc, int batch, long strideA, long strideB, long strideC, int b_rows_per_window,
                  long b_window_stride, int accumulate, void* ws, long ws_bytes, msmd_stream_t stream);
 long msmd_gemm_tn_workspace(int M, int N, int K, int batch);
-/* msmd_gemm_tn with the split-contraction slab reduction INSIDE the launch (no second kernel): tile_counters = n_counters ints,
- * at least ceil(N / 128) * ceil(K / 128) * batch, ZERO on entry and left zero on exit; caller-owned, not shared between streams
- * that may run such launches concurrently.  The workgroup that completes a tile's last partial slab sums the slabs in split
- * order, so the result is independent of the schedule (and equal to msmd_gemm_tn's). */
-int msmd_gemm_tn_fused(const void* A, const void* B, float* C, float* colsum, int M, int N, int K, long lda, long ldb,
-                       long ldc, int batch, long strideA, long strideB, long strideC, int b_rows_per_window,
-                       long b_window_stride, int accumulate, void* ws, long ws_bytes, int* tile_counters, long n_counters,
-                       msmd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * y = post_act(LayerNorm(act(x + residual)) * gamma + beta) + post_add      (row-wise over `cols`)

@@ -39,8 +39,6 @@ struct TnArgs {
   float inv_rpw;
   int accumulate;  // C += product, colsum += sums (gradient accumulation straight into .grad)
   int plain_order; // tuning key 1 = 1: items in (tile, split) launch order instead of XCD-contiguous eighths
-  int* counters;   // split-contraction launches, one int per (batch, n tile, k tile), zero between launches: the workgroup that
-                   // finishes a tile's LAST partial slab sums all of them (in split order) into C -- no reduction launch
 };
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -230,7 +228,6 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnArgs p) {
 
   // epilogue: acc[i][j][e] = C[n = n0 + wn + 16 j + fr][k = k0 + wk + 16 i + 4 fq + e]
   const bool partial = p.splits > 1;
-  __shared__ int s_last;
   float* __restrict__ C = partial ? p.ws + split * p.slab + (long)z * p.N * p.K : p.C + z * p.strideC;
   const long ldc = partial ? p.K : p.ldc;
   const bool vec = (ldc % 4 == 0);
@@ -255,36 +252,6 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnArgs p) {
       if (partial || p.accumulate) atomicAdd(p.colsum + n, acs[j][0]);
       else p.colsum[n] = acs[j][0];
     }
-  }
-  if (!partial || !p.counters) return;
-  // ---- the slab reduction, by whoever finishes this tile last.  Every workgroup publishes its slab (device-scope release: the
-  // partial products of the other splits were written through OTHER XCDs' L2s), then takes a ticket; the holder of the last
-  // ticket acquires and sums the `splits` slabs IN SPLIT ORDER (the same sum, in the same order, whichever workgroup it is:
-  // results do not depend on the schedule) and leaves the counter at zero for the next launch.
-  __threadfence();
-  __syncthreads();
-  int* cnt = p.counters + ((long)z * p.nt_n + n_tile) * p.nt_k + k_tile;
-  if (tid == 0) {
-    const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = ticket == p.splits - 1;
-    if (s_last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  float* __restrict__ Cf = p.C + z * p.strideC;
-  const float* wsz = p.ws + (long)z * p.N * p.K;
-  // the 128 x 128 tile as 4096 quads of 4 k: thread t takes quads t, t + 512, ... (a row of the tile = 32 consecutive quads)
-  for (int qd = tid; qd < 128 * 32; qd += 512) {
-    const int n = n0 + (qd >> 5), k = k0 + (qd & 31) * 4;
-    if (n >= p.N || k >= p.K) continue;
-    const float* src = wsz + (long)n * p.K + k;
-    f32x4 a = __builtin_nontemporal_load((const f32x4*)src);
-    for (int sp = 1; sp < p.splits; ++sp) a += __builtin_nontemporal_load((const f32x4*)(src + sp * p.slab));
-    float* dst = Cf + (long)n * p.ldc + k;
-    if (p.accumulate) { a[0] += dst[0]; a[1] += dst[1]; a[2] += dst[2]; a[3] += dst[3]; }
-    if (p.ldc % 4 == 0) *(f32x4*)dst = a;
-    else { dst[0] = a[0]; dst[1] = a[1]; dst[2] = a[2]; dst[3] = a[3]; }
   }
 }
 
@@ -334,10 +301,10 @@ extern "C" long msmd_gemm_tn_workspace(int M, int N, int K, int batch) {
   return splits > 1 ? splits * batch * (long)N * K * (long)sizeof(float) : 0;
 }
 
-static int gemm_tn_impl(const void* A, const void* B, float* C, float* colsum, int M, int N, int K, long lda,
-                        long ldb, long ldc, int batch, long strideA, long strideB, long strideC,
-                        int b_rows_per_window, long b_window_stride, int accumulate, void* ws,
-                        long ws_bytes, int* counters, long n_counters, msmd_stream_t stream) {
+extern "C" int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsum, int M, int N, int K, long lda,
+                            long ldb, long ldc, int batch, long strideA, long strideB, long strideC,
+                            int b_rows_per_window, long b_window_stride, int accumulate, void* ws,
+                            long ws_bytes, msmd_stream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (N & 7) || (K & 7) || (lda & 7) || (ldb & 7) || batch < 1) return 1;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15) || ((uintptr_t)ws & 15)) return 1;
   if (colsum && batch != 1) return 1;
@@ -367,7 +334,6 @@ static int gemm_tn_impl(const void* A, const void* B, float* C, float* colsum, i
   if (p.b_rpw && ((b_window_stride & 7) || M >= (1 << 24))) return 1;
   p.accumulate = accumulate ? 1 : 0;
   p.plain_order = MSMD_TUNE(1) == 1;
-  p.counters = (counters && n_counters >= tiles && !((uintptr_t)counters & 3)) ? counters : nullptr;
   if (p.splits > 1 && colsum && !accumulate) {
     hipError_t e = msmd_zero_async(colsum, sizeof(float) * N, st);
     if (e != hipSuccess) return (int)e;
@@ -383,31 +349,10 @@ static int gemm_tn_impl(const void* A, const void* B, float* C, float* colsum, i
     attr_done = true;
   }
   hipLaunchKernelGGL(kfn, dim3(((p.nt_n * p.nt_k * p.splits + 7) / 8) * 8, 1, batch), dim3(512), lds, st, p);
-  if (p.splits > 1 && !p.counters) {
+  if (p.splits > 1) {
     const long quads = (long)N * (K / 4);
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((quads + 255) / 256), batch), dim3(256), 0, st, p.ws, C,
                        p.splits, slab, N, K, ldc, strideC, p.accumulate);
   }
   MSMD_RETURN_LAST();
-}
-
-extern "C" int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsum, int M, int N, int K, long lda,
-                            long ldb, long ldc, int batch, long strideA, long strideB, long strideC,
-                            int b_rows_per_window, long b_window_stride, int accumulate, void* ws,
-                            long ws_bytes, msmd_stream_t stream) {
-  return gemm_tn_impl(A, B, C, colsum, M, N, K, lda, ldb, ldc, batch, strideA, strideB, strideC, b_rows_per_window,
-                      b_window_stride, accumulate, ws, ws_bytes, nullptr, 0, stream);
-}
-
-// msmd_gemm_tn with the slab reduction INSIDE the launch: `tile_counters` = n_counters ints (>= ceil(N/128) ceil(K/128) batch),
-// ZERO on entry and left zero on exit, owned by the caller and not shared between streams that may run such launches
-// concurrently.  The workgroup that completes a tile's last partial slab sums the slabs in split order -- the result does not
-// depend on which workgroup that is.  One launch instead of two per weight gradient (117 reduction launches per training step).
-extern "C" int msmd_gemm_tn_fused(const void* A, const void* B, float* C, float* colsum, int M, int N, int K, long lda,
-                                  long ldb, long ldc, int batch, long strideA, long strideB, long strideC,
-                                  int b_rows_per_window, long b_window_stride, int accumulate, void* ws, long ws_bytes,
-                                  int* tile_counters, long n_counters, msmd_stream_t stream) {
-  if (!tile_counters || n_counters <= 0) return 1;
-  return gemm_tn_impl(A, B, C, colsum, M, N, K, lda, ldb, ldc, batch, strideA, strideB, strideC, b_rows_per_window,
-                      b_window_stride, accumulate, ws, ws_bytes, tile_counters, n_counters, stream);
 }

@@ -401,18 +401,6 @@ def exp_set_tuning(key, value):
 
 
 g_tn_split = True
-TN_FUSED_REDUCE = True       # False: msmd_gemm_tn + its separate slab-reduction launch
-_TN_COUNTERS = {}
-
-
-def _tn_counters(device, n=1 << 14):
-    """Zero-kept ticket counters of msmd_gemm_tn_fused for (device, current stream); 16 384 tiles cover every weight of the path
-    (the largest, 3072 x 768, is 144 tiles)."""
-    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
-    t = _TN_COUNTERS.get(key)
-    if t is None:
-        t = _TN_COUNTERS[key] = torch.zeros(n, device=device, dtype=torch.int32)
-    return t
 
 
 def gemm_tn(a, b, want_colsum=False, *, M=None, N=None, K=None, lda=None, ldb=None, batch=1, strideA=0, strideB=0,
@@ -436,17 +424,9 @@ def gemm_tn(a, b, want_colsum=False, *, M=None, N=None, K=None, lda=None, ldb=No
         torch.empty(N, device=a.device, dtype=torch.float32) if want_colsum else None)
     nws = lib.msmd_gemm_tn_workspace(M, N, K, batch) if g_tn_split else 0
     ws = torch.empty(nws, device=a.device, dtype=torch.uint8) if nws > 0 else None
-    if nws > 0 and TN_FUSED_REDUCE:
-        # the slab reduction inside the launch (msmd_gemm_tn_fused): per-tile tickets in a small zero-kept counter buffer, one per
-        # (device, stream) so that launches which may overlap never share tickets
-        cnt = _tn_counters(a.device)
-        _lib.check(lib.msmd_gemm_tn_fused(_p(a), _p(b), _p(out), _p(cs), M, N, K, lda, ldb, K, batch, strideA, strideB, N * K,
-                                          b_rows_per_window, b_window_stride, int(bool(accumulate)) | (int(splits) << 8), _p(ws),
-                                          nws, _p(cnt), cnt.numel(), _stream()), "msmd_gemm_tn_fused")
-    else:
-        _lib.check(lib.msmd_gemm_tn(_p(a), _p(b), _p(out), _p(cs), M, N, K, lda, ldb, K, batch, strideA, strideB, N * K,
-                                    b_rows_per_window, b_window_stride, int(bool(accumulate)) | (int(splits) << 8), _p(ws), nws,
-                                    _stream()), "msmd_gemm_tn")
+    _lib.check(lib.msmd_gemm_tn(_p(a), _p(b), _p(out), _p(cs), M, N, K, lda, ldb, K, batch, strideA, strideB, N * K,
+                                b_rows_per_window, b_window_stride, int(bool(accumulate)) | (int(splits) << 8), _p(ws), nws,
+                                _stream()), "msmd_gemm_tn")
     return (out, cs) if (want_colsum or colsum_out is not None) else out
 
 
