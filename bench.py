@@ -103,10 +103,12 @@ def event_pair_overhead_us():
     return over[len(over) // 2]
 
 
-def roofline_leg(model, b, mode, steps=3, run_step=None):
+def roofline_leg(model, b, mode, steps=3, run_step=None, exclude=None, traffic_key=None):
     """Per-launch HIP-event timing of every msmd_gemm launch of `steps` eager steps; the dominant kernel is the
     128x128-tile kernel of the mode (bf16: gemm2_kernel, f16x2: gemm2s_kernel; fp32: gemm_kernel<float>).
-    `run_step` (default: the forward step on batch b) is what gets traced: --mode train passes its eager iteration."""
+    `run_step` (default: the forward step on batch b) is what gets traced: --mode train passes its eager iteration, the
+    sampler leg its eager denoising steps.  `exclude(M, N, K, batch)` drops launches that are not part of a step (the
+    sampler's hoisted once-per-call projections); `traffic_key` names the PMC summary to read `traffic` from."""
     from msmd_amd import ops
     step_fn = run_step or (lambda: step(model, b))
     step_fn()
@@ -121,6 +123,8 @@ def roofline_leg(model, b, mode, steps=3, run_step=None):
     n_launch = big_n = tall_n = 0
     kq = 32 if mode == "f16x2" else 64
     for (M, N, K, batch, dt, e0, e1) in trace:
+        if exclude is not None and exclude(M, N, K, batch):
+            continue
         f = 2.0 * M * N * K * batch
         d = max(e0.elapsed_time(e1) - overhead, 1e-4)
         flops += f
@@ -144,7 +148,7 @@ def roofline_leg(model, b, mode, steps=3, run_step=None):
               "f16x2": "gemm2s_kernel<128,128,4,2,2> (three f16 MFMAs per algorithmic product)",
               "fp32": "gemm_kernel<float,128,128> (v_mfma_f32_16x16x4_f32)"}[mode]
     out = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
-               traffic=pmc_traffic(mode), kernel=kernel + " (csrc/gemm.hip)", launches_per_step=big_n // steps,
+               traffic=pmc_traffic(mode, traffic_key), kernel=kernel + " (csrc/gemm.hip)", launches_per_step=big_n // steps,
                gflop_per_step=round(big_f / steps / 1e9, 1), ms_per_step_in_kernel=round(big_ms / steps, 3),
                avg_launch_us=round(big_ms / max(big_n, 1) * 1e3, 2),
                all_gemm_tflops=round(flops / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
@@ -167,11 +171,16 @@ def roofline_leg(model, b, mode, steps=3, run_step=None):
     return out
 
 
-def pmc_traffic(mode):
+def pmc_traffic(mode, key=None, tile="128ELi128E"):
     """HBM bytes per launch of the dominant kernel from this round's committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE in SEPARATE runs; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC counters
-    cannot be read from inside this process: the figure is a constant from profiles/ (null when absent), not this run."""
-    for name in ("r04_pmc_hbm_fetch_write_per_kernel.json", "r03_pmc_hbm_fetch_write_per_kernel.json", "r02_pmc_hbm_fetch_write_per_kernel.json"):
+    cannot be read from inside this process: the figure is a constant from profiles/ (null when absent), not this run.
+    key: which workload's summary (None = the forward step; "sampler" = profiles/r05_pmc_sampler_fetch_write_per_kernel.json)."""
+    names = ("r05_pmc_hbm_fetch_write_per_kernel.json", "r04_pmc_hbm_fetch_write_per_kernel.json", "r03_pmc_hbm_fetch_write_per_kernel.json",
+             "r02_pmc_hbm_fetch_write_per_kernel.json")
+    if key is not None:
+        names = (f"r05_pmc_{key}_fetch_write_per_kernel.json",)
+    for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -180,7 +189,7 @@ def pmc_traffic(mode):
             want = {"bf16": "gemm2_kernel", "fp16": "gemm2_kernel", "f16x2": "gemm2s_kernel", "fp32": "gemm_kernel"}[mode]
             # (the multi-round launches of the same tile run as gemm2p_kernel, its persistent form)
             ks = [v for n, v in d.items() if any(w + "I" in n.replace("<", "I") for w in (want, want.replace("gemm2_", "gemm2p_")))
-                  and "128ELi128E" in n.replace(", ", "ELi").replace("<", "I")]
+                  and tile in n.replace(", ", "ELi").replace("<", "I")]
             ks = ks or [v for n, v in d.items() if want in n and "128" in n and ("gemm2s" in n) == (mode == "f16x2")]
             if ks:
                 # since round 4 the 128 x 128 kernel is one symbol per epilogue family: launch-weighted mean over them
@@ -306,6 +315,44 @@ class _LazyNoise:
         return torch.randn(self.shape, generator=g, device=self.device)
 
 
+def sampler_roofline(model, af, shape, style, ind, xT, device, steps=6):
+    """`roofline` block of the sampler's dominant kernel: per-launch HIP-event durations of the GEMMs of `steps` EAGER denoising
+    steps on ONE LANE's share of the batch (the hipGraph loop runs msmd_amd.sampler.LANES groups of clips side by side, each
+    with the launches timed here: B / lanes clips x 3 CFG entries = 96 sequences x 111 rows at the default).  The hoisted
+    once-per-call projections (K / V of the audio memory, N = 1024) are not part of a step and are left out."""
+    from msmd_amd import sampler as smp
+    from msmd_amd.model import DiffusionSchedule
+    B = af.shape[0]
+    lanes = getattr(model, "sampler_lanes", smp.LANES)
+    while lanes > 1 and (B % lanes or 3 * B // lanes < smp.MIN_LANE_SEQS):
+        lanes -= 1
+    Bl = B // lanes
+    sched = model.diffusion_sched
+    model.diffusion_sched = DiffusionSchedule(steps, "cosine").to(device)
+    noise = _LazyNoise((Bl, 100, 67), device, 78)
+    try:
+        def run():
+            model.sample(af[:Bl], shape[:Bl], style[:Bl], motion_at_T=xT[:Bl], indicator=ind[:Bl], cfg_scale=1.15, noise=noise)
+        r = roofline_leg(model, None, "fp16", steps=1, run_step=run, exclude=lambda M, N, K, batch: N == 1024 or batch > 1,
+                         traffic_key="sampler")
+    finally:
+        model.diffusion_sched = sched
+    fam = r.get("both_tiles") or r
+    out = dict(bound="mfma", achieved=fam["achieved"], peak=r["peak"], unit="TFLOP/s", frac=fam["frac"], traffic=r["traffic"],
+               kernel=("gemm2_kernel<f16,128,128,4,2,2,pipelined> + its persistent form gemm2p_kernel (csrc/gemm.hip): the decoder "
+                       "layers' QKV / out-projection / FFN GEMMs of one lane"),
+               launches_per_step=fam["launches_per_step"] // steps, ms_per_step_in_kernel=round(fam["ms_per_step_in_kernel"] / steps, 4),
+               avg_launch_us=round(fam["ms_per_step_in_kernel"] * 1e3 / max(1, fam["launches_per_step"]), 2),
+               sequences_per_lane=3 * Bl, lanes=lanes,
+               all_gemm_tflops=r["all_gemm_tflops"], all_gemm_launches_per_step=r["all_gemm_launches_per_step"] // steps,
+               all_gemm_ms_per_step=round(r["all_gemm_ms_per_step"] / steps, 4), event_pair_overhead_us=r["event_pair_overhead_us"],
+               note="HIP-event durations of eager launches of ONE lane alone on the chip (the graph loop runs `lanes` of them side by "
+                    "side, so a rocprofv3 trace of the loop shows longer per-launch times at a higher chip throughput); "
+                    "rocprofv3 summaries: profiles/r05_sampler_*; traffic = 2 x FETCH_SIZE + WRITE_SIZE of this kernel from the "
+                    "sampler's own --pmc passes (profiles/r05_pmc_sampler_fetch_write_per_kernel.json), null when absent")
+    return out
+
+
 def leg_sampler(device, B=64, T=500):
     """configs[4]: sample() B=64, T=500, 3 CFG entries.  Timed in fp16 storage (the config's dtype) AND in the parity-grade
     f16x2 mode, each as hipGraph replays; `mfma_frac` divides the reference-NOMINAL FLOPs (3 x 7.886 GFLOP per sequence and
@@ -335,12 +382,19 @@ def leg_sampler(device, B=64, T=500):
         executed, ops.GEMM_FLOPS = ops.GEMM_FLOPS[0], None
         x0[dtype] = xe.float()
         tf = B * 3 * DENOISER_FLOP * T / dt / 1e12
+        roof = None
+        if dtype == "fp16":
+            roof = sampler_roofline(model, af, shape, style, ind, xT, device)
         out[dtype] = dict(config=f"configs[4]: sample() B={B}, T={T} DDPM steps x 3 CFG entries, {dtype}, one hipGraph replay per step",
                           ms_per_step=round(dt / T * 1e3, 3), frames_per_s=round(B * 100 / dt, 1), tflops_nominal=round(tf, 1),
                           mfma_frac=round(tf / PEAK_MFMA_TFLOPS, 4),
                           gemm_tflop_executed_per_call=round(executed / 1e12, 2),
                           mfma_frac_executed=round(executed / dt / 1e12 / PEAK_MFMA_TFLOPS, 4),
                           finite=bool(torch.isfinite(x).all() and torch.isfinite(xe).all()))
+        if roof is not None:
+            out[dtype]["roofline"] = roof
+        lanes = next(iter(model._step_graphs.values())).lanes if getattr(model, "_step_graphs", None) else 1
+        out[dtype]["lanes"] = lanes
         del model
         torch.cuda.empty_cache()
     r = out["fp16"]

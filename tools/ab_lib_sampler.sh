@@ -5,6 +5,6 @@ A=$1; B=$2
 for rep in 1 2; do
   for lib in $A $B; do
     echo "== $(basename $lib)"
-    MSMD_LIB=$lib python tools/ab_sampler_lanes.py 2>&1 | grep "ms/step"
+    MSMD_LIB=$lib MSMD_LIB_ALLOW_MISSING=1 python tools/ab_sampler_lanes.py 2>&1 | grep "ms/step"
   done
 done

@@ -78,6 +78,8 @@ def load(path: str = LIB_PATH):
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
+            if os.environ.get("MSMD_LIB") and os.environ.get("MSMD_LIB_ALLOW_MISSING") == "1":
+                continue     # developers' same-box A/B against an OLDER build (tools/ab_lib*.sh): calls of newer entries then fail
             raise MsmdLibraryError(f"{path} does not export {name} declared in {HEADER}") from e
         fn.argtypes = argtypes
         fn.restype = RESTYPE[name]
