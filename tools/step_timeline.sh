@@ -4,7 +4,12 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tl
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o p -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-two-streams-leg --no-roofline --legs none "$@" > /tmp/tl.log 2>&1 || echo "profiler run failed"
+# PROG=<script under the repo root> [args]: trace that program instead of bench.py (e.g. PROG=tools/bench_sampler.py DELIM=step_select ... 64)
+if [ -n "$PROG" ]; then
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o p -- python3 $ROOT/$PROG "$@" > /tmp/tl.log 2>&1 || echo "profiler run failed"
+else
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o p -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-two-streams-leg --no-roofline --legs none "$@" > /tmp/tl.log 2>&1 || echo "profiler run failed"
+fi
 python3 - <<'PY'
 import csv, glob, collections
 f = glob.glob("/tmp/tl/**/*kernel_trace.csv", recursive=True)[0]
