@@ -965,127 +965,10 @@ __global__ __launch_bounds__(256) void person_query_attention_kernel(const T* __
 }
 
 
-// Weight-stationary form for many sequences (the sampler's N = 96 .. 192): the kernel above reads a head's 64 x d slice of Wq
-// once per (sequence, head) wave -- N x d x d x 2 B = 100 MB through the L2s at N = 192, which is what its 22 us are.  Here a
-// workgroup owns ONE head and 8 sequences (a wave each): the slice is staged into LDS once (64 KB, 16-byte linear copies, rows
-// XOR-swizzled by (row & 7) x 16 B so the projection's 8-row x 128-byte reads spread over all banks), then every wave runs
-// the projection out of LDS and the Tq = 1 attention as above.  L2 traffic: N / 8 x d x d x 2 B = 12.6 MB.  d = 512, 16-bit.
-template <typename T>
-__global__ __launch_bounds__(512) void person_query_attention_ws_kernel(const T* __restrict__ x, long x_seq_stride,
-                                                                        const T* __restrict__ Wq, const float* __restrict__ bq,
-                                                                        const T* __restrict__ K, const T* __restrict__ V,
-                                                                        long kv_bstride, long kv_tstride, T* __restrict__ out,
-                                                                        int N, int Tk, float scale,
-                                                                        const float* __restrict__ wq_colsum, float ln_eps) {
-  constexpr int D = 512, NIT = 16;
-  typedef typename Vec8T<T>::type V8;
-  __shared__ __attribute__((aligned(16))) T s_w[64 * D];      // 64 KB: row r, 16-byte chunk j at chunk index r*64 + (j ^ (r & 7))
-  __shared__ float sq[8][64];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int g = lane >> 3, c = lane & 7;
-  const int h = blockIdx.x, n = blockIdx.y * 8 + wid;
-  const bool live = n < N;
-  const int nn = live ? n : N - 1;
-  // the K stream and the token row do not depend on the weights: requested before the slice is staged
-  const T* kbase = K + (long)nn * kv_bstride + h * 64 + c * 8;
-  const T* vbase = V + (long)nn * kv_bstride + h * 64 + c * 8;
-  u32x4 kraw[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it)
-    if (it * 8 < Tk) kraw[it] = *(const u32x4*)(kbase + (long)min(it * 8 + g, Tk - 1) * kv_tstride);
-  const T* x0 = x + (long)nn * x_seq_stride;
-  {
-    const u32x4* src = (const u32x4*)(Wq + (long)h * 64 * D);
-    u32x4* dst = (u32x4*)s_w;
-    u32x4 tmp[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) tmp[k] = src[k * 512 + threadIdx.x];      // 4096 chunks of 16 B, linear
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int ch = k * 512 + threadIdx.x, r = ch >> 6, j = ch & 63;
-      dst[r * 64 + (j ^ (r & 7))] = tmp[k];
-    }
-  }
-  __syncthreads();
-  float qv[8];
-#pragma unroll
-  for (int rb = 0; rb < 8; ++rb) qv[rb] = 0.f;
-  float xs1 = 0.f, xs2 = 0.f;
-#pragma unroll 2
-  for (int i = 0; i < 8; ++i) {      // (not fully unrolled: 64 LDS reads in flight at once would not fit the registers)
-    float xv[8];
-    const V8 xr = *(const V8*)(x0 + (c + 8 * i) * 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { xv[e] = (float)xr[e]; xs1 += xv[e]; xs2 = fmaf(xv[e], xv[e], xs2); }
-#pragma unroll
-    for (int rb = 0; rb < 8; ++rb) {
-      const int r = rb * 8 + g, j = c + 8 * i;
-      const V8 wv = *(const V8*)(s_w + ((long)r * 64 + (j ^ (r & 7))) * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) qv[rb] = fmaf(xv[e], (float)wv[e], qv[rb]);
-    }
-  }
-  float ln_mu = 0.f, ln_rs = 1.f;
-  if (wq_colsum) {
-    ln_mu = group8_sum(xs1) * (1.0f / D);
-    ln_rs = rsqrtf(fmaxf(group8_sum(xs2) * (1.0f / D) - ln_mu * ln_mu, 0.f) + ln_eps);
-  }
-#pragma unroll
-  for (int rb = 0; rb < 8; ++rb) {
-    float t = group8_sum(qv[rb]);
-    const int r = h * 64 + rb * 8 + g;
-    if (wq_colsum) t = ln_rs * (t - ln_mu * wq_colsum[r]);
-    if (c == 0) sq[wid][rb * 8 + g] = (t + (bq ? bq[r] : 0.f)) * scale;
-  }
-  __builtin_amdgcn_wave_barrier();
-  float q8[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) q8[e] = sq[wid][c * 8 + e];
-  float sc[NIT];
-  float m = -INFINITY;
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int key = it * 8 + g;
-    sc[it] = -INFINITY;
-    if (it * 8 < Tk) {
-      const V8 v8 = __builtin_bit_cast(V8, kraw[it]);
-      float a = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) a = fmaf(q8[e], (float)v8[e], a);
-      a = group8_sum(a);
-      if (key < Tk) { sc[it] = a; m = fmaxf(m, a); }
-    }
-  }
-  m = wave_max(m);
-  float l = 0.f, o[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = 0.f;
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int key = it * 8 + g;
-    if (it * 8 < Tk) {
-      const float pv = key < Tk ? __expf(sc[it] - m) : 0.f;
-      l += pv;
-      const V8 v8 = *(const V8*)(vbase + (long)min(key, Tk - 1) * kv_tstride);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = fmaf(pv, (float)v8[e], o[e]);
-    }
-  }
-  l = wave_sum(l) * 0.125f;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float t = o[e];
-    t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
-    o[e] = t / l;
-  }
-  if (g == 0 && live) {
-    V8 ov;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ov[e] = (T)o[e];
-    *(V8*)(out + (long)n * D + h * 64 + c * 8) = ov;
-  }
-}
-
+// (A weight-stationary form -- a workgroup owns one head and 8 sequences, the head's 64 x d slice of Wq staged into LDS once
+// instead of being read per (sequence, head) wave: 12.6 MB instead of 100 MB through the L2s at N = 192 -- was built in round 5:
+// 27.6 us against this kernel's 22.0 in the sampler step (one 8-wave workgroup on 192 CUs, the staging round trip in front of
+// every chain).  The chain is latency, not L2 traffic; not kept.)
 static int person_query_impl(const void* x, long x_seq_stride, const void* Wq, const float* bq, const void* K,
                              const void* V, long kv_bstride, long kv_tstride, void* out, int N, int H, int Tk, int d,
                              float scale, int dtype, msmd_stream_t stream, const float* wq_colsum, float ln_eps) {
@@ -1095,18 +978,6 @@ static int person_query_impl(const void* x, long x_seq_stride, const void* Wq, c
       ((uintptr_t)K & 15) || ((uintptr_t)V & 15))
     return 1;
   hipStream_t st = (hipStream_t)stream;
-  if (d == 512 && Tk <= 128 && N >= 32 && dtype != MSMD_F32) {      // many sequences: a head's weight slice staged once per 8 of them
-    const dim3 gws(H, (N + 7) / 8);
-    if (dtype == MSMD_F16)
-      hipLaunchKernelGGL(person_query_attention_ws_kernel<f16_t>, gws, dim3(512), 0, st, (const f16_t*)x, x_seq_stride,
-                         (const f16_t*)Wq, bq, (const f16_t*)K, (const f16_t*)V, kv_bstride, kv_tstride, (f16_t*)out, N, Tk, scale,
-                         wq_colsum, ln_eps);
-    else
-      hipLaunchKernelGGL(person_query_attention_ws_kernel<bf16_t>, gws, dim3(512), 0, st, (const bf16_t*)x, x_seq_stride,
-                         (const bf16_t*)Wq, bq, (const bf16_t*)K, (const bf16_t*)V, kv_bstride, kv_tstride, (bf16_t*)out, N, Tk,
-                         scale, wq_colsum, ln_eps);
-    MSMD_RETURN_LAST();
-  }
   const dim3 grid((N * H + 3) / 4), block(256);
 #define LAUNCH_PQA(T)                                                                                                  \
   do {                                                                                                                 \

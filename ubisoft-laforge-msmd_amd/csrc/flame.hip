@@ -544,23 +544,20 @@ __device__ __forceinline__ void vm_wait_n(int n) {   // n = (pieces per load gro
 // then wrong by construction.
 // WP: also store the un-skinned vertices p = template + coef . dirs (B, V, 3) -- what the backward of the skinning needs
 // (training through the vertex-space loss); 8 instead of 4 store instructions per tile and wave.
-// TR: whole-row stores.  The direct stores above are 192-byte runs (16 lanes x 12 B) per wave and frame: as a PURE store
-// stream that shape reaches 2.99 TB/s on this machine, whole 1 536-byte rows (the workgroup's 128 vertices of one frame) as
-// 16-byte-per-lane stores reach 3.80 (tools/store_bench.hip, profiles/r04_store_bench.txt) -- and the kernel ran at 87 % of
-// the first figure, i.e. on its store shape.  With TR every wave puts its 16 x 16 x 3 results into an LDS image of the tile
-// [16 frames][128 vertices x 3] (row stride 388 floats: the four frame groups of a wave land 16 banks apart) and, one barrier
-// later (the tile loop's own: one barrier per tile, two images), the waves write the image out row-wise: wave w takes frames
-// 2w, 2w + 1 = 3 072 bytes = three wave-wide 16-byte stores (3 store instructions per tile and wave instead of 4, all full).
-template <int KG, int NS, int NWV, int ABL = 0, bool WP = false, int RB = 0, bool TR = false>
+// (Whole-row stores through an LDS image of the tile -- every wave puts its 16 x 16 x 3 results into [16 frames][128 vertices
+// x 3] and, one barrier later, the waves write the image out as three wave-wide 16-byte stores of whole 1 536-byte rows, the
+// shape that reaches 3.80 instead of 2.99 TB/s as a PURE store stream -- were built again in round 5 with the image double
+// buffered on the tile loop's own barrier: 0.703 ms against 0.592 at 25 600 frames, same box, alternating.  The image costs
+// 12 LDS writes + 3 reads per lane and tile and ties the waves to one barrier per tile, i.e. it removes the drift between the
+// waves that the two-tiles-per-barrier schedule below lives on; the store shape is not what is left to win here.)
+template <int KG, int NS, int NWV, int ABL = 0, bool WP = false, int RB = 0>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void lbs_skin_v2_kernel(const unsigned char* __restrict__ tiles,
                         const float* __restrict__ tmpl, const bf16_t* __restrict__ dirs_hl,
                         const float* __restrict__ wts, float* __restrict__ verts, int B, int V, int Vp,
                         int frames_per_block, int vtn, float* __restrict__ vposed = nullptr, int xcd_adj = 0,
                         const int* __restrict__ shape_varies = nullptr, const float* __restrict__ tmpl_folded = nullptr) {
-  constexpr int SPT = TR ? 3 : (WP ? 8 : 4);   // store instructions per tile and wave
-  constexpr int ORS = 388, OIMG = 16 * ORS;    // TR: floats per image row (384 + 4) and per tile image
-  static_assert(!TR || (NWV == 8 && RB == 0 && !WP && ABL == 0), "whole-row stores: 128-vertex workgroups, one barrier per tile");
+  constexpr int SPT = WP ? 8 : 4;   // store instructions per tile and wave
   // all frames share their first LBS_KFOLD shape coefficients (msmd_flame_prepare): folded template, skip those K groups
   const bool uni = shape_varies != nullptr && tmpl_folded != nullptr && *shape_varies == 0;
   const int g_first = uni ? LBS_KFOLD / 32 : 0;
@@ -683,16 +680,6 @@ void lbs_skin_v2_kernel(const unsigned char* __restrict__ tiles,
       for (int e = 0; e < 4; ++e) out[c][e] = fmaf(T[0][e], px[e], fmaf(T[1][e], py[e], fmaf(T[2][e], pz[e], T[3][e])));
     }
     struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
-    if constexpr (TR) {
-      float* ob = (float*)(smem + NS * STAGE) + (t & 1) * OIMG + (16 * wid + i) * 3;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        F3 o;
-        o.x = out[0][e]; o.y = out[1][e]; o.z = out[2][e];
-        *(F3*)(ob + (4 * q + e) * ORS) = o;
-      }
-      return;
-    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int f = min(f0 + 4 * q + e, B - 1);
@@ -708,48 +695,17 @@ void lbs_skin_v2_kernel(const unsigned char* __restrict__ tiles,
     }
   };
 
-  // TR: write tile t's image out, wave w the frame rows 2w and 2w + 1 (192 sixteen-byte pieces = 3 per lane)
-  auto flush = [&](int t) {
-    const float* ob = (const float*)(smem + NS * STAGE) + (t & 1) * OIMG;
-    const int f0 = f_begin + 16 * t;
-    const int nfl = min(VPB, V - v_tile * VPB) * 3;          // floats of a row that exist (the last vertex slice is short)
-    struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
-#pragma unroll
-    for (int pc = 0; pc < 3; ++pc) {
-      const int idx = pc * 64 + lane;
-      const int row = 2 * wid + idx / 96, col = (idx % 96) * 4;
-      const f32x4 v = *(const f32x4*)(ob + row * ORS + col);
-      float* dst = verts + ((long)min(f0 + row, B - 1) * V + (long)v_tile * VPB) * 3 + col;
-      if (col + 3 < nfl) {
-        F4 o;
-        o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-        *(F4*)dst = o;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (col + k < nfl) dst[k] = v[k];
-      }
-    }
-  };
   if constexpr (RB == 0) {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
       if (s < ntiles) issue(s);
     for (int t = 0; t < ntiles; ++t) {
       // ops younger than tile t's loads, in issue order: min(NS-2, ntiles-1-t) load groups (my_np each) and
-      // min(NS-1, t) store groups (SPT each) -- TR: the stores of tile j go out in iteration j + 1, after that iteration's
-      // loads, so one group fewer is younger (extra element-wise stores of a short last slice only make the wait stricter)
-      vm_wait_n((ABL & 9) ? 0 : my_np * min(NS - 2, ntiles - 1 - t) + SPT * min(NS - 1, TR ? max(t - 1, 0) : t));
-      if constexpr (TR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's image writes of tile t - 1
+      // min(NS-1, t) store groups (SPT each)
+      vm_wait_n((ABL & 9) ? 0 : my_np * min(NS - 2, ntiles - 1 - t) + SPT * min(NS - 1, t));
       __builtin_amdgcn_s_barrier();
       if (t + NS - 1 < ntiles && !(ABL & 8)) issue(t + NS - 1);
-      if constexpr (TR) { if (t > 0) flush(t - 1); }
       do_tile(t);
-    }
-    if constexpr (TR) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      flush(ntiles - 1);
     }
   } else {
     // One workgroup barrier per RB tiles (NS = 2 RB slots: the group being read and the group in flight): between
@@ -826,13 +782,7 @@ static int lbs_skin_v2_impl(const void* skin_tiles, const float* v_template, con
     }
 #endif
   } else {
-    // whole-row stores through an LDS image of the tile (TR): one barrier per tile, 4-stage ring + two 24 KB images
-    constexpr int lds_tr = 4 * 18 * 1024 + 2 * 16 * 388 * 4;
-    auto kfn = lbs_skin_v2_kernel<6, 4, 8, 0, false, 0, true>;
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_tr);
-    hipLaunchKernelGGL(kfn, grid, dim3(512), lds_tr, (hipStream_t)stream, (const unsigned char*)skin_tiles, v_template,
-                       (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb, vt, (float*)nullptr, xcd_adj, shape_varies,
-                       tmpl_folded);
+    LBS_V2_LAUNCH(4, 8, 0, 2);                        // one barrier per two tiles + wave priorities
   }
 #undef LBS_V2_LAUNCH
   MSMD_RETURN_LAST();
