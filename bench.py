@@ -512,6 +512,37 @@ def leg_rotations_landmarks(device, N=1 << 22, frames=25600):
     return {"rotations_landmarks": out}
 
 
+def leg_attention(device):
+    """The two attention launches of the path in isolation (csrc/attention.hip attn_whole_kernel: softmax(Q K^T) V per sequence and
+    head in one workgroup pass): the encoder's (configs[1]: B = 32, 12 heads, T = 200, bf16) and the denoiser's self-attention as
+    the sampler launches it per lane (configs[4]: 96 sequences x 8 heads, 111 tokens, fp16).  Against BOTH roofs: FLOPs =
+    4 B H T^2 64 (the two contractions), bytes = the fused Q | K | V rows read + the O rows written."""
+    from msmd_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(0)
+    out = {}
+    for name, B, H, T, dt in (("encoder_b32_h12_t200_bf16", 32, 12, 200, torch.bfloat16), ("denoiser_n96_h8_t111_fp16", 96, 8, 111, torch.float16),
+                              ("denoiser_n192_h8_t111_fp16", 192, 8, 111, torch.float16)):
+        d = H * 64
+        qkv = torch.randn(B, T, 3 * d, device=device, generator=g).to(dt)
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        for _ in range(3):
+            ops.attention(q, k, v, H, 0.125)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e9
+        for _ in range(3):
+            e0.record()
+            for _ in range(50):
+                ops.attention(q, k, v, H, 0.125)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 50)
+        flop, nbytes = 4.0 * B * H * T * T * 64, B * T * 4 * d * 2
+        out[name] = dict(us=round(best * 1e3, 2), tflops=round(flop / best / 1e9, 1), mfma_frac=round(flop / best / 1e9 / PEAK_MFMA_TFLOPS, 4),
+                         gb_per_s=round(nbytes / best / 1e6, 1), hbm_frac=round(nbytes / best / 1e6 / PEAK_HBM_GBS, 4),
+                         bound="hbm (rows read once, 64 FLOP per byte at T = 200: below the machine balance of ~310)")
+    return {"attention": out}
+
+
 def leg_train(device, B=32, steps=5):
     from msmd_amd.config import synthetic_args
     from msmd_amd.model import get_diffusion_model
@@ -578,12 +609,12 @@ def run_legs(device, which="all"):
     """`which`: "all" or a comma-separated subset of sampler,lbs,train,hubert (profiling runs time one leg at a time)."""
     legs = {}
     for name, fn in (("sampler_b64_t500", leg_sampler), ("lbs", leg_lbs), ("rotations_landmarks", leg_rotations_landmarks),
-                     ("train_step_b32", leg_train), ("hubert_large_10s_b32", leg_hubert_large)):
+                     ("attention", leg_attention), ("train_step_b32", leg_train), ("hubert_large_10s_b32", leg_hubert_large)):
         if which != "all" and not any(name.startswith(w) for w in which.split(",")):
             continue
         try:
             r = fn(device)
-            if name in ("lbs", "rotations_landmarks"):
+            if name in ("lbs", "rotations_landmarks", "attention"):
                 legs.update(r)
             else:
                 legs[name] = r

@@ -916,24 +916,28 @@ extern "C" int msmd_lbs_skin_bwd(const float* grad_verts, const float* v_posed, 
 }
 
 // ---------------------------------------------------------------------------------------------------
-__global__ void landmarks_kernel(const float* __restrict__ verts, const int* __restrict__ faces,
-                                 const int* __restrict__ idx, long idx_bs, const float* __restrict__ bary, long bary_bs,
-                                 float* __restrict__ out, int B, int V, int L) {
+// One thread per (frame, landmark): face -> three vertex ids -> three 12-byte vertex reads (ONE dwordx3 each: the gathers are
+// what this kernel is made of, and a scalar-per-component version issued nine single-dword requests per thread -- 15.7 M L2
+// requests for 25 600 frames, which is what its 139 us were) -> one 12-byte store.  The index chain (idx, faces) is read
+// through the read-only path; per-landmark tables are cache resident.
+__global__ __launch_bounds__(256) void landmarks_kernel(const float* __restrict__ verts, const int* __restrict__ faces,
+                                                        const int* __restrict__ idx, long idx_bs, const float* __restrict__ bary,
+                                                        long bary_bs, float* __restrict__ out, int B, int V, int L) {
+  struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+  struct __attribute__((packed, aligned(4))) I3 { int a, b, c; };
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= B * L) return;
-  const int b = t / L, l = t % L;
-  const int face = idx[b * idx_bs + l];
-  const float* bc = bary + b * bary_bs + (long)l * 3;
-  float o[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-  for (int f = 0; f < 3; ++f) {
-    const int vi = faces[(long)face * 3 + f];
-    const float* vp = verts + ((long)b * V + vi) * 3;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) o[c] += vp[c] * bc[f];
-  }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) out[(long)t * 3 + c] = o[c];
+  const int b = t / L, l = t - b * L;
+  const int face = __ldg(idx + b * idx_bs + l);
+  const I3 vi = *(const I3*)(faces + (long)face * 3);
+  const F3 bc = *(const F3*)(bary + b * bary_bs + (long)l * 3);
+  const float* vb = verts + (long)b * V * 3;
+  const F3 p0 = *(const F3*)(vb + (long)vi.a * 3), p1 = *(const F3*)(vb + (long)vi.b * 3), p2 = *(const F3*)(vb + (long)vi.c * 3);
+  F3 o;      // the reference's order of accumulation (utils/lbs.py:136: sum over the three corners, corner 0 first)
+  o.x = p0.x * bc.x; o.y = p0.y * bc.x; o.z = p0.z * bc.x;
+  o.x += p1.x * bc.y; o.y += p1.y * bc.y; o.z += p1.z * bc.y;
+  o.x += p2.x * bc.z; o.y += p2.y * bc.z; o.z += p2.z * bc.z;
+  *(F3*)(out + (long)t * 3) = o;
 }
 
 extern "C" int msmd_landmarks(const float* verts, const int* faces, const int* lmk_faces_idx, long idx_bstride,
