@@ -225,17 +225,6 @@ int msmd_person_query_attention_ln(const void* x, long x_seq_stride, const void*
                                    long kv_tstride, void* out, int N, int H, int Tk, int d, float scale, int dtype,
                                    msmd_stream_t stream);
 
-/* Decoder self-attention block in ONE launch per sequence (reference model.py:874-878, nn.TransformerDecoderLayer:
- * x = norm1(x + self_attn(x)); the sampler's diagonal path):
- *   out[n] = LN_{g1,b1}( resid'[n] + MHA(qkv[n]) Wo^T + bo ),   resid' = resid, or LN_{g3,b3}(resid) when g3 / b3 are given
- * (the residual rows may be the UN-normalised output rows of the previous layer's FFN: its norm3 is applied here).
- * qkv rows are [Q | K | V] (3 x 512 elements) at qkv + n*qkv_bstride + t*qkv_tstride (elements); T <= 112 tokens, d = 512,
- * H = 8; qkv, Wo (512, 512) row-major, resid (N, T, 512), out (N, T, 512; must not alias resid) are `dtype` (MSMD_F16 |
- * MSMD_BF16); bo, g1, b1, g3, b3 fp32.  Replaces msmd_attention + the out-projection msmd_gemm_ln + norm1. */
-int msmd_self_attn_block(const void* qkv, long qkv_bstride, long qkv_tstride, const void* Wo, const float* bo,
-                         const void* resid, const float* g3, const float* b3, const float* g1, const float* b1, void* out,
-                         int N, int T, int d, int H, float scale, float eps, int dtype, msmd_stream_t stream);
-
 /* Training-mode attention forward: as msmd_attention with attention-probability dropout p_drop (HF
  * attention_dropout, nn.MultiheadAttention(dropout=0.1) inside the decoder / encoder layers).  The keep mask is
  * Philox4x32-10(seed = rng_state[0], step = rng_state[1], site, counter = ((b H + h) Tq + q) * 128 + 4 * (key / 32) + (key / 4) % 4):

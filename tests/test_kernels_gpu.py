@@ -688,41 +688,3 @@ def test_layernorm_pre_and_folded_person_query(dtype):
     tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
     assert maxabs(a_got.float().cpu().numpy(), a_ref.float().cpu().numpy()) < tol
 
-
-
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("N,T,ln3", [(5, 111, True), (3, 111, False), (2, 37, True), (70, 112, True), (1, 16, False)])
-def test_self_attn_block_one_launch_per_sequence(dtype, N, T, ln3):
-    """msmd_self_attn_block (reference model.py:874-878: x = norm1(x + self_attn(x)) of a decoder layer, the residual optionally
-    the un-normalised output of the previous layer's FFN with its norm3 applied on the fly): against float64 on the same 16-bit
-    operands, and against the three launches it replaces (msmd_attention, out-projection msmd_gemm with residual, msmd_layernorm)
-    within the mode's rounding."""
-    o = ops()
-    g = torch.Generator(device="cpu").manual_seed(1000 * N + T)
-    d, H = 512, 8
-    qkv = (torch.randn(N, T, 3 * d, generator=g) * 0.8).to(dtype).to(DEV)
-    wo = (torch.randn(d, d, generator=g) / math.sqrt(d)).to(dtype).to(DEV)
-    bo = (torch.randn(d, generator=g) * 0.1).to(DEV)
-    resid = (torch.randn(N, T, d, generator=g) * 1.3 + 0.2).to(dtype).to(DEV)
-    g1, b1 = (torch.rand(d, generator=g) + 0.5).to(DEV), (torch.randn(d, generator=g) * 0.1).to(DEV)
-    g3, b3 = (torch.rand(d, generator=g) + 0.5).to(DEV), (torch.randn(d, generator=g) * 0.1).to(DEV)
-    scale = 64 ** -0.5
-    got = o.self_attn_block(qkv, wo, bo, resid, (g3, b3) if ln3 else None, (g1, b1), H, scale)
-    torch.cuda.synchronize()
-    # float64 reference
-    f = lambda t: t.double().cpu()
-    Q, K, V = (f(qkv[..., i * d:(i + 1) * d]).view(N, T, H, 64).transpose(1, 2) for i in range(3))
-    att = (torch.softmax(Q @ K.transpose(-1, -2) * scale, -1) @ V).transpose(1, 2).reshape(N, T, d)
-    ln = lambda x, gg, bb: torch.nn.functional.layer_norm(x, (d,), f(gg), f(bb), 1e-5)
-    r = ln(f(resid), g3, b3) if ln3 else f(resid)
-    want = ln(r + att @ f(wo).t() + f(bo), g1, b1)
-    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
-    err = float((f(got) - want).abs().max())
-    # the replaced launches on the same operands
-    a = o.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale)
-    rr = o.layernorm(resid, g3, b3) if ln3 else resid
-    three = o.layernorm(o.gemm(a, wo, bo, residual=rr), g1, b1)
-    err3 = float((f(three) - want).abs().max())
-    print(f"self_attn_block {dtype} N={N} T={T} ln3={ln3}: err {err:.2e} (three launches: {err3:.2e}; |x| max {float(want.abs().max()):.2f})")
-    assert err <= max(1.5 * err3, 8 * ulp * float(want.abs().max()))
-    assert bool(torch.isfinite(got).all())

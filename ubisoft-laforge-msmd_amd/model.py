@@ -393,26 +393,16 @@ class DenoisingNetwork_MSMD(nn.Module):
             nxt = None
             if li + 1 < len(P.layers):
                 nxt = P.layers[li + 1].f_sa[0] if (fold and diag) else P.layers[li + 1].sa_w
+            a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale,
+                              prefetch=None if P.split else (L.sa_ow, L.l1[0], L.l2[0], nxt))   # the layer's next weights
             fused_pq = getattr(self, "fused_person_query", N >= 64)
-            # the whole self-attention block -- attention over all heads, out-projection, residual (the previous layer's norm3
-            # applied on the fly) and norm1 -- as ONE launch per sequence where a sequence per workgroup fills the chip
-            block = (diag and fold and fused_pq and d == 512 and H == 8 and Tn <= 112 and
-                     getattr(self, "fused_self_block", N >= 48))
-            if block:
-                x1 = ops.self_attn_block(qkv, L.sa_ow, L.sa_ob, x if u is None else u, None if u is None else ln, L.n1, H, scale)
-                fold_n1 = False
-            else:
-                a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale,
-                                  prefetch=None if P.split else (L.sa_ow, L.l1[0], L.l2[0], nxt))   # the layer's next weights
-                # norm1 without a launch of its own (diagonal path, fused person query): its two consumers apply it -- the
-                # person-token query projection through folded weights, the norm2 launch as its first stage (layernorm_pre)
-                fold_n1 = fold and diag and fused_pq
-                u1 = ops.gemm(a, L.sa_ow, L.sa_ob, residual=x) if u is None else \
-                    ops.gemm_ln(a, L.sa_ow, L.sa_ob, u, r_stats=st, r_gamma=ln[0], r_beta=ln[1])
-                if not fold_n1:
-                    x = ops.layernorm(u1, *L.n1)
-            if block:
-                x = x1
+            # norm1 without a launch of its own (diagonal path, fused person query): its two consumers apply it -- the
+            # person-token query projection through folded weights, the norm2 launch as its first stage (layernorm_pre)
+            fold_n1 = fold and diag and fused_pq
+            u1 = ops.gemm(a, L.sa_ow, L.sa_ob, residual=x) if u is None else \
+                ops.gemm_ln(a, L.sa_ow, L.sa_ob, u, r_stats=st, r_gamma=ln[0], r_beta=ln[1])
+            if not fold_n1:
+                x = ops.layernorm(u1, *L.n1)
             kv = kv_list[li] if kv_list is not None else ops.gemm(mem, L.ca_kvw, L.ca_kvb)
             if diag:
                 # only the person token (row 0) has a real softmax; rows t >= 1 come from the precomputed R

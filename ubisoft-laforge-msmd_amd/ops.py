@@ -1009,25 +1009,6 @@ def person_query_attention(x, wq, bq, kv, n_heads, scale, wq_colsum=None, eps=1e
     return out
 
 
-def self_attn_block(qkv, wo, bo, resid, ln3, ln1, n_heads, scale, eps=1e-5):
-    """x1 = LN1(resid' + MHA(qkv) wo^T + bo) for a decoder layer, one launch per sequence (msmd_self_attn_block): qkv (N, T, 3d) =
-    [Q | K | V] rows of the fused projection, resid (N, T, d) the block's input -- un-normalised when ln3 = (gamma, beta) of the
-    previous layer's norm3 is given, which is then applied on the fly -- ln1 = (gamma, beta) of norm1.  d = 512, 8 heads, T <= 112."""
-    _need_cuda(qkv, wo, resid)
-    N, T, d3 = qkv.shape
-    d = d3 // 3
-    if not (qkv.stride(2) == 1 and wo.is_contiguous() and wo.shape == (d, d) and resid.is_contiguous() and resid.shape == (N, T, d)):
-        raise ValueError("self_attn_block: shapes / layout")
-    if not (qkv.dtype == wo.dtype == resid.dtype):
-        raise TypeError("self_attn_block: qkv, wo, resid must share a dtype")
-    out = torch.empty_like(resid)
-    g3, b3 = ln3 if ln3 is not None else (None, None)
-    _lib.check(_lib.load().msmd_self_attn_block(_p(qkv), qkv.stride(0), qkv.stride(1), _p(wo), _p(bo), _p(resid), _p(g3), _p(b3),
-                                                _p(ln1[0]), _p(ln1[1]), _p(out), N, T, d, n_heads, float(scale), float(eps),
-                                                _dt(qkv), _stream()), "msmd_self_attn_block")
-    return out
-
-
 def cast_transpose_multi(flat, meta, n, tiles, cast_arena, t_arena):
     """One launch: bf16 cast + bf16 transpose of n (N, K) matrices of the flat fp32 arena (meta: see msmd_hip.h)."""
     _need_cuda(flat, meta, cast_arena, t_arena)
