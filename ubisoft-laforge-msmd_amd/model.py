@@ -238,7 +238,10 @@ class DenoisingNetwork_MSMD(nn.Module):
         P.ds0 = (cd(sd["diff_step_map.0.weight"]), f32(sd["diff_step_map.0.bias"]))
         P.ds2 = (cd(sd["diff_step_map.2.weight"]), f32(sd["diff_step_map.2.bias"]))
         P.pp = (padk(sd["person_proj.weight"]), f32(sd["person_proj.bias"]))
-        P.fp = (padk(sd["feature_proj.weight"]), f32(sd["feature_proj.bias"]))
+        # feature_proj's K = 68 is padded to a whole 64-element K tile in the 16-bit modes (zeros: the packed input rows are
+        # zero-filled to the same width), so it runs on the LDS-DMA GEMM like every other projection (K = 72 took the
+        # register-staged kernel: 29.8 us per sampler step for 1.6 GFLOP)
+        P.fp = (padk(sd["feature_proj.weight"], 32 if split else (64 if dtype != torch.float32 else 8)), f32(sd["feature_proj.bias"]))
         P.kp_person, P.kp_feat = P.pp[0].shape[1], P.fp[0].shape[1]
         P.mask = self.alignment_mask.to(torch.uint8).contiguous() if self.alignment_mask is not None else None
         # align_mask_width == 1 (the default): motion token t >= 1 sees exactly audio frame t - 1 and the person token
