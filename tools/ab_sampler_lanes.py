@@ -1,5 +1,5 @@
 """Same-process A/B of MSMD.sample's hipGraph loop with 1 / 2 / 4 lanes (msmd_amd.sampler.LANES), alternating, 3 rounds.
-env: DTYPE (fp16), T (200), B (64), LANES (1,2,4)"""
+env: DTYPE (fp16), T (200), B (64), LANES (1,2)"""
 import os
 import sys
 import time
@@ -13,8 +13,7 @@ from msmd_amd.model import DiffusionSchedule, get_diffusion_model
 
 T, B = int(os.environ.get("T", "200")), int(os.environ.get("B", "64"))
 lanes = [int(x) for x in os.environ.get("LANES", "1,2").split(",")]
-fused = [False]
-lanes = [(n, f) for f in fused for n in lanes]
+lanes = [(n, False) for n in lanes]
 model = get_diffusion_model(synthetic_args(compute_dtype=os.environ.get("DTYPE", "fp16")), "cuda").eval()
 model.diffusion_sched = DiffusionSchedule(T, "cosine").to("cuda")
 af = torch.randn(B, 100, 512, device="cuda"); shape = torch.zeros(B, 100, device="cuda"); style = torch.randn(B, 256, device="cuda")
@@ -23,7 +22,6 @@ res = {n: [] for n in lanes}
 for rep in range(3):
     for n, f in lanes:
         model.sampler_lanes = n
-        model.denoising_net.fused_cross_row0 = f
         model.__dict__.pop("_step_graphs", None)
         x, _, _ = model.sample(af, shape, style, indicator=ind, cfg_scale=1.15)  # capture + warm-up
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -35,4 +33,4 @@ for rep in range(3):
             print(f"lanes asked {n}, used {used}")
 for n, f in lanes:
     r = sorted(res[n, f])
-    print(f"lanes {n} cross_row0_ln {int(f)}: {r[len(r) // 2]:.3f} ms/step (min {r[0]:.3f}) B={B} T={T}")
+    print(f"lanes {n}: {r[len(r) // 2]:.3f} ms/step (min {r[0]:.3f}) B={B} T={T}")
