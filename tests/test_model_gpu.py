@@ -516,6 +516,21 @@ def test_capture_forward_replays_equal_eager_on_new_inputs():
                     train_with_CFG=False, eps=eps)
         torch.cuda.synchronize()
         assert all(torch.equal(g, r) for g, r in zip(got, ref))
+    # lanes: the two clips as two groups, each on a HIP stream of its own inside the one graph -- every group's result is
+    # `forward` of that group bit for bit (capture_forward verifies this itself on perturbed inputs); against the one-lane
+    # forward of the whole batch the 16-bit mode may differ in last bits (statistics slabs / tiles follow the row count)
+    run2 = model.capture_forward(dev(x["motion"]), mk("cf_a0"), dev(x["shape"]), dev(x["style"]), ts, dev(x["indicator"]), eps, lanes=2)
+    assert run2.lanes == 2 and run2.lane_drift is not None and run2.lane_drift < 0.1
+    a = mk("cf_a3")
+    got = [o.clone() for o in run2(audio=a)]
+    torch.cuda.synchronize()
+    for i in range(2):
+        sl = slice(i, i + 1)
+        ref = model(dev(x["motion"])[sl], a[sl], dev(x["shape"])[sl], dev(x["style"])[sl], time_step=ts[sl],
+                    indicator=dev(x["indicator"])[sl], train_with_CFG=False, eps=eps[sl])
+        assert all(torch.equal(g[sl], r) for g, r in zip(got, ref))
+    with pytest.raises(ValueError):
+        model.capture_forward(dev(x["motion"]), mk("cf_a0"), dev(x["shape"]), dev(x["style"]), ts, dev(x["indicator"]), eps, lanes=3)
 
 
 @pytest.mark.parametrize("B,S,frames", [(1, 32000, 50), (3, 48000, 75), (33, 16000, 25), (2, 31999, 50), (2, 64001, 100)])
