@@ -24,7 +24,7 @@ for _ in range(3):
 graphs, outs = {}, {}
 for name, stmt in settings:
     ops.GEMM_ROUTER = None
-    exec(stmt, {"ops": ops, "torch": torch, "os": os, "model": model})
+    exec(stmt, {"ops": ops, "torch": torch, "os": os})
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):

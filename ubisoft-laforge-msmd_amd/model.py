@@ -290,51 +290,25 @@ class DenoisingNetwork_MSMD(nn.Module):
         return P
 
     # ------------------------------------------------------------------ pieces (shared with the sampler)
-    def static_bases(self, static_style_feat, dtype, out_dtype=None, out=None):
+    def static_bases(self, static_style_feat, dtype, out_dtype=None):
         """(Ns, 1, d_style) -> (Ns, nb, dm): the 4 style->static-pose MLPs (model.py:964-971); step-invariant."""
         P = self.pack(dtype)
         nb, dm, d = self.num_of_basis, self.motion_feat_dim, self.feature_dim
         s = ops.cast(static_style_feat.reshape(-1, static_style_feat.shape[-1]).contiguous(), dtype)
         Ns = s.shape[0]
         h = ops.gemm(s, *P.st0, act=ops.ACT_GELU)  # (Ns, nb*d)
-        stat = out if out is not None else torch.empty(Ns, nb, dm, device=s.device, dtype=out_dtype or dtype)
+        stat = torch.empty(Ns, nb, dm, device=s.device, dtype=out_dtype or dtype)
         ops.gemm(h, P.st2[0], P.st2[1], None, out=stat, M=Ns, N=dm, K=d, lda=nb * d, ldw=d, ldc=nb * dm, batch=nb,
                  strideA=d, strideW=dm * d, strideC=dm, strideBias=dm)
         return stat
 
-    def person_token(self, person_feat, step, dtype, out=None):
+    def person_token(self, person_feat, step, dtype):
         """person_proj(person_feat) + diff_step_map(TE.pe[0, step]) -> (N, d) (model.py:931-933)."""
         P = self.pack(dtype)
         te = P.te_cd[step]
         emb = ops.gemm(ops.gemm(te, *P.ds0, act=ops.ACT_GELU), *P.ds2)
         pf = ops.pad_cols(person_feat.reshape(person_feat.shape[0], -1).float().contiguous(), P.kp_person, dtype)
-        return ops.gemm(pf, *P.pp, residual=emb, out=out)
-
-    def prologue_async(self, motion_feat, person_feat, static_style_feat, prev_motion_feat, step, indicator, dtype, qsample):
-        """Everything of `forward` that does not depend on the audio -- person / step token, the packed (q-sampled) input rows,
-        the static-style bases: ten small launches -- on a side HIP stream, so a caller that still has the audio encoder to run
-        (MSMD.forward on raw audio) runs them beside it instead of after it.  The three results are allocated on the CALLER's
-        stream (they are consumed there, after `forward` waits for the side stream); only intermediates live on the side."""
-        P = self.pack(dtype)
-        N = person_feat.shape[0]
-        L, Lp = motion_feat.shape[1], prev_motion_feat.shape[1]
-        dev = person_feat.device
-        tok0 = torch.empty(N, self.feature_dim, device=dev, dtype=dtype)
-        feats = torch.empty(N, 1 + Lp + L, P.kp_feat, device=dev, dtype=dtype)
-        Ns = static_style_feat.reshape(-1, static_style_feat.shape[-1]).shape[0]
-        stat = torch.empty(Ns, self.num_of_basis, self.motion_feat_dim, device=dev, dtype=torch.float32)
-        side = self.__dict__.setdefault("_side_streams", {}).get(dev)
-        if side is None:
-            side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            step = torch.as_tensor(step, device=dev, dtype=torch.long)
-            self.person_token(person_feat, step, dtype, out=tok0)
-            eps, c0, c1 = qsample if qsample is not None else (None, None, None)
-            ops.denoiser_pack_input(motion_feat.float().contiguous(), prev_motion_feat.float().contiguous(),
-                                    indicator.float().contiguous() if self.use_indicator else None, feats, eps, c0, c1)
-            self.static_bases(static_style_feat, dtype, out=stat)
-        return tok0, feats, stat, side
+        return ops.gemm(pf, *P.pp, residual=emb)
 
     def memory_kv(self, mem, dtype, stacked=False):
         """Cross-attention K/V projections of the audio memory for every layer: step-invariant in the
@@ -503,34 +477,27 @@ class DenoisingNetwork_MSMD(nn.Module):
         return ops.gemm(h, *P.md2, out_dtype=torch.float32)
 
     def forward(self, motion_feat, audio_feat, person_feat, static_style_feat, prev_motion_feat, prev_audio_feat, step,
-                indicator=None, keep_separate=False, dtype=None, _qsample=None, _audio_cd=None, _pre=None):
-        """reference model.py:914-996.  Returns (N, L_p + L, d_motion) fp32.  `_pre`: the result of `prologue_async` on the
-        same operands (the audio-independent launches, already running on a side stream)."""
+                indicator=None, keep_separate=False, dtype=None, _qsample=None, _audio_cd=None):
+        """reference model.py:914-996.  Returns (N, L_p + L, d_motion) fp32."""
         dtype = dtype or getattr(self, "compute_dtype", torch.float32)
         if self.use_indicator and indicator is None:
             raise TypeError("expected Tensor as element 1 in argument 0, but got NoneType")  # reference model.py:944
         P = self.pack(dtype)
         N = person_feat.shape[0]
         L, Lp, dm, nb = motion_feat.shape[1], prev_motion_feat.shape[1], self.motion_feat_dim, self.num_of_basis
-        stat = None
-        if _pre is not None:
-            tok0, feats, stat, side = _pre
-            torch.cuda.current_stream(tok0.device).wait_stream(side)
-        else:
-            step = torch.as_tensor(step, device=self.device, dtype=torch.long)
-            tok0 = self.person_token(person_feat, step, dtype)
-            feats = torch.empty(N, 1 + Lp + L, P.kp_feat, device=self.device, dtype=dtype)
-            eps, c0, c1 = _qsample if _qsample is not None else (None, None, None)
-            ops.denoiser_pack_input(motion_feat.float().contiguous(), prev_motion_feat.float().contiguous(),
-                                    indicator.float().contiguous() if self.use_indicator else None, feats, eps, c0, c1)
+        step = torch.as_tensor(step, device=self.device, dtype=torch.long)
+        tok0 = self.person_token(person_feat, step, dtype)
+        feats = torch.empty(N, 1 + Lp + L, P.kp_feat, device=self.device, dtype=dtype)
+        eps, c0, c1 = _qsample if _qsample is not None else (None, None, None)
+        ops.denoiser_pack_input(motion_feat.float().contiguous(), prev_motion_feat.float().contiguous(),
+                                indicator.float().contiguous() if self.use_indicator else None, feats, eps, c0, c1)
         # audio memory [previous window | this window] in the compute dtype: two casting copies into one buffer
         La, Lpa = audio_feat.shape[1], prev_audio_feat.shape[1]
         mem = torch.empty(N, Lpa + La, audio_feat.shape[2], device=self.device, dtype=dtype)
         mem[:, :Lpa].copy_(prev_audio_feat)
         mem[:, Lpa:].copy_(_audio_cd if _audio_cd is not None else audio_feat)
         dec = self.trunk(feats, tok0, mem, dtype)
-        if stat is None:
-            stat = self.static_bases(static_style_feat, dtype, out_dtype=torch.float32)   # the head mixes in fp32
+        stat = self.static_bases(static_style_feat, dtype, out_dtype=torch.float32)   # the head mixes in fp32
         if keep_separate:
             dynamic = dec[:, :, :dm]
             alphas = dec[:, :, dm:]
@@ -693,8 +660,19 @@ class MSMD(nn.Module):
         if self.use_style:
             assert style_feat is not None, "Missing style features!"
         batch_size = motion_feat.shape[0]
-        if audio_or_feat.ndim not in (2, 3):
+        if audio_or_feat.ndim == 2:
+            assert audio_or_feat.shape[1] == 16000 * self.n_motions / self.fps, \
+                f"Incorrect audio length {audio_or_feat.shape[1]}"
+            audio_cd = self._audio_feat(audio_or_feat, self.n_motions, dtype)      # compute dtype: what the denoiser reads
+            audio_feat_saved = audio_cd.float()
+        elif audio_or_feat.ndim == 3:
+            assert audio_or_feat.shape[1] == self.n_motions, f"Incorrect audio feature length {audio_or_feat.shape[1]}"
+            audio_feat_saved = audio_or_feat
+        else:
             raise ValueError(f"Incorrect audio input shape {audio_or_feat.shape}")
+        audio_feat = audio_feat_saved
+        if audio_or_feat.ndim != 2:
+            audio_cd = None
         if shape_feat.ndim == 2:
             shape_feat = shape_feat.unsqueeze(1)
         if style_feat is not None and style_feat.ndim == 2:
@@ -703,40 +681,8 @@ class MSMD(nn.Module):
             prev_motion_feat = self.start_motion_feat.expand(batch_size, -1, -1)
         if prev_audio_feat is None:
             prev_audio_feat = self.start_audio_feat.expand(batch_size, -1, -1)
-        cfg_masks = len(self.guiding_conditions) > 0 and train_with_CFG
-        # The denoiser's audio-independent launches (person / step token, packed q-sampled rows, static-style bases) go onto a
-        # side stream BEFORE the encoder is issued and run beside it.  Only without CFG masking (its draws come after the audio
-        # features in the reference's order, model.py:190-218, and the style mask feeds the person token).
-        pre = None
-        if (audio_or_feat.ndim == 2 and audio_or_feat.is_cuda and not cfg_masks and not keep_separate
-                and getattr(self, "overlap_prologue", True)):
-            assert audio_or_feat.shape[1] == 16000 * self.n_motions / self.fps, \
-                f"Incorrect audio length {audio_or_feat.shape[1]}"
-            person_feat = shape_feat if style_feat is None else torch.cat([shape_feat, style_feat], dim=-1)
-            if time_step is None:
-                time_step = self.diffusion_sched.uniform_sample_t(batch_size)
-            ts = torch.as_tensor(time_step, device=self.device, dtype=torch.long)
-            t0, t1 = self.diffusion_sched.qsample_tables()
-            c0, c1 = t0[ts], t1[ts]
-            if eps is None:
-                eps = torch.randn_like(motion_feat)
-            eps = eps.float().contiguous()
-            if self.denoising_net.use_indicator and indicator is None:
-                raise TypeError("expected Tensor as element 1 in argument 0, but got NoneType")  # reference model.py:944
-            pre = self.denoising_net.prologue_async(motion_feat, person_feat, style_feat, prev_motion_feat, ts, indicator, dtype,
-                                                    (eps, c0, c1))
-        if audio_or_feat.ndim == 2:
-            assert audio_or_feat.shape[1] == 16000 * self.n_motions / self.fps, \
-                f"Incorrect audio length {audio_or_feat.shape[1]}"
-            audio_cd = self._audio_feat(audio_or_feat, self.n_motions, dtype)      # compute dtype: what the denoiser reads
-            audio_feat_saved = audio_cd.float()
-        else:
-            assert audio_or_feat.shape[1] == self.n_motions, f"Incorrect audio feature length {audio_or_feat.shape[1]}"
-            audio_feat_saved = audio_or_feat
-            audio_cd = None
-        audio_feat = audio_feat_saved
         # classifier-free guidance masking (model.py:190-218)
-        if cfg_masks:
+        if len(self.guiding_conditions) > 0 and train_with_CFG:
             assert len(self.guiding_conditions) <= 2, "Only support 1 or 2 CFG conditions!"
             if len(self.guiding_conditions) == 1 or self.cfg_mode == "independent":
                 null_cond_prob = 0.5 if len(self.guiding_conditions) >= 2 else 0.1
@@ -756,20 +702,19 @@ class MSMD(nn.Module):
                 if "audio" in self.guiding_conditions:
                     audio_feat = torch.where((mask_flag > 0.9).view(-1, 1, 1),
                                              self.null_audio_feat.expand(batch_size, self.n_motions, -1), audio_feat)
-        if pre is None:
-            person_feat = shape_feat if style_feat is None else torch.cat([shape_feat, style_feat], dim=-1)
-            if time_step is None:
-                time_step = self.diffusion_sched.uniform_sample_t(batch_size)
-            ts = torch.as_tensor(time_step, device=self.device, dtype=torch.long)
-            t0, t1 = self.diffusion_sched.qsample_tables()
-            c0, c1 = t0[ts], t1[ts]                                     # sqrt(alpha_bar_t), sqrt(1 - alpha_bar_t)
-            if eps is None:
-                eps = torch.randn_like(motion_feat)
-            eps = eps.float().contiguous()
+        person_feat = shape_feat if style_feat is None else torch.cat([shape_feat, style_feat], dim=-1)
+        if time_step is None:
+            time_step = self.diffusion_sched.uniform_sample_t(batch_size)
+        ts = torch.as_tensor(time_step, device=self.device, dtype=torch.long)
+        t0, t1 = self.diffusion_sched.qsample_tables()
+        c0, c1 = t0[ts], t1[ts]                                     # sqrt(alpha_bar_t), sqrt(1 - alpha_bar_t)
+        if eps is None:
+            eps = torch.randn_like(motion_feat)
+        eps = eps.float().contiguous()
         # q-sample is fused into the denoiser's input packing kernel (model.py:231-236)
         out = self.denoising_net(motion_feat, audio_feat, person_feat, style_feat, prev_motion_feat, prev_audio_feat,
                                  ts, indicator, keep_separate=keep_separate, dtype=dtype, _qsample=(eps, c0, c1),
-                                 _audio_cd=audio_cd if audio_feat is audio_feat_saved else None, _pre=pre)
+                                 _audio_cd=audio_cd if audio_feat is audio_feat_saved else None)
         if keep_separate:
             dyn, stat, alpha_t = out
             if self.use_head_alpha:
