@@ -188,8 +188,9 @@ def pmc_traffic(mode, key=None, tile="128ELi128E"):
             d = json.load(open(path))
             want = {"bf16": "gemm2_kernel", "fp16": "gemm2_kernel", "f16x2": "gemm2s_kernel", "fp32": "gemm_kernel"}[mode]
             # (the multi-round launches of the same tile run as gemm2p_kernel, its persistent form)
+            tiles = (tile, "192ELi128E") if key == "sampler" else (tile,)      # the sampler's family spans both tile shapes
             ks = [v for n, v in d.items() if any(w + "I" in n.replace("<", "I") for w in (want, want.replace("gemm2_", "gemm2p_")))
-                  and tile in n.replace(", ", "ELi").replace("<", "I")]
+                  and any(t in n.replace(", ", "ELi").replace("<", "I") for t in tiles)]
             ks = ks or [v for n, v in d.items() if want in n and "128" in n and ("gemm2s" in n) == (mode == "f16x2")]
             if ks:
                 # since round 4 the 128 x 128 kernel is one symbol per epilogue family: launch-weighted mean over them
@@ -330,6 +331,8 @@ def sampler_roofline(model, af, shape, style, ind, xT, device, steps=6):
     sched = model.diffusion_sched
     model.diffusion_sched = DiffusionSchedule(steps, "cosine").to(device)
     noise = _LazyNoise((Bl, 100, 67), device, 78)
+    from msmd_amd import ops
+    tile_keep, ops.GEMM_LN_TILE = ops.GEMM_LN_TILE, (15 if lanes > 1 else ops.GEMM_LN_TILE)   # the multi-lane graph's tile choice
     try:
         def run():
             model.sample(af[:Bl], shape[:Bl], style[:Bl], motion_at_T=xT[:Bl], indicator=ind[:Bl], cfg_scale=1.15, noise=noise)
@@ -337,10 +340,11 @@ def sampler_roofline(model, af, shape, style, ind, xT, device, steps=6):
                          traffic_key="sampler")
     finally:
         model.diffusion_sched = sched
+        ops.GEMM_LN_TILE = tile_keep
     fam = r.get("both_tiles") or r
     out = dict(bound="mfma", achieved=fam["achieved"], peak=r["peak"], unit="TFLOP/s", frac=fam["frac"], traffic=r["traffic"],
-               kernel=("gemm2_kernel<f16,128,128,4,2,2,pipelined> + its persistent form gemm2p_kernel (csrc/gemm.hip): the decoder "
-                       "layers' QKV / out-projection / FFN GEMMs of one lane"),
+               kernel=("gemm2_kernel<f16,{192|128},128,4,2,2,pipelined> + the persistent form gemm2p_kernel (csrc/gemm.hip): the decoder "
+                       "layers' QKV / out-projection / FFN-2 (192 x 128 tile beside another lane) and FFN-1 (128 x 128) GEMMs of one lane"),
                launches_per_step=fam["launches_per_step"] // steps, ms_per_step_in_kernel=round(fam["ms_per_step_in_kernel"] / steps, 4),
                avg_launch_us=round(fam["ms_per_step_in_kernel"] * 1e3 / max(1, fam["launches_per_step"]), 2),
                sequences_per_lane=3 * Bl, lanes=lanes,

@@ -8,11 +8,13 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+from msmd_amd import ops
 from msmd_amd.config import synthetic_args
 from msmd_amd.model import DiffusionSchedule, get_diffusion_model
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+ops.GEMM_LN_TILE = 15      # the tile the two-lane step graph routes its LayerNorm-epilogue GEMMs to (msmd_amd/sampler.py)
 model = get_diffusion_model(synthetic_args(compute_dtype=os.environ.get("DTYPE", "fp16")), "cuda").eval()
 model.diffusion_sched = DiffusionSchedule(T, "cosine").to("cuda")
 g = torch.Generator(device="cuda").manual_seed(0)

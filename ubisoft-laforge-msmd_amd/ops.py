@@ -313,6 +313,10 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
     return out
 
 
+GEMM_LN_TILE = None            # 15 | 17 | None: tile of msmd_gemm_ln's big-tile family for the calls made while it is set (the
+                               # sampler sets 15 -- 192 x 128 -- around the capture of a multi-lane step graph, see sampler.py)
+
+
 def gemm_ln(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None, *, a_stats=None, w_colsum=None,
             r_stats=None, r_gamma=None, r_beta=None, stats_out=False, eps=1e-5):
     """C = act(LN_A(a) @ w^T + bias) + LN_R(residual) with the LayerNorms folded into the GEMM epilogue (msmd_gemm_ln):
@@ -348,7 +352,7 @@ def gemm_ln(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=No
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.check(lib.msmd_gemm_ln(_p(a), _p(w), _p(bias), _p(residual), _p(out), M, N, K, _dt(a), _dt(out), a.stride(-2) if a.dim() >= 2 else K,
-                                w.stride(0), N, ldr, act | GEMM_LN_FLAGS | (((66 if GEMM_LN_ALL_IN_ONE else (GEMM_LN_ROUTER(M, N, K) or 0) if GEMM_LN_ROUTER is not None else 0)) << 8), _p(a_stats), _p(w_colsum), _p(r_stats), _p(r_gamma),
+                                w.stride(0), N, ldr, act | GEMM_LN_FLAGS | (((66 if GEMM_LN_ALL_IN_ONE else (GEMM_LN_ROUTER(M, N, K) or 0) if GEMM_LN_ROUTER is not None else (GEMM_LN_TILE or 0))) << 8), _p(a_stats), _p(w_colsum), _p(r_stats), _p(r_gamma),
                                 _p(r_beta), _p(st), slab_in, slab_out, float(eps), _stream()), "msmd_gemm_ln")
     if GEMM_TRACE is not None:
         e1.record()

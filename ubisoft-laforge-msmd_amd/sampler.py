@@ -303,6 +303,11 @@ class _StepGraph:
                         ln.body()
             for st in self.streams:                         # ... join
                 cur.wait_stream(st)
+        # With more than one lane the LayerNorm-epilogue GEMMs (QKV, out-projection, FFN-2 of a lane: M = 10 656 rows at B = 64) take
+        # the 192 x 128 tile: alone on the chip its grids are short of a round (672 / 224 tiles on 512 slots) and the 128 x 128
+        # tile wins, but beside another lane's launches the holes are filled and the larger tile's better loop shows (same box,
+        # alternating: 2.286 -> 2.237, 2.208 -> 2.177 ms per step).  Same products in the same order: results are bit-identical.
+        tile_keep, ops.GEMM_LN_TILE = ops.GEMM_LN_TILE, (15 if lanes > 1 else ops.GEMM_LN_TILE)
         # warm-up on a side stream (allocator + lazy kernel loading), then capture
         for ln in self.lane:
             ln.t_dev.fill_(1)
@@ -316,9 +321,12 @@ class _StepGraph:
         # graph serves the whole loop.
         self.k = max(d for d in range(1, min(STEPS_PER_GRAPH, T) + 1) if T % d == 0)
         self.graph = torch.cuda.CUDAGraph()
-        with ops.capture_guard():
-            with torch.cuda.graph(self.graph):
-                bodies(self.k)
+        try:
+            with ops.capture_guard():
+                with torch.cuda.graph(self.graph):
+                    bodies(self.k)
+        finally:
+            ops.GEMM_LN_TILE = tile_keep
 
     def run(self, T, motion_at_T, ops_in, coefficients):
         for ln in self.lane:
