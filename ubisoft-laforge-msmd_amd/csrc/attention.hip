@@ -860,22 +860,57 @@ __global__ __launch_bounds__(256) void person_query_attention_kernel(const T* __
   const T* vbase = V + (long)n * kv_bstride + h * 64 + c * 8;
   // 2-byte storage, Tk <= 128: the K / V stream (the only HBM-sized traffic here) does not depend on the query, so all
   // of it is requested before the projection starts and lands behind it
+  // (K before the projection, V behind it: holding both through the projection left registers for ONE 9-load batch of the
+  // projection in flight -- eight serial L2 round trips, half of the launch's 22 us in the sampler step; with V requested after
+  // the projection two batches fit under 256 registers, i.e. two workgroups per CU: four round trips)
   constexpr bool PRE = sizeof(T) == 2 && NIT <= 16;
   u32x4 kraw[PRE ? NIT : 1], vraw[PRE ? NIT : 1];
   if constexpr (PRE) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it)
-      if (it * 8 < Tk) {
-        const long ro = (long)min(it * 8 + g, Tk - 1) * kv_tstride;
-        kraw[it] = *(const u32x4*)(kbase + ro);
-        vraw[it] = *(const u32x4*)(vbase + ro);
-      }
+      if (it * 8 < Tk) kraw[it] = *(const u32x4*)(kbase + (long)min(it * 8 + g, Tk - 1) * kv_tstride);
   }
   float qv[8];
 #pragma unroll
   for (int rb = 0; rb < 8; ++rb) qv[rb] = 0.f;
+  // the lane's 8 bias / column-sum values, requested here (under the projection): read where they are used they were 16
+  // dependent single loads behind run-time tests, one L2 round trip each
+  float bqv[8], csv[8];
+#pragma unroll
+  for (int rb = 0; rb < 8; ++rb) {
+    const int r = h * 64 + rb * 8 + g;
+    bqv[rb] = bq ? bq[r] : 0.f;
+    csv[rb] = wq_colsum ? wq_colsum[r] : 0.f;
+  }
   float xs1 = 0.f, xs2 = 0.f;          // sum and sum of squares of this lane's part of x0 (the 8 lanes of a group cover it)
-  for (int i = 0; i < nch; ++i) {
+  int i_done = 0;
+  if constexpr (PRE) {
+    // two chunks of the row per batch: 2 + 16 sixteen-byte loads in flight, then their 128 FMAs per lane
+    constexpr int UB = 2;
+#pragma unroll 1
+    for (; i_done + UB <= nch; i_done += UB) {
+      typedef typename Vec8T<T>::type V8;
+      V8 xr[UB], wr[UB][8];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        xr[u] = *(const V8*)(x0 + (c + 8 * (i_done + u)) * 8);
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb) wr[u][rb] = *(const V8*)(Wq + (long)(h * 64 + rb * 8 + g) * d + (c + 8 * (i_done + u)) * 8);
+      }
+      __builtin_amdgcn_sched_barrier(0);      // all 18 requests go out before the first use (the scheduler otherwise sinks each
+#pragma unroll                                // load to its FMAs to save registers: one L2 round trip per load)
+      for (int u = 0; u < UB; ++u) {
+        float xv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xv[e] = (float)xr[u][e]; xs1 += xv[e]; xs2 = fmaf(xv[e], xv[e], xs2); }
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) qv[rb] = fmaf(xv[e], (float)wr[u][rb][e], qv[rb]);
+      }
+    }
+  }
+  for (int i = i_done; i < nch; ++i) {
     float xv[8];
     load8<T>(x0 + (c + 8 * i) * 8, xv);
 #pragma unroll
@@ -897,9 +932,13 @@ __global__ __launch_bounds__(256) void person_query_attention_kernel(const T* __
 #pragma unroll
   for (int rb = 0; rb < 8; ++rb) {
     float t = group8_sum(qv[rb]);
-    const int r = h * 64 + rb * 8 + g;
-    if (wq_colsum) t = ln_rs * (t - ln_mu * wq_colsum[r]);
-    if (c == 0) sq[wid][rb * 8 + g] = (t + (bq ? bq[r] : 0.f)) * scale;
+    if (wq_colsum) t = ln_rs * (t - ln_mu * csv[rb]);
+    if (c == 0) sq[wid][rb * 8 + g] = (t + bqv[rb]) * scale;
+  }
+  if constexpr (PRE) {      // V goes out now and lands behind the scores and the softmax (unconditional, clamped rows: loads
+#pragma unroll              // under a branch are sunk to their use, one L2 round trip each)
+    for (int it = 0; it < NIT; ++it) vraw[it] = *(const u32x4*)(vbase + (long)min(it * 8 + g, Tk - 1) * kv_tstride);
+    __builtin_amdgcn_sched_barrier(0);
   }
   __builtin_amdgcn_wave_barrier();
   float q8[8];
