@@ -67,15 +67,14 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const AttnArgs p) {
   auto prefetch = [&](int kv0) {
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
-      const int c = tid + i * NT;
+      // unconditional loads of clamped keys (zeroed on the way into LDS): loads under a run-time test go out one piece at a time
+      const int c = min(tid + i * NT, 64 * NCH - 1);
       const int row = c / NCH, ch = c % NCH;
-      const int key = kv0 + row;
-      pk[i] = pv[i] = u32x4{0, 0, 0, 0};
-      if (c < 64 * NCH && key < p.Tk) {
-        pk[i] = *(const u32x4*)(Kb + (long)key * p.kt + ch * (16 / sizeof(T)));
-        pv[i] = *(const u32x4*)(Vb + (long)key * p.vt + ch * (16 / sizeof(T)));
-      }
+      const int key = min(kv0 + row, p.Tk - 1);
+      pk[i] = *(const u32x4*)(Kb + (long)key * p.kt + ch * (16 / sizeof(T)));
+      pv[i] = *(const u32x4*)(Vb + (long)key * p.vt + ch * (16 / sizeof(T)));
     }
+    __builtin_amdgcn_sched_barrier(0);
   };
   prefetch(0);
   // msmd_attention_prefetch / training: byte ranges (the weights of the GEMMs that follow) pulled through the memory-side
@@ -102,12 +101,14 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const AttnArgs p) {
       const int c = tid + i * NT;
       if (c < 64 * NCH) {
         const int row = c / NCH, ch = c % NCH;
+        const bool live = kv0 + row < p.Tk;
+        const u32x4 kk = live ? pk[i] : u32x4{0, 0, 0, 0}, vv = live ? pv[i] : u32x4{0, 0, 0, 0};
         if constexpr (BF) {
-          *(u32x4*)(sK + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = pk[i];
-          *(u32x4*)(sV + row * 128 + ((((ch >> 1) ^ ((row >> 1) & 3)) << 5) + ((ch & 1) << 4))) = pv[i];
+          *(u32x4*)(sK + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kk;
+          *(u32x4*)(sV + row * 128 + ((((ch >> 1) ^ ((row >> 1) & 3)) << 5) + ((ch & 1) << 4))) = vv;
         } else {
-          *(u32x4*)(sK + row * 256 + ((ch ^ (row & 15)) << 4)) = pk[i];
-          *(u32x4*)(sV + row * 272 + (ch << 4)) = pv[i];
+          *(u32x4*)(sK + row * 256 + ((ch ^ (row & 15)) << 4)) = kk;
+          *(u32x4*)(sV + row * 272 + (ch << 4)) = vv;
         }
       }
     }
@@ -313,26 +314,28 @@ __global__ __launch_bounds__(64 * NW) void attn_whole_kernel(const AttnArgs p) {
   unsigned char* sV = smem + rows * 128;
 
   // every load of the kernel goes out here: K, V chunks (16 B), then this lane's Q fragments
+  // (unconditional loads of CLAMPED rows, zeroed on the way into LDS: with the loads under `if (row < Tk)` the compiler closed
+  // every conditional block with s_waitcnt vmcnt(0) -- the NPF pieces went out one pair at a time, 2-4 serial HBM round trips
+  // in front of the first MFMA of a 17-28 us launch)
   constexpr int NPF = (ROWS * 8 + NT - 1) / NT;
   u32x4 pk[NPF], pv[NPF];
 #pragma unroll
   for (int i = 0; i < NPF; ++i) {
-    const int c = tid + i * NT, row = c >> 3, ch = c & 7;
-    pk[i] = pv[i] = u32x4{0, 0, 0, 0};
-    if (row < p.Tk) {
-      pk[i] = *(const u32x4*)(Kb + (long)row * p.kt + ch * 8);
-      pv[i] = *(const u32x4*)(Vb + (long)row * p.vt + ch * 8);
-    }
+    const int c = tid + i * NT, row = min(c >> 3, p.Tk - 1), ch = c & 7;
+    pk[i] = *(const u32x4*)(Kb + (long)row * p.kt + ch * 8);
+    pv[i] = *(const u32x4*)(Vb + (long)row * p.vt + ch * 8);
   }
   u32x4 qf[2];
 #pragma unroll
   for (int g = 0; g < 2; ++g) qf[g] = *(const u32x4*)(Qp + 32 * g + 8 * fq);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < NPF; ++i) {
     const int c = tid + i * NT, row = c >> 3, ch = c & 7;
     if (row < rows) {
-      *(u32x4*)(sK + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = pk[i];
-      *(u32x4*)(sV + row * 128 + ((((ch >> 1) ^ ((row >> 1) & 3)) << 5) + ((ch & 1) << 4))) = pv[i];
+      const bool live = row < p.Tk;
+      *(u32x4*)(sK + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = live ? pk[i] : u32x4{0, 0, 0, 0};
+      *(u32x4*)(sV + row * 128 + ((((ch >> 1) ^ ((row >> 1) & 3)) << 5) + ((ch & 1) << 4))) = live ? pv[i] : u32x4{0, 0, 0, 0};
     }
   }
   __syncthreads();
@@ -513,18 +516,18 @@ __global__ __launch_bounds__(64 * NW) void attn_split_kernel(const AttnArgs p) {
 
   constexpr int NPF = (64 * 16 + NT - 1) / NT;
   u32x4 pk[NPF], pv[NPF];
+  // (unconditional loads of clamped keys, zeroed on the way into LDS: loads under a run-time test are closed with
+  // s_waitcnt vmcnt(0) per block, i.e. they go out one piece at a time -- see attn_whole_kernel)
   auto prefetch = [&](int kv0) {
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
-      const int c = tid + i * NT;
+      const int c = min(tid + i * NT, 64 * 16 - 1);
       const int row = c >> 4, ch = c & 15;
-      const int key = kv0 + row;
-      pk[i] = pv[i] = u32x4{0, 0, 0, 0};
-      if (c < 64 * 16 && key < p.Tk) {
-        pk[i] = *(const u32x4*)(Kb + 2 * (long)key * p.kt + ch * 8);
-        pv[i] = *(const u32x4*)(Vb + 2 * (long)key * p.vt + ch * 8);
-      }
+      const int key = min(kv0 + row, p.Tk - 1);
+      pk[i] = *(const u32x4*)(Kb + 2 * (long)key * p.kt + ch * 8);
+      pv[i] = *(const u32x4*)(Vb + 2 * (long)key * p.vt + ch * 8);
     }
+    __builtin_amdgcn_sched_barrier(0);
   };
   prefetch(0);
   for (int kv0 = 0; kv0 < p.Tk; kv0 += 64) {
@@ -534,8 +537,9 @@ __global__ __launch_bounds__(64 * NW) void attn_split_kernel(const AttnArgs p) {
       const int c = tid + i * NT;
       if (c < 64 * 16) {
         const int row = c >> 4, ch = c & 15;
-        *(u32x4*)(sK + row * 256 + ((ch ^ (row & 15)) << 4)) = pk[i];
-        *(u32x4*)(sV + row * 256 + ((ch ^ vsw(row)) << 4)) = pv[i];
+        const bool live = kv0 + row < p.Tk;
+        *(u32x4*)(sK + row * 256 + ((ch ^ (row & 15)) << 4)) = live ? pk[i] : u32x4{0, 0, 0, 0};
+        *(u32x4*)(sV + row * 256 + ((ch ^ vsw(row)) << 4)) = live ? pv[i] : u32x4{0, 0, 0, 0};
       }
     }
     __syncthreads();
