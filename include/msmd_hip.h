@@ -46,11 +46,12 @@ int msmd_abi_version(void);
  * knobs travels per call -- the GEMM kernel variant and epilogue flags in `act` (msmd_gemm below), the contraction
  * split count of msmd_gemm_tn in its `accumulate` argument.  The experimental kernel families of DESIGN.md section 5 /
  * 5b and their A/B switch exist only in the developer build (`make -C csrc EXP=1` -> libmsmd_hip_exp.so). */
-#define MSMD_GEMM_VARIANT(v) ((v) << 8)   /* bits 8-15 of `act`: 0 = shape heuristic, 9 / 12 / 13 / 14 / 15 / 17 (bf16, fp16), 1 / 5 / 14 (f16x2) */
+#define MSMD_GEMM_VARIANT(v) ((v) << 8)   /* bits 8-15 of `act`: 0 = shape heuristic, 9 / 12 / 13 / 14 / 15 / 17 / 80 (bf16, fp16), 1 / 5 / 14 (f16x2) */
 #define MSMD_GEMM_WRITE_THROUGH (1 << 16) /* output stores carry `sc1`: the bytes leave the XCD's L2 as they are stored */
 #define MSMD_GEMM_PAIRED_STORES (1 << 17) /* 16-bit outputs: lane pairs swap a fragment row, one 16-byte store each */
 #define MSMD_GEMM_STAGGER (1 << 18)       /* multi-round launches: the second workgroup of every CU starts half a tile period late */
 #define MSMD_GEMM_ONE_TILE_PER_WORKGROUP (1 << 19) /* opt out of the persistent form of multi-round launches (A/B; same bits) */
+#define MSMD_GEMM_NO_256_TILE (1 << 20)   /* opt out of the 256 x 256 8-phase kernel (variant 80) where the heuristic would pick it (A/B) */
 
 /* Measurement aid: one wavefront that spins for `us` microseconds of the 100 MHz constant clock (s_memrealtime) and
  * optionally stores the ticks it actually spun.  bench.py times it at two lengths to calibrate the overhead of a HIP

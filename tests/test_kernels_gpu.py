@@ -580,6 +580,86 @@ def test_gemm_persistent_multi_round_form_is_bit_identical(dtype):
         assert torch.equal(x0, x1)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_256_tile_8_phase_kernel_equals_the_128_tile_kernels(dtype):
+    """Variant 80 (gemm8_kernel: 256 x 256 tiles, 8-phase schedule, epilogue through LDS) multiplies in the same order per
+    output element as the 128 x 128 kernels: plain (bias, GELU, residual) outputs must be the SAME bits, on ragged M (6 500 and 300 rows: the last row tile mostly / the only row tile partly empty), K = 128 (no
+    steady-state K tile), 192 (one) and 768, and a windowed (conv) A operand.  Through msmd_gemm_ln the LayerNorm forms sum
+    their row statistics in another order: outputs within one 16-bit step (and equal almost everywhere), statistics to 2e-3.
+    A call it does not take (N % 256 != 0) falls back to the library's own choice."""
+    from msmd_amd import ops as O
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(23)
+    for M, N, K in ((6500, 768, 768), (300, 512, 128), (1100, 256, 192)):
+        a = torch.randn(M, K, generator=g).to(DEV, dtype)
+        w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV, dtype)
+        b = torch.randn(N, generator=g).to(DEV)
+        r = torch.randn(M, N, generator=g).to(DEV, dtype)
+        for act in (o.ACT_NONE, o.ACT_GELU):
+            for res in (None, r):
+                c0 = o.gemm(a, w, b, res, act=act, variant=17, flags=0)
+                c1 = o.gemm(a, w, b, res, act=act, variant=80, flags=0)
+                if act == o.ACT_GELU and res is not None:
+                    # GELU's last multiply and the residual add may or may not be contracted into one FMA by the compiler
+                    # in either kernel: one 16-bit step at rounding ties, nothing else
+                    d = (c0.float() - c1.float()).abs()
+                    assert float(d.max()) <= 2.0 ** (-7 if dtype == torch.bfloat16 else -10) * 8 and float((d > 0).float().mean()) < 0.01
+                else:
+                    assert torch.equal(c0, c1), (M, N, K, act, res is not None, float((c0.float() - c1.float()).abs().max()))
+        assert torch.equal(o.gemm(a, w, None, None, variant=80), o.gemm(a, w, None, None, variant=17))
+    # not taken: falls back
+    a = torch.randn(500, 256, generator=g).to(DEV, dtype)
+    w = (torch.randn(384, 256, generator=g) / 16).to(DEV, dtype)
+    assert torch.equal(o.gemm(a, w, None, None, variant=80), o.gemm(a, w, None, None))
+    # windowed A: Conv1d(k=3, stride=2) rows over a (B, T, C) signal
+    B, T, C, Nc = 3, 2001, 512, 512
+    x = torch.randn(B, T, C, generator=g).to(DEV, dtype)
+    wc = (torch.randn(Nc, 3 * C, generator=g) / math.sqrt(3 * C)).to(DEV, dtype)
+    To = (T - 3) // 2 + 1
+    kw = dict(M=B * To, N=Nc, K=3 * C, lda=2 * C, rows_per_batch=To, a_batch_stride=T * C, ldw=3 * C, ldc=Nc)
+    y0 = torch.empty(B, To, Nc, device=DEV, dtype=dtype)
+    y1 = torch.empty_like(y0)
+    o.gemm(x, wc, None, None, o.ACT_GELU, out=y0, variant=15, **kw)
+    o.gemm(x, wc, None, None, o.ACT_GELU, out=y1, variant=80, **kw)
+    assert torch.equal(y0, y1)
+    # LayerNorm forms through msmd_gemm_ln (tile hint 80 against the 128 x 128 kernel)
+    M, D, F = 6500, 768, 3072
+    u0 = (torch.randn(M, D, generator=g) * 2 + 0.3).to(DEV, dtype)
+    a2 = torch.randn(M, D, generator=g).to(DEV, dtype)
+    w1 = (torch.randn(D, D, generator=g) / math.sqrt(D)).to(DEV, dtype)
+    b1 = torch.randn(D, generator=g).to(DEV)
+    g0, be0 = (torch.rand(D, generator=g) + 0.5).to(DEV), (torch.randn(D, generator=g) * 0.1).to(DEV)
+    xs = u0.double().reshape(M, -1, 64)
+    st0 = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).transpose(0, 1).float().contiguous()
+    w2f, cs2, b2f = o.fold_layernorm(torch.randn(F, D, generator=g).to(DEV) / math.sqrt(D), torch.randn(F, generator=g).to(DEV),
+                                     (torch.rand(D, generator=g) + 0.5).to(DEV), (torch.randn(D, generator=g) * 0.1).to(DEV), dtype)
+    outs = []
+    for tile in (17, 80):
+        O.GEMM_LN_TILE = tile
+        try:
+            c1, s1 = o.gemm_ln(a2, w1, b1, u0, r_stats=st0, r_gamma=g0, r_beta=be0, stats_out=True)
+            c1p, s1p = o.gemm_ln(a2, w1, b1, u0, stats_out=True)
+            O.GEMM_LN_TILE = 17
+            cin, sin = outs[0][0:2] if outs else (c1, s1)       # both consumers read the SAME producer output
+            O.GEMM_LN_TILE = tile
+            f = o.gemm_ln(cin, w2f, b2f, act=o.ACT_GELU, a_stats=sin, w_colsum=cs2)
+            q = o.gemm_ln(cin, w2f, b2f, a_stats=sin, w_colsum=cs2)
+        finally:
+            O.GEMM_LN_TILE = None
+        outs.append((c1, s1, c1p, s1p, f, q))
+    (c1a, s1a, c1pa, s1pa, fa, qa), (c1b, s1b, c1pb, s1pb, fb, qb) = outs
+    step = 2.0 ** (-7 if dtype == torch.bfloat16 else -10) * 8      # one 16-bit step of |x| < 8
+    assert torch.equal(c1pa, c1pb)                                  # plain residual: nothing depends on the statistics' order
+    assert float((c1a.float() - c1b.float()).abs().max()) <= step
+    assert s1a.shape == s1b.shape and float((s1pa - s1pb).abs().max()) < 2e-3
+    xs = c1b.double().reshape(M, -1, 64)            # the statistics are those of the rows this kernel stored
+    assert float((s1b - torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).transpose(0, 1).float()).abs().max()) < 2e-3
+    # LayerNorm-operand form on the same operand and statistics: the row scalars come from sums in another order, so the
+    # outputs may move by one 16-bit step where rounding was at a tie; no more
+    assert float((fa.float() - fb.float()).abs().max()) <= step and float((qa.float() - qb.float()).abs().max()) <= step
+    assert float((fa != fb).float().mean()) < 0.01
+
+
 @pytest.mark.parametrize("M", [1000, 6500, 16100])     # 64 x 64 tiles / 32-column slabs; 128 x 128 and (tall grids) 192 x 128 tiles / 64-column slabs; ragged M
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_gemm_ln_folds_layernorm_into_producer_and_consumer(dtype, M):

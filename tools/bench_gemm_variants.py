@@ -22,6 +22,13 @@ if os.environ.get("SHAPES") == "sampler":      # the sampler's decoder layers: M
 if os.environ.get("SHAPES") == "denoiser":     # the forward step's decoder layers: M = 32 x 111 rows
     shapes = [("sa_out", 3552, 512, 512), ("ffn2", 3552, 512, 2048), ("ffn1", 3552, 2048, 512), ("qkv", 3552, 1536, 512),
               ("kv_all", 3520, 8192, 512), ("md0", 3520, 256, 512)]
+if os.environ.get("SHAPES") == "guide":        # the shapes cdna_hip_programming.md quotes its 256^2 8-phase template on (+ ours)
+    shapes = [("4k", 4096, 4096, 4096), ("8k", 8192, 8192, 8192), ("big", 16384, 4096, 3072), ("conv1", 205024, 512, 1536),
+              ("qkv", 6400, 2304, 768), ("dec_qkv", 21312, 1536, 512), ("dec_ffn2", 21312, 512, 2048)]
+if os.environ.get("SHAPES") == "conv":         # the k = 3 / k = 2 layers of the conv stack at B = 32 x 4 s, and HuBERT-large's encoder at B = 32 x 10 s
+    shapes = [("conv1", 204768, 512, 1536), ("conv2", 102368, 512, 1536), ("conv3", 51168, 512, 1536), ("conv4", 25568, 512, 1536),
+              ("conv5", 12768, 512, 1024), ("hl_qkv", 15968, 3072, 1024), ("hl_out", 15968, 1024, 1024), ("hl_ffn1", 15968, 4096, 1024),
+              ("hl_ffn2", 15968, 1024, 4096), ("tr_qkv", 12800, 2304, 768), ("tr_ffn1", 12800, 3072, 768), ("tr_ffn2", 12800, 768, 3072)]
 if os.environ.get("SHAPES") == "train":        # the training step's encoder layers with both windows in one batch: M = 64 x 200 rows
     shapes = [("out", 12800, 768, 768), ("ffn2", 12800, 768, 3072), ("ffn1", 12800, 3072, 768), ("qkv", 12800, 2304, 768),
               ("dec_out", 7104, 512, 512), ("dec_ffn1", 7104, 2048, 512), ("dec_ffn2", 7104, 512, 2048), ("dec_qkv", 7104, 1536, 512)]

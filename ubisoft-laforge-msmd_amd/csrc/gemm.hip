@@ -1288,6 +1288,296 @@ void gemm4_kernel(const GemmArgs p) {
   gemm_epilogue<TO, FM, FN, sizeof(TO) == 2 && FM * FN <= 8, (FM * FN > 8)>(p, acc, z, m0 + wm, n0 + wn, fr, fq);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// gemm8_kernel: 256 x 256 x 64 tiles, ONE 8-wave workgroup per CU, the 8-phase schedule of cdna_hip_programming.md section 5
+// ("The 256^2 8-phase template") on this library's operand layout.  tools/gemm8_probe.hip is the bare schedule: 1 305 TFLOP/s at
+// 4096^3 and 1 303 at 16384 x 4096 x 3072 on random operands (the guide quotes 1 320-1 340 / 1 470 at 4096^3 / 8192^3) against
+// 1 012-1 105 for the 128 x 128 / 192 x 128 kernels above -- round 3's first attempt at this schedule (exp/gemm_variants.inc,
+// gemm8p: 902) lost a third of that to a branch around every staging step, per-fragment epilogues that fell into 528 bytes of
+// scratch and 8-byte stores in 32-byte runs.  What is different here:
+//   * the steady-state K tile is branch-free (the last two K tiles are separate copies without staging);
+//   * the epilogue goes through LDS: accumulators are written as fp32 into a 64-row x 256-column block (two blocks of 64 KB =
+//     the operand ring, alternating), then every wave takes whole 1 KB rows back -- a lane owns 4 consecutive columns of one
+//     row per step -- so bias / activation / both LayerNorm forms / residual are a few registers of per-column constants and
+//     per-row scalars, residual rows are read and output rows written as whole 512-byte runs, and the statistics of the
+//     stored rows (64-column slabs, the layout the 128 x 128 kernels write) are four 16-lane reductions.
+//   waves: 2 (wr, along M) x 4 (wc, along N); a wave owns 64 rows of EACH 128-row half of the X tile and 32 columns of EACH
+//   128-column half of the W tile: four 64 x 32 quadrants (h, g), 16 MFMAs each per K tile = one PHASE; the two wave rows run
+//   one barrier apart, so one multiplies while the other reads fragments and issues the next loads.
+//   LDS: 2 K-tile buffers x {X0, X1, W0, W1} half-tiles of 128 rows x 128 bytes (16 KB, swizzled as everywhere here) = 128 KB.
+//   phase p of K tile t (buffer t & 1):  fragment reads | ONE half-tile of LDS-DMA (2 pieces per thread) | [counted vmcnt,
+//   phase 4 only] | s_barrier | 16 MFMAs | s_barrier
+//     ph1: reads W0 (4, issued first) + X0 (8), lgkmcnt(8) retires the W0 reads before the barrier;  quadrant (0,0);  stages X1(t+1)
+//     ph2: reads W1 (4);                                                                         quadrant (0,1);  stages W0(t+2)
+//     ph3: reads X1 (8);                                                                         quadrant (1,1);  stages X0(t+2)
+//     ph4: no reads (W0 is still in registers);  vmcnt(6) -> K tile t+1 has landed;              quadrant (1,0);  stages W1(t+2)
+// Per output element the products and their order are gemm2_kernel's (k ascending, one 16x16x32 MFMA per 32): the plain
+// outputs are bit-identical to the 128 x 128 kernels'; the row statistics of the LayerNorm forms are summed in another order.
+// Calls it takes (launch_gemm8): 16-bit operands and output, N % 256 == 0, K % 64 == 0, K >= 128, one problem per launch,
+// inference epilogues (EPIA 11 / 21 plain, 12 / 22 LayerNorm-operand, 13 LayerNorm-residual + statistics).
+template <typename TI, int EPIA>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm8_kernel(const GemmArgs p) {
+  typedef TI TO;
+  constexpr int EPI = EPIA % 10, ACTK = EPIA / 10 - 1;
+  constexpr int HALF = 128 * 128;        // bytes of one half-tile
+  constexpr int BUF = 4 * HALF;          // X0 X1 W0 W1
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  // tile order: the grid is exactly the tiles; workgroups pid, pid + 8, ... share an XCD (one L2), and each XCD takes one
+  // contiguous run of the row-major tile list -- counts differ by at most one, which matters at ONE workgroup per CU (the
+  // (8 / xn) x xn XCD grid of the kernels above leaves XCDs with 39 and 26 tiles of the 225 of 6400 x 2304: two rounds)
+  const int pid = blockIdx.x, nwg = p.mt * p.nt;
+  const int xcd = pid & 7, xq = nwg >> 3, xr = nwg & 7;
+  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (pid >> 3);
+  const int m_tile = tile / p.nt, n_tile = tile - m_tile * p.nt;
+  const bf16_t* __restrict__ A = (const bf16_t*)p.A;
+  const bf16_t* __restrict__ W = (const bf16_t*)p.W;
+  const int m0 = m_tile * 256, n0 = n_tile * 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+
+  // LDS-DMA sources: piece i (0, 1) of this wave inside a half-tile is its 1 KB chunk i * 8 + wid = rows 8 chunk .. + 7
+  const bf16_t* src[4][2];   // [X0 X1 W0 W1][piece]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (i * 8 + wid) * 8 + (lane >> 3), phys = lane & 7;
+    const int c = phys ^ ((row >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      src[h][i] = A + a_row_offset(p, min(m0 + h * 128 + row, p.M - 1)) + c * 8;
+      src[2 + h][i] = W + (long)min(n0 + h * 128 + row, p.N - 1) * p.ldw + c * 8;
+    }
+  }
+  const unsigned dma_base = wid * 1024;     // + buffer + half + piece * 8192
+  auto stage = [&](int which, int kt, unsigned bufoff) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[which][i] + (long)kt * 64),
+                                       (lds_void_t*)(smem + (dma_base + bufoff + which * HALF + i * 8192)), 16, 0, 0);
+  };
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw = (fr >> 1) & 7;
+  const unsigned ch0 = (fq ^ sw) << 4;
+  // fragment addresses (k-step 0 / 1) inside buffer 0; the buffer is toggled by XOR BUF
+  unsigned xa0 = (wr * 64 + fr) * 128 + ch0, xa1 = xa0 ^ 64;
+  unsigned wa0 = 2 * HALF + (wc * 32 + fr) * 128 + ch0, wa1 = wa0 ^ 64;
+
+  f32x4 acc[2][2][2][4];   // [h][g][i (W fragment)][j (X fragment)]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[h][g][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 fx[2][4], fw0[2][2], fw1[2][2];   // [k-step][fragment]
+
+  auto read_x = [&](int h) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      fx[0][j] = *(const u32x4*)(smem + xa0 + h * HALF + j * 2048);
+      fx[1][j] = *(const u32x4*)(smem + xa1 + h * HALF + j * 2048);
+    }
+  };
+  auto read_w = [&](int g, u32x4 (&fw)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fw[0][i] = *(const u32x4*)(smem + wa0 + g * HALF + i * 2048);
+      fw[1][i] = *(const u32x4*)(smem + wa1 + g * HALF + i * 2048);
+    }
+  };
+  auto quadrant = [&](f32x4 (&a)[2][4], const u32x4 (&fw)[2][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Mfma<TI>::run(fw[ks][i], fx[ks][j], a[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define G8_BAR()                        \
+  do {                                  \
+    __builtin_amdgcn_sched_barrier(0);  \
+    __builtin_amdgcn_s_barrier();       \
+    __builtin_amdgcn_sched_barrier(0);  \
+  } while (0)
+
+  // LayerNorm forms: the statistics of the 32 rows this wave finishes (rows m0 + 64 pass + 8 wid + it: lane = 8 pass + it) are
+  // requested before the K loop -- the producer ran on other XCDs, the first touch misses this L2 -- lanes 0-31 take the even
+  // slabs, lanes 32-63 the odd ones, up to 8 each; reduced after the loop
+  constexpr int LNQ = 8;
+  f32x2 lnraw[EPI >= 2 ? LNQ : 1];
+  const float* ln_stats = EPI == 2 ? p.a_stats : p.r_stats;
+  const int ln_nt = EPI == 2 ? p.a_nt : p.r_nt;
+  if constexpr (EPI >= 2) {
+#pragma unroll
+    for (int q = 0; q < LNQ; ++q) lnraw[q] = f32x2{0.f, 0.f};
+    if (ln_stats) {
+      const int r32 = lane & 31;
+      const f32x2* rp = (const f32x2*)ln_stats + min(m0 + (r32 >> 3) * 64 + wid * 8 + (r32 & 7), p.M - 1);
+#pragma unroll
+      for (int q = 0; q < LNQ; ++q) {
+        const int t = (lane >> 5) + 2 * q;
+        if (t < ln_nt) lnraw[q] = rp[(long)t * p.M];
+      }
+    }
+  }
+
+  const int nk = p.K / 64;
+  // prologue: K tile 0 whole, K tile 1 except X1 (which phase 1 of tile 0 stages)
+  stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
+  stage(2, 1, BUF); stage(0, 1, BUF); stage(3, 1, BUF);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: wave row 1 runs one barrier behind row 0
+
+  unsigned cur = 0;   // byte offset of the buffer of K tile t
+  // MODE 0: steady state; 1: K tile nk - 2 (only X1 of the last tile is left to stage); 2: the last K tile
+  auto ktile = [&](int t, auto MODE_) {
+    constexpr int MODE = decltype(MODE_)::value;
+    // ---- phase 1
+    read_w(0, fw0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_x(0);
+    if (MODE <= 1) stage(1, t + 1, cur ^ BUF);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the four W0 reads (issued first) have returned
+    G8_BAR();
+    quadrant(acc[0][0], fw0);
+    G8_BAR();
+    // ---- phase 2
+    read_w(1, fw1);
+    if (MODE == 0) stage(2, t + 2, cur);
+    G8_BAR();
+    quadrant(acc[0][1], fw1);
+    G8_BAR();
+    // ---- phase 3
+    read_x(1);
+    if (MODE == 0) stage(0, t + 2, cur);
+    G8_BAR();
+    quadrant(acc[1][1], fw1);
+    G8_BAR();
+    // ---- phase 4
+    if (MODE == 0) stage(3, t + 2, cur);
+    if (MODE == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // all but the three youngest half-tiles: tile t + 1 is in
+    if (MODE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G8_BAR();
+    quadrant(acc[1][0], fw0);
+    G8_BAR();
+    cur ^= BUF; xa0 ^= BUF; xa1 ^= BUF; wa0 ^= BUF; wa1 ^= BUF;
+  };
+  for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>{});
+  ktile(nk - 2, std::integral_constant<int, 1>{});
+  ktile(nk - 1, std::integral_constant<int, 2>{});
+  if (wr == 0) __builtin_amdgcn_s_barrier();   // row 0 pays back the stagger: every wave has read its last fragments
+#undef G8_BAR
+
+  // ---- epilogue through LDS.  Pass ps = 2 h + wr' covers tile rows 64 ps .. 64 ps + 63: the four waves of wave row wr' write
+  // their two quadrants of half h as fp32 (16-byte chunk c of row r at r * 1024 + ((c ^ (r & 15)) << 4): conflict-free for
+  // the fragment writes and the row reads), then wave w finishes rows 8 w .. 8 w + 7 of the block.
+  typedef typename Vec4T<TO>::type V4;
+  const int ncol = n0 + lane * 4;                  // this lane's four columns in every row it finishes
+  f32x4 cbias = f32x4{0.f, 0.f, 0.f, 0.f}, cx = f32x4{1.f, 1.f, 1.f, 1.f}, cy = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (p.bias) cbias = *(const f32x4*)(p.bias + ncol);
+  if constexpr (EPI == 2) cx = *(const f32x4*)(p.w_colsum + ncol);
+  if constexpr (EPI == 3) {
+    if (p.r_stats) { cx = *(const f32x4*)(p.r_gamma + ncol); cy = *(const f32x4*)(p.r_beta + ncol); }
+  }
+  float mu_l = 0.f, rs_l = 1.f;                    // of row (lane & 31) of this wave's 32
+  if constexpr (EPI >= 2) {
+    if (ln_stats) {
+      float S = 0.f, Q = 0.f;
+#pragma unroll
+      for (int q = 0; q < LNQ; ++q) { S += lnraw[q][0]; Q += lnraw[q][1]; }
+      if (ln_nt > 2 * LNQ) {        // more than 16 slabs per row: the rest, serially
+        const int r32 = lane & 31;
+        const f32x2* rp = (const f32x2*)ln_stats + min(m0 + (r32 >> 3) * 64 + wid * 8 + (r32 & 7), p.M - 1);
+        for (int t = 2 * LNQ + (lane >> 5); t < ln_nt; t += 2) { const f32x2 w = rp[(long)t * p.M]; S += w[0]; Q += w[1]; }
+      }
+      S += __shfl_xor(S, 32, 64);
+      Q += __shfl_xor(Q, 32, 64);
+      const float inv_cols = 1.0f / (float)(EPI == 2 ? p.K : p.N);
+      mu_l = S * inv_cols;
+      rs_l = rsqrtf(fmaxf(Q * inv_cols - mu_l * mu_l, 0.f) + p.ln_eps);
+    }
+  }
+  const bool has_r = p.R != nullptr;
+  auto write_block = [&](const f32x4 (&q0)[2][4], const f32x4 (&q1)[2][4], unsigned base) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = j * 16 + fr, c = g * 32 + wc * 8 + i * 4 + fq;
+          *(f32x4*)(smem + base + row * 1024 + ((c ^ fr) << 4)) = g == 0 ? q0[i][j] : q1[i][j];
+        }
+  };
+  auto finish_block = [&](int ps, unsigned base) {
+    // residual rows first: eight 512-byte runs per wave, in flight while the block is read back
+    V4 rr[8];
+    if (EPI != 2 && has_r) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int m = min(m0 + ps * 64 + wid * 8 + it, p.M - 1);
+        rr[it] = *(const V4*)((const TO*)p.R + (long)m * p.ldr + ncol);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = wid * 8 + it, m = m0 + ps * 64 + row;
+      const f32x4 a = *(const f32x4*)(smem + base + row * 1024 + ((lane ^ (row & 15)) << 4));
+      float mu = 0.f, rs = 1.f;
+      if constexpr (EPI >= 2) {
+        mu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu_l), ps * 8 + it));
+        rs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs_l), ps * 8 + it));
+      }
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = a[e];
+        if constexpr (EPI == 2) x = rs * (x - mu * cx[e]);
+        v[e] = act_out_c<TO, ACTK>(x + cbias[e], p.act);
+        if constexpr (EPI == 3) v[e] += fmaf(((float)rr[it][e] - mu) * rs, cx[e], cy[e]);
+        else if (has_r) v[e] += (float)rr[it][e];
+      }
+      const V4 o = pack4<TO>(v[0], v[1], v[2], v[3]);
+      if (m < p.M) *(V4*)((TO*)p.C + (long)m * p.ldc + ncol) = o;
+      if constexpr (EPI == 3) {
+        if (p.stats_out) {      // sums of what the consumer will read, per 64-column slab = 16 lanes
+          float S = 0.f, Q = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float w = (float)o[e]; S += w; Q = fmaf(w, w, Q); }
+#pragma unroll
+          for (int d = 1; d < 16; d <<= 1) { S += __shfl_xor(S, d, 64); Q += __shfl_xor(Q, d, 64); }
+          if ((lane & 15) == 0 && m < p.M) *(f32x2*)(p.stats_out + ((long)((n0 >> 6) + (lane >> 4)) * p.M + m) * 2) = f32x2{S, Q};
+        }
+      }
+    }
+  };
+#define G8_EBAR()                                     \
+  do {                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_s_barrier();                     \
+  } while (0)
+  if (wr == 0) write_block(acc[0][0], acc[0][1], 0);
+  G8_EBAR();
+  if (wr == 1) write_block(acc[0][0], acc[0][1], 65536);
+  finish_block(0, 0);
+  G8_EBAR();
+  if (wr == 0) write_block(acc[1][0], acc[1][1], 0);
+  finish_block(1, 65536);
+  G8_EBAR();
+  if (wr == 1) write_block(acc[1][0], acc[1][1], 65536);
+  finish_block(2, 0);
+  G8_EBAR();
+  finish_block(3, 65536);
+#undef G8_EBAR
+}
+
 #ifdef MSMD_EXPERIMENTAL
 // Developer knobs exist ONLY in the experimental build (make EXP=1 -> libmsmd_hip_exp.so): the product library has no
 // process-global state -- kernel variant and epilogue flags travel per call in `act` (include/msmd_hip.h).
@@ -1432,6 +1722,64 @@ static int launch_gemm4(GemmArgs& p, int batch, hipStream_t st) {
   MSMD_RETURN_LAST();
 }
 
+// gemm8_kernel: which calls it takes, and the launch.  Returns -1 for a call it does not take.
+static bool gemm8_takes(const GemmArgs& p, int batch, int osz) {
+  if (osz != 2 || batch != 1 || p.batch_inner != 1 || (p.N % 256) || (p.K % 64) || p.K < 128 || !p.vec_ok) return false;
+  if (p.Z || p.p_drop > 0.f || (p.flags & 8)) return false;               // inference epilogues only
+  if (((uintptr_t)p.bias & 15) || ((uintptr_t)p.C & 7) || ((uintptr_t)p.R & 7)) return false;
+  const int epi = p.a_stats ? 2 : (p.r_stats || p.stats_out) ? 3 : 1;
+  if (epi == 2 && (p.R || !p.bias || !p.w_colsum)) return false;
+  if (epi == 3 && (!p.R || !p.bias || p.act != MSMD_ACT_NONE)) return false;
+  return p.act == MSMD_ACT_NONE || p.act == MSMD_ACT_GELU;
+}
+
+// ... and which of those it wins (hot, isolated, tools/bench_gemm_variants.py SHAPES=guide|conv|sampler|encoder; us for the
+// 128 x 128 / 192 x 128 kernels -> this one): the launch must fill its last round of 256 one-per-CU workgroups and, with a short K
+// (12 K tiles or fewer: 13 us of prologue + epilogue per round against 1.4 us per K tile), nearly completely.
+//   wins   conv1-4 (204768 ... 25568 x 512 x 1536: 375 -> 323, 198 -> 186, 92 -> 85, 52 -> 44), 6400 x 2304 x 768 (33 -> 29.4),
+//          21312 x 1536 x 512 (50 -> 47), 12800 x 2304 x 768 (59 -> 57), HuBERT-large 15968 x {3072, 1024, 4096} x 1024 (114 -> 109,
+//          43 -> 37, 153 -> 143) and 15968 x 1024 x 4096 (133 -> 103), 16384 x 4096 x 3072 (364 -> 311 = 1 326 TFLOP/s)
+//   loses  under-filled rounds: 6400 x 768 x {768, 3072} (75 tiles), 6400 x 3072 x 768 (300: 40 -> 52), 12800 x 3072 x 768 (600: 80 -> 86),
+//          21312 x 512 x {512, 2048} (168: 22.6 -> 26, 49 -> 51), 21312 x 2048 x 512 (672 = 2.6 rounds, K = 512: 67 -> 69)
+static bool gemm8_wins(int M, int N, int K) {
+  const long tiles = (long)((M + 255) / 256) * (N / 256);
+  if (tiles < 192) return false;
+  const double fill = (double)tiles / (256.0 * (double)((tiles + 255) / 256));
+  return fill >= 0.75 && (K >= 1024 || fill >= 0.878);
+}
+
+template <typename TI, int EPIA>
+static int launch_gemm8_e(GemmArgs& p, hipStream_t st) {
+  constexpr int lds = 2 * 4 * 128 * 128;   // 128 KB: the operand ring = the epilogue's two row blocks
+  static bool attr_done = false;
+  auto kfn = gemm8_kernel<TI, EPIA>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  p.mt = (p.M + 255) / 256; p.nt = p.N / 256;
+  hipLaunchKernelGGL(kfn, dim3(p.mt * p.nt, 1, 1), dim3(512), lds, st, p);
+  MSMD_RETURN_LAST();
+}
+
+template <typename TO, typename TI>
+static int launch_gemm8(GemmArgs& p, int batch, hipStream_t st) {
+  if constexpr (sizeof(TO) != 2) {
+    return -1;
+  } else {
+    if (!gemm8_takes(p, batch, 2)) return -1;
+    const int epi = p.a_stats ? 2 : (p.r_stats || p.stats_out) ? 3 : 1;
+    switch (epi + (p.act == MSMD_ACT_GELU ? 20 : 10)) {
+      case 11: return launch_gemm8_e<TI, 11>(p, st);
+      case 21: return launch_gemm8_e<TI, 21>(p, st);
+      case 12: return launch_gemm8_e<TI, 12>(p, st);
+      case 22: return launch_gemm8_e<TI, 22>(p, st);
+      case 13: return launch_gemm8_e<TI, 13>(p, st);
+      default: return -1;
+    }
+  }
+}
+
 template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, int ACTK = -1>
 static int launch_gemm2s(GemmArgs& p, int batch, hipStream_t st) {
   if constexpr (ACTK == -1 && NSTAGE * (BM + BN) * 128 <= 80 * 1024) {      // the routed tiles: the activation as a constant of the kernel
@@ -1502,6 +1850,7 @@ static int dispatch_gemm2(GemmArgs& p, int batch, hipStream_t st, int variant) {
     case 15: return launch_gemm2_epi<TO, 192, 128, 4, 2, 2, true>(p, batch, st);  // tall grids (M >= 16 k): 80 KB, still 2 workgroups / CU
     case 17: return launch_gemm2_epi<TO, 128, 128, 4, 2, 2, true>(p, batch, st);
     case 66: return launch_gemm2<TO, 128, 128, 4, 2, 2, true>(p, batch, st);       // 17 as ONE kernel with every epilogue (round 3's form)
+    case 80: return launch_gemm8<TO, bf16_t>(p, batch, st);                        // 256 x 256, 8-phase schedule, one workgroup per CU
     // v4 kernels (fragment reads pipelined inside the wave, barrier between the k-steps):
     case 60: return launch_gemm4<TO, 256, 128, 4, 2, 3>(p, batch, st);                   // 144 KB, 1 workgroup / CU, 8 waves of 64 x 64
     case 61: return launch_gemm4<TO, 256, 128, 4, 2, 2>(p, batch, st);                   // 96 KB
@@ -1583,6 +1932,7 @@ static int dispatch_gemm2_f16(GemmArgs& p, int batch, hipStream_t st, int varian
     case 14: return launch_gemm2_epi<TO, 256, 64, 8, 1, 2, true, f16_t>(p, batch, st);
     case 15: return launch_gemm2_epi<TO, 192, 128, 4, 2, 2, true, f16_t>(p, batch, st);
     case 17: return launch_gemm2_epi<TO, 128, 128, 4, 2, 2, true, f16_t>(p, batch, st);
+    case 80: return launch_gemm8<TO, f16_t>(p, batch, st);
     default: return -1;
   }
 }
@@ -1607,7 +1957,7 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
                      int internal_flags = 0) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch_inner <= 0 || !A || !W || !C) return 1;
   const int hint = (act >> 8) & 0xff;  // caller-chosen kernel variant (host-side autotune), 0 = heuristic below
-  const int flags = ((act >> 16) & 0x7) | (((act >> 19) & 1) << 4) | internal_flags;  // MSMD_GEMM_WRITE_THROUGH / MSMD_GEMM_PAIRED_STORES (include/msmd_hip.h)
+  const int flags = ((act >> 16) & 0x7) | (((act >> 19) & 1) << 4) | (((act >> 20) & 1) << 5) | internal_flags;  // MSMD_GEMM_WRITE_THROUGH / MSMD_GEMM_PAIRED_STORES (include/msmd_hip.h)
   act &= 0xff;
   if (in_dtype == MSMD_F16X2) {
     // split-pair operands: logical sizes in, fp16 strides (x 2) into the kernel; 32-element blocks must stay whole
@@ -1673,10 +2023,13 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
     // Measured on MI355X (tools/bench_gemm.py): the 128x128 LDS-DMA kernel wins once the grid fills the
     // chip at 2 workgroups per CU; below that, 64x64 tiles (deep ring for long K) keep more CUs busy.
     int variant = MSMD_TUNE(0) ? MSMD_TUNE(0) : hint;
+    if (variant == 80 && !gemm8_takes(p, nz, osz)) variant = 0;     // a hint the call cannot follow: the library's own choice
     if (variant == 0) {
       const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nz;
       const long tiles192 = (long)((M + 191) / 192) * ((N + 127) / 128) * nz;
-      if (N > 64 && M >= 16000 && tiles192 >= 400) {
+      if (!(flags & 32) && gemm8_takes(p, nz, osz) && gemm8_wins(M, N, K)) {
+        variant = 80;      // 256 x 256 tiles, 8-phase schedule (flags bit 5 = caller opts out: A/B)
+      } else if (N > 64 && M >= 16000 && tiles192 >= 400) {
         // tall grids: 192 x 128 tiles (76.8 FLOP per staged byte instead of 64, still two workgroups per CU).  Measured against
         // the 128 x 128 tile: conv1 454 -> 379 us, 21312 x 512 x 2048 58.7 -> 49.6, 21312 x 2048 x 512 76.6 -> 64.7; worse
         // below ~16 k rows (12800 x 512 x 1024: 22 -> 28 us) and mixed at M = 6400
@@ -1699,12 +2052,14 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
   if (in_dtype == MSMD_F16 && (out_dtype == MSMD_F16 || out_dtype == MSMD_F32) && (K % 64) == 0 && MSMD_TUNE(0) >= 0) {
     // fp16 storage: same LDS-DMA kernels with v_mfma_f32_16x16x32_f16 (the heuristic's variants only)
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nz;
-    int variant = hint ? hint : ((N > 64 && tiles128 >= 192) ? 17 : ((K >= 1024) ? 9 : 12));
-    if (!hint && N <= 64 && (long)((M + 255) / 256) * nz >= 256) variant = 14;
-    if (!hint && N > 64 && M >= 16000 && (long)((M + 191) / 192) * ((N + 127) / 128) * nz >= 400) variant = 15;
-    if (!hint && N > 64 && out_dtype == MSMD_F16 && !z_out && !(p_drop > 0.f) && !(flags & 8) &&
+    const bool no_hint = !hint || (hint == 80 && !gemm8_takes(p, nz, osz));
+    int variant = !no_hint ? hint : ((N > 64 && tiles128 >= 192) ? 17 : ((K >= 1024) ? 9 : 12));
+    if (no_hint && N <= 64 && (long)((M + 255) / 256) * nz >= 256) variant = 14;
+    if (no_hint && N > 64 && M >= 16000 && (long)((M + 191) / 192) * ((N + 127) / 128) * nz >= 400) variant = 15;
+    if (no_hint && N > 64 && out_dtype == MSMD_F16 && !z_out && !(p_drop > 0.f) && !(flags & 8) &&
         tall_rounds_favour_192(M, tiles128, (long)((M + 191) / 192) * ((N + 127) / 128) * nz))
       variant = 15;
+    if (no_hint && !(flags & 32) && gemm8_takes(p, nz, osz) && gemm8_wins(M, N, K)) variant = 80;
     const int r = out_dtype == MSMD_F16 ? dispatch_gemm2_f16<f16_t>(p, nz, st, variant)
                                         : dispatch_gemm2_f16<float>(p, nz, st, variant);
     if (r >= 0) return r;
@@ -1771,6 +2126,9 @@ extern "C" int msmd_gemm_ln(const void* A, const void* W, const float* bias, con
   {   // caller's tile hint for the big-tile family (same 64-column statistics slabs): 15 = 192 x 128, 17 = 128 x 128, 66 = A/B form of 17
     const int hint = (act >> 8) & 0xff;
     if (big && (hint == 15 || hint == 17 || hint == 66)) variant = hint;
+    // 80 = the 256 x 256 kernel: writes the same 64-column statistics slabs, reads either width
+    const bool can8 = gemm8_takes(p, 1, 2) && (!stats_out || slab_out == 64);
+    if (can8 && (hint == 80 || (hint == 0 && !(act & MSMD_GEMM_NO_256_TILE) && gemm8_wins(M, N, K)))) variant = 80;
   }
   const int r = in_dtype == MSMD_BF16 ? dispatch_gemm2<bf16_t>(p, 1, st, variant) : dispatch_gemm2_f16<f16_t>(p, 1, st, variant);
   return r >= 0 ? r : 1;

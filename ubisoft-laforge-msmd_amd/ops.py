@@ -169,6 +169,7 @@ _TUNED = {}
 # scopes a change, e.g. while a hipGraph is captured -- the choice is then baked into that graph).
 GEMM_WRITE_THROUGH, GEMM_PAIRED_STORES, GEMM_STAGGER = 1 << 16, 1 << 17, 1 << 18
 GEMM_ONE_TILE_PER_WORKGROUP = 1 << 19      # opt out of the persistent form of multi-round launches (A/B; same bits)
+GEMM_NO_256_TILE = 1 << 20                 # opt out of the 256 x 256 8-phase kernel where the library would pick it (A/B; plain outputs same bits)
 GEMM_LN_FLAGS = 0              # extra `act` bits msmd_gemm_ln calls carry (A/B hook: GEMM_ONE_TILE_PER_WORKGROUP)
 GEMM_LN_ROUTER = None          # optional (M, N, K) -> 15 | 17 | None: tile hint for msmd_gemm_ln's big-tile family
 GEMM_LN_ALL_IN_ONE = False     # A/B hook (tools/ab_forward.py): msmd_gemm_ln on the one-kernel-with-every-epilogue form (variant 66)
@@ -202,6 +203,11 @@ _GEMM_DEFAULT = {"variant": 0, "flags": GEMM_PAIRED_STORES, "split_variant": 0} 
 if os.environ.get("MSMD_GEMM_ONE_TILE", "0") == "1":      # developers' A/B switch (tools/ab_env.sh): every launch in the one-tile-per-workgroup form
     _GEMM_DEFAULT["flags"] |= GEMM_ONE_TILE_PER_WORKGROUP
     GEMM_LN_FLAGS = GEMM_ONE_TILE_PER_WORKGROUP
+
+
+if os.environ.get("MSMD_GEMM_NO_256", "0") == "1":        # developers' A/B switch: no launch on the 256 x 256 kernel
+    _GEMM_DEFAULT["flags"] |= GEMM_NO_256_TILE
+    GEMM_LN_FLAGS |= GEMM_NO_256_TILE
 
 
 class gemm_defaults:
