@@ -31,7 +31,8 @@ constexpr int BUF = 4 * HALF;     // X0 X1 W0 W1
     __builtin_amdgcn_sched_barrier(0);  \
   } while (0)
 
-// VAR bit 0: no s_setprio pair; bit 1: no stagger of the wave rows; bit 2: plain tile order (no XCD chunks)
+// VAR bit 0: no s_setprio pair; bit 1: no stagger of the wave rows; bit 2: plain tile order (no XCD chunks);
+// bit 3: every tile reads the first 4096 rows of A (an L2-resident operand: what does streaming A from HBM cost a tall grid?)
 template <int VAR>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm8(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* __restrict__ C, int M, int N, int K, int mt, int nt) {
@@ -56,7 +57,7 @@ void gemm8(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* _
     const int c = phys ^ ((row >> 1) & 7);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      src[h][i] = A + (long)(m0 + h * 128 + row) * K + c * 8;
+      src[h][i] = A + (long)(((VAR & 8) ? (m0 & 4095) : m0) + h * 128 + row) * K + c * 8;
       src[2 + h][i] = W + (long)(n0 + h * 128 + row) * K + c * 8;
     }
   }
@@ -220,6 +221,7 @@ int main(int argc, char** argv) {
       case 1: run<1>(A, W, C, M, N, K, st); break;
       case 2: run<2>(A, W, C, M, N, K, st); break;
       case 4: run<4>(A, W, C, M, N, K, st); break;
+      case 8: run<8>(A, W, C, M, N, K, st); break;
       default: printf("variant?\n"); exit(1);
     }
   };
@@ -242,7 +244,7 @@ int main(int argc, char** argv) {
   for (int i = 0; i < n_s; ++i) {
     const float c = bf2f(hC[(size_t)mn[2 * i] * N + mn[2 * i + 1]]);
     const double e = fabs(c - ref[i]), tol = 0.01 * fabs(ref[i]) + 0.02;
-    if (!(e <= tol)) ++bad;
+    if (!(e <= tol) && !(var & 8)) ++bad;
     if (e > worst) worst = e;
   }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

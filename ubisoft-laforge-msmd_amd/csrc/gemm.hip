@@ -1323,37 +1323,49 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int BUF = 4 * HALF;          // X0 X1 W0 W1
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  // tile order: the grid is exactly the tiles; workgroups pid, pid + 8, ... share an XCD (one L2), and each XCD takes one
-  // contiguous run of the row-major tile list -- counts differ by at most one, which matters at ONE workgroup per CU (the
-  // (8 / xn) x xn XCD grid of the kernels above leaves XCDs with 39 and 26 tiles of the 225 of 6400 x 2304: two rounds)
-  const int pid = blockIdx.x, nwg = p.mt * p.nt;
-  const int xcd = pid & 7, xq = nwg >> 3, xr = nwg & 7;
-  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (pid >> 3);
-  const int m_tile = tile / p.nt, n_tile = tile - m_tile * p.nt;
+  // Tile order: workgroups pid, pid + 8, ... share an XCD (one L2); each XCD takes one contiguous run of the row-major tile
+  // list -- counts differ by at most one, which matters at ONE workgroup per CU (the (8 / xn) x xn XCD grid of the kernels
+  // above leaves XCDs with 39 and 26 tiles of the 225 of 6400 x 2304: two rounds).  The grid is min(tiles, 256) workgroups:
+  // a workgroup walks its XCD's run with the stride of that XCD's workgroup count (persistent: see the tile loop below).
+  const int pid = blockIdx.x, ntiles = p.mt * p.nt, nwg = gridDim.x;
+  const int xcd = pid & 7;
+  const int run0 = (xcd < (ntiles & 7) ? xcd * ((ntiles >> 3) + 1) : (ntiles & 7) * ((ntiles >> 3) + 1) + (xcd - (ntiles & 7)) * (ntiles >> 3));
+  const int run_n = (ntiles >> 3) + (xcd < (ntiles & 7) ? 1 : 0);
+  const int stride = (nwg >> 3) + (xcd < (nwg & 7) ? 1 : 0);
+  int tl = pid >> 3;                     // position in the XCD's run
   const bf16_t* __restrict__ A = (const bf16_t*)p.A;
   const bf16_t* __restrict__ W = (const bf16_t*)p.W;
-  const int m0 = m_tile * 256, n0 = n_tile * 256;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
 
   // LDS-DMA sources: piece i (0, 1) of this wave inside a half-tile is its 1 KB chunk i * 8 + wid = rows 8 chunk .. + 7
-  const bf16_t* src[4][2];   // [X0 X1 W0 W1][piece]
+  unsigned src[4][2];        // [X0 X1 W0 W1][piece]: byte offsets from A / W (the launcher refuses operands past 4 GB)
+  int m0 = 0, n0 = 0;
+  // (called twice per tile -- before the epilogue of the previous one for the first K tile, after it for the rest -- from a
+  // lane id the compiler cannot match, so that the eight pointers are not kept across the epilogue: with the 128 accumulators
+  // and the epilogue's rows live they were the spill)
+  auto set_tile = [&](int t) {
+    const int m_tile = (run0 + t) / p.nt, n_tile = (run0 + t) - m_tile * p.nt;
+    m0 = m_tile * 256; n0 = n_tile * 256;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (i * 8 + wid) * 8 + (lane >> 3), phys = lane & 7;
-    const int c = phys ^ ((row >> 1) & 7);
+    for (int i = 0; i < 2; ++i) {
+      const int row = (i * 8 + wid) * 8 + (ln >> 3), phys = ln & 7;
+      const int c = phys ^ ((row >> 1) & 7);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      src[h][i] = A + a_row_offset(p, min(m0 + h * 128 + row, p.M - 1)) + c * 8;
-      src[2 + h][i] = W + (long)min(n0 + h * 128 + row, p.N - 1) * p.ldw + c * 8;
+      for (int h = 0; h < 2; ++h) {
+        src[h][i] = (unsigned)((a_row_offset(p, min(m0 + h * 128 + row, p.M - 1)) + c * 8) * 2);
+        src[2 + h][i] = (unsigned)(((long)min(n0 + h * 128 + row, p.N - 1) * p.ldw + c * 8) * 2);
+      }
     }
-  }
+  };
   const unsigned dma_base = wid * 1024;     // + buffer + half + piece * 8192
   auto stage = [&](int which, int kt, unsigned bufoff) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[which][i] + (long)kt * 64),
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)((const char*)(which < 2 ? A : W) + (size_t)(src[which][i] + (unsigned)kt * 128u)),
                                        (lds_void_t*)(smem + (dma_base + bufoff + which * HALF + i * 8192)), 16, 0, 0);
   };
 
@@ -1365,14 +1377,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   unsigned wa0 = 2 * HALF + (wc * 32 + fr) * 128 + ch0, wa1 = wa0 ^ 64;
 
   f32x4 acc[2][2][2][4];   // [h][g][i (W fragment)][j (X fragment)]
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[h][g][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   u32x4 fx[2][4], fw0[2][2], fw1[2][2];   // [k-step][fragment]
 
   auto read_x = [&](int h) {
@@ -1405,176 +1409,225 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_s_barrier();       \
     __builtin_amdgcn_sched_barrier(0);  \
   } while (0)
+#define G8_EBAR()                                      \
+  do {                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_s_barrier();                      \
+  } while (0)
 
-  // LayerNorm forms: the statistics of the 32 rows this wave finishes (rows m0 + 64 pass + 8 wid + it: lane = 8 pass + it) are
-  // requested before the K loop -- the producer ran on other XCDs, the first touch misses this L2 -- lanes 0-31 take the even
-  // slabs, lanes 32-63 the odd ones, up to 8 each; reduced after the loop
-  constexpr int LNQ = 8;
-  f32x2 lnraw[EPI >= 2 ? LNQ : 1];
+  // LayerNorm forms: the row statistics of the 32 rows this wave finishes (rows m0 + 64 ps + 8 wid + it) come in by LDS-DMA --
+  // no registers across the K loop, and requested a whole K loop before they are read: the producer ran on other XCDs, the
+  // first touch misses this L2.  One 16-byte piece = rows (2 rp, 2 rp + 1) of one 64-column slab (slab-major (slabs, M, 2)
+  // fp32, M even); lane = 16 so + 4 ps + rp takes slab 4 q + so in piece q; 4 KB per wave behind the operand ring.
   const float* ln_stats = EPI == 2 ? p.a_stats : p.r_stats;
   const int ln_nt = EPI == 2 ? p.a_nt : p.r_nt;
-  if constexpr (EPI >= 2) {
+  auto ln_request = [&]() {
+    if constexpr (EPI >= 2) {
+      if (ln_stats) {
+        int ll = lane;
+        asm volatile("" : "+v"(ll));
+        const int m = min(m0 + ((ll >> 2) & 3) * 64 + wid * 8 + (ll & 3) * 2, p.M - 2);
 #pragma unroll
-    for (int q = 0; q < LNQ; ++q) lnraw[q] = f32x2{0.f, 0.f};
-    if (ln_stats) {
-      const int r32 = lane & 31;
-      const f32x2* rp = (const f32x2*)ln_stats + min(m0 + (r32 >> 3) * 64 + wid * 8 + (r32 & 7), p.M - 1);
-#pragma unroll
-      for (int q = 0; q < LNQ; ++q) {
-        const int t = (lane >> 5) + 2 * q;
-        if (t < ln_nt) lnraw[q] = rp[(long)t * p.M];
+        for (int q = 0; q < 4; ++q) {
+          if (4 * q < ln_nt) {
+            const int t = min(4 * q + (ll >> 4), ln_nt - 1);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(ln_stats + ((long)t * p.M + m) * 2),
+                                             (lds_void_t*)(smem + (2 * BUF + wid * 4096 + q * 1024)), 16, 0, 0);
+          }
+        }
       }
     }
-  }
+  };
 
   const int nk = p.K / 64;
-  // prologue: K tile 0 whole, K tile 1 except X1 (which phase 1 of tile 0 stages)
+  typedef typename Vec4T<TO>::type V4;
+  const bool has_r = p.R != nullptr;
+
+  // prologue of the first tile: K tile 0 whole, K tile 1 except X1 (which phase 1 of tile 0 stages)
+  set_tile(tl);
+  ln_request();
   stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
   stage(2, 1, BUF); stage(0, 1, BUF); stage(3, 1, BUF);
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: wave row 1 runs one barrier behind row 0
 
-  unsigned cur = 0;   // byte offset of the buffer of K tile t
-  // MODE 0: steady state; 1: K tile nk - 2 (only X1 of the last tile is left to stage); 2: the last K tile
-  auto ktile = [&](int t, auto MODE_) {
-    constexpr int MODE = decltype(MODE_)::value;
-    // ---- phase 1
-    read_w(0, fw0);
-    __builtin_amdgcn_sched_barrier(0);
-    read_x(0);
-    if (MODE <= 1) stage(1, t + 1, cur ^ BUF);
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the four W0 reads (issued first) have returned
-    G8_BAR();
-    quadrant(acc[0][0], fw0);
-    G8_BAR();
-    // ---- phase 2
-    read_w(1, fw1);
-    if (MODE == 0) stage(2, t + 2, cur);
-    G8_BAR();
-    quadrant(acc[0][1], fw1);
-    G8_BAR();
-    // ---- phase 3
-    read_x(1);
-    if (MODE == 0) stage(0, t + 2, cur);
-    G8_BAR();
-    quadrant(acc[1][1], fw1);
-    G8_BAR();
-    // ---- phase 4
-    if (MODE == 0) stage(3, t + 2, cur);
-    if (MODE == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // all but the three youngest half-tiles: tile t + 1 is in
-    if (MODE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    G8_BAR();
-    quadrant(acc[1][0], fw0);
-    G8_BAR();
-    cur ^= BUF; xa0 ^= BUF; xa1 ^= BUF; wa0 ^= BUF; wa1 ^= BUF;
-  };
-  for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>{});
-  ktile(nk - 2, std::integral_constant<int, 1>{});
-  ktile(nk - 1, std::integral_constant<int, 2>{});
-  if (wr == 0) __builtin_amdgcn_s_barrier();   // row 0 pays back the stagger: every wave has read its last fragments
-#undef G8_BAR
-
-  // ---- epilogue through LDS.  Pass ps = 2 h + wr' covers tile rows 64 ps .. 64 ps + 63: the four waves of wave row wr' write
-  // their two quadrants of half h as fp32 (16-byte chunk c of row r at r * 1024 + ((c ^ (r & 15)) << 4): conflict-free for
-  // the fragment writes and the row reads), then wave w finishes rows 8 w .. 8 w + 7 of the block.
-  typedef typename Vec4T<TO>::type V4;
-  const int ncol = n0 + lane * 4;                  // this lane's four columns in every row it finishes
-  f32x4 cbias = f32x4{0.f, 0.f, 0.f, 0.f}, cx = f32x4{1.f, 1.f, 1.f, 1.f}, cy = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (p.bias) cbias = *(const f32x4*)(p.bias + ncol);
-  if constexpr (EPI == 2) cx = *(const f32x4*)(p.w_colsum + ncol);
-  if constexpr (EPI == 3) {
-    if (p.r_stats) { cx = *(const f32x4*)(p.r_gamma + ncol); cy = *(const f32x4*)(p.r_beta + ncol); }
-  }
-  float mu_l = 0.f, rs_l = 1.f;                    // of row (lane & 31) of this wave's 32
-  if constexpr (EPI >= 2) {
-    if (ln_stats) {
-      float S = 0.f, Q = 0.f;
+  while (true) {
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: wave row 1 runs one barrier behind row 0
 #pragma unroll
-      for (int q = 0; q < LNQ; ++q) { S += lnraw[q][0]; Q += lnraw[q][1]; }
-      if (ln_nt > 2 * LNQ) {        // more than 16 slabs per row: the rest, serially
-        const int r32 = lane & 31;
-        const f32x2* rp = (const f32x2*)ln_stats + min(m0 + (r32 >> 3) * 64 + wid * 8 + (r32 & 7), p.M - 1);
-        for (int t = 2 * LNQ + (lane >> 5); t < ln_nt; t += 2) { const f32x2 w = rp[(long)t * p.M]; S += w[0]; Q += w[1]; }
-      }
-      S += __shfl_xor(S, 32, 64);
-      Q += __shfl_xor(Q, 32, 64);
-      const float inv_cols = 1.0f / (float)(EPI == 2 ? p.K : p.N);
-      mu_l = S * inv_cols;
-      rs_l = rsqrtf(fmaxf(Q * inv_cols - mu_l * mu_l, 0.f) + p.ln_eps);
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[h][g][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned cur = 0;   // byte offset of the buffer of K tile t
+    // MODE 0: steady state; 1: K tile nk - 2 (only X1 of the last tile is left to stage); 2: the last K tile
+    auto ktile = [&](int t, auto MODE_) {
+      constexpr int MODE = decltype(MODE_)::value;
+      // ---- phase 1
+      read_w(0, fw0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_x(0);
+      if (MODE <= 1) stage(1, t + 1, cur ^ BUF);
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the four W0 reads (issued first) have returned
+      G8_BAR();
+      quadrant(acc[0][0], fw0);
+      G8_BAR();
+      // ---- phase 2
+      read_w(1, fw1);
+      if (MODE == 0) stage(2, t + 2, cur);
+      G8_BAR();
+      quadrant(acc[0][1], fw1);
+      G8_BAR();
+      // ---- phase 3
+      read_x(1);
+      if (MODE == 0) stage(0, t + 2, cur);
+      G8_BAR();
+      quadrant(acc[1][1], fw1);
+      G8_BAR();
+      // ---- phase 4
+      if (MODE == 0) stage(3, t + 2, cur);
+      if (MODE == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // all but the three youngest half-tiles: tile t + 1 is in
+      if (MODE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      G8_BAR();
+      quadrant(acc[1][0], fw0);
+      G8_BAR();
+      cur ^= BUF; xa0 ^= BUF; xa1 ^= BUF; wa0 ^= BUF; wa1 ^= BUF;
+    };
+    for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>{});
+    ktile(nk - 2, std::integral_constant<int, 1>{});
+    ktile(nk - 1, std::integral_constant<int, 2>{});
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // row 0 pays back the stagger: every wave has read its last fragments
+    if (nk & 1) { xa0 ^= BUF; xa1 ^= BUF; wa0 ^= BUF; wa1 ^= BUF; }   // the next tile starts in buffer 0 again
+
+    // ---- epilogue through LDS, in the upper half of the ring (the lower half already takes the next tile's first K tile).
+    // Pass ps = 2 h + wr' covers tile rows 64 ps .. 64 ps + 63: the four waves of wave row wr' write their two quadrants of
+    // half h as fp32 (16-byte chunk c of row r at r * 1024 + ((c ^ (r & 15)) << 4): conflict-free for the fragment writes and
+    // the row reads), then wave w finishes rows 8 w .. 8 w + 7 of the block.
+    const int em0 = m0, en0 = n0;                    // this tile (m0 / n0 move on to the next one below)
+    // everything the epilogue derives from the lane id comes from a copy the compiler cannot match with the K loop's: hoisted
+    // out of the tile loop those values lived across the K loop and pushed its staging pointers into scratch
+    int el = lane;
+    asm volatile("" : "+v"(el));
+    const int efr = el & 15, efq = el >> 4;
+    const int ncol = en0 + el * 4;                   // this lane's four columns in every row it finishes
+    f32x4 cbias = f32x4{0.f, 0.f, 0.f, 0.f}, cx = f32x4{1.f, 1.f, 1.f, 1.f}, cy = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) cbias = *(const f32x4*)(p.bias + ncol);
+    if constexpr (EPI == 2) cx = *(const f32x4*)(p.w_colsum + ncol);
+    if constexpr (EPI == 3) {
+      if (p.r_stats) { cx = *(const f32x4*)(p.r_gamma + ncol); cy = *(const f32x4*)(p.r_beta + ncol); }
     }
-  }
-  const bool has_r = p.R != nullptr;
-  auto write_block = [&](const f32x4 (&q0)[2][4], const f32x4 (&q1)[2][4], unsigned base) {
+    float mu_l = 0.f, rs_l = 1.f;                    // of row (lane & 31) of this wave's 32
+    if constexpr (EPI >= 2) {
+      if (ln_stats) {
+        const int r32 = el & 31, half = el >> 5;
+        const unsigned base = 2 * BUF + wid * 4096 + (((r32 >> 3) * 4 + ((r32 & 7) >> 1)) << 4) + ((r32 & 1) << 3);
+        float S = 0.f, Q = 0.f;
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int row = j * 16 + fr, c = g * 32 + wc * 8 + i * 4 + fq;
-          *(f32x4*)(smem + base + row * 1024 + ((c ^ fr) << 4)) = g == 0 ? q0[i][j] : q1[i][j];
+        for (int u = 0; u < 8; ++u) {                // slabs half, half + 2, ... below 16
+          const int t = 2 * u + half;
+          const f32x2 w = *(const f32x2*)(smem + base + (t >> 2) * 1024 + ((t & 3) << 8));
+          if (t < ln_nt) { S += w[0]; Q += w[1]; }
         }
-  };
-  auto finish_block = [&](int ps, unsigned base) {
-    // residual rows first: eight 512-byte runs per wave, in flight while the block is read back
-    V4 rr[8];
-    if (EPI != 2 && has_r) {
+        if (ln_nt > 16) {             // more than 16 slabs per row: the rest from memory, serially
+          const f32x2* rp = (const f32x2*)ln_stats + min(em0 + (r32 >> 3) * 64 + wid * 8 + (r32 & 7), p.M - 1);
+          for (int t = 16 + half; t < ln_nt; t += 2) { const f32x2 w = rp[(long)t * p.M]; S += w[0]; Q += w[1]; }
+        }
+        S += __shfl_xor(S, 32, 64);
+        Q += __shfl_xor(Q, 32, 64);
+        const float inv_cols = 1.0f / (float)(EPI == 2 ? p.K : p.N);
+        mu_l = S * inv_cols;
+        rs_l = rsqrtf(fmaxf(Q * inv_cols - mu_l * mu_l, 0.f) + p.ln_eps);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's statistics are in registers: its 4 KB may be refilled
+      }
+    }
+    // the next tile of this workgroup: its first K tile goes out now and lands under the epilogue
+    tl += stride;
+    const bool more = tl < run_n;
+    if (more) {
+      set_tile(tl);
+      stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
+      ln_request();
+    }
+    auto write_block = [&](const f32x4 (&q0)[2][4], const f32x4 (&q1)[2][4]) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = j * 16 + efr, c = g * 32 + wc * 8 + i * 4 + efq;
+            *(f32x4*)(smem + BUF + row * 1024 + ((c ^ efr) << 4)) = g == 0 ? q0[i][j] : q1[i][j];
+          }
+    };
+    auto finish_block = [&](int ps) {
+      // residual rows first: eight 512-byte runs per wave, in flight while the block is read back
+      V4 rr[8];
+      if (EPI != 2 && has_r) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int m = min(em0 + ps * 64 + wid * 8 + it, p.M - 1);
+          rr[it] = *(const V4*)((const TO*)p.R + (long)m * p.ldr + ncol);
+        }
+      }
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const int m = min(m0 + ps * 64 + wid * 8 + it, p.M - 1);
-        rr[it] = *(const V4*)((const TO*)p.R + (long)m * p.ldr + ncol);
-      }
-    }
+        const int row = wid * 8 + it, m = em0 + ps * 64 + row;
+        const f32x4 a = *(const f32x4*)(smem + BUF + row * 1024 + ((el ^ (row & 15)) << 4));
+        float mu = 0.f, rs = 1.f;
+        if constexpr (EPI >= 2) {
+          mu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu_l), ps * 8 + it));
+          rs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs_l), ps * 8 + it));
+        }
+        float v[4];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = wid * 8 + it, m = m0 + ps * 64 + row;
-      const f32x4 a = *(const f32x4*)(smem + base + row * 1024 + ((lane ^ (row & 15)) << 4));
-      float mu = 0.f, rs = 1.f;
-      if constexpr (EPI >= 2) {
-        mu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu_l), ps * 8 + it));
-        rs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs_l), ps * 8 + it));
-      }
-      float v[4];
+        for (int e = 0; e < 4; ++e) {
+          float x = a[e];
+          if constexpr (EPI == 2) x = rs * (x - mu * cx[e]);
+          v[e] = act_out_c<TO, ACTK>(x + cbias[e], p.act);
+          if constexpr (EPI == 3) v[e] += fmaf(((float)rr[it][e] - mu) * rs, cx[e], cy[e]);
+          else if (has_r) v[e] += (float)rr[it][e];
+        }
+        const V4 o = pack4<TO>(v[0], v[1], v[2], v[3]);
+        if (m < p.M) *(V4*)((TO*)p.C + (long)m * p.ldc + ncol) = o;
+        if constexpr (EPI == 3) {
+          if (p.stats_out) {      // sums of what the consumer will read, per 64-column slab = 16 lanes
+            float S = 0.f, Q = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float x = a[e];
-        if constexpr (EPI == 2) x = rs * (x - mu * cx[e]);
-        v[e] = act_out_c<TO, ACTK>(x + cbias[e], p.act);
-        if constexpr (EPI == 3) v[e] += fmaf(((float)rr[it][e] - mu) * rs, cx[e], cy[e]);
-        else if (has_r) v[e] += (float)rr[it][e];
-      }
-      const V4 o = pack4<TO>(v[0], v[1], v[2], v[3]);
-      if (m < p.M) *(V4*)((TO*)p.C + (long)m * p.ldc + ncol) = o;
-      if constexpr (EPI == 3) {
-        if (p.stats_out) {      // sums of what the consumer will read, per 64-column slab = 16 lanes
-          float S = 0.f, Q = 0.f;
+            for (int e = 0; e < 4; ++e) { const float w = (float)o[e]; S += w; Q = fmaf(w, w, Q); }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const float w = (float)o[e]; S += w; Q = fmaf(w, w, Q); }
-#pragma unroll
-          for (int d = 1; d < 16; d <<= 1) { S += __shfl_xor(S, d, 64); Q += __shfl_xor(Q, d, 64); }
-          if ((lane & 15) == 0 && m < p.M) *(f32x2*)(p.stats_out + ((long)((n0 >> 6) + (lane >> 4)) * p.M + m) * 2) = f32x2{S, Q};
+            for (int d = 1; d < 16; d <<= 1) { S += __shfl_xor(S, d, 64); Q += __shfl_xor(Q, d, 64); }
+            if ((el & 15) == 0 && m < p.M) *(f32x2*)(p.stats_out + ((long)((en0 >> 6) + (el >> 4)) * p.M + m) * 2) = f32x2{S, Q};
+          }
         }
       }
-    }
-  };
-#define G8_EBAR()                                     \
-  do {                                                \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    __builtin_amdgcn_s_barrier();                     \
-  } while (0)
-  if (wr == 0) write_block(acc[0][0], acc[0][1], 0);
-  G8_EBAR();
-  if (wr == 1) write_block(acc[0][0], acc[0][1], 65536);
-  finish_block(0, 0);
-  G8_EBAR();
-  if (wr == 0) write_block(acc[1][0], acc[1][1], 0);
-  finish_block(1, 65536);
-  G8_EBAR();
-  if (wr == 1) write_block(acc[1][0], acc[1][1], 65536);
-  finish_block(2, 0);
-  G8_EBAR();
-  finish_block(3, 65536);
+    };
+    if (wr == 0) write_block(acc[0][0], acc[0][1]);
+    G8_EBAR();
+    finish_block(0);
+    G8_EBAR();
+    if (wr == 1) write_block(acc[0][0], acc[0][1]);
+    G8_EBAR();
+    finish_block(1);
+    G8_EBAR();
+    if (wr == 0) write_block(acc[1][0], acc[1][1]);
+    G8_EBAR();
+    finish_block(2);
+    G8_EBAR();
+    if (wr == 1) write_block(acc[1][0], acc[1][1]);
+    G8_EBAR();
+    finish_block(3);
+    if (!more) break;
+    // the upper half of the ring is free again once every wave has read its rows of the last block; the first K tile has
+    // been in flight since before the epilogue: K tile 1 except X1 follows, and the loop's own counted waits take over
+    G8_EBAR();
+    set_tile(tl);
+    stage(2, 1, BUF); stage(0, 1, BUF); stage(3, 1, BUF);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#undef G8_BAR
 #undef G8_EBAR
 }
 
@@ -1727,7 +1780,12 @@ static bool gemm8_takes(const GemmArgs& p, int batch, int osz) {
   if (osz != 2 || batch != 1 || p.batch_inner != 1 || (p.N % 256) || (p.K % 64) || p.K < 128 || !p.vec_ok) return false;
   if (p.Z || p.p_drop > 0.f || (p.flags & 8)) return false;               // inference epilogues only
   if (((uintptr_t)p.bias & 15) || ((uintptr_t)p.C & 7) || ((uintptr_t)p.R & 7)) return false;
+  {   // the staging offsets are 32-bit byte offsets from A / W
+    const long a_rows = p.rows_per_batch < p.M ? ((long)((p.M - 1) / p.rows_per_batch) * p.a_batch_stride + (long)(p.rows_per_batch - 1) * p.lda) : (long)(p.M - 1) * p.lda;
+    if ((a_rows + p.K) * 2 >= (1L << 32) || ((long)(p.N - 1) * p.ldw + p.K) * 2 >= (1L << 32)) return false;
+  }
   const int epi = p.a_stats ? 2 : (p.r_stats || p.stats_out) ? 3 : 1;
+  if ((p.a_stats || p.r_stats) && ((p.M & 1) || ((uintptr_t)p.a_stats & 15) || ((uintptr_t)p.r_stats & 15))) return false;   // row pairs by 16-byte LDS-DMA
   if (epi == 2 && (p.R || !p.bias || !p.w_colsum)) return false;
   if (epi == 3 && (!p.R || !p.bias || p.act != MSMD_ACT_NONE)) return false;
   return p.act == MSMD_ACT_NONE || p.act == MSMD_ACT_GELU;
@@ -1750,7 +1808,7 @@ static bool gemm8_wins(int M, int N, int K) {
 
 template <typename TI, int EPIA>
 static int launch_gemm8_e(GemmArgs& p, hipStream_t st) {
-  constexpr int lds = 2 * 4 * 128 * 128;   // 128 KB: the operand ring = the epilogue's two row blocks
+  constexpr int lds = 2 * 4 * 128 * 128 + (EPIA % 10 >= 2 ? 8 * 4096 : 0);   // 128 KB operand ring (its upper half = the epilogue's row block) + the LayerNorm forms' row statistics
   static bool attr_done = false;
   auto kfn = gemm8_kernel<TI, EPIA>;
   if (!attr_done) {
@@ -1758,7 +1816,8 @@ static int launch_gemm8_e(GemmArgs& p, hipStream_t st) {
     attr_done = true;
   }
   p.mt = (p.M + 255) / 256; p.nt = p.N / 256;
-  hipLaunchKernelGGL(kfn, dim3(p.mt * p.nt, 1, 1), dim3(512), lds, st, p);
+  const int tiles = p.mt * p.nt;
+  hipLaunchKernelGGL(kfn, dim3(tiles < 256 ? tiles : 256, 1, 1), dim3(512), lds, st, p);
   MSMD_RETURN_LAST();
 }
 
