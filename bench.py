@@ -119,10 +119,10 @@ def roofline_leg(model, b, mode, steps=3, run_step=None, exclude=None, traffic_k
         step_fn()
     torch.cuda.synchronize()
     trace, ops.GEMM_TRACE = ops.GEMM_TRACE, None
-    flops = ms = big_f = big_ms = tall_f = tall_ms = 0.0
-    n_launch = big_n = tall_n = 0
+    flops = ms = big_f = big_ms = tall_f = tall_ms = t256_f = t256_ms = 0.0
+    n_launch = big_n = tall_n = t256_n = 0
     kq = 32 if mode == "f16x2" else 64
-    for (M, N, K, batch, dt, e0, e1) in trace:
+    for (M, N, K, batch, dt, e0, e1, on_256) in trace:
         if exclude is not None and exclude(M, N, K, batch):
             continue
         f = 2.0 * M * N * K * batch
@@ -131,6 +131,11 @@ def roofline_leg(model, b, mode, steps=3, run_step=None, exclude=None, traffic_k
         ms += d
         n_launch += 1
         tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
+        if on_256:      # the 256 x 256 8-phase kernel (csrc/gemm.hip gemm8_kernel; ops.gemm / gemm_ln record the library's routing)
+            t256_f += f
+            t256_ms += d
+            t256_n += 1
+            continue
         if N > 64 and tiles >= 192 and (mode == "fp32" or K % kq == 0):
             # csrc/gemm.hip routes tall 16-bit grids (M >= 16000, >= 400 tiles of 192 x 128) to the 192 x 128 sibling of the
             # 128 x 128 kernel: a different kernel name in the rocprofv3 summary, so it is reported beside, not inside
@@ -159,6 +164,17 @@ def roofline_leg(model, b, mode, steps=3, run_step=None, exclude=None, traffic_k
                     "traffic is a constant from this round's --pmc passes in profiles/, not this run")
     if mode == "f16x2":
         out["mfma_issue_frac"] = round(3.0 * achieved / peak, 4)   # the MFMA pipe executes 3 products per algorithmic one
+    if t256_n:
+        t2 = t256_f / (t256_ms * 1e-3) / 1e12
+        out["tile_256x256"] = dict(kernel="gemm8_kernel<%s> (csrc/gemm.hip: 256 x 256 tiles, 8-phase schedule, one workgroup per CU; the conv "
+                                          "stack, the encoder QKV projections and every launch whose rounds of 256 tiles fill)" % mode,
+                                   launches_per_step=t256_n // steps, achieved=round(t2, 2), frac=round(t2 / peak, 4),
+                                   gflop_per_step=round(t256_f / steps / 1e9, 1), ms_per_step_in_kernel=round(t256_ms / steps, 3),
+                                   avg_launch_us=round(t256_ms / t256_n * 1e3, 2))
+        mf = (big_f + tall_f + t256_f) / ((big_ms + tall_ms + t256_ms) * 1e-3) / 1e12
+        out["all_mfma_tile_kernels"] = dict(achieved=round(mf, 2), frac=round(mf / peak, 4),
+                                            launches_per_step=(big_n + tall_n + t256_n) // steps,
+                                            ms_per_step_in_kernel=round((big_ms + tall_ms + t256_ms) / steps, 3))
     if tall_n:
         ta = tall_f / (tall_ms * 1e-3) / 1e12
         fam = (big_f + tall_f) / ((big_ms + tall_ms) * 1e-3) / 1e12

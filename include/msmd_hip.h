@@ -71,7 +71,8 @@ int msmd_spin_us(float us, long* ticks_out, msmd_stream_t stream);
  *   for split output also N % 4 == 0 and ldc / ldr / strideC / strideR multiples of 32.
  *   batch > 1 launches independent problems with the given element strides (grouped conv).
  *   act: MSMD_ACT_* in bits 0-7; bits 8-15 may carry a kernel-variant hint (MSMD_GEMM_VARIANT; 0 = the library's own
- *   shape heuristic; every variant computes bit-identical results); bits 16-23 epilogue flags (MSMD_GEMM_WRITE_THROUGH,
+ *   shape heuristic; every variant computes bit-identical results -- up to one fused multiply-add's rounding
+ *   where an activation meets a residual, see tests/test_kernels_gpu.py); bits 16-23 epilogue flags (MSMD_GEMM_WRITE_THROUGH,
  *   MSMD_GEMM_PAIRED_STORES: how the output is stored, never what is stored).
  *   Requirements: K % (16 / sizeof(in)) == 0, lda/ldw/a_batch_stride/strideA/strideW multiples of the same.
  * Replaces: nn.Linear / nn.Conv1d / nn.MultiheadAttention projections at reference model.py:115,856-906,
@@ -82,6 +83,12 @@ int msmd_gemm(const void* A, const void* W, const float* bias, const void* resid
               long lda, int rows_per_batch, long a_batch_stride, long ldw, long ldc, long ldr, int act,
               int batch, long strideA, long strideW, long strideC, long strideBias, long strideR,
               msmd_stream_t stream);
+
+/* The shape rule of msmd_gemm / msmd_gemm_ln for their 256 x 256-tile kernel (variant 80: 16-bit operands and output of one
+ * problem, N % 256 == 0, K % 64 == 0, K >= 128, inference epilogues): 1 when a call of this shape that the kernel can take
+ * is routed to it, 0 otherwise.  Pure function of (M, N, K); lets a caller that times launches (bench.py's roofline leg) file
+ * each one under the kernel that ran it.  No counterpart in the reference. */
+int msmd_gemm_256_tile_rule(int M, int N, int K);
 
 /* msmd_gemm with the training epilogue:  C = dropout_p(act(A . W^T + bias)) + residual, and optionally
  * z_out = A . W^T + bias (the pre-activation the backward needs; layout and dtype of C).  The keep mask is

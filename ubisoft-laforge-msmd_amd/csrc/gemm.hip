@@ -2133,6 +2133,10 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
   return 1;
 }
 
+extern "C" int msmd_gemm_256_tile_rule(int M, int N, int K) {
+  return (M > 0 && N > 0 && K >= 128 && (N % 256) == 0 && (K % 64) == 0 && gemm8_wins(M, N, K)) ? 1 : 0;
+}
+
 extern "C" int msmd_gemm(const void* A, const void* W, const float* bias, const void* residual, void* C, int M,
                          int N, int K, int in_dtype, int out_dtype, long lda, int rows_per_batch,
                          long a_batch_stride, long ldw, long ldc, long ldr, int act, int batch, long strideA,

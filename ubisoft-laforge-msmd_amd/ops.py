@@ -315,7 +315,11 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
         _lib.check(lib.msmd_gemm(*args), "msmd_gemm")
     if GEMM_TRACE is not None:
         e1.record()
-        GEMM_TRACE.append((M, N, K, batch, _dt(a), e0, e1))
+        # last field: did the library run this launch on its 256 x 256-tile kernel (what the kernel takes + the shape rule)
+        t256 = (variant in (0, 80) and not (flags & GEMM_NO_256_TILE) and batch == 1 and z_out is None and not p_drop > 0.0
+                and a.dtype in (torch.bfloat16, torch.float16) and out.dtype == a.dtype
+                and (variant == 80 or bool(lib.msmd_gemm_256_tile_rule(M, N, K))) and N % 256 == 0 and K % 64 == 0 and K >= 128)
+        GEMM_TRACE.append((M, N, K, batch, _dt(a), e0, e1, t256))
     return out
 
 
@@ -362,7 +366,10 @@ def gemm_ln(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=No
                                 _p(r_beta), _p(st), slab_in, slab_out, float(eps), _stream()), "msmd_gemm_ln")
     if GEMM_TRACE is not None:
         e1.record()
-        GEMM_TRACE.append((M, N, K, 1, _dt(a), e0, e1))
+        hint = 66 if GEMM_LN_ALL_IN_ONE else ((GEMM_LN_ROUTER(M, N, K) or 0) if GEMM_LN_ROUTER is not None else (GEMM_LN_TILE or 0))
+        t256 = ((hint == 80 or (hint == 0 and not (GEMM_LN_FLAGS & GEMM_NO_256_TILE) and bool(lib.msmd_gemm_256_tile_rule(M, N, K))))
+                and N % 256 == 0 and K >= 128 and (st is None or slab_out == 64) and (sin is None or M % 2 == 0))
+        GEMM_TRACE.append((M, N, K, 1, _dt(a), e0, e1, t256))
     return (out, st) if st is not None else out
 
 
@@ -396,7 +403,7 @@ def gemm_act_bwd(dy, wt, z, act, p_drop=0.0, rng_state=None, site=0):
                                             int(site), _stream()), "msmd_gemm_actbwd")
     if GEMM_TRACE is not None:
         e1.record()
-        GEMM_TRACE.append((M, N, K, 1, _dt(dy), e0, e1))
+        GEMM_TRACE.append((M, N, K, 1, _dt(dy), e0, e1, False))
     return out
 
 

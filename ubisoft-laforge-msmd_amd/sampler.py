@@ -307,7 +307,8 @@ class _StepGraph:
         # the 192 x 128 tile: alone on the chip its grids are short of a round (672 / 224 tiles on 512 slots) and the 128 x 128
         # tile wins, but beside another lane's launches the holes are filled and the larger tile's better loop shows (same box,
         # alternating: 2.286 -> 2.237, 2.208 -> 2.177 ms per step).  Same products in the same order: results are bit-identical.
-        tile_keep, ops.GEMM_LN_TILE = ops.GEMM_LN_TILE, (15 if lanes > 1 else ops.GEMM_LN_TILE)
+        lane_tile = int(os.environ.get("MSMD_SAMPLER_LANE_TILE", "15")) or None      # developers' A/B: 0 = the library's own choice
+        tile_keep, ops.GEMM_LN_TILE = ops.GEMM_LN_TILE, (lane_tile if lanes > 1 else ops.GEMM_LN_TILE)
         # warm-up on a side stream (allocator + lazy kernel loading), then capture
         for ln in self.lane:
             ln.t_dev.fill_(1)
