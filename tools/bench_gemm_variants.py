@@ -10,7 +10,9 @@ import torch
 from msmd_amd import ops
 
 # "17" = variant 17; "17s" = the same with MSMD_GEMM_STAGGER
-variants = [(int(v.rstrip("s")), ops.GEMM_PAIRED_STORES | (ops.GEMM_STAGGER if v.endswith("s") else 0)) for v in (sys.argv[1] if len(sys.argv) > 1 else "17,40").split(",")]
+# "17" = variant 17; "17s" = the same with MSMD_GEMM_STAGGER; "80w" = with MSMD_GEMM_WRITE_THROUGH
+variants = [(int(v.rstrip("sw")), ops.GEMM_PAIRED_STORES | (ops.GEMM_STAGGER if v.endswith("s") else 0) | (ops.GEMM_WRITE_THROUGH if v.endswith("w") else 0))
+            for v in (sys.argv[1] if len(sys.argv) > 1 else "17,40").split(",")]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 shapes = [("conv1", 205024, 512, 1536), ("conv3", 51232, 512, 1536), ("conv5", 12800, 512, 1024), ("qkv", 6400, 2304, 768),
           ("ffn1", 6400, 3072, 768), ("ffn2", 6400, 768, 3072), ("out", 6400, 768, 768), ("dec_qkv", 21120, 1536, 512),
@@ -54,5 +56,5 @@ for name, M, N, K in shapes:
             e1.record()
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / reps)
-        line.append(f"v{v}{'s' if fl & ops.GEMM_STAGGER else ''}: {best * 1e3:7.1f} us {2.0 * M * N * K / best / 1e9:7.1f} TF{'' if same else ' MISMATCH'}")
+        line.append(f"v{v}{'s' if fl & ops.GEMM_STAGGER else ''}{'w' if fl & ops.GEMM_WRITE_THROUGH else ''}: {best * 1e3:7.1f} us {2.0 * M * N * K / best / 1e9:7.1f} TF{'' if same else ' MISMATCH'}")
     print(f"{name:9s} {M:6d}x{N:4d}x{K:4d}  " + "   ".join(line), flush=True)

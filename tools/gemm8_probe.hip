@@ -32,7 +32,8 @@ constexpr int BUF = 4 * HALF;     // X0 X1 W0 W1
   } while (0)
 
 // VAR bit 0: no s_setprio pair; bit 1: no stagger of the wave rows; bit 2: plain tile order (no XCD chunks);
-// bit 3: every tile reads the first 4096 rows of A (an L2-resident operand: what does streaming A from HBM cost a tall grid?)
+// bit 3: every tile reads the first 4096 rows of A (an L2-resident operand: what does streaming A from HBM cost a tall grid?);
+// bit 4: no output stores (only a lane whose result is NaN stores): what does draining the output cost a one-round launch?
 template <int VAR>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm8(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* __restrict__ C, int M, int N, int K, int mt, int nt) {
@@ -171,7 +172,7 @@ void gemm8(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* _
           const int m = m0 + h * 128 + wr * 64 + j * 16 + fr, n = n0 + g * 128 + wc * 32 + i * 16 + fq * 4;
           const f32x4 v = acc[h][g][i][j];
           bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-          *(bf16x4*)(C + (long)m * N + n) = o;
+          if (!(VAR & 16) || v[0] != v[0]) *(bf16x4*)(C + (long)m * N + n) = o;
         }
 }
 
@@ -222,6 +223,7 @@ int main(int argc, char** argv) {
       case 2: run<2>(A, W, C, M, N, K, st); break;
       case 4: run<4>(A, W, C, M, N, K, st); break;
       case 8: run<8>(A, W, C, M, N, K, st); break;
+      case 16: run<16>(A, W, C, M, N, K, st); break;
       default: printf("variant?\n"); exit(1);
     }
   };
@@ -244,7 +246,7 @@ int main(int argc, char** argv) {
   for (int i = 0; i < n_s; ++i) {
     const float c = bf2f(hC[(size_t)mn[2 * i] * N + mn[2 * i + 1]]);
     const double e = fabs(c - ref[i]), tol = 0.01 * fabs(ref[i]) + 0.02;
-    if (!(e <= tol) && !(var & 8)) ++bad;
+    if (!(e <= tol) && !(var & 24)) ++bad;
     if (e > worst) worst = e;
   }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

@@ -94,8 +94,25 @@ template <> struct Vec4T<f16_t> { typedef f16x4 type; };
 template <typename T> struct Vec8T;
 template <> struct Vec8T<bf16_t> { typedef bf16x8 type; };
 template <> struct Vec8T<f16_t> { typedef f16x8 type; };
+// Four fp32 values -> four stored values.  16-bit types: TWO packed conversions (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, round to
+// nearest even, both new on gfx950).  Written as four scalar casts, hipcc emitted one conversion per VALUE inside the GEMM
+// epilogues (second operand a dummy), a NaN select behind each bf16 one and v_perm_b32 to pair the halves: 10 vector
+// instructions per 4 outputs where 2 do -- a fifth of the vector work of a 128 x 128 tile's epilogue.  Same bits for every
+// finite value (the instruction is the one the casts lower to); asm without `volatile`, so the scheduler stays free.
 template <typename T> __device__ __forceinline__ typename Vec4T<T>::type pack4(float a, float b, float c, float d) {
-  return typename Vec4T<T>::type{(T)a, (T)b, (T)c, (T)d};
+  if constexpr (__is_same(T, bf16_t)) {
+    u32x2 r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r[0]) : "v"(a), "v"(b));
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r[1]) : "v"(c), "v"(d));
+    return __builtin_bit_cast(bf16x4, r);
+  } else if constexpr (__is_same(T, f16_t)) {
+    u32x2 r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r[0]) : "v"(a), "v"(b));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r[1]) : "v"(c), "v"(d));
+    return __builtin_bit_cast(f16x4, r);
+  } else {
+    return typename Vec4T<T>::type{(T)a, (T)b, (T)c, (T)d};
+  }
 }
 // 16x16x32 MFMA on 8 x 16-bit operands held as 4 dwords
 template <typename T> __device__ __forceinline__ f32x4 mfma16(const u32x4 a, const u32x4 b, const f32x4 c) {

@@ -1442,6 +1442,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int nk = p.K / 64;
   typedef typename Vec4T<TO>::type V4;
   const bool has_r = p.R != nullptr;
+  const bool wt = p.flags & 1;     // write-through stores (MSMD_GEMM_WRITE_THROUGH): the rows leave the L2 as they are stored
 
   // prologue of the first tile: K tile 0 whole, K tile 1 except X1 (which phase 1 of tile 0 stages)
   set_tile(tl);
@@ -1590,7 +1591,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           else if (has_r) v[e] += (float)rr[it][e];
         }
         const V4 o = pack4<TO>(v[0], v[1], v[2], v[3]);
-        if (m < p.M) *(V4*)((TO*)p.C + (long)m * p.ldc + ncol) = o;
+        if (m < p.M) {
+          if (wt) store8_wt((TO*)p.C + (long)m * p.ldc + ncol, __builtin_bit_cast(u32x2, o));
+          else *(V4*)((TO*)p.C + (long)m * p.ldc + ncol) = o;
+        }
         if constexpr (EPI == 3) {
           if (p.stats_out) {      // sums of what the consumer will read, per 64-column slab = 16 lanes
             float S = 0.f, Q = 0.f;
@@ -1817,6 +1821,10 @@ static int launch_gemm8_e(GemmArgs& p, hipStream_t st) {
   }
   p.mt = (p.M + 255) / 256; p.nt = p.N / 256;
   const int tiles = p.mt * p.nt;
+  // Up to two rounds the launch ends in one burst of output rows: with write-through stores they leave the L2s while the
+  // epilogue is still running instead of at the end-of-kernel write-back (6400 x 2304 x 768: 30.3-31.2 -> 28.1-29.3 us, 21312 x
+  // 1536 x 512: 50.4 -> 47.3; many-round launches are indifferent or lose: 15968 x 3072 x 1024 101 -> 110)
+  if (tiles <= 512) p.flags |= 1;
   hipLaunchKernelGGL(kfn, dim3(tiles < 256 ? tiles : 256, 1, 1), dim3(512), lds, st, p);
   MSMD_RETURN_LAST();
 }
