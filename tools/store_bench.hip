@@ -1,7 +1,7 @@
 // Dev microbenchmark: how fast can 8 waves per CU write a (B, V, 3) fp32 tensor in the skinning kernel's tile order?
 // Patterns: 0 = lane (vertex i, frames 4q+e): 4 dwordx3 per 16x16 tile (192-B runs); 1 = lane (frame i, vertices 4q..4q+3):
 // 3 dwordx4 (48-B pieces); 2 = the workgroup's 16 rows x 1536 B as whole-row dwordx4 (what an LDS transposition would give);
-// 3 = pattern 2 with nontemporal stores; 4 = pattern 0 nontemporal.
+// 3 = pattern 2 with nontemporal stores; 4 = pattern 0 nontemporal; 5 = pattern 0 with sc1 (write-through) stores; 6 = pattern 2 with sc1.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(512) void k(float* __restrict__ out, int B, int V, 
   for (int t = 0; t < ntiles; ++t) {
     const int f0 = f_begin + 16 * t;
     val += 1.0f;
-    if constexpr (P == 0 || P == 4) {
+    if constexpr (P == 0 || P == 4 || P == 5) {
       const int ve = min(v0w + i, V - 1);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -31,6 +31,11 @@ __global__ __launch_bounds__(512) void k(float* __restrict__ out, int B, int V, 
         F3 o{val, val + e, val - e};
         F3* d = (F3*)(out + ((long)f * V + ve) * 3);
         if constexpr (P == 4) { __builtin_nontemporal_store(o.x, &d->x); __builtin_nontemporal_store(o.y, &d->y); __builtin_nontemporal_store(o.z, &d->z); }
+        else if constexpr (P == 5) {
+          typedef float f32x3 __attribute__((ext_vector_type(3)));
+          const f32x3 o3 = {o.x, o.y, o.z};
+          asm volatile("global_store_dwordx3 %0, %1, off sc1" ::"v"(d), "v"(o3) : "memory");
+        }
         else *d = o;
       }
     } else if constexpr (P == 1) {
@@ -46,7 +51,9 @@ __global__ __launch_bounds__(512) void k(float* __restrict__ out, int B, int V, 
         const int f = min(f0 + r, B - 1);
         f32x4u* d = (f32x4u*)(out + ((long)f * V + vbase) * 3) + c;
         const f32x4 o = f32x4{val, val + s, val, val};
-        if constexpr (P == 3) __builtin_nontemporal_store(o, (f32x4*)d); else *d = o;
+        if constexpr (P == 3) __builtin_nontemporal_store(o, (f32x4*)d);
+        else if constexpr (P == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(d), "v"(o) : "memory");
+        else *d = o;
       }
     }
   }
@@ -125,6 +132,8 @@ int main(int argc, char** argv) {
   t = run<2>(out, B, V, 10); printf("pattern 2 (whole 1536-B rows, dwordx4)      %8.1f us  %7.0f GB/s\n", t * 1e3, gb / t * 1e3);
   t = run<3>(out, B, V, 10); printf("pattern 3 (whole rows, nontemporal)         %8.1f us  %7.0f GB/s\n", t * 1e3, gb / t * 1e3);
   t = run<4>(out, B, V, 10); printf("pattern 4 (dword x 3 nontemporal)           %8.1f us  %7.0f GB/s\n", t * 1e3, gb / t * 1e3);
+  t = run<5>(out, B, V, 10); printf("pattern 5 (pattern 0, sc1 write-through)    %8.1f us  %7.0f GB/s\n", t * 1e3, gb / t * 1e3);
+  t = run<6>(out, B, V, 10); printf("pattern 6 (whole rows, sc1 write-through)   %8.1f us  %7.0f GB/s\n", t * 1e3, gb / t * 1e3);
   t = runw<1, 0>(out, B, V, 10); printf("W = 1 (1536-B runs)                          %8.1f us  %7.0f GB/s\n", t * 1e3, gb / t * 1e3);
   t = runw<2, 0>(out, B, V, 10); printf("W = 2 (3072-B runs)                          %8.1f us  %7.0f GB/s\n", t * 1e3, gb / t * 1e3);
   t = runw<4, 0>(out, B, V, 10); printf("W = 4 (6144-B runs)                          %8.1f us  %7.0f GB/s\n", t * 1e3, gb / t * 1e3);
