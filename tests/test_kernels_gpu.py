@@ -666,6 +666,19 @@ def _ln_forms_256_tile(o, O, g, dtype, M, D, F):
     # outputs may move by one 16-bit step where rounding was at a tie; no more
     assert float((fa.float() - fb.float()).abs().max()) <= step and float((qa.float() - qb.float()).abs().max()) <= step
     assert float((fa != fb).float().mean()) < 0.01
+    # statistics in 32-column slabs (what a 64 x 64-tile producer writes): 24 slabs per row here, i.e. past the 16 the kernel
+    # keeps in LDS -- the rest is summed from memory
+    xs = c1a.double().reshape(M, -1, 32)
+    st32 = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).transpose(0, 1).float().contiguous()
+    q32 = []
+    for tile in (17, 80):
+        O.GEMM_LN_TILE = tile
+        try:
+            q32.append(o.gemm_ln(c1a, w2f, b2f, a_stats=st32, w_colsum=cs2))
+        finally:
+            O.GEMM_LN_TILE = None
+    assert float((q32[0].float() - q32[1].float()).abs().max()) <= step and float((q32[0] != q32[1]).float().mean()) < 0.01
+    assert float((q32[1].float() - qa.float()).abs().max()) <= 2 * step      # and the same rows as with 64-column statistics
 
 
 @pytest.mark.parametrize("M", [1000, 6500, 16100])     # 64 x 64 tiles / 32-column slabs; 128 x 128 and (tall grids) 192 x 128 tiles / 64-column slabs; ragged M
