@@ -170,7 +170,7 @@ def roofline_leg(model, b, mode, steps=3, run_step=None, exclude=None, traffic_k
                                           "stack, the encoder QKV projections and every launch whose rounds of 256 tiles fill)" % mode,
                                    launches_per_step=t256_n // steps, achieved=round(t2, 2), frac=round(t2 / peak, 4),
                                    gflop_per_step=round(t256_f / steps / 1e9, 1), ms_per_step_in_kernel=round(t256_ms / steps, 3),
-                                   avg_launch_us=round(t256_ms / t256_n * 1e3, 2))
+                                   avg_launch_us=round(t256_ms / t256_n * 1e3, 2), traffic=pmc_traffic_256(traffic_key))
         mf = (big_f + tall_f + t256_f) / ((big_ms + tall_ms + t256_ms) * 1e-3) / 1e12
         out["all_mfma_tile_kernels"] = dict(achieved=round(mf, 2), frac=round(mf / peak, 4),
                                             launches_per_step=(big_n + tall_n + t256_n) // steps,
@@ -215,6 +215,18 @@ def pmc_traffic(mode, key=None, tile="128ELi128E"):
         except Exception:
             pass
     return None
+
+
+def pmc_traffic_256(key=None):
+    """HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, launch-weighted over its epilogue forms) of gemm8_kernel from the same
+    committed --pmc passes as pmc_traffic; None when the summary has no such kernel."""
+    path = os.path.join(ROOT, "profiles", f"r05_pmc_{key}_fetch_write_per_kernel.json" if key else "r05_pmc_hbm_fetch_write_per_kernel.json")
+    try:
+        ks = [v for n, v in json.load(open(path)).items() if "gemm8_kernel" in n]
+        n = sum(v.get("launches", 0) for v in ks)
+        return round(sum(v.get("launches", 0) * (2.0 * v["fetch_kb_avg"] + v["write_kb_avg"]) for v in ks) / n * 1024.0) if n else None
+    except Exception:
+        return None
 
 
 # ----------------------------------------------------------------------------------------------- CPU baseline / oracle
