@@ -846,6 +846,18 @@ def run_forward(a, rank, world, device):
             pm.append(ent)
         out["parity_mode"] = pm
         model.set_compute_dtype(a.dtype)
+    # Co-headline: the fastest mode INSIDE north_star's 1e-4 (the reference computes in fp32, training_script.py:548-551) --
+    # the f16x2 split-pair mode -- with its own roofline block, at the top level of the line.
+    pg = (out if a.dtype == "f16x2" else next((e for e in out.get("parity_mode") or [] if e["dtype"] == "f16x2"), None))
+    if pg is not None:
+        out["parity_grade"] = dict(dtype="f16x2", ms_per_step=pg["ms_per_step"],
+                                   frames_per_s=pg["value"] if pg is out else pg["frames_per_s"],
+                                   max_abs_err_vs_oracle=pg.get("max_abs_err_vs_oracle"), error_bound=1e-4,
+                                   meets_1e_4=None if pg.get("max_abs_err_vs_oracle") is None else bool(pg["max_abs_err_vs_oracle"] < 1e-4),
+                                   roofline=pg.get("roofline"),
+                                   note="same workload and timing as the headline; every contraction on MSMD_F16X2 split pairs "
+                                        "(three f16 MFMAs per product: roofline.frac is ALGORITHMIC flops / the dense f16 peak, "
+                                        "mfma_issue_frac = 3 x that is what the matrix pipe executes)")
     if a.two_streams_leg and not a.eager and a.streams == 1:
         model.set_compute_dtype(a.dtype)
         ms2 = multi_stream_forward(model, a, rank, device, 2)
@@ -855,7 +867,7 @@ def run_forward(a, rank, world, device):
             model.set_compute_dtype("f16x2")
             ms2 = multi_stream_forward(model, a, rank, device, 2)
             if ms2 is not None:
-                ms2["gemm"] = "gemm2s_kernel<128,128,4,2,2>"
+                ms2["gemm"] = "gemm2s_kernel<128,128,4,2,2> + gemm8_kernel<f16, SPLIT>"
                 out["forward_two_streams_f16x2"] = ms2
             model.set_compute_dtype(a.dtype)
     del model

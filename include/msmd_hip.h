@@ -46,12 +46,16 @@ int msmd_abi_version(void);
  * knobs travels per call -- the GEMM kernel variant and epilogue flags in `act` (msmd_gemm below), the contraction
  * split count of msmd_gemm_tn in its `accumulate` argument.  The experimental kernel families of DESIGN.md section 5 /
  * 5b and their A/B switch exist only in the developer build (`make -C csrc EXP=1` -> libmsmd_hip_exp.so). */
-#define MSMD_GEMM_VARIANT(v) ((v) << 8)   /* bits 8-15 of `act`: 0 = shape heuristic, 9 / 12 / 13 / 14 / 15 / 17 / 80 (bf16, fp16), 1 / 5 / 14 (f16x2) */
+#define MSMD_GEMM_VARIANT(v) ((v) << 8)   /* bits 8-15 of `act`: 0 = shape heuristic, 9 / 12 / 13 / 14 / 15 / 17 / 80 (bf16, fp16), 1 / 5 / 14 / 80 (f16x2) */
 #define MSMD_GEMM_WRITE_THROUGH (1 << 16) /* output stores carry `sc1`: the bytes leave the XCD's L2 as they are stored */
 #define MSMD_GEMM_PAIRED_STORES (1 << 17) /* 16-bit outputs: lane pairs swap a fragment row, one 16-byte store each */
 #define MSMD_GEMM_STAGGER (1 << 18)       /* multi-round launches: the second workgroup of every CU starts half a tile period late */
 #define MSMD_GEMM_ONE_TILE_PER_WORKGROUP (1 << 19) /* opt out of the persistent form of multi-round launches (A/B; same bits) */
 #define MSMD_GEMM_NO_256_TILE (1 << 20)   /* opt out of the 256 x 256 8-phase kernel (variant 80) where the heuristic would pick it (A/B) */
+#define MSMD_GEMM_W_BELOW_32 (1 << 21)    /* MSMD_F16X2 operands: the caller states |W| < 32 everywhere (model weights).  The 256 x 256
+                                             kernel (variant 80) may then scale W's hi plane by 2^11 in registers and keep ONE sum in
+                                             units of 2^-11 instead of folding the cross terms once per K tile (11-17 % faster).  Without
+                                             the bit nothing is assumed about W.  A W element of 32 or more under this bit overflows fp16. */
 
 /* Measurement aid: one wavefront that spins for `us` microseconds of the 100 MHz constant clock (s_memrealtime) and
  * optionally stores the ticks it actually spun.  bench.py times it at two lengths to calibrate the overhead of a HIP
@@ -89,6 +93,9 @@ int msmd_gemm(const void* A, const void* W, const float* bias, const void* resid
  * is routed to it, 0 otherwise.  Pure function of (M, N, K); lets a caller that times launches (bench.py's roofline leg) file
  * each one under the kernel that ran it.  No counterpart in the reference. */
 int msmd_gemm_256_tile_rule(int M, int N, int K);
+/* The same for MSMD_F16X2 operands (variant 80 of the split GEMM: one problem, N % 256 == 0, K % 32 == 0, K >= 64, fp32 or split
+ * output); w_below_32 = the call carries MSMD_GEMM_W_BELOW_32 (the fold-free form of the kernel wins on more shapes). */
+int msmd_gemm_256_tile_rule_f16x2(int M, int N, int K, int w_below_32);
 
 /* msmd_gemm with the training epilogue:  C = dropout_p(act(A . W^T + bias)) + residual, and optionally
  * z_out = A . W^T + bias (the pre-activation the backward needs; layout and dtype of C).  The keep mask is

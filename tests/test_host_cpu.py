@@ -65,7 +65,8 @@ def test_library_is_stateless_and_has_no_packed_fp32_math(tmp_path):
                 name = line.split(":", 1)[1].strip()
             elif line.startswith(".private_segment_fixed_size:") and name is not None:
                 size = int(line.split(":", 1)[1])
-                hot = any(t in name for t in ("gemm_kernel", "gemm2_kernel", "gemm2p_kernel", "gemm2s_kernel", "attn_kernel", "attn_whole_kernel",
+                # gemm8_kernel's counted waits (vmcnt(6), lgkmcnt(8)) assume NO scratch traffic in its K loop: a spill is a silent LDS race there
+                hot = any(t in name for t in ("gemm_kernel", "gemm2_kernel", "gemm2p_kernel", "gemm2s_kernel", "gemm8_kernel", "attn_kernel", "attn_whole_kernel",
                                               "attn_split_kernel", "gemm_tn_kernel", "conv0_mfma_kernel", "lbs_skin_v2_kernel"))
                 if hot:
                     n_hot += 1

@@ -82,6 +82,69 @@ def test_split_gemm_matches_float64(M, N, K):
         assert maxabs(cs.float().cpu().numpy(), want) < 6e-6
 
 
+@pytest.mark.parametrize("below_32", [False, True])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1000, 512, 1536), (6400, 768, 768), (5, 512, 384), (777, 256, 96),
+                                   (20000, 1024, 64), (6400, 2304, 768)])
+def test_split_gemm_256_tile_8_phase_kernel_matches_float64(M, N, K, below_32):
+    """Variant 80 of the split GEMM (gemm8_kernel, SPLIT: 256 x 256 tiles, the 8-phase schedule, cross terms folded once per K
+    tile) against a float64 product of the same fp32 inputs, at the bound the 128 x 128 split kernel is held to: plain, GELU +
+    residual, fp32 and split output; ragged M, one tile, an odd K-tile count (96 / 32), the shortest K loop (two K tiles) and a
+    grid of 316 tiles (workgroups that walk a second tile).  The hint is honoured only for calls the kernel takes (N % 256 == 0,
+    K % 32 == 0, K >= 64): that it really ran is checked by bits -- it sums the cross terms in another order than variant 1.
+    below_32: the weight went through ops.split_weight, gemm() passes MSMD_GEMM_W_BELOW_32 and the kernel keeps one sum in units
+    of 2^-11 (W's hi plane x 2^11 in registers) instead of folding; one weight sits at 31.5 to pin the stated range."""
+    o = ops()
+    a = synth.normalish(f"sgemm8/a/{M}x{K}", (M, K))
+    w = (synth.uniform(f"sgemm8/w/{N}x{K}", (N, K), -1, 1) / math.sqrt(K)).astype(np.float32)
+    b = synth.uniform(f"sgemm8/b/{N}", (N,), -0.5, 0.5)
+    r = synth.normalish(f"sgemm8/r/{M}x{N}", (M, N))
+    if below_32:
+        w[N // 2, K // 3] = 31.5
+        a[:, K // 3] *= 2.0 ** -8         # keeps the row scale the bound below is stated for
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + b
+    As, Ws = o.to_split(dev(a)), (o.split_weight(dev(w)) if below_32 else o.to_split(dev(w)))
+    assert Ws.below_32 == below_32
+    c1 = o.gemm(As, Ws, dev(b), variant=1).cpu().numpy()
+    c8 = o.gemm(As, Ws, dev(b), variant=80).cpu().numpy()
+    assert maxabs(c8, ref) < 4e-6, maxabs(c8, ref)
+    assert maxabs(c8, ref) < 2 * maxabs(c1, ref) + 2e-7          # the per-K-tile fold costs no accuracy worth naming
+    if M * N >= 65536 and K >= 96:
+        assert not np.array_equal(c8, c1), "variant 80 returned variant 1's bits: the hint was not followed"
+    from oracle import nn as onn
+    want = onn.gelu(ref) + r
+    got = o.gemm(As, Ws, dev(b), dev(r), o.ACT_GELU, variant=80).cpu().numpy()
+    assert maxabs(got, want) < 6e-6
+    Rs = o.to_split(dev(r))
+    cs = o.gemm(As, Ws, dev(b), Rs, o.ACT_GELU, out_dtype=o.SPLIT, variant=80)
+    assert isinstance(cs, o.Split) and cs.shape == (M, N)
+    assert maxabs(cs.float().cpu().numpy(), want) < 6e-6
+    # the split rows it writes are the pairs split_f16x2 makes of its fp32 results: hi = RN_f16(x), lo = RN_f16((x - hi) 2^11)
+    c8s = o.gemm(As, Ws, dev(b), out_dtype=o.SPLIT, variant=80)
+    assert torch.equal(c8s.t, o.to_split(dev(c8)).t)
+    # the library's own choice (variant 0) is one of the two kernels
+    c0 = o.gemm(As, Ws, dev(b)).cpu().numpy()
+    assert np.array_equal(c0, c8) or np.array_equal(c0, c1)
+
+
+def test_split_gemm_256_tile_kernel_takes_the_windowed_conv_operand():
+    """Conv1d over channels-last split rows (overlapping windows as the A operand) on variant 80: 3 taps x 64 channels, stride 2."""
+    o = ops()
+    B, T, C, k, stride, Cout = 5, 301, 64, 3, 2, 256
+    x = synth.normalish("sconv8/x", (B, T, C))
+    w = (synth.uniform("sconv8/w", (Cout, C, k), -1, 1) / math.sqrt(C * k)).astype(np.float32)
+    Tout = (T - k) // stride + 1
+    win = np.stack([x[:, t * stride:t * stride + k, :] for t in range(Tout)], 1).astype(np.float64)     # (B, Tout, k, C)
+    ref = np.einsum("btkc,ock->bto", win, w.astype(np.float64))
+    wp = o.to_split(dev(np.ascontiguousarray(w.transpose(0, 2, 1).reshape(Cout, k * C))))
+    with o.gemm_defaults(split_variant=80):
+        y = o.conv1d_cl(o.to_split(dev(x)), wp, None, kernel=k, stride=stride, out_dtype=torch.float32)
+        ys = o.conv1d_cl(o.to_split(dev(x)), wp, None, kernel=k, stride=stride, out_dtype=o.SPLIT)
+    with o.gemm_defaults(split_variant=1):
+        y1 = o.conv1d_cl(o.to_split(dev(x)), wp, None, kernel=k, stride=stride, out_dtype=torch.float32)
+    assert maxabs(y.cpu().numpy(), ref) < 4e-6 and maxabs(ys.float().cpu().numpy(), ref) < 4e-6
+    assert not torch.equal(y, y1)
+
+
 def test_split_gemm_is_strided_conv1d_and_batched():
     """Windowed A operand (Conv1d over channels-last rows) and the batched / grouped form in split storage."""
     o = ops()

@@ -1315,10 +1315,25 @@ void gemm4_kernel(const GemmArgs p) {
 // outputs are bit-identical to the 128 x 128 kernels'; the row statistics of the LayerNorm forms are summed in another order.
 // Calls it takes (launch_gemm8): 16-bit operands and output, N % 256 == 0, K % 64 == 0, K >= 128, one problem per launch,
 // inference epilogues (EPIA 11 / 21 plain, 12 / 22 LayerNorm-operand, 13 LayerNorm-residual + statistics).
-template <typename TI, int EPIA>
+//
+// SPLIT (round 6): the same tile, ring and schedule on MSMD_F16X2 split-pair operands (TI = f16_t; gemm2s_kernel's storage: a
+// 128-byte row piece = [hi x 32 | lo x 32] of 32 logical k).  A K tile is then 32 logical k, its "k-step 0" fragments (chunks
+// 0-3) are the hi planes and its "k-step 1" fragments (chunks 4-7) the lo planes: staging, LDS image and every fragment address
+// are unchanged, only the multiplies differ -- per fragment pair  t = Wh.Al + Wl.Ah  (two MFMAs from a zero accumulator),
+// acc = fma(t, 2^-11, acc)  (four vector FMAs, issued under the neighbouring MFMAs),  acc += Wh.Ah:  24 MFMAs per phase
+// instead of 16 on the same LDS bytes.  The cross terms are folded once per K tile because a second accumulator set for the
+// whole K loop (gemm2s_kernel's acc1) would be another 128 registers.  SPLIT = 1: C and the residual in split storage; 2: fp32.
+// SPLIT + 4 (the caller states |W| < 32, MSMD_GEMM_W_BELOW_32): no fold at all -- the wave multiplies its hi-plane W fragments
+// by 2^11 in registers (four v_pk_mul_f16 per fragment, exact below 32 in magnitude), so that  (2^11 Wh).Ah + Wh.AL + WL.Ah  is
+// ONE sum in units of 2^-11 (AL / WL = the stored lo planes, already x 2^11), scaled back in the epilogue: 16 vector
+// instructions per K tile instead of 128, one accumulator set, the matrix pipe 11-17 % busier (conv1 875 -> 779 us, QKV 81 ->
+// 68, same box).  LayerNorm forms are not built for it (the split path runs LayerNorm as its own kernel): EPI = 1 only.
+template <typename TI, int EPIA, int SPLIT = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm8_kernel(const GemmArgs p) {
-  typedef TI TO;
+  typedef typename std::conditional<(SPLIT & 3) == 2, float, TI>::type TO;
+  constexpr bool WS = (SPLIT & 4) != 0;   // W's hi plane scaled in registers, single accumulator
   constexpr int EPI = EPIA % 10, ACTK = EPIA / 10 - 1;
+  static_assert(SPLIT == 0 || (EPI == 1 && __is_same(TI, f16_t)), "split operands: fp16 planes, plain epilogue");
   constexpr int HALF = 128 * 128;        // bytes of one half-tile
   constexpr int BUF = 4 * HALF;          // X0 X1 W0 W1
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1378,6 +1393,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   f32x4 acc[2][2][2][4];   // [h][g][i (W fragment)][j (X fragment)]
   u32x4 fx[2][4], fw0[2][2], fw1[2][2];   // [k-step][fragment]
+  u32x4 fs0[2], fs1[2];                   // WS: the hi-plane W fragments x 2^11
+  auto scale_w = [&](const u32x4 (&fw)[2][2], u32x4 (&fs)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f16x8 h = __builtin_bit_cast(f16x8, fw[0][i]);
+      h = h * (f16_t)MSMD_SPLIT_SCALE;
+      fs[i] = __builtin_bit_cast(u32x4, h);
+    }
+  };
 
   auto read_x = [&](int h) {
 #pragma unroll
@@ -1393,14 +1417,58 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       fw[1][i] = *(const u32x4*)(smem + wa1 + g * HALF + i * 2048);
     }
   };
-  auto quadrant = [&](f32x4 (&a)[2][4], const u32x4 (&fw)[2][2]) {
+  auto quadrant = [&](f32x4 (&a)[2][4], const u32x4 (&fw)[2][2], const u32x4 (&fs)[2]) {
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (SPLIT == 0) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Mfma<TI>::run(fw[ks][i], fx[ks][j], a[i][j]);
+    } else if constexpr (WS) {
+      // one sum in units of 2^-11: Wh.AL, WL.Ah, (2^11 Wh).Ah -- each accumulator is touched every 8th MFMA
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Mfma<TI>::run(fw[ks][i], fx[ks][j], a[i][j]);
+        for (int j = 0; j < 4; ++j) Mfma<TI>::run(fw[0][i], fx[1][j], a[i][j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Mfma<TI>::run(fw[1][i], fx[0][j], a[i][j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Mfma<TI>::run(fs[i], fx[0][j], a[i][j]);
+    } else {
+      // [0] = hi planes, [1] = lo planes (x 2^11) of one 32-deep k-step; products in gemm2s_kernel's order (Wh.Al, then Wl.Ah)
+      f32x4 t[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; Mfma<TI>::run(fw[0][i], fx[1][j], t[i][j]); }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Mfma<TI>::run(fw[1][i], fx[0][j], t[i][j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[i][j][e] = fmaf(t[i][j][e], MSMD_SPLIT_INV, a[i][j][e]);
+          Mfma<TI>::run(fw[0][i], fx[0][j], a[i][j]);
+        }
+      // issue order: the four FMAs of fold q sit in the shadow of an MFMA issued after the one that finished t[q] (left to
+      // itself the scheduler put 17 of the 32 FMAs in one run with the matrix pipe idle behind an s_nop 5)
+      __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+    }
     __builtin_amdgcn_s_setprio(0);
   };
 #define G8_BAR()                        \
@@ -1439,7 +1507,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
 
-  const int nk = p.K / 64;
+  const int nk = p.K / (SPLIT ? 32 : 64);       // K tiles of 128 bytes per operand row
   typedef typename Vec4T<TO>::type V4;
   const bool has_r = p.R != nullptr;
   const bool wt = p.flags & 1;     // write-through stores (MSMD_GEMM_WRITE_THROUGH): the rows leave the L2 as they are stored
@@ -1472,27 +1540,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       read_x(0);
       if (MODE <= 1) stage(1, t + 1, cur ^ BUF);
       asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the four W0 reads (issued first) have returned
+      if constexpr (WS) scale_w(fw0, fs0);                 // ... in this wave's read segment, the other wave row is multiplying
       G8_BAR();
-      quadrant(acc[0][0], fw0);
+      quadrant(acc[0][0], fw0, fs0);
       G8_BAR();
       // ---- phase 2
       read_w(1, fw1);
       if (MODE == 0) stage(2, t + 2, cur);
+      if constexpr (WS) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        scale_w(fw1, fs1);
+      }
       G8_BAR();
-      quadrant(acc[0][1], fw1);
+      quadrant(acc[0][1], fw1, fs1);
       G8_BAR();
       // ---- phase 3
       read_x(1);
       if (MODE == 0) stage(0, t + 2, cur);
       G8_BAR();
-      quadrant(acc[1][1], fw1);
+      quadrant(acc[1][1], fw1, fs1);
       G8_BAR();
       // ---- phase 4
       if (MODE == 0) stage(3, t + 2, cur);
       if (MODE == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // all but the three youngest half-tiles: tile t + 1 is in
       if (MODE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       G8_BAR();
-      quadrant(acc[1][0], fw0);
+      quadrant(acc[1][0], fw0, fs0);
       G8_BAR();
       cur ^= BUF; xa0 ^= BUF; xa1 ^= BUF; wa0 ^= BUF; wa1 ^= BUF;
     };
@@ -1563,6 +1636,75 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           }
     };
     auto finish_block = [&](int ps) {
+      if constexpr ((SPLIT & 3) == 2) {
+        // fp32 C / residual: a lane's four columns are 16 bytes, a row is one 1 KB run
+        f32x4 rr[8];
+        if (has_r) {
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int m = min(em0 + ps * 64 + wid * 8 + it, p.M - 1);
+            rr[it] = *(const f32x4*)((const float*)p.R + (long)m * p.ldr + ncol);
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = wid * 8 + it, m = em0 + ps * 64 + row;
+          const f32x4 a = *(const f32x4*)(smem + BUF + row * 1024 + ((el ^ (row & 15)) << 4));
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = act_split<ACTK>(WS ? fmaf(a[e], MSMD_SPLIT_INV, cbias[e]) : a[e] + cbias[e], p.act);
+            if (has_r) o[e] += rr[it][e];
+          }
+          if (m < p.M) {
+            if (wt) store16_wt((float*)p.C + (long)m * p.ldc + ncol, __builtin_bit_cast(u32x4, o));
+            else *(f32x4*)((float*)p.C + (long)m * p.ldc + ncol) = o;
+          }
+        }
+      } else if constexpr ((SPLIT & 3) == 1) {
+        // split C / residual rows ([hi x 32 | lo x 32] blocks, 2 ldc / 2 ldr fp16 per row).  Lanes 2 q and 2 q + 1 own the
+        // eight logical columns 8 q .. 8 q + 7 of a row between them: the even lane moves their hi plane (16 bytes), the odd
+        // lane their lo plane (the 16 bytes 64 further), the two exchange halves by DPP -- every wave instruction reads or
+        // writes one whole 1 KB row piece instead of 8-byte pieces in 64-byte runs.
+        const bool odd = el & 1;
+        const long coff = 2L * en0 + ((el >> 3) << 6) + (((el >> 1) & 3) << 3) + (odd ? 32 : 0);
+        auto swap1 = [](unsigned x) { return (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, false); };   // quad_perm [1, 0, 3, 2]
+        u32x4 rr[8];
+        if (has_r) {
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int m = min(em0 + ps * 64 + wid * 8 + it, p.M - 1);
+            rr[it] = *(const u32x4*)((const f16_t*)p.R + (long)m * 2 * p.ldr + coff);
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = wid * 8 + it, m = em0 + ps * 64 + row;
+          const f32x4 a = *(const f32x4*)(smem + BUF + row * 1024 + ((el ^ (row & 15)) << 4));
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = act_split<ACTK>(WS ? fmaf(a[e], MSMD_SPLIT_INV, cbias[e]) : a[e] + cbias[e], p.act);
+          if (has_r) {
+            // even lane holds [h own | h partner], odd lane [l partner | l own]
+            const unsigned g0 = swap1(odd ? rr[it][0] : rr[it][2]), g1 = swap1(odd ? rr[it][1] : rr[it][3]);
+            const f16x2 h01 = __builtin_bit_cast(f16x2, odd ? g0 : rr[it][0]), h23 = __builtin_bit_cast(f16x2, odd ? g1 : rr[it][1]);
+            const f16x2 l01 = __builtin_bit_cast(f16x2, odd ? rr[it][2] : g0), l23 = __builtin_bit_cast(f16x2, odd ? rr[it][3] : g1);
+            v[0] += unsplit_f16x2(h01[0], l01[0]); v[1] += unsplit_f16x2(h01[1], l01[1]);
+            v[2] += unsplit_f16x2(h23[0], l23[0]); v[3] += unsplit_f16x2(h23[1], l23[1]);
+          }
+          f16_t h[4], l[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split_f16x2(v[e], h[e], l[e]);
+          const unsigned hp0 = __builtin_bit_cast(unsigned, f16x2{h[0], h[1]}), hp1 = __builtin_bit_cast(unsigned, f16x2{h[2], h[3]});
+          const unsigned lp0 = __builtin_bit_cast(unsigned, f16x2{l[0], l[1]}), lp1 = __builtin_bit_cast(unsigned, f16x2{l[2], l[3]});
+          const unsigned g0 = swap1(odd ? hp0 : lp0), g1 = swap1(odd ? hp1 : lp1);
+          const u32x4 o = odd ? u32x4{g0, g1, lp0, lp1} : u32x4{hp0, hp1, g0, g1};
+          if (m < p.M) {
+            if (wt) store16_wt((f16_t*)p.C + (long)m * 2 * p.ldc + coff, o);
+            else *(u32x4*)((f16_t*)p.C + (long)m * 2 * p.ldc + coff) = o;
+          }
+        }
+      } else {
       // residual rows first: eight 512-byte runs per wave, in flight while the block is read back
       V4 rr[8];
       if (EPI != 2 && has_r) {
@@ -1605,6 +1747,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if ((el & 15) == 0 && m < p.M) *(f32x2*)(p.stats_out + ((long)((en0 >> 6) + (el >> 4)) * p.M + m) * 2) = f32x2{S, Q};
           }
         }
+      }
       }
     };
     if (wr == 0) write_block(acc[0][0], acc[0][1]);
@@ -1847,6 +1990,48 @@ static int launch_gemm8(GemmArgs& p, int batch, hipStream_t st) {
   }
 }
 
+// gemm8_kernel on split-pair operands (SPLIT): the calls it takes, the rule, the launch.  p carries fp16 strides for A / W
+// (doubled by gemm_impl) and logical ldc / ldr.
+static bool gemm8s_takes(const GemmArgs& p, int batch, bool split_out) {
+  if (batch != 1 || p.batch_inner != 1 || (p.N % 256) || (p.K % 32) || p.K < 64 || !p.vec_ok) return false;
+  if (((uintptr_t)p.bias & 15) || ((uintptr_t)p.C & 15) || ((uintptr_t)p.R & 15)) return false;
+  if (split_out ? ((p.ldc % 32) || (p.R && (p.ldr % 32))) : ((p.ldc % 4) || (p.R && (p.ldr % 4)))) return false;
+  const long a_rows = p.rows_per_batch < p.M ? ((long)((p.M - 1) / p.rows_per_batch) * p.a_batch_stride + (long)(p.rows_per_batch - 1) * p.lda) : (long)(p.M - 1) * p.lda;
+  if ((a_rows + 2L * p.K) * 2 >= (1L << 32) || ((long)(p.N - 1) * p.ldw + 2L * p.K) * 2 >= (1L << 32)) return false;   // 32-bit staging offsets
+  return p.act == MSMD_ACT_NONE || p.act == MSMD_ACT_GELU;
+}
+// ... and which of those it wins (tools/bench_gemm_split.py, us, 128 x 128 gemm2s_kernel -> this kernel folding -> fold-free with
+// MSMD_GEMM_W_BELOW_32; fp32 output, GELU).  Three MFMAs per fragment pair on the same staged bytes: a K tile (32 logical k)
+// takes 1.5 x the 16-bit kernel's (64 k) while prologue / epilogue cost per round is the same, so under-filled rounds cost
+// relatively less than gemm8_wins() charges them.
+//   conv1-4 204768 ... 25568 x 512 x 1536 (1 600 ... 200 tiles): 951 -> 870 -> 791, 481 -> 482 -> 438, 254 -> 240 -> 214, 133 -> 114 -> 100
+//   6400 x 2304 x 768 (225): 78 -> 76 -> 66;  21312 x 1536 x 512 (504): 118 -> 110 -> 101;  21312 x 2048 x 512 (672): 158 -> 153 -> 139
+//   21312 x 512 x 2048 (168, fill 0.66): 135 -> 141 -> 120;  21312 x 512 x 512 (168): 47.9 -> 48.8 -> 44.0
+//   loses: 6400 x 3072 x 768 (300, fill 0.59): 100 -> 125 -> 114;  75-100 tiles: 6400 x 768 x {768, 3072} 38 -> 58 -> 52, 114 -> 171 -> 148,
+//          12768 x 512 x 1024 49 -> 73 -> 64
+static bool gemm8s_wins(int M, int N, int K, bool w_below_32) {
+  const long tiles = (long)((M + 255) / 256) * (N / 256);
+  if (tiles < 160) return false;
+  const double fill = (double)tiles / (256.0 * (double)((tiles + 255) / 256));
+  return fill >= (w_below_32 ? 0.65 : 0.75);
+}
+template <typename TO, int ACTK, int WS>
+static int launch_gemm8s(GemmArgs& p, hipStream_t st) {
+  constexpr int lds = 2 * 4 * 128 * 128;
+  constexpr int SPLIT = (sizeof(TO) == 4 ? 2 : 1) + 4 * WS;
+  static bool attr_done = false;
+  auto kfn = gemm8_kernel<f16_t, 11 + 10 * ACTK, SPLIT>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  p.mt = (p.M + 255) / 256; p.nt = p.N / 256;
+  const int tiles = p.mt * p.nt;
+  if (tiles <= 512) p.flags |= 1;      // write-through stores for launches of up to two rounds (launch_gemm8_e)
+  hipLaunchKernelGGL(kfn, dim3(tiles < 256 ? tiles : 256, 1, 1), dim3(512), lds, st, p);
+  MSMD_RETURN_LAST();
+}
+
 template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, int ACTK = -1>
 static int launch_gemm2s(GemmArgs& p, int batch, hipStream_t st) {
   if constexpr (ACTK == -1 && NSTAGE * (BM + BN) * 128 <= 80 * 1024) {      // the routed tiles: the activation as a constant of the kernel
@@ -1885,6 +2070,10 @@ static int dispatch_gemm2s(GemmArgs& p, int batch, hipStream_t st, int variant) 
     case 1: return launch_gemm2s<TO, 128, 128, 4, 2, 2>(p, batch, st);   // 64 KB, 2 workgroups / CU (default)
     case 5: return launch_gemm2s<TO, 64, 64, 2, 2, 4>(p, batch, st);     // small grids
     case 14: return launch_gemm2s<TO, 256, 64, 8, 1, 2>(p, batch, st);   // narrow outputs (N <= 64): the positional conv
+    case 80:                                                             // 256 x 256 tiles, 8-phase schedule (gemm8_kernel, SPLIT)
+      if (!gemm8s_takes(p, batch, sizeof(TO) == 2)) return -1;
+      if (p.flags & 64) return p.act == MSMD_ACT_GELU ? launch_gemm8s<TO, 1, 1>(p, st) : launch_gemm8s<TO, 0, 1>(p, st);   // MSMD_GEMM_W_BELOW_32
+      return p.act == MSMD_ACT_GELU ? launch_gemm8s<TO, 1, 0>(p, st) : launch_gemm8s<TO, 0, 0>(p, st);
 #ifdef MSMD_EXPERIMENTAL
     case 2: return launch_gemm2s<TO, 128, 128, 4, 2, 4>(p, batch, st);   // 128 KB, deep ring
     case 3: return launch_gemm2s<TO, 128, 128, 2, 2, 2>(p, batch, st);   // 4 waves of 64 x 64
@@ -2024,7 +2213,7 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
                      int internal_flags = 0) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch_inner <= 0 || !A || !W || !C) return 1;
   const int hint = (act >> 8) & 0xff;  // caller-chosen kernel variant (host-side autotune), 0 = heuristic below
-  const int flags = ((act >> 16) & 0x7) | (((act >> 19) & 1) << 4) | (((act >> 20) & 1) << 5) | internal_flags;  // MSMD_GEMM_WRITE_THROUGH / MSMD_GEMM_PAIRED_STORES (include/msmd_hip.h)
+  const int flags = ((act >> 16) & 0x7) | (((act >> 19) & 1) << 4) | (((act >> 20) & 1) << 5) | (((act >> 21) & 1) << 6) | internal_flags;  // MSMD_GEMM_WRITE_THROUGH / MSMD_GEMM_PAIRED_STORES (include/msmd_hip.h)
   act &= 0xff;
   if (in_dtype == MSMD_F16X2) {
     // split-pair operands: logical sizes in, fp16 strides (x 2) into the kernel; 32-element blocks must stay whole
@@ -2042,7 +2231,7 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
     p.inv_rpb = 1.0f / (float)rows_per_batch;
     p.strideA = 2 * strideA; p.strideW = 2 * strideW; p.strideC = strideC; p.strideBias = strideBias; p.strideR = strideR;
     p.batch_inner = batch_inner; p.strideA2 = 2 * strideA2; p.strideW2 = 2 * strideW2; p.strideC2 = strideC2;
-    p.Z = nullptr; p.p_drop = 0.f; p.rng = nullptr; p.site = 0; p.xn = 1; p.flags = flags & 1;
+    p.Z = nullptr; p.p_drop = 0.f; p.rng = nullptr; p.site = 0; p.xn = 1; p.flags = flags & (1 | 64);
     if (out_dtype == MSMD_F16X2) {
       if ((N & 3) || ldc % 32 || strideC % 32 || strideC2 % 32 || (residual && (ldr % 32 || strideR % 32))) return 1;
       if (bias && (((uintptr_t)bias & 15) || (strideBias & 3))) return 1;
@@ -2054,10 +2243,12 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
     hipStream_t st = (hipStream_t)stream;
     const int nz = batch * batch_inner;
     int variant = MSMD_TUNE(3) > 0 ? MSMD_TUNE(3) : hint;
+    if (variant == 80 && !gemm8s_takes(p, nz, out_dtype == MSMD_F16X2)) variant = 0;   // a hint the call cannot follow
     if (variant == 0) {
       const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nz;
       variant = (N > 64 && tiles128 >= 192) ? 1 : 5;
       if (N <= 64 && (long)((M + 255) / 256) * nz >= 256) variant = 14;
+      if (!(flags & 32) && gemm8s_takes(p, nz, out_dtype == MSMD_F16X2) && gemm8s_wins(M, N, K, (flags & 64) != 0)) variant = 80;
     }
     const int r = out_dtype == MSMD_F32 ? dispatch_gemm2s<float>(p, nz, st, variant)
                                         : dispatch_gemm2s<f16_t>(p, nz, st, variant);
@@ -2143,6 +2334,10 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
 
 extern "C" int msmd_gemm_256_tile_rule(int M, int N, int K) {
   return (M > 0 && N > 0 && K >= 128 && (N % 256) == 0 && (K % 64) == 0 && gemm8_wins(M, N, K)) ? 1 : 0;
+}
+
+extern "C" int msmd_gemm_256_tile_rule_f16x2(int M, int N, int K, int w_below_32) {
+  return (M > 0 && N > 0 && K >= 64 && (N % 256) == 0 && (K % 32) == 0 && gemm8s_wins(M, N, K, w_below_32 != 0)) ? 1 : 0;
 }
 
 extern "C" int msmd_gemm(const void* A, const void* W, const float* bias, const void* residual, void* C, int M,

@@ -218,7 +218,7 @@ class DenoisingNetwork_MSMD(nn.Module):
         sd = {k: v.detach() for k, v in self.state_dict().items()}
         d, nb, dm = self.feature_dim, self.num_of_basis, self.motion_feat_dim
         f32 = lambda t: t.float().contiguous()
-        cd = (lambda t: ops.to_split(t.float().contiguous())) if split else (lambda t: t.to(dtype).contiguous())
+        cd = ops.split_weight if split else (lambda t: t.to(dtype).contiguous())
 
         def padk(w, mult=32 if split else 8):
             K = w.shape[1]
@@ -624,7 +624,7 @@ class MSMD(nn.Module):
         split = self.split_mode and dtype == torch.float32
         if self._afm is None or self._afm[0] != (dtype, split):
             w = self.audio_feature_map.weight.detach()
-            self._afm = ((dtype, split), ops.to_split(w.float().contiguous()) if split else w.to(dtype).contiguous(),
+            self._afm = ((dtype, split), ops.split_weight(w) if split else w.to(dtype).contiguous(),
                          self.audio_feature_map.bias.detach().float().contiguous())
         return self._afm[1], self._afm[2]
 

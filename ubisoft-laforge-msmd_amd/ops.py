@@ -23,14 +23,15 @@ class Split:
     """A tensor in MSMD_F16X2 split storage: logical shape (..., C) fp32-grade values, physically `.t` = (..., 2 C)
     fp16 in 32-element blocks [hi x 32 | lo x 32] (x ~= hi + lo / 2048).  Only what the call sites need: logical shape /
     strides, slicing (last-dim slices on multiples of 32), the device pointer.  `.float()` converts back."""
-    __slots__ = ("t",)
+    __slots__ = ("t", "below_32")
     dtype = SPLIT
     is_cuda = True
 
-    def __init__(self, t):
+    def __init__(self, t, below_32=False):
         if t.dtype != torch.float16 or t.shape[-1] % 64 or t.stride(-1) != 1:
             raise TypeError("Split wraps an fp16 tensor whose last dim is 2 x (a multiple of 32)")
         self.t = t
+        self.below_32 = below_32    # every |value| < 32, checked once by split_weight(): lets gemm() pass MSMD_GEMM_W_BELOW_32
 
     @property
     def shape(self):
@@ -71,11 +72,11 @@ class Split:
             if a % 32 or (b % 32 and b != C):
                 raise IndexError("Split: last-dim slices must fall on multiples of 32")
             idx = idx[:-1] + (slice(2 * a, 2 * b),)
-        return Split(self.t[idx])
+        return Split(self.t[idx], self.below_32)
 
     def view(self, *shape):
         shape = shape[0] if len(shape) == 1 and not isinstance(shape[0], int) else shape
-        return Split(self.t.view(*shape[:-1], 2 * shape[-1]))
+        return Split(self.t.view(*shape[:-1], 2 * shape[-1]), self.below_32)
 
     reshape = view
 
@@ -108,6 +109,14 @@ def to_split(x, cols_out=None):
     out = torch.empty(*x.shape[:-1], 2 * cols_out, device=x.device, dtype=torch.float16)
     _lib.check(_lib.load().msmd_split_f16x2(_p(x), _p(out), rows, C, C, cols_out, _stream()), "msmd_split_f16x2")
     return Split(out)
+
+
+def split_weight(w):
+    """to_split for a WEIGHT (packed once at load): also records whether every |w| < 32, which gemm() hands to the library as
+    MSMD_GEMM_W_BELOW_32 (include/msmd_hip.h).  One host sync per weight, at pack time only."""
+    s = to_split(w.float().contiguous())
+    s.below_32 = bool(w.numel() == 0 or float(w.detach().abs().max()) < 31.99)   # RN_f16(31.99) = 31.984375 = 65504 / 2^11
+    return s
 
 
 def unsplit(s, cols=None):
@@ -170,6 +179,7 @@ _TUNED = {}
 GEMM_WRITE_THROUGH, GEMM_PAIRED_STORES, GEMM_STAGGER = 1 << 16, 1 << 17, 1 << 18
 GEMM_ONE_TILE_PER_WORKGROUP = 1 << 19      # opt out of the persistent form of multi-round launches (A/B; same bits)
 GEMM_NO_256_TILE = 1 << 20                 # opt out of the 256 x 256 8-phase kernel where the library would pick it (A/B; plain outputs same bits)
+GEMM_W_BELOW_32 = 1 << 21                  # split operands: |W| < 32 everywhere (set by gemm() from Split.below_32)
 GEMM_LN_FLAGS = 0              # extra `act` bits msmd_gemm_ln calls carry (A/B hook: GEMM_ONE_TILE_PER_WORKGROUP)
 GEMM_LN_ROUTER = None          # optional (M, N, K) -> 15 | 17 | None: tile hint for msmd_gemm_ln's big-tile family
 GEMM_LN_ALL_IN_ONE = False     # A/B hook (tools/ab_forward.py): msmd_gemm_ln on the one-kernel-with-every-epilogue form (variant 66)
@@ -298,6 +308,8 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
         if GEMM_ROUTER is not None and not isinstance(a, Split):
             variant = GEMM_ROUTER(M, N, K, batch) or variant
     flags = _GEMM_DEFAULT["flags"] if flags is None else flags
+    if isinstance(w, Split) and w.below_32:
+        flags |= GEMM_W_BELOW_32
     act = act | (variant << 8) | flags
     args = [_p(a), _p(w), _p(bias), _p(residual), _p(out), M, N, K, _dt(a), _dt(out), lda, rows_per_batch,
             a_batch_stride, ldw, ldc, ldr, act, batch, strideA, strideW, strideC, strideBias, strideR, _stream()]
@@ -316,9 +328,13 @@ def gemm(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=None,
     if GEMM_TRACE is not None:
         e1.record()
         # last field: did the library run this launch on its 256 x 256-tile kernel (what the kernel takes + the shape rule)
-        t256 = (variant in (0, 80) and not (flags & GEMM_NO_256_TILE) and batch == 1 and z_out is None and not p_drop > 0.0
-                and a.dtype in (torch.bfloat16, torch.float16) and out.dtype == a.dtype
-                and (variant == 80 or bool(lib.msmd_gemm_256_tile_rule(M, N, K))) and N % 256 == 0 and K % 64 == 0 and K >= 128)
+        if isinstance(a, Split):
+            t256 = (variant in (0, 80) and not (flags & GEMM_NO_256_TILE) and batch == 1 and N % 256 == 0 and K % 32 == 0 and K >= 64
+                    and (variant == 80 or bool(lib.msmd_gemm_256_tile_rule_f16x2(M, N, K, int(bool(flags & GEMM_W_BELOW_32))))))
+        else:
+            t256 = (variant in (0, 80) and not (flags & GEMM_NO_256_TILE) and batch == 1 and z_out is None and not p_drop > 0.0
+                    and a.dtype in (torch.bfloat16, torch.float16) and out.dtype == a.dtype
+                    and (variant == 80 or bool(lib.msmd_gemm_256_tile_rule(M, N, K))) and N % 256 == 0 and K % 64 == 0 and K >= 128)
         GEMM_TRACE.append((M, N, K, batch, _dt(a), e0, e1, t256))
     return out
 

@@ -67,7 +67,7 @@ class StyleEncoder_VAE2(nn.Module):
             return self._packed
         sd = {k: v.detach() for k, v in self.state_dict().items()}
         f32 = lambda t: t.float().contiguous()
-        cd = (lambda t: ops.to_split(t.float().contiguous())) if split else (lambda t: t.to(dtype).contiguous())
+        cd = ops.split_weight if split else (lambda t: t.to(dtype).contiguous())
         P = SimpleNamespace()
         mult = 32 if split else 8
         self.cin_pad = (self.input_dim + mult - 1) // mult * mult

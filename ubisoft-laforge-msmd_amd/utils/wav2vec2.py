@@ -281,7 +281,7 @@ class Wav2Vec2Model(nn.Module):
         P = SimpleNamespace()
         P.split = split
         f32 = lambda t: t.float().contiguous()
-        cd = (lambda t: ops.to_split(t.float().contiguous())) if split else (lambda t: t.to(dtype).contiguous())
+        cd = ops.split_weight if split else (lambda t: t.to(dtype).contiguous())
         P.w0 = f32(sd[fe + "0.conv.weight"].reshape(c.conv_dim, CONV_KERNEL[0]))
         P.gn_g, P.gn_b = f32(sd[fe + "0.layer_norm.weight"]), f32(sd[fe + "0.layer_norm.bias"])
         nconv = len(CONV_KERNEL)
@@ -302,7 +302,7 @@ class Wav2Vec2Model(nn.Module):
         sd = {k: v.detach() for k, v in self.state_dict().items()}
         P = SimpleNamespace(**vars(self.pack_fe(dtype)))
         f32 = lambda t: t.float().contiguous()
-        cd = (lambda t: ops.to_split(t.float().contiguous())) if split else (lambda t: t.to(dtype).contiguous())
+        cd = ops.split_weight if split else (lambda t: t.to(dtype).contiguous())
         P.fp_ln = (f32(sd["feature_projection.layer_norm.weight"]), f32(sd["feature_projection.layer_norm.bias"]))
         P.fp_w, P.fp_b = cd(sd["feature_projection.projection.weight"]), f32(sd["feature_projection.projection.bias"])
         # positional conv: fold weight norm (dim=2): w = g * v / ||v||_{dims 0,1}
