@@ -631,6 +631,99 @@ def test_gemm_256_tile_8_phase_kernel_equals_the_128_tile_kernels(dtype):
         _ln_forms_256_tile(o, O, g, dtype, M, D, F)
 
 
+def _ulp_of_row_max(ref, dtype):
+    """one unit in the last place of the 16-bit type at each row's largest |reference| value"""
+    rm = ref.abs().amax(dim=1, keepdim=True).clamp_min(2.0 ** -14)
+    return torch.exp2(torch.floor(torch.log2(rm)) - (7 if dtype == torch.bfloat16 else 10))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("variant", [80, 17, 15, 13, 9, 12])
+def test_gemm_every_routed_variant_meets_the_float64_reference(dtype, variant):
+    """Every kernel variant the library routes 16-bit launches to (80 = gemm8_kernel 256 x 256 8-phase, 17 / 13 = 128 x 128,
+    15 = 192 x 128, 9 / 12 = 64 x 64), FORCED by its per-call hint, against a float64 product of the same (already rounded)
+    operands at the shapes the forward / HuBERT-large / sampler steps route to variant 80: bias, GELU, residual, GELU +
+    residual, and the conv stack's windowed A operand.  Bound: ONE unit in the last place of the output type at the row's
+    largest value (fp32 accumulation error is far below the output rounding)."""
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(80 + variant)
+    gelu64 = lambda t: torch.nn.functional.gelu(t)
+    for M, N, K in ((6400, 2304, 768), (15968, 3072, 1024), (15968, 1024, 1024), (15968, 1024, 4096), (21312, 1536, 512)):
+        if variant in (9, 12) and M * N > 6400 * 2304:
+            continue          # the 64 x 64 tiles are routed to small grids only: one large shape is enough for them
+        a = torch.randn(M, K, generator=g).to(DEV, dtype)
+        w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV, dtype)
+        b = torch.randn(N, generator=g).to(DEV)
+        r = torch.randn(M, N, generator=g).to(DEV, dtype)
+        lin = a.double() @ w.double().T + b.double()
+        for act in (o.ACT_NONE, o.ACT_GELU):
+            for res in (None, r):
+                ref = gelu64(lin) if act == o.ACT_GELU else lin
+                if res is not None:
+                    ref = ref + res.double()
+                got = o.gemm(a, w, b, res, act=act, variant=variant, flags=0).double()
+                bad = ((got - ref).abs() > _ulp_of_row_max(ref, dtype))
+                assert not bool(bad.any()), (variant, M, N, K, act, res is not None, int(bad.sum()), float((got - ref).abs().max()))
+        del lin
+    # windowed A: conv1 of the feature extractor's k = 3 / stride 2 layers on 4 clips of 4 s (12 815 input frames of 512 channels)
+    if variant in (80, 15, 17):
+        B, T, C, Nc = 4, 12815, 512, 512
+        x = torch.randn(B, T, C, generator=g).to(DEV, dtype)
+        wc = (torch.randn(Nc, 3 * C, generator=g) / math.sqrt(3 * C)).to(DEV, dtype)
+        To = (T - 3) // 2 + 1
+        rows = x.unfold(1, 3, 2).permute(0, 1, 3, 2).reshape(B * To, 3 * C)      # (B, To, C, 3) -> rows [tap][channel]
+        ref = gelu64(rows.double() @ wc.double().T)
+        y = torch.empty(B, To, Nc, device=DEV, dtype=dtype)
+        o.gemm(x, wc, None, None, o.ACT_GELU, out=y, variant=variant, M=B * To, N=Nc, K=3 * C, lda=2 * C, rows_per_batch=To,
+               a_batch_stride=T * C, ldw=3 * C, ldc=Nc)
+        got = y.reshape(B * To, Nc).double()
+        assert not bool(((got - ref).abs() > _ulp_of_row_max(ref, dtype)).any())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("tile", [80, 17])
+def test_gemm_ln_forms_meet_the_float64_reference(dtype, tile):
+    """msmd_gemm_ln's two epilogue families (LayerNorm of the residual + statistics of the stored rows; LayerNorm folded into the
+    A operand) on the 256 x 256 kernel (tile hint 80) and the 128 x 128 kernel (17), each against float64 arithmetic on the same
+    16-bit operands and the same fp32 row statistics: outputs within TWO units in the last place at the row's largest value (the
+    folded form subtracts mu * colsum from the product in fp32), statistics of the stored rows to 1e-5 relative of the row's sum
+    of squares."""
+    from msmd_amd import ops as O
+    o = ops()
+    g = torch.Generator(device="cpu").manual_seed(8017 + tile)
+    M, D, F = 6400, 768, 3072
+    u0 = (torch.randn(M, D, generator=g) * 2 + 0.3).to(DEV, dtype)
+    a2 = torch.randn(M, D, generator=g).to(DEV, dtype)
+    w1 = (torch.randn(D, D, generator=g) / math.sqrt(D)).to(DEV, dtype)
+    b1 = torch.randn(D, generator=g).to(DEV)
+    g0, be0 = (torch.rand(D, generator=g) + 0.5).to(DEV), (torch.randn(D, generator=g) * 0.1).to(DEV)
+    xs = u0.double().reshape(M, -1, 64)
+    st0 = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).transpose(0, 1).float().contiguous()      # (D / 64, M, 2)
+    w2f, cs2, b2f = o.fold_layernorm(torch.randn(F, D, generator=g).to(DEV) / math.sqrt(D), torch.randn(F, generator=g).to(DEV),
+                                     (torch.rand(D, generator=g) + 0.5).to(DEV), (torch.randn(D, generator=g) * 0.1).to(DEV), dtype)
+
+    def moments(st, cols):      # what the kernels derive from the fp32 slab statistics, in float64
+        S, Q = st.double().sum(0)[:, 0], st.double().sum(0)[:, 1]
+        mu = S / cols
+        return mu[:, None], torch.rsqrt((Q / cols - mu * mu).clamp_min(0) + 1e-5)[:, None]
+
+    O.GEMM_LN_TILE = tile
+    try:
+        c1, s1 = o.gemm_ln(a2, w1, b1, u0, r_stats=st0, r_gamma=g0, r_beta=be0, stats_out=True)
+        f = o.gemm_ln(c1, w2f, b2f, act=o.ACT_GELU, a_stats=s1, w_colsum=cs2)
+    finally:
+        O.GEMM_LN_TILE = None
+    mu0, rs0 = moments(st0, D)
+    ref1 = a2.double() @ w1.double().T + b1.double() + (u0.double() - mu0) * rs0 * g0.double() + be0.double()
+    assert not bool(((c1.double() - ref1).abs() > 2 * _ulp_of_row_max(ref1, dtype)).any())
+    cs = c1.double().reshape(M, -1, 64)
+    want = torch.stack([cs.sum(-1), (cs * cs).sum(-1)], -1).transpose(0, 1)
+    assert float(((s1.double() - want).abs() / want[..., 1:2].clamp_min(1.0)).max()) < 1e-5
+    mu1, rs1 = moments(s1, D)
+    ref2 = torch.nn.functional.gelu(rs1 * (c1.double() @ w2f.double().T - mu1 * cs2.double()) + b2f.double())
+    assert not bool(((f.double() - ref2).abs() > 2 * _ulp_of_row_max(ref2, dtype)).any())
+
+
 def _ln_forms_256_tile(o, O, g, dtype, M, D, F):
     u0 = (torch.randn(M, D, generator=g) * 2 + 0.3).to(DEV, dtype)
     a2 = torch.randn(M, D, generator=g).to(DEV, dtype)
