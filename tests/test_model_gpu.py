@@ -305,8 +305,10 @@ def test_bf16_mode_tolerance():
 
 def test_sampler_hip_graph_matches_eager():
     """The captured-step (hipGraph, device-side step counter) loop must equal the eager loop bit for bit when
-    both draw the same noise (zeros here: torch.randn_like is patched before capture)."""
+    both draw the same noise (zeros here: sampler._step_noise is patched before capture).  With real noise, a seeded run gives
+    the same bits on one lane and on two (the step's noise is drawn once for the whole batch and sliced per lane)."""
     from msmd_amd.model import DiffusionSchedule
+    from msmd_amd import sampler as smp
     model, args = get_model("wav2vec2", "fp32")
     x = denoiser_inputs(2, args, tag="sm")
     T = 6
@@ -321,28 +323,27 @@ def test_sampler_hip_graph_matches_eager():
                                        dev(x["prev_audio"]), motion_at_T=xT, indicator=dev(x["indicator"]), noise=zeros,
                                        **kw)
             model.__dict__.pop("_step_graphs", None)
-            with mock.patch("torch.randn_like", side_effect=lambda t: torch.zeros_like(t)):
+            with mock.patch.object(smp, "_step_noise", side_effect=lambda B, L, dm, d: torch.zeros(B, L, dm, device=d)):
                 graph, _, _ = model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]),
                                            dev(x["prev_motion"]), dev(x["prev_audio"]), motion_at_T=xT,
                                            indicator=dev(x["indicator"]), **kw)
             assert torch.equal(eager, graph), kw
             # two LANES (each clip's chain of steps on a HIP stream of its own, forked / joined inside the captured graph;
             # the default from 48 sequences per lane up): the same bits again
-            from msmd_amd import sampler as smp
             model.__dict__.pop("_step_graphs", None)
             with mock.patch.object(smp, "MIN_LANE_SEQS", 1), mock.patch.object(smp, "LANES", 2), \
-                    mock.patch("torch.randn_like", side_effect=lambda t: torch.zeros_like(t)):
+                    mock.patch.object(smp, "_step_noise", side_effect=lambda B, L, dm, d: torch.zeros(B, L, dm, device=d)):
                 laned, _, _ = model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]),
                                            dev(x["prev_motion"]), dev(x["prev_audio"]), motion_at_T=xT,
                                            indicator=dev(x["indicator"]), **kw)
                 assert next(iter(model._step_graphs.values())).lanes == 2
             assert torch.equal(eager, laned), kw
             model.__dict__.pop("_step_graphs", None)
-            with mock.patch("torch.randn_like", side_effect=lambda t: torch.zeros_like(t)):     # back to the one-lane graph
+            with mock.patch.object(smp, "_step_noise", side_effect=lambda B, L, dm, d: torch.zeros(B, L, dm, device=d)):     # back to the one-lane graph
                 model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]), dev(x["prev_motion"]), dev(x["prev_audio"]),
                              motion_at_T=xT, indicator=dev(x["indicator"]), **kw)
         # second call re-uses the cached graph with new operands
-        with mock.patch("torch.randn_like", side_effect=lambda t: torch.zeros_like(t)):
+        with mock.patch.object(smp, "_step_noise", side_effect=lambda B, L, dm, d: torch.zeros(B, L, dm, device=d)):
             again, _, _ = model.sample(dev(x["audio_feat"]) * 0.5, dev(x["shape"]), dev(x["style"]), dev(x["prev_motion"]),
                                        dev(x["prev_audio"]), motion_at_T=xT, indicator=dev(x["indicator"]), **kw)
         ref, _, _ = model.sample(dev(x["audio_feat"]) * 0.5, dev(x["shape"]), dev(x["style"]), dev(x["prev_motion"]),
@@ -352,6 +353,17 @@ def test_sampler_hip_graph_matches_eager():
         rnd, _, _ = model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]), motion_at_T=xT,
                                  indicator=dev(x["indicator"]))
         assert torch.isfinite(rnd).all() and not torch.equal(rnd, eager)
+        # ... and the same clip gets the same noise under a given seed whatever the lane count
+        seeded = []
+        for lanes in (1, 2):
+            model.__dict__.pop("_step_graphs", None)
+            with mock.patch.object(smp, "MIN_LANE_SEQS", 1), mock.patch.object(smp, "LANES", lanes):
+                torch.manual_seed(4242)
+                out, _, _ = model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]), motion_at_T=xT,
+                                         indicator=dev(x["indicator"]))
+                assert next(iter(model._step_graphs.values())).lanes == lanes
+            seeded.append(out)
+        assert torch.equal(seeded[0], seeded[1]) and not torch.equal(seeded[0], rnd)
     finally:
         model.diffusion_sched = old
         model.__dict__.pop("_step_graphs", None)

@@ -1922,6 +1922,18 @@ static int launch_gemm4(GemmArgs& p, int batch, hipStream_t st) {
   MSMD_RETURN_LAST();
 }
 
+// One persistent workgroup per CU: the grid cap is the device's CU count (256 on MI355X; the tile-run logic of the kernel
+// works for any workgroup count, the shape rules below are fitted on 256).
+static int gemm8_workgroup_cap() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus = n;
+  }
+  return cus;
+}
+
 // gemm8_kernel: which calls it takes, and the launch.  Returns -1 for a call it does not take.
 static bool gemm8_takes(const GemmArgs& p, int batch, int osz) {
   if (osz != 2 || batch != 1 || p.batch_inner != 1 || (p.N % 256) || (p.K % 64) || p.K < 128 || !p.vec_ok) return false;
@@ -1968,7 +1980,7 @@ static int launch_gemm8_e(GemmArgs& p, hipStream_t st) {
   // epilogue is still running instead of at the end-of-kernel write-back (6400 x 2304 x 768: 30.3-31.2 -> 28.1-29.3 us, 21312 x
   // 1536 x 512: 50.4 -> 47.3; many-round launches are indifferent or lose: 15968 x 3072 x 1024 101 -> 110)
   if (tiles <= 512) p.flags |= 1;
-  hipLaunchKernelGGL(kfn, dim3(tiles < 256 ? tiles : 256, 1, 1), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(kfn, dim3(tiles < gemm8_workgroup_cap() ? tiles : gemm8_workgroup_cap(), 1, 1), dim3(512), lds, st, p);
   MSMD_RETURN_LAST();
 }
 
@@ -2028,7 +2040,7 @@ static int launch_gemm8s(GemmArgs& p, hipStream_t st) {
   p.mt = (p.M + 255) / 256; p.nt = p.N / 256;
   const int tiles = p.mt * p.nt;
   if (tiles <= 512) p.flags |= 1;      // write-through stores for launches of up to two rounds (launch_gemm8_e)
-  hipLaunchKernelGGL(kfn, dim3(tiles < 256 ? tiles : 256, 1, 1), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(kfn, dim3(tiles < gemm8_workgroup_cap() ? tiles : gemm8_workgroup_cap(), 1, 1), dim3(512), lds, st, p);
   MSMD_RETURN_LAST();
 }
 

@@ -305,7 +305,7 @@ extern "C" int msmd_layernorm(const void* x, const void* residual, const float* 
   hipStream_t st = (hipStream_t)stream;
   if (in_dtype == MSMD_F32 && out_dtype == MSMD_F32)
     return launch_ln<float, float>(x, residual, gamma, beta, post_add, y, rows, cols, eps, act, st);
-  if (in_dtype == out_dtype && in_dtype != MSMD_F32 && act == 0 && !post_add) {
+  if (in_dtype == out_dtype && (in_dtype == MSMD_BF16 || in_dtype == MSMD_F16) && act == 0 && !post_add) {   // any other code (MSMD_F16X2, junk) falls through to `return 1`
     const bool took = in_dtype == MSMD_BF16 ? launch_ln16<bf16_t>(x, residual, gamma, beta, y, rows, cols, eps, st, nullptr, nullptr)
                                             : launch_ln16<f16_t>(x, residual, gamma, beta, y, rows, cols, eps, st, nullptr, nullptr);
     if (took) MSMD_RETURN_LAST();

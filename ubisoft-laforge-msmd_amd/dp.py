@@ -113,10 +113,10 @@ class RcclComm:
         self.comm = None
 
     def __del__(self):
-        try:
-            self.destroy()
-        except Exception:      # interpreter teardown: the runtime may be gone already
-            pass
+        # ncclCommDestroy is a COLLECTIVE-ordered call: run from the garbage collector or at interpreter teardown it can hang
+        # when the peer ranks are not destroying their communicators at the same point.  Only an explicit destroy() tears the
+        # communicator down; a forgotten one is dropped with the process.
+        self.comm = None
 
 
 ALIGN = 64  # elements: every tensor starts on a 256-byte boundary of its arena (kernels need 16-byte operands)
@@ -190,6 +190,12 @@ class GradBucketReducer:
         dev = self.params[0].device
         self.arena = torch.zeros(total, device=dev, dtype=torch.float32)
         self.stage = torch.zeros(total, device=dev, dtype=bucket_dtype) if bucket_dtype is not None else None
+        if bucket_dtype == torch.float16 and self.world > 1:
+            import warnings
+            # contributions are staged / world to keep the sum inside fp16's range, with no loss scaling on this path:
+            # gradient elements below ~6e-5 * world go subnormal, below ~6e-8 * world they are lost.  bf16 has fp32's range.
+            warnings.warn("GradBucketReducer: fp16 buckets flush gradient elements below ~6e-8 x world_size; bf16 is the "
+                          "supported 16-bit bucket type", stacklevel=2)
         self.buckets = []  # (start, end, [param indices])
         cap = int(bucket_mb * (1 << 20) / 4)
         start = 0
@@ -330,7 +336,7 @@ class GradBucketReducer:
                 # fp16 has no headroom for a sum over ranks (max 65 504, no loss scaling on this path): stage contribution / world,
                 # so the SUM is the mean and cannot exceed the largest single contribution; scaled back after the exchange.
                 # bf16 staging (fp32's exponent range) needs no such guard and is the recommended 16-bit bucket type.
-                buf.copy_(view * (1.0 / self.world))
+                torch.mul(view, 1.0 / self.world, out=buf)   # scaled and cast straight into the staging arena (no bucket-sized temporary)
             else:
                 buf.copy_(view)                  # fp32 -> 16 bit (one rounding of this rank's contribution)
         if self.comm is not None:

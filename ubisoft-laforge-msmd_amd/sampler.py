@@ -220,6 +220,11 @@ LANES = min(4, max(1, int(os.environ.get("MSMD_SAMPLER_LANES", "2"))))
 MIN_LANE_SEQS = 48
 
 
+def _step_noise(B, L, dm, dev):
+    """z ~ N(0, I) of one denoising step for the whole batch (reference model.py:383: torch.randn_like(x)); tests patch this."""
+    return torch.randn(B, L, dm, device=dev, dtype=torch.float32)
+
+
 class _Lane:
     """Static operand buffers + the step body of one lane (Bl clips x n_entries CFG entries, entry-major rows)."""
 
@@ -233,7 +238,7 @@ class _Lane:
         self.mem = take(like["mem"])
         self.kv = [take(k) for k in like["kv_list"]]
         self.cross = [take(r) for r in like["cross_list"]] if like.get("cross_list") is not None else None
-        self.stat_per_clip = like["stat"].shape[0] == clips.numel() * shared["lanes"]
+        self.stat_per_clip = bool(like["stat_per_clip"])     # stated by sample(): one row of static bases per clip (not one shared row)
         self.stat = (torch.zeros((Bl,) + tuple(like["stat"].shape[1:]), device=dev, dtype=like["stat"].dtype)
                      if self.stat_per_clip else shared["stat"])
         self.tok = take(like["tok_person"])
@@ -242,7 +247,7 @@ class _Lane:
         self.coefs = torch.zeros(3, device=dev, dtype=torch.float32)
         self.feats = torch.zeros(Nl, 1 + Lp + L, P.kp_feat, device=dev, dtype=dtype)
 
-        def body():
+        def body(z):
             ops.sampler_step_select(shared["emb_all"], shared["coef_table"], self.t_dev, self.emb_row, self.coefs)
             ops.denoiser_pack_input(self.x, self.prev_m, self.ind, self.feats)
             dec = net.trunk(self.feats, self.tok, self.mem, dtype, kv_list=self.kv, row0_add=self.emb_row,
@@ -251,7 +256,8 @@ class _Lane:
                                        net.regularize_alpha == "sigmoid")
             if dyn:
                 res = ops.dynamic_threshold_(res.float().contiguous(), L, *dyn)
-            z = torch.randn_like(self.x)  # graph-safe philox stream; sigma_1 = 0 reproduces z = 0 at t = 1
+            # z: this lane's clips of the step's noise, drawn for the WHOLE batch on the forking stream (_StepGraph.bodies): what a
+            # clip receives under a given seed does not depend on the lane count; sigma_1 = 0 reproduces z = 0 at t = 1
             ops.cfg_ddpm_step_dev(self.x, res, z, shared["scales"], self.coefs, n_entries, Lp, mode, target)
         self.body = body
 
@@ -291,16 +297,19 @@ class _StepGraph:
         self.streams = [torch.cuda.Stream() for _ in range(lanes)] if lanes > 1 else [None]
 
         def bodies(k):
+            # one (B, L, dm) draw per step from the graph-safe philox stream, on the forking stream, sliced per lane: the same
+            # generator calls whatever the lane count (each lane drawing its own made seeded output depend on MSMD_SAMPLER_LANES)
+            zs = [_step_noise(B, L, dm, dev) for _ in range(k)]
             if lanes == 1:
-                for _ in range(k):
-                    self.lane[0].body()
+                for s_ in range(k):
+                    self.lane[0].body(zs[s_])
                 return
             cur = torch.cuda.current_stream()
-            for ln, st in zip(self.lane, self.streams):     # fork ... every lane records its k steps back to back ...
+            for li, (ln, st) in enumerate(zip(self.lane, self.streams)):     # fork ... every lane records its k steps back to back ...
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
-                    for _ in range(k):
-                        ln.body()
+                    for s_ in range(k):
+                        ln.body(zs[s_][li * Bl:(li + 1) * Bl])
             for st in self.streams:                         # ... join
                 cur.wait_stream(st)
         # With more than one lane the LayerNorm-epilogue GEMMs (QKV, out-projection, FFN-2 of a lane: M = 10 656 rows at B = 64) take
@@ -350,9 +359,9 @@ class _StepGraph:
 
 def _graph_loop(model, net, dtype, dev, T, N, n_entries, Lp, L, dm, nb, mode, target, P, motion_at_T, prev_m, ind_in,
                 mem, kv_list, stat, tok_person, emb_all, scales, coefficients, dyn=None, cross_list=None):
-    like = dict(prev_m=prev_m, ind_in=ind_in, mem=mem, kv_list=kv_list, cross_list=cross_list, stat=stat, tok_person=tok_person,
-                emb_all=emb_all, scales=scales)
     B = N // n_entries
+    like = dict(prev_m=prev_m, ind_in=ind_in, mem=mem, kv_list=kv_list, cross_list=cross_list, stat=stat, tok_person=tok_person,
+                emb_all=emb_all, scales=scales, stat_per_clip=(stat.shape[0] == B and B > 1))
     lanes = getattr(model, "sampler_lanes", LANES)
     while lanes > 1 and (B % lanes or N // lanes < MIN_LANE_SEQS):
         lanes -= 1
