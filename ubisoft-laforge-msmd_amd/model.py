@@ -330,7 +330,7 @@ class DenoisingNetwork_MSMD(nn.Module):
         out = []
         for L, kv in zip(P.layers, kv_list):
             N, Tk, _ = kv.shape
-            R = torch.empty(N, Tk + 1, d, device=kv.device, dtype=dtype)
+            R = torch.zeros(N, Tk + 1, d, device=kv.device, dtype=dtype)     # row 0: finite until trunk() fills it (the last layer leaves it)
             v = kv[..., d:]
             if P.split:
                 v = ops.to_split(kv)[..., d:]   # same (N, Tk, 2d) layout in split storage, then the V half
@@ -388,6 +388,15 @@ class DenoisingNetwork_MSMD(nn.Module):
                 ln = L.n3
             x = ops.layernorm(u, *ln)
         u = st = ln = None        # diagonal path with fold: the previous layer's un-normalised norm3 input
+        # Diagonal path: after a layer's self-attention only ROW 0 of a sequence (the person token) depends on that layer's real
+        # cross-attention, and everything from there to the next layer's self-attention is row-wise.  The output is rows 1..
+        # (motion_dec below), so the LAST layer's person chain (query + Tq = 1 attention + 192-row out-projection, ~50 us of
+        # latency-bound launches) feeds nothing: skipped, same bits in every returned row (sampler B = 64: -1.0 .. -1.4 %).
+        # (Round 6 also ran the chain of the other layers -- with norm1 / norm2 / FFN on those rows alone -- as a compact (N, d)
+        # problem on a forked stream beside the main stream's norm + FFN, rejoining rows and statistics by a scatter kernel:
+        # correct, +0.8 % on one lane (five more small launches and a K = 2048 GEMM of 192 rows are as long as the main
+        # stream's FFN), and two lanes already hide the chain: removed)
+        n_layers = len(P.layers)
         for li, L in enumerate(P.layers if not (fold and not diag) else ()):
             if u is None:
                 qkv = ops.gemm(x, L.sa_w, L.sa_b)
@@ -407,7 +416,12 @@ class DenoisingNetwork_MSMD(nn.Module):
             if not fold_n1:
                 x = ops.layernorm(u1, *L.n1)
             kv = kv_list[li] if kv_list is not None else ops.gemm(mem, L.ca_kvw, L.ca_kvb)
-            if diag:
+            last = li + 1 == n_layers
+            if diag and last and getattr(self, "skip_dead_person_chain", True):
+                # rows 1.. of the output do not see this layer's person token: R[:, 0] keeps whatever it holds
+                R = cross_list[li]
+                x = ops.layernorm_pre(u1, *L.n1, R, *L.n2) if fold_n1 else ops.layernorm(x, *L.n2, residual=R)
+            elif diag:
                 # only the person token (row 0) has a real softmax; rows t >= 1 come from the precomputed R
                 R = cross_list[li]
                 # same-box A/B in the sampler graph: fused -1 % at N = 192 sequences, +1.5 % at N = 3 (a longer serial
@@ -456,8 +470,9 @@ class DenoisingNetwork_MSMD(nn.Module):
             x, xs = ops.layernorm(ops.gemm(a, L.sa_ow, L.sa_ob, residual=x), *L.n1, split="both")
             if diag:
                 R, kv = cross_list[li], kv_list[li]                                      # fp32 R (N, Tn, d); kv fp32
-                a0 = ops.person_query_attention(x, L.ca_qw_valu, L.ca_qb, kv, H, scale)   # (N, d) fp32, vector ALU
-                ops.gemm(a0, L.ca_ow, L.ca_ob, None, ops.ACT_NONE, out=R, M=N, K=d, ldc=Tn * d)
+                if not (li + 1 == len(P.layers) and getattr(self, "skip_dead_person_chain", True)):   # (see trunk)
+                    a0 = ops.person_query_attention(x, L.ca_qw_valu, L.ca_qb, kv, H, scale)   # (N, d) fp32, vector ALU
+                    ops.gemm(a0, L.ca_ow, L.ca_ob, None, ops.ACT_NONE, out=R, M=N, K=d, ldc=Tn * d)
                 x, xs = ops.layernorm(x, *L.n2, residual=R, split="both")
             else:
                 if kv_list is not None:
