@@ -750,15 +750,14 @@ def _ln_forms_256_tile(o, O, g, dtype, M, D, F):
         outs.append((c1, s1, c1p, s1p, f, q))
     (c1a, s1a, c1pa, s1pa, fa, qa), (c1b, s1b, c1pb, s1pb, fb, qb) = outs
     step = 2.0 ** (-7 if dtype == torch.bfloat16 else -10) * 8      # one 16-bit step of |x| < 8
-    assert torch.equal(c1pa, c1pb)                                  # plain residual: nothing depends on the statistics' order
-    assert float((c1a.float() - c1b.float()).abs().max()) <= step
-    assert s1a.shape == s1b.shape and float((s1pa - s1pb).abs().max()) < 2e-3
+    # Round 6: both kernels sum a row's statistics in ONE association (as producer and as consumer), so every LayerNorm form
+    # is the same bits on either tile -- a row's result does not depend on the kernel its launch was routed to
+    assert torch.equal(c1pa, c1pb) and torch.equal(c1a, c1b)
+    assert s1a.shape == s1b.shape and torch.equal(s1pa, s1pb) and torch.equal(s1a, s1b)
     xs = c1b.double().reshape(M, -1, 64)            # the statistics are those of the rows this kernel stored
     assert float((s1b - torch.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).transpose(0, 1).float()).abs().max()) < 2e-3
-    # LayerNorm-operand form on the same operand and statistics: the row scalars come from sums in another order, so the
-    # outputs may move by one 16-bit step where rounding was at a tie; no more
-    assert float((fa.float() - fb.float()).abs().max()) <= step and float((qa.float() - qb.float()).abs().max()) <= step
-    assert float((fa != fb).float().mean()) < 0.01
+    # LayerNorm-operand form on the same operand and statistics: the same bits (GELU's last multiply meets no residual here)
+    assert torch.equal(fa, fb) and torch.equal(qa, qb)
     # statistics in 32-column slabs (what a 64 x 64-tile producer writes): 24 slabs per row here, i.e. past the 16 the kernel
     # keeps in LDS -- the rest is summed from memory
     xs = c1a.double().reshape(M, -1, 32)
@@ -770,11 +769,11 @@ def _ln_forms_256_tile(o, O, g, dtype, M, D, F):
             q32.append(o.gemm_ln(c1a, w2f, b2f, a_stats=st32, w_colsum=cs2))
         finally:
             O.GEMM_LN_TILE = None
-    assert float((q32[0].float() - q32[1].float()).abs().max()) <= step and float((q32[0] != q32[1]).float().mean()) < 0.01
+    assert torch.equal(q32[0], q32[1])
     assert float((q32[1].float() - qa.float()).abs().max()) <= 2 * step      # and the same rows as with 64-column statistics
 
 
-@pytest.mark.parametrize("M", [1000, 6500, 16100])     # 64 x 64 tiles / 32-column slabs; 128 x 128 and (tall grids) 192 x 128 tiles / 64-column slabs; ragged M
+@pytest.mark.parametrize("M", [1000, 6500, 16100])     # small grid (consumer on 64 x 64 tiles); 128 x 128 and (tall grids) 192 x 128 tiles; 64-column slabs always; ragged M
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_gemm_ln_folds_layernorm_into_producer_and_consumer(dtype, M):
     """msmd_gemm_ln: Linear -> +residual -> LayerNorm -> Linear as two launches.  Producer: C1 = A W1^T + b1 + LN_R(r)
@@ -813,7 +812,7 @@ def test_gemm_ln_folds_layernorm_into_producer_and_consumer(dtype, M):
     assert maxabs(c1.double().cpu().numpy(), ref1.numpy()) < tol * 4      # O(4) values
     # the statistics are those of the STORED rows (what the consumer will multiply), fp32 sums of a slab's values
     slab = D // st1.shape[0]
-    assert slab == (64 if M >= 6500 else 32)
+    assert slab == 64       # by N alone (round 6): a row's statistics do not depend on the row count of the launch that wrote them
     assert maxabs(st1.cpu().numpy(), stats(c1.cpu(), slab).numpy()) < 2e-3
     # consumer: GELU(LN(c1) W2^T + b2)
     wf, cs, bf = o.fold_layernorm(w2.to(DEV), b2.to(DEV), g1.to(DEV), be1.to(DEV), dtype)

@@ -303,6 +303,60 @@ def test_bf16_mode_tolerance():
     assert maxabs(feat.cpu().numpy(), ga["feat"]) <= 0.08
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16", "f16x2"])
+def test_a_clips_result_does_not_depend_on_its_batch(mode):
+    """extract_audio_feature and a 3-step sample() of clip 0 alone, with four other clips and inside the bench's batch of 32:
+    the same bits.  (Round 5: up to 0.04-0.06 in bf16 -- 64 x 64 / 128 x 128 / 256 x 256-tile kernels summed the LayerNorm
+    statistics in different associations and the person-token query changed form at 64 sequences.)"""
+    from msmd_amd.model import DiffusionSchedule
+    model, args = get_model("wav2vec2", mode)
+    T = 3
+    old = model.diffusion_sched
+    model.diffusion_sched = DiffusionSchedule(T, "cosine").to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    audio = dev(synth.audio_clips(32, 64000, tag="binv"))
+    style = torch.randn(32, 256, device=DEV, generator=g)
+    xT = torch.randn(32, 100, 67, device=DEV, generator=g)
+    noise = {t: torch.randn(32, 100, 67, device=DEV, generator=g) for t in range(2, T + 1)}
+    shape, ind = torch.zeros(32, 100, device=DEV), torch.ones(32, 100, device=DEV)
+    outs = []
+    try:
+        for B in (1, 5, 32):
+            f = model.extract_audio_feature(audio[:B])
+            x, _, _ = model.sample(f, shape[:B], style[:B], motion_at_T=xT[:B], indicator=ind[:B],
+                                   noise={t: z[:B] for t, z in noise.items()})
+            outs.append((f[0].clone(), x[0].clone()))
+    finally:
+        model.diffusion_sched = old
+    for f, x in outs[1:]:
+        assert torch.equal(f, outs[0][0]) and torch.equal(x, outs[0][1])
+
+
+@pytest.mark.parametrize("mode", ["fp32", "f16x2", "bf16"])
+def test_sampler_last_layer_person_chain_skip_returns_the_same_bits(mode):
+    """On the diagonal-mask path the last decoder layer's person-token cross-attention feeds row 0 only, and the network's
+    output is rows 1.. (reference model.py:986-996 slices them): trunk() skips that chain.  Same bits with and without."""
+    from msmd_amd.model import DiffusionSchedule
+    model, args = get_model("wav2vec2", mode)
+    x = denoiser_inputs(2, args, tag="sm")
+    T = 3
+    old = model.diffusion_sched
+    model.diffusion_sched = DiffusionSchedule(T, "cosine").to(DEV)
+    xT = dev(synth.normalish("sm/xT", (2, 100, 67)))
+    noise = {t: dev(synth.normalish(f"sm/z{t}", (2, 100, 67))) for t in range(2, T + 1)}
+    outs = []
+    try:
+        for skip in (True, False):
+            model.denoising_net.skip_dead_person_chain = skip
+            o, _, _ = model.sample(dev(x["audio_feat"]), dev(x["shape"]), dev(x["style"]), dev(x["prev_motion"]),
+                                   dev(x["prev_audio"]), motion_at_T=xT, indicator=dev(x["indicator"]), noise=noise)
+            outs.append(o)
+    finally:
+        model.diffusion_sched = old
+        model.denoising_net.__dict__.pop("skip_dead_person_chain", None)
+    assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
+
+
 def test_sampler_hip_graph_matches_eager():
     """The captured-step (hipGraph, device-side step counter) loop must equal the eager loop bit for bit when
     both draw the same noise (zeros here: sampler._step_noise is patched before capture).  With real noise, a seeded run gives
@@ -485,9 +539,10 @@ def test_diagonal_cross_attention_fast_path_equals_general_path():
     call = lambda: net(dev(x["motion"]), dev(x["audio_feat"]), person, dev(x["style"])[:, None], dev(x["prev_motion"]),
                        dev(x["prev_audio"]), [7, 250, 499], dev(x["indicator"]))
     net.diag_single_pass = True
-    fast2 = call()                              # small batch: q-projection GEMM + Tq = 1 attention for the person row
+    net.fused_person_query = False
+    fast2 = call()                              # two launches: q-projection GEMM + Tq = 1 attention for the person row
     net.fused_person_query = True
-    fast = call()                               # large-batch form: msmd_person_query_attention
+    fast = call()                               # the default for any batch (round 6): msmd_person_query_attention
     del net.fused_person_query
     net.diag_single_pass = False
     net.diag_fast_path = False
@@ -532,7 +587,8 @@ def test_capture_forward_replays_equal_eager_on_new_inputs():
     # `forward` of that group bit for bit (capture_forward verifies this itself on perturbed inputs); against the one-lane
     # forward of the whole batch the 16-bit mode may differ in last bits (statistics slabs / tiles follow the row count)
     run2 = model.capture_forward(dev(x["motion"]), mk("cf_a0"), dev(x["shape"]), dev(x["style"]), ts, dev(x["indicator"]), eps, lanes=2)
-    assert run2.lanes == 2 and run2.lane_drift is not None and run2.lane_drift < 0.1
+    assert run2.lanes == 2 and run2.lane_drift is not None
+    assert run2.lane_drift == 0.0        # round 6: a clip's result no longer depends on the batch (or lane) it is computed in
     a = mk("cf_a3")
     got = [o.clone() for o in run2(audio=a)]
     torch.cuda.synchronize()
@@ -621,10 +677,13 @@ def test_hubert_large_full_depth_10s_against_torch_cpu_restatement(dtype):
     ref = tc.audio_encoder(sd, torch.from_numpy(oae.pad_audio(audio[:1])), 25, frame_num=500, n_heads=16,
                            stable_layer_norm=True).numpy()
     err = maxabs(h[:1].float().cpu().numpy(), ref)
-    print(f"hubert-large 24 layers, {dtype}: max-abs-err vs torch-CPU {err:.3g} (|h| max {np.abs(ref).max():.3g}; bound {PARITY_BOUNDS[dtype]:.3g})")
-    assert err < PARITY_BOUNDS[dtype]
-    # rows do not depend on their batch (16-bit storage: one rounding of O(1) values)
-    assert maxabs(h[1:].float().cpu().numpy(), h1.float().cpu().numpy()) < (2e-5 if dtype != "bf16" else 0.04)
+    from msmd_amd.config import HUBERT_LARGE_BF16_HIDDEN_BOUND
+    bound = HUBERT_LARGE_BF16_HIDDEN_BOUND if dtype == "bf16" else PARITY_BOUNDS[dtype]
+    print(f"hubert-large 24 layers, {dtype}: max-abs-err vs torch-CPU {err:.3g} (|h| max {np.abs(ref).max():.3g}; bound {bound:.3g})")
+    assert err < bound
+    # rows do not depend on their batch: the same bits for clip 1 alone and behind clip 0 (16-bit modes: every kernel sums a
+    # row's LayerNorm statistics in one association whatever tile the launch's row count routes it to)
+    assert np.array_equal(h[1:].float().cpu().numpy(), h1.float().cpu().numpy())
 
 
 @pytest.mark.parametrize("dtype", ["f16x2", "fp16"])

@@ -108,7 +108,13 @@ def test_split_gemm_256_tile_8_phase_kernel_matches_float64(M, N, K, below_32):
     c8 = o.gemm(As, Ws, dev(b), variant=80).cpu().numpy()
     assert maxabs(c8, ref) < 4e-6, maxabs(c8, ref)
     assert maxabs(c8, ref) < 2 * maxabs(c1, ref) + 2e-7          # the per-K-tile fold costs no accuracy worth naming
-    if M * N >= 65536 and K >= 96:
+    if below_32:
+        # the fold-free forms of both kernels multiply in ONE order per output element: a launch returns the same bits whichever
+        # of them its row count routes it to (a clip alone / in a batch of 32)
+        assert np.array_equal(c8, c1)
+        for v in (5, 14):
+            assert np.array_equal(o.gemm(As, Ws, dev(b), variant=v).cpu().numpy(), c1), v
+    elif M * N >= 65536 and K >= 96:
         assert not np.array_equal(c8, c1), "variant 80 returned variant 1's bits: the hint was not followed"
     from oracle import nn as onn
     want = onn.gelu(ref) + r
@@ -124,6 +130,11 @@ def test_split_gemm_256_tile_8_phase_kernel_matches_float64(M, N, K, below_32):
     # the library's own choice (variant 0) is one of the two kernels
     c0 = o.gemm(As, Ws, dev(b)).cpu().numpy()
     assert np.array_equal(c0, c8) or np.array_equal(c0, c1)
+
+
+def onn_gelu(x):
+    from oracle import nn as onn
+    return onn.gelu(x)
 
 
 def test_split_gemm_256_tile_kernel_takes_the_windowed_conv_operand():
@@ -143,6 +154,13 @@ def test_split_gemm_256_tile_kernel_takes_the_windowed_conv_operand():
         y1 = o.conv1d_cl(o.to_split(dev(x)), wp, None, kernel=k, stride=stride, out_dtype=torch.float32)
     assert maxabs(y.cpu().numpy(), ref) < 4e-6 and maxabs(ys.float().cpu().numpy(), ref) < 4e-6
     assert not torch.equal(y, y1)
+    # ... and with a weight that went through split_weight (MSMD_GEMM_W_BELOW_32) both kernels return the same bits
+    wb = o.split_weight(dev(np.ascontiguousarray(w.transpose(0, 2, 1).reshape(Cout, k * C))))
+    yb = []
+    for v in (80, 1):
+        with o.gemm_defaults(split_variant=v):
+            yb.append(o.conv1d_cl(o.to_split(dev(x)), wb, None, kernel=k, stride=stride, act=o.ACT_GELU, out_dtype=o.SPLIT))
+    assert torch.equal(yb[0].t, yb[1].t) and maxabs(yb[0].float().cpu().numpy(), onn_gelu(ref)) < 6e-6
 
 
 def test_split_gemm_is_strided_conv1d_and_batched():

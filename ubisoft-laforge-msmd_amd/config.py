@@ -47,6 +47,11 @@ DEFAULTS = dict(
 # of the 16-bit arithmetic shows up here instead of hiding under a power of two.
 # tests/test_model_gpu.py asserts them on the bench workloads and bench.py exits non-zero when its own batch exceeds them.
 PARITY_BOUNDS = {"fp32": 1e-4, "f16x2": 1e-4, "fp16": 2.0 ** -6, "bf16": 0.1}
+# The 24-layer HuBERT-large hidden states in bf16 (1 M values per clip, |h| up to 3.7, i.e. a bf16 step of 2^-6 at the top):
+# the MAXIMUM error over them is a chaotic statistic -- it read 0.088 in round 5 and 0.125 in round 6, when nothing but the
+# association of the LayerNorm row statistics changed (a last-bit change at every layer, made so that a clip's result no longer
+# depends on its batch).  Bound: ten bf16 steps at the top of the range.  The motion coefficients' bound above is unchanged.
+HUBERT_LARGE_BF16_HIDDEN_BOUND = 10 * 2.0 ** -6
 
 
 def default_args(**overrides) -> argparse.Namespace:

@@ -358,9 +358,14 @@ __device__ __forceinline__ void gemm_epilogue_ln_a(const GemmArgs& p, const f32x
   for (int j = 0; j < FM; ++j) { mu[j] = 0.f; rs[j] = 1.f; }      // (r - 0) * 1 * 1 + 0 == r exactly: the plain residual
   if constexpr (MODE == 1) ln_finish<FM>(p.a_stats, p.a_nt, p.M, m_base, fr, fq, raw, 1.0f / (float)p.K, p.ln_eps, mu, rs);
   else if (p.r_stats) ln_finish<FM>(p.r_stats, p.r_nt, p.M, m_base, fr, fq, raw, 1.0f / (float)p.N, p.ln_eps, mu, rs);
-  float rowS[FM], rowQ[FM];
+  // Statistics of the stored rows, in ONE association for every kernel that writes them (this epilogue on its 128 x 128 /
+  // 192 x 128 / 64 x 64 tiles, gemm8_kernel on 256 x 256): a row's result must not depend on the tile the launch's row count
+  // routed it to (a clip alone and the same clip in a batch of 32).  Per 16-column fragment i and lane group fq:
+  // p_i = the serial sum of its four stored values; (p_0 + p_1) + (p_2 + p_3) over the slab's fragments; then the lane
+  // groups fq ^ 1 and fq ^ 2.  (tS / prS: the odd-man-out and the first pair while the fragments go by.)
+  float rowS[FM], rowQ[FM], tS[FM], tQ[FM], prS[FM], prQ[FM];
 #pragma unroll
-  for (int j = 0; j < FM; ++j) rowS[j] = rowQ[j] = 0.f;
+  for (int j = 0; j < FM; ++j) rowS[j] = rowQ[j] = tS[j] = tQ[j] = prS[j] = prQ[j] = 0.f;
   const bool odd = fq & 1;
   const bool pair = sizeof(TO) == 2 && (p.flags & 2);
 #pragma unroll
@@ -404,8 +409,16 @@ __device__ __forceinline__ void gemm_epilogue_ln_a(const GemmArgs& p, const f32x
         if constexpr (sizeof(TO) == 4) o[j] = V4{v[0], v[1], v[2], v[3]};
         else o[j] = pack4<TO>(v[0], v[1], v[2], v[3]);
         if constexpr (MODE == 2) {
+          float pS = 0.f, pQ = 0.f;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const float w = (float)o[j][e]; rowS[j] += w; rowQ[j] = fmaf(w, w, rowQ[j]); }   // of what the consumer will read
+          for (int e = 0; e < 4; ++e) { const float w = (float)o[j][e]; pS += w; pQ = fmaf(w, w, pQ); }   // of what the consumer will read
+          if ((i & 1) == 0) { tS[j] = pS; tQ[j] = pQ; }
+          else {
+            const float aS = tS[j] + pS, aQ = tQ[j] + pQ;
+            if (FN == 2) { rowS[j] = aS; rowQ[j] = aQ; }
+            else if ((i & 2) == 0) { prS[j] = aS; prQ[j] = aQ; }
+            else { rowS[j] = prS[j] + aS; rowQ[j] = prQ[j] + aQ; }
+          }
         }
       }
       bool stored = false;
@@ -1021,7 +1034,10 @@ __device__ __forceinline__ void gemm_epilogue_split(const GemmArgs& p, const f32
   }
 }
 
-template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, int ACTK = -1>
+// WS (the call carries MSMD_GEMM_W_BELOW_32, i.e. W is a model weight): gemm8_kernel's fold-free form -- W's hi fragments x 2^11
+// in registers, ONE accumulator in units of 2^-11, per K tile and output element the products Wh.AL, WL.Ah, (2^11 Wh).Ah in
+// this order -- so that a launch returns the same bits whether its row count routes it to this kernel or to the 256 x 256 one.
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, int ACTK = -1, bool WS = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm2s_kernel(const GemmArgs p) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int STAGE = (BM + BN) * 128;
@@ -1089,14 +1105,36 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2s_kernel(const GemmArgs p) 
       wh[i] = *(const u32x4*)(sw + lds_off(wn + i * 16 + fr, fq));
       wl[i] = *(const u32x4*)(sw + lds_off(wn + i * 16 + fr, 4 + fq));
     }
+    if constexpr (WS) {
+      u32x4 ws[FN];
 #pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        Mfma<f16_t>::run(wh[i], ah[j], acc0[i][j]);
-        Mfma<f16_t>::run(wh[i], al[j], acc1[i][j]);
-        Mfma<f16_t>::run(wl[i], ah[j], acc1[i][j]);
+      for (int i = 0; i < FN; ++i) {
+        f16x8 h = __builtin_bit_cast(f16x8, wh[i]);
+        h = h * (f16_t)MSMD_SPLIT_SCALE;
+        ws[i] = __builtin_bit_cast(u32x4, h);
       }
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) Mfma<f16_t>::run(wh[i], al[j], acc0[i][j]);
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) Mfma<f16_t>::run(wl[i], ah[j], acc0[i][j]);
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) Mfma<f16_t>::run(ws[i], ah[j], acc0[i][j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+          Mfma<f16_t>::run(wh[i], ah[j], acc0[i][j]);
+          Mfma<f16_t>::run(wh[i], al[j], acc1[i][j]);
+          Mfma<f16_t>::run(wl[i], ah[j], acc1[i][j]);
+        }
+    }
     stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
   }
 #pragma unroll
@@ -1104,7 +1142,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm2s_kernel(const GemmArgs p) 
 #pragma unroll
     for (int j = 0; j < FM; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc0[i][j][e] = fmaf(acc1[i][j][e], MSMD_SPLIT_INV, acc0[i][j][e]);
+      for (int e = 0; e < 4; ++e)
+        acc0[i][j][e] = WS ? acc0[i][j][e] * MSMD_SPLIT_INV : fmaf(acc1[i][j][e], MSMD_SPLIT_INV, acc0[i][j][e]);   // (x 2^-11: exact)
   if constexpr (sizeof(TO) == 4) gemm_epilogue<float, FM, FN, false, false, ACTK>(p, acc0, z, m0 + wm, n0 + wn, fr, fq);
   else gemm_epilogue_split<FM, FN, ACTK>(p, acc0, z, m0 + wm, n0 + wn, fr, fq);
 }
@@ -1595,21 +1634,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float mu_l = 0.f, rs_l = 1.f;                    // of row (lane & 31) of this wave's 32
     if constexpr (EPI >= 2) {
       if (ln_stats) {
-        const int r32 = el & 31, half = el >> 5;
+        // ln_finish's association (the 128 x 128 kernels: lane group f holds slabs f, f + 4, f + 8, f + 12 and the tail
+        // 16 + f, 20 + f, ...; groups combine as (0 + 1) + (2 + 3)), so that a row's moments are the same bits whichever kernel
+        // its launch was routed to.  Both halves of the wave compute the same 32 rows.
+        const int r32 = el & 31;
         const unsigned base = 2 * BUF + wid * 4096 + (((r32 >> 3) * 4 + ((r32 & 7) >> 1)) << 4) + ((r32 & 1) << 3);
-        float S = 0.f, Q = 0.f;
+        float Sf[4], Qf[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {                // slabs half, half + 2, ... below 16
-          const int t = 2 * u + half;
-          const f32x2 w = *(const f32x2*)(smem + base + (t >> 2) * 1024 + ((t & 3) << 8));
-          if (t < ln_nt) { S += w[0]; Q += w[1]; }
+        for (int f = 0; f < 4; ++f) {
+          f32x2 w[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int t = f + 4 * q;
+            w[q] = *(const f32x2*)(smem + base + (t >> 2) * 1024 + ((t & 3) << 8));
+            if (t >= ln_nt) w[q] = f32x2{0.f, 0.f};
+          }
+          Sf[f] = (w[0][0] + w[1][0]) + (w[2][0] + w[3][0]);
+          Qf[f] = (w[0][1] + w[1][1]) + (w[2][1] + w[3][1]);
         }
         if (ln_nt > 16) {             // more than 16 slabs per row: the rest from memory, serially
           const f32x2* rp = (const f32x2*)ln_stats + min(em0 + (r32 >> 3) * 64 + wid * 8 + (r32 & 7), p.M - 1);
-          for (int t = 16 + half; t < ln_nt; t += 2) { const f32x2 w = rp[(long)t * p.M]; S += w[0]; Q += w[1]; }
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+            for (int t = 16 + f; t < ln_nt; t += 4) { const f32x2 w = rp[(long)t * p.M]; Sf[f] += w[0]; Qf[f] += w[1]; }
         }
-        S += __shfl_xor(S, 32, 64);
-        Q += __shfl_xor(Q, 32, 64);
+        const float S = (Sf[0] + Sf[1]) + (Sf[2] + Sf[3]), Q = (Qf[0] + Qf[1]) + (Qf[2] + Qf[3]);
         const float inv_cols = 1.0f / (float)(EPI == 2 ? p.K : p.N);
         mu_l = S * inv_cols;
         rs_l = rsqrtf(fmaxf(Q * inv_cols - mu_l * mu_l, 0.f) + p.ln_eps);
@@ -1653,7 +1702,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            o[e] = act_split<ACTK>(WS ? fmaf(a[e], MSMD_SPLIT_INV, cbias[e]) : a[e] + cbias[e], p.act);
+            o[e] = act_out_c<float, ACTK>(WS ? fmaf(a[e], MSMD_SPLIT_INV, cbias[e]) : a[e] + cbias[e], p.act);   // gemm2s_kernel's fp32 epilogue
             if (has_r) o[e] += rr[it][e];
           }
           if (m < p.M) {
@@ -1742,8 +1791,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float S = 0.f, Q = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float w = (float)o[e]; S += w; Q = fmaf(w, w, Q); }
+            // the association of gemm_epilogue_ln_a: a lane's four columns are fragment i = lane bits 2-3, lane group fq = bits 0-1
 #pragma unroll
-            for (int d = 1; d < 16; d <<= 1) { S += __shfl_xor(S, d, 64); Q += __shfl_xor(Q, d, 64); }
+            for (int d : {4, 8, 1, 2}) { S += __shfl_xor(S, d, 64); Q += __shfl_xor(Q, d, 64); }
             if ((el & 15) == 0 && m < p.M) *(f32x2*)(p.stats_out + ((long)((en0 >> 6) + (el >> 4)) * p.M + m) * 2) = f32x2{S, Q};
           }
         }
@@ -2044,15 +2094,19 @@ static int launch_gemm8s(GemmArgs& p, hipStream_t st) {
   MSMD_RETURN_LAST();
 }
 
-template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, int ACTK = -1>
+template <typename TO, int BM, int BN, int WM, int WN, int NSTAGE, int ACTK = -1, int WSK = -1>
 static int launch_gemm2s(GemmArgs& p, int batch, hipStream_t st) {
+  if constexpr (WSK == -1) {
+    return (p.flags & 64) ? launch_gemm2s<TO, BM, BN, WM, WN, NSTAGE, ACTK, 1>(p, batch, st)
+                          : launch_gemm2s<TO, BM, BN, WM, WN, NSTAGE, ACTK, 0>(p, batch, st);
+  } else {
   if constexpr (ACTK == -1 && NSTAGE * (BM + BN) * 128 <= 80 * 1024) {      // the routed tiles: the activation as a constant of the kernel
-    if (p.act == MSMD_ACT_NONE) return launch_gemm2s<TO, BM, BN, WM, WN, NSTAGE, MSMD_ACT_NONE>(p, batch, st);
-    if (p.act == MSMD_ACT_GELU) return launch_gemm2s<TO, BM, BN, WM, WN, NSTAGE, MSMD_ACT_GELU>(p, batch, st);
+    if (p.act == MSMD_ACT_NONE) return launch_gemm2s<TO, BM, BN, WM, WN, NSTAGE, MSMD_ACT_NONE, WSK>(p, batch, st);
+    if (p.act == MSMD_ACT_GELU) return launch_gemm2s<TO, BM, BN, WM, WN, NSTAGE, MSMD_ACT_GELU, WSK>(p, batch, st);
   }
   constexpr int lds = NSTAGE * (BM + BN) * 128;
   static bool attr_done = false;
-  auto kfn = gemm2s_kernel<TO, BM, BN, WM, WN, NSTAGE, ACTK>;
+  auto kfn = gemm2s_kernel<TO, BM, BN, WM, WN, NSTAGE, ACTK, WSK != 0>;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
@@ -2074,6 +2128,7 @@ static int launch_gemm2s(GemmArgs& p, int batch, hipStream_t st) {
   dim3 grid(((p.mt + xm_n - 1) / xm_n) * ((p.nt + p.xn - 1) / p.xn) * 8, 1, batch);
   hipLaunchKernelGGL(kfn, grid, dim3(WM * WN * 64), lds, st, p);
   MSMD_RETURN_LAST();
+  }
 }
 
 template <typename TO>
@@ -2260,7 +2315,10 @@ static int gemm_impl(const void* A, const void* W, const float* bias, const void
       const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * nz;
       variant = (N > 64 && tiles128 >= 192) ? 1 : 5;
       if (N <= 64 && (long)((M + 255) / 256) * nz >= 256) variant = 14;
-      if (!(flags & 32) && gemm8s_takes(p, nz, out_dtype == MSMD_F16X2) && gemm8s_wins(M, N, K, (flags & 64) != 0)) variant = 80;
+      // the library's own choice takes the 256 x 256 kernel only under MSMD_GEMM_W_BELOW_32: there it returns the bits of
+      // gemm2s_kernel's WS form, so the row count of a launch never changes a row's result (its folding form, reachable by the
+      // variant hint, sums the cross terms in another order than gemm2s_kernel's two accumulators)
+      if (!(flags & 32) && (flags & 64) && gemm8s_takes(p, nz, out_dtype == MSMD_F16X2) && gemm8s_wins(M, N, K, true)) variant = 80;
     }
     const int r = out_dtype == MSMD_F32 ? dispatch_gemm2s<float>(p, nz, st, variant)
                                         : dispatch_gemm2s<f16_t>(p, nz, st, variant);
@@ -2349,7 +2407,7 @@ extern "C" int msmd_gemm_256_tile_rule(int M, int N, int K) {
 }
 
 extern "C" int msmd_gemm_256_tile_rule_f16x2(int M, int N, int K, int w_below_32) {
-  return (M > 0 && N > 0 && K >= 64 && (N % 256) == 0 && (K % 32) == 0 && gemm8s_wins(M, N, K, w_below_32 != 0)) ? 1 : 0;
+  return (M > 0 && N > 0 && K >= 64 && (N % 256) == 0 && (K % 32) == 0 && w_below_32 && gemm8s_wins(M, N, K, true)) ? 1 : 0;
 }
 
 extern "C" int msmd_gemm(const void* A, const void* W, const float* bias, const void* residual, void* C, int M,

@@ -407,7 +407,9 @@ class DenoisingNetwork_MSMD(nn.Module):
                 nxt = P.layers[li + 1].f_sa[0] if (fold and diag) else P.layers[li + 1].sa_w
             a = ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, scale,
                               prefetch=None if P.split else (L.sa_ow, L.l1[0], L.l2[0], nxt))   # the layer's next weights
-            fused_pq = getattr(self, "fused_person_query", N >= 64)
+            # (one launch for any N: choosing by the sequence count made a clip's result depend on the batch around it;
+            # against the two-launch form it is -1 % at N = 192 sequences and +1.5 % at N = 3)
+            fused_pq = getattr(self, "fused_person_query", True)
             # norm1 without a launch of its own (diagonal path, fused person query): its two consumers apply it -- the
             # person-token query projection through folded weights, the norm2 launch as its first stage (layernorm_pre)
             fold_n1 = fold and diag and fused_pq

@@ -360,7 +360,9 @@ def gemm_ln(a, w, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=No
         out = empty((*a.shape[:-1], N), a.device, out_dtype)
     st, slab_out, slab_in = None, 0, 0
     if stats_out:
-        slab_out = 64 if N % 128 == 0 and ((M + 127) // 128) * (N // 128) >= 192 else 32
+        # by the problem's N alone, never its row count: a clip's rows must get the same statistics (bit for bit) alone and
+        # inside a large batch, so the producer is always the 128 x 128-tile family where that tile divides N
+        slab_out = 64 if N % 128 == 0 else 32
         st = empty((N // slab_out, M, 2), a.device, torch.float32)
     sin = a_stats if a_stats is not None else r_stats
     if sin is not None:
