@@ -451,7 +451,7 @@ def leg_lbs(device, frames_list=(6400, 25600)):
     only = os.environ.get("MSMD_BENCH_LBS")      # profiling runs: "6400" | "25600" | "shape" = one workload per process
     if only in ("6400", "25600"):
         frames_list = (int(only),)
-    for n in (() if only == "shape" else frames_list):
+    for n in (() if only in ("shape", "25600_fp16") else frames_list):
         g = torch.Generator(device="cpu").manual_seed(n)
         exp = (0.5 * torch.randn(n, 50, generator=g)).to(device)
         pose = (0.2 * torch.randn(n, 6, generator=g)).to(device)
@@ -472,7 +472,33 @@ def leg_lbs(device, frames_list=(6400, 25600)):
                                hbm_frac=round(gbs / PEAK_HBM_GBS, 4), precision=fl.lbs_precision or "bf16x3 (split-bf16 MFMA, fp32 accumulate)",
                                bytes_per_frame=LBS_BYTES_PER_FRAME,
                                inputs="shape = 0 for every frame (SURVEY 8d): the one-subject fold of msmd_flame_prepare")
-    if only in ("6400", "25600"):
+    if only in (None, "25600_fp16"):
+        # opt-in fp16 vertices (msmd_lbs_skin_v2_f16; BASELINE configs[4] names the fp16 LBS pass): rows of 5024 x 3 halves
+        n = 25600
+        g = torch.Generator(device="cpu").manual_seed(n)
+        exp = (0.5 * torch.randn(n, 50, generator=g)).to(device)
+        pose = (0.2 * torch.randn(n, 6, generator=g)).to(device)
+        shape = torch.zeros(n, 100, device=device)
+        fl.vertex_dtype = torch.float16
+        try:
+            for _ in range(3):
+                fl(shape, exp, pose, return_lm2d=False, return_lm3d=False)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fl(shape, exp, pose, return_lm2d=False, return_lm3d=False)
+            e1.record()
+            torch.cuda.synchronize()
+        finally:
+            del fl.vertex_dtype
+        ms = e0.elapsed_time(e1) / 20
+        bpf = 4 * 165 + 2 * 3 * 5024
+        out["lbs_25600_fp16_vertices"] = dict(ms=round(ms, 4), frames_per_s=round(n / ms * 1e3), gb_per_s=round(n * bpf / ms / 1e6, 1),
+                                              hbm_frac=round(n * bpf / ms / 1e6 / PEAK_HBM_GBS, 4), bytes_per_frame=bpf,
+                                              bound="|v16 - v32| <= 2^-11 |v32| (one fp16 rounding of the fp32 kernel's vertex)",
+                                              inputs="as lbs_25600; vertices stored as fp16 in rows of 5024 x 3 (opt-in FLAME.vertex_dtype)")
+    if only in ("6400", "25600", "25600_fp16"):
         return out
     # the general path the reference's lbs() computes (utils/lbs.py:185): a different shape vector per frame
     n = frames_list[-1]

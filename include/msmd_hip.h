@@ -421,6 +421,15 @@ int msmd_lbs_skin_v2(const void* skin_tiles, const float* v_template, const void
                      float* verts, int B, int J, int V, int Vp, int Kp, const int* shape_varies,
                      const float* v_template_folded, msmd_stream_t stream);
 
+/* msmd_lbs_skin_v2 with fp16 vertices (opt-in; BASELINE configs[4] names the fp16 LBS pass): verts16 (B, V_ld, 3) fp16, V_ld
+ * even and >= V (rows of V * 3 halves would put every other frame on a 2-byte boundary; slot V of a row receives a copy of
+ * vertex V - 1).  Same arithmetic, fp32 until the store: |error| <= 2^-11 relative to the fp32 kernel's vertex.  Half the
+ * store stream that bounds the fp32 kernel: 30 144 + 660 algorithmic bytes per frame at V = 5023.  Reference:
+ * utils/lbs.py:210-221 (fp32 there). */
+int msmd_lbs_skin_v2_f16(const void* skin_tiles, const float* v_template, const void* dirs_hl, const float* lbs_weights,
+                         void* verts16, int B, int J, int V, int V_ld, int Vp, int Kp, const int* shape_varies,
+                         const float* v_template_folded, msmd_stream_t stream);
+
 /* Training through FLAME (the reference's use_vertex_space branch: training_script.py:167-176 -> utils/common.py:486-513
  * -> utils/lbs.py:141-223, differentiated by autograd there).
  * msmd_lbs_skin_v2_train: msmd_lbs_skin_v2 that also stores the un-skinned vertices v_posed = template + coef . dirs.

@@ -631,6 +631,35 @@ def test_gemm_256_tile_8_phase_kernel_equals_the_128_tile_kernels(dtype):
         _ln_forms_256_tile(o, O, g, dtype, M, D, F)
 
 
+def test_flame_lbs_fp16_vertices_against_the_numpy_oracle():
+    """msmd_lbs_skin_v2_f16 (opt-in FLAME.vertex_dtype = torch.float16; BASELINE configs[4] names the fp16 LBS pass): the fp32
+    kernel's arithmetic with one fp16 rounding at the store -- every vertex within 2^-11 relative (+ the fp32 kernel's 5e-6) of
+    the numpy FLAME oracle, equal to the fp32 kernel's output rounded to fp16 bit for bit; ragged frame counts (tile of 16,
+    the lane pairs' frame trade), the odd vertex count (5023: rows padded to 5024) and landmarks from the fp16 vertices."""
+    from msmd_amd.utils.flame import FLAME, FLAMEConfig
+    from types import SimpleNamespace
+    asset = synth.flame_asset()
+    cfg = SimpleNamespace(**vars(FLAMEConfig))
+    cfg.asset = asset
+    fl = FLAME(cfg).to(DEV)
+    orc = ofl.FlameOracle(asset)
+    for B in (1, 17, 100, 1003):
+        xi = flame_inputs(B, tag=f"flame16_{B}")
+        args = (dev(xi["shape"]), dev(xi["exp"]), dev(xi["pose"]))
+        v32 = fl(*args, return_lm2d=False, return_lm3d=False)[0]
+        fl.vertex_dtype = torch.float16
+        try:
+            v16, _, lm3d = fl(*args, return_lm2d=False, return_lm3d=True)
+        finally:
+            del fl.vertex_dtype
+        assert v16.dtype == torch.float16 and v16.shape == (B, 5023, 3) and v16.stride(0) == 5024 * 3
+        assert torch.equal(v16, v32.to(torch.float16)), B
+        vr, _, lr = orc.forward(xi["shape"], xi["exp"], xi["pose"], return_lm2d=False, return_lm3d=True)
+        err = np.abs(v16.float().cpu().numpy() - vr)
+        assert np.all(err <= np.abs(vr) * 2.0 ** -11 + 5e-6), (B, float(err.max()))
+        assert maxabs(lm3d.cpu().numpy(), lr) <= 2.0 ** -11 * float(np.abs(vr).max()) + 5e-6
+
+
 def _ulp_of_row_max(ref, dtype):
     """one unit in the last place of the 16-bit type at each row's largest |reference| value"""
     rm = ref.abs().amax(dim=1, keepdim=True).clamp_min(2.0 ** -14)

@@ -550,14 +550,21 @@ __device__ __forceinline__ void vm_wait_n(int n) {   // n = (pieces per load gro
 // buffered on the tile loop's own barrier: 0.703 ms against 0.592 at 25 600 frames, same box, alternating.  The image costs
 // 12 LDS writes + 3 reads per lane and tile and ties the waves to one barrier per tile, i.e. it removes the drift between the
 // waves that the two-tiles-per-barrier schedule below lives on; the store shape is not what is left to win here.)
-template <int KG, int NS, int NWV, int ABL = 0, bool WP = false, int RB = 0>
+// OUT16 (msmd_lbs_skin_v2_f16, round 6): fp16 vertices in rows of V_ld (even, >= V) vertices -- the kernel is bound by its store
+// stream, this halves it.  Lanes 2 p and 2 p + 1 (vertices v, v + 1) trade two frames each by DPP so that every lane stores the
+// 12 contiguous bytes [x y z x y z] of its vertex PAIR for two of the tile's four frames: 2 store instructions of 96-byte runs
+// per 8 lanes instead of 4 of 192-byte runs per 16.  (V = 5023 is odd: a row of V * 3 halves would put every other frame on a
+// 2-byte boundary; hence the padded row.  Slot V of a row receives a copy of vertex V - 1.)
+template <int KG, int NS, int NWV, int ABL = 0, bool WP = false, int RB = 0, bool OUT16 = false>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void lbs_skin_v2_kernel(const unsigned char* __restrict__ tiles,
                         const float* __restrict__ tmpl, const bf16_t* __restrict__ dirs_hl,
                         const float* __restrict__ wts, float* __restrict__ verts, int B, int V, int Vp,
                         int frames_per_block, int vtn, float* __restrict__ vposed = nullptr, int xcd_adj = 0,
-                        const int* __restrict__ shape_varies = nullptr, const float* __restrict__ tmpl_folded = nullptr) {
-  constexpr int SPT = WP ? 8 : 4;   // store instructions per tile and wave
+                        const int* __restrict__ shape_varies = nullptr, const float* __restrict__ tmpl_folded = nullptr,
+                        int V_ld = 0) {
+  static_assert(!(OUT16 && WP), "the training form stores fp32");
+  constexpr int SPT = WP ? 8 : (OUT16 ? 2 : 4);   // store instructions per tile and wave
   // all frames share their first LBS_KFOLD shape coefficients (msmd_flame_prepare): folded template, skip those K groups
   const bool uni = shape_varies != nullptr && tmpl_folded != nullptr && *shape_varies == 0;
   const int g_first = uni ? LBS_KFOLD / 32 : 0;
@@ -679,6 +686,31 @@ void lbs_skin_v2_kernel(const unsigned char* __restrict__ tiles,
 #pragma unroll
       for (int e = 0; e < 4; ++e) out[c][e] = fmaf(T[0][e], px[e], fmaf(T[1][e], py[e], fmaf(T[2][e], pz[e], T[3][e])));
     }
+    if constexpr (OUT16) {
+      // even lane keeps frames e = 0, 1 and gives 2, 3; odd lane the other way round; lower vertex of the pair = the even lane's
+      const bool oddl = i & 1;
+      auto swap1 = [](float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, false)); };
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float own[3], got[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          own[c] = oddl ? out[c][2 + s2] : out[c][s2];
+          got[c] = swap1(oddl ? out[c][s2] : out[c][2 + s2]);
+        }
+        const float lo0 = oddl ? got[0] : own[0], lo1 = oddl ? got[1] : own[1], lo2 = oddl ? got[2] : own[2];
+        const float up0 = oddl ? own[0] : got[0], up1 = oddl ? own[1] : got[1], up2 = oddl ? own[2] : got[2];
+        struct __attribute__((aligned(4))) U3 { unsigned a, b, c; };
+        U3 o;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(o.a) : "v"(lo0), "v"(lo1));
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(o.b) : "v"(lo2), "v"(up0));
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(o.c) : "v"(up1), "v"(up2));
+        const int f = min(f0 + 4 * q + (oddl ? 2 : 0) + s2, B - 1);
+        if constexpr (ABL & 1) asm volatile("" :: "v"(o.a), "v"(o.b), "v"(o.c), "v"(f));
+        else *(U3*)((f16_t*)verts + ((long)f * V_ld + (ve & ~1)) * 3) = o;   // 8 lanes = 96 contiguous bytes per frame
+      }
+      return;
+    }
     struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -738,8 +770,10 @@ void lbs_skin_v2_kernel(const unsigned char* __restrict__ tiles,
 
 static int lbs_skin_v2_impl(const void* skin_tiles, const float* v_template, const void* dirs_hl,
                             const float* lbs_weights, float* verts, float* vposed, int B, int J, int V, int Vp, int Kp,
-                            msmd_stream_t stream, const int* shape_varies = nullptr, const float* tmpl_folded = nullptr) {
+                            msmd_stream_t stream, const int* shape_varies = nullptr, const float* tmpl_folded = nullptr,
+                            int V_ld16 = 0) {
   if (B <= 0 || V <= 0 || Vp < V || J != 5 || Kp != 192 || !skin_tiles) return 1;
+  if (V_ld16 && (V_ld16 < V || (V_ld16 & 1) || vposed || ((uintptr_t)verts & 3))) return 1;
   // tuning key 9: 1 = two 4-wave workgroups per CU (64 vertices each, 3-stage rings) instead of one 8-wave workgroup
   // (128 vertices, 4-stage ring).  Measured at 25 600 frames: 783 vs 732 us -- the smaller workgroups double the
   // staged bytes per vertex and their phase drift buys less than that costs.
@@ -758,7 +792,7 @@ static int lbs_skin_v2_impl(const void* skin_tiles, const float* v_template, con
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                       \
     hipLaunchKernelGGL(kfn, grid, dim3(64 * NWV), lds, (hipStream_t)stream, (const unsigned char*)skin_tiles,           \
                        v_template, (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb, vt, \
-                       (float*)nullptr, xcd_adj, shape_varies, tmpl_folded);                                                                              \
+                       (float*)nullptr, xcd_adj, shape_varies, tmpl_folded, 0);                                                                           \
   } while (0)
   if (vposed) {
     constexpr int lds = 4 * 18 * 1024;
@@ -766,7 +800,7 @@ static int lbs_skin_v2_impl(const void* skin_tiles, const float* v_template, con
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int vt8w = (V + 127) / 128;
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, (hipStream_t)stream, (const unsigned char*)skin_tiles,
-                       v_template, (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb, vt8w, vposed, xcd_adj, (const int*)nullptr, (const float*)nullptr);
+                       v_template, (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb, vt8w, vposed, xcd_adj, (const int*)nullptr, (const float*)nullptr, 0);
 #ifdef MSMD_EXPERIMENTAL
   } else if (!big) {
     LBS_V2_LAUNCH(3, 4, 0);
@@ -781,6 +815,13 @@ static int lbs_skin_v2_impl(const void* skin_tiles, const float* v_template, con
       default: LBS_V2_LAUNCH(4, 8, 0); break;         // 100: one barrier per tile (the round-2a schedule)
     }
 #endif
+  } else if (V_ld16) {
+    constexpr int lds = 4 * 18 * 1024;
+    auto kfn = lbs_skin_v2_kernel<6, 4, 8, 0, false, 2, true>;
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, (hipStream_t)stream, (const unsigned char*)skin_tiles, v_template,
+                       (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb, vt, (float*)nullptr, xcd_adj, shape_varies,
+                       tmpl_folded, V_ld16);
   } else {
     LBS_V2_LAUNCH(4, 8, 0, 2);                        // one barrier per two tiles + wave priorities
   }
@@ -793,6 +834,14 @@ extern "C" int msmd_lbs_skin_v2(const void* skin_tiles, const float* v_template,
                                 const int* shape_varies, const float* v_template_folded, msmd_stream_t stream) {
   return lbs_skin_v2_impl(skin_tiles, v_template, dirs_hl, lbs_weights, verts, nullptr, B, J, V, Vp, Kp, stream,
                           shape_varies, v_template_folded);
+}
+
+extern "C" int msmd_lbs_skin_v2_f16(const void* skin_tiles, const float* v_template, const void* dirs_hl,
+                                    const float* lbs_weights, void* verts16, int B, int J, int V, int V_ld, int Vp, int Kp,
+                                    const int* shape_varies, const float* v_template_folded, msmd_stream_t stream) {
+  if (V_ld <= 0) return 1;
+  return lbs_skin_v2_impl(skin_tiles, v_template, dirs_hl, lbs_weights, (float*)verts16, nullptr, B, J, V, Vp, Kp, stream,
+                          shape_varies, v_template_folded, V_ld);
 }
 
 // Training form: the same kernel, additionally writing the un-skinned vertices v_posed (B, V, 3) for msmd_lbs_skin_bwd.

@@ -823,11 +823,22 @@ def lbs_skin_bf16x3(coef_hl, A, v_template_planes, dirs_hl, weight_planes, V):
     return verts
 
 
-def lbs_skin_v2(skin_tiles, B, v_template_planes, dirs_hl, weight_planes, V, Kp=192, shape_varies=None, folded=None):
+def lbs_skin_v2(skin_tiles, B, v_template_planes, dirs_hl, weight_planes, V, Kp=192, shape_varies=None, folded=None,
+                out_dtype=torch.float32):
+    """out_dtype=torch.float16 (opt-in, msmd_lbs_skin_v2_f16): the vertices as fp16 -- a (B, V, 3) VIEW of rows padded to an
+    even vertex count (row stride (V + V % 2) * 3); half the store stream that bounds the kernel."""
     lib = _lib.load()
     assert skin_tiles.numel() * skin_tiles.element_size() == ((B + 15) // 16) * SKIN_TILE_BYTES
     J = weight_planes.shape[0]
     Vp = dirs_hl.shape[-2]
+    if out_dtype == torch.float16:
+        V_ld = V + (V & 1)
+        v16 = torch.empty(B, V_ld, 3, device=skin_tiles.device, dtype=torch.float16)
+        _lib.check(lib.msmd_lbs_skin_v2_f16(_p(skin_tiles), _p(v_template_planes), _p(dirs_hl), _p(weight_planes), _p(v16), B, J, V,
+                                            V_ld, Vp, Kp, _p(shape_varies), _p(folded), _stream()), "msmd_lbs_skin_v2_f16")
+        return v16[:, :V]
+    if out_dtype != torch.float32:
+        raise TypeError("lbs_skin_v2: fp32 or fp16 vertices")
     verts = torch.empty(B, V, 3, device=skin_tiles.device, dtype=torch.float32)
     _lib.check(lib.msmd_lbs_skin_v2(_p(skin_tiles), _p(v_template_planes), _p(dirs_hl), _p(weight_planes),
                                     _p(verts), B, J, V, Vp, Kp, _p(shape_varies), _p(folded), _stream()),

@@ -138,9 +138,14 @@ class FLAME(nn.Module):
             tiles, varies, folded = ops.flame_prepare(f32c(shape_params), f32c(expression_params), f32c(pose_params),
                                                       f32c(eye_pose_params), c.JS, c.parents, ignore_global_rot, c.dirs,
                                                       c.template_planes)
+            # vertex_dtype = torch.float16 (opt-in attribute; BASELINE configs[4]'s fp16 LBS pass): fp16 vertices, half the stores
+            vd = getattr(self, "vertex_dtype", torch.float32)
             vertices = ops.lbs_skin_v2(tiles, B, c.template_planes, c.dirs_hl, c.weight_planes, c.V, shape_varies=varies,
-                                       folded=folded)
-            landmarks3d = ops.landmarks(vertices, p["faces"], p["full_idx"], self.full_lmk_bary_coords) if return_lm3d else None
+                                       folded=folded, out_dtype=vd)
+            landmarks3d = None
+            if return_lm3d:
+                landmarks3d = ops.landmarks(vertices if vd == torch.float32 else vertices.float().contiguous(), p["faces"],
+                                            p["full_idx"], self.full_lmk_bary_coords)
             return vertices, None, landmarks3d
         betas = torch.cat([shape_params, expression_params], dim=1).float().contiguous()
         if pose2rot:
