@@ -749,6 +749,29 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
         assert "roofline" in d
 
 
+def test_bench_eight_ranks_rehearsal_on_one_gpu():
+    """The same with EIGHT ranks in --mode train with hipGraph segments (the launch the driver makes on an 8-GPU node, RCCL
+    there): eight real processes on cuda:0 go through rendezvous, capture, the bucket reducer's exchange between graph
+    segments in bucket order, the all-rank non-finite stop and rank 0's line.  8 clips per rank (at the real 32 eight ranks
+    need 8 x 36 GB of the one device); children by subprocess only -- no exec of a process that has initialised the GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MSMD_DIST_BACKEND="gloo", MSMD_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "8",
+                        "--steps", "2", "--warmup", "1", "--mode", "train", "--batch", "8", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=1500, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["value"] > 0 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp8"
+    assert "hipGraph" in d["config"]["launch"]
+
+
 def test_first_graph_replay_after_another_variant_equals_the_eager_backward():
     """Segmented hipGraphs of the four truncation variants share one memory pool and alternate from iteration to iteration.
     Every gradient of the FIRST replay of a variant after another variant (and an optimizer step) has run must equal the
