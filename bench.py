@@ -192,10 +192,10 @@ def pmc_traffic(mode, key=None, tile="128ELi128E"):
     WRITE_SIZE in SEPARATE runs; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC counters
     cannot be read from inside this process: the figure is a constant from profiles/ (null when absent), not this run.
     key: which workload's summary (None = the forward step; "sampler" = profiles/r05_pmc_sampler_fetch_write_per_kernel.json)."""
-    names = ("r05_pmc_hbm_fetch_write_per_kernel.json", "r04_pmc_hbm_fetch_write_per_kernel.json", "r03_pmc_hbm_fetch_write_per_kernel.json",
+    names = ("r06_pmc_hbm_fetch_write_per_kernel.json", "r05_pmc_hbm_fetch_write_per_kernel.json", "r04_pmc_hbm_fetch_write_per_kernel.json", "r03_pmc_hbm_fetch_write_per_kernel.json",
              "r02_pmc_hbm_fetch_write_per_kernel.json")
     if key is not None:
-        names = (f"r05_pmc_{key}_fetch_write_per_kernel.json",)
+        names = (f"r06_pmc_{key}_fetch_write_per_kernel.json", f"r05_pmc_{key}_fetch_write_per_kernel.json")
     for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
@@ -220,7 +220,8 @@ def pmc_traffic(mode, key=None, tile="128ELi128E"):
 def pmc_traffic_256(key=None):
     """HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, launch-weighted over its epilogue forms) of gemm8_kernel from the same
     committed --pmc passes as pmc_traffic; None when the summary has no such kernel."""
-    path = os.path.join(ROOT, "profiles", f"r05_pmc_{key}_fetch_write_per_kernel.json" if key else "r05_pmc_hbm_fetch_write_per_kernel.json")
+    path = next((q for q in (os.path.join(ROOT, "profiles", (f"{r}_pmc_{key}_fetch_write_per_kernel.json" if key else f"{r}_pmc_hbm_fetch_write_per_kernel.json"))
+                             for r in ("r06", "r05")) if os.path.exists(q)), "")
     try:
         ks = [v for n, v in json.load(open(path)).items() if "gemm8_kernel" in n]
         n = sum(v.get("launches", 0) for v in ks)
