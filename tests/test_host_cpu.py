@@ -67,7 +67,7 @@ def test_library_is_stateless_and_has_no_packed_fp32_math(tmp_path):
                 size = int(line.split(":", 1)[1])
                 # gemm8_kernel's counted waits (vmcnt(6), lgkmcnt(8)) assume NO scratch traffic in its K loop: a spill is a silent LDS race there
                 hot = any(t in name for t in ("gemm_kernel", "gemm2_kernel", "gemm2p_kernel", "gemm2s_kernel", "gemm8_kernel", "attn_kernel", "attn_whole_kernel",
-                                              "attn_split_kernel", "gemm_tn_kernel", "gemm_tn8_kernel", "conv0_mfma_kernel", "lbs_skin_v2_kernel"))
+                                              "attn_split_kernel", "gemm_tn_kernel", "conv0_mfma_kernel", "lbs_skin_v2_kernel"))
                 if hot:
                     n_hot += 1
                     # known: the 13-wave split-attention variants (832 threads: 128 registers per lane) spill 11-12 dwords;

@@ -359,37 +359,6 @@ def test_gemm_tn_weight_gradient_product(M, N, K):
     assert float((c3.double() - ref3).abs().max()) < 2e-3 * float(ref3.abs().max())
 
 
-@pytest.mark.parametrize("M,N,K", [(12800, 768, 768), (12800, 2304, 768), (7104, 512, 2048), (4133, 264, 520), (1024, 256, 256)])
-def test_gemm_tn_256_tile_8_phase_kernel(M, N, K):
-    """gemm_tn8_kernel (256 x 256 output tiles, gemm8_kernel's 8-phase schedule on transposed LDS reads), forced by the per-call
-    kernel hint, against fp64 on the same bf16 operands: the training step's encoder / decoder weight-gradient shapes, ragged
-    N / K tiles and a contraction tail (4133 = 64 x 64 + 37), the bias-gradient column sums, forced split counts (1 = no
-    slabs, 3, the library's own), accumulation into an existing gradient -- and within fp32 summation noise of the 128 x 128
-    kernel's result."""
-    o = ops()
-    g = torch.Generator(device="cpu").manual_seed(M + N + K)
-    a = (torch.randn(M, N, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
-    b = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
-    ref = a.double().t() @ b.double()
-    cs_ref = a.double().sum(0)
-    tol = 2e-3 * float(ref.abs().max()) + 1e-3
-    c1 = o.gemm_tn(a, b, kernel=1)
-    for splits in (0, 1, 3):
-        c, cs = o.gemm_tn(a, b, want_colsum=True, splits=splits, kernel=2)
-        torch.cuda.synchronize()
-        assert float((c.double() - ref).abs().max()) < tol, (splits, float((c.double() - ref).abs().max()))
-        assert float((cs.double() - cs_ref).abs().max()) < 2e-3 * float(cs_ref.abs().max()) + 1e-3
-        assert float((c - c1).abs().max()) < 1e-4 * float(ref.abs().max()) + 1e-5
-        for _ in range(3):      # the same bits every time (the ring's hand-offs are ordered by counted waits and barriers)
-            assert torch.equal(o.gemm_tn(a, b, splits=splits, kernel=2), c)
-    base = torch.randn(N, K, generator=g).to(DEV)
-    acc = base.clone()
-    bias_acc = torch.ones(N, device=DEV)
-    o.gemm_tn(a, b, out=acc, colsum_out=bias_acc, accumulate=True, kernel=2)
-    assert float((acc.double() - (ref + base.double())).abs().max()) < tol
-    assert float((bias_acc.double() - (cs_ref + 1.0)).abs().max()) < 2e-3 * float(cs_ref.abs().max()) + 1e-3
-
-
 def test_gemm_tn_windowed_operand_is_conv_weight_gradient():
     """B operand as overlapping conv windows of a padded group-major signal (PosConvFn.backward): equals the
     explicit unfold + matmul in fp64."""

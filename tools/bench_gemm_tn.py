@@ -1,6 +1,5 @@
 """Weight-gradient GEMM (msmd_gemm_tn + its slab reduction) at the training step's shapes, by contraction split count.
-  python tools/bench_gemm_tn.py            RESULT lines: us per call (both launches), TFLOP/s
-  KERNEL=1|2 forces the 128 x 128 / the 256 x 256 8-phase kernel (default 0 = the library's choice)"""
+  python tools/bench_gemm_tn.py            RESULT lines: us per call (both launches), TFLOP/s"""
 import os
 import sys
 
@@ -25,9 +24,9 @@ for (M, N, K) in SHAPES:
     cs = torch.zeros(N, device="cuda")
     auto = None
     line = []
-    for splits in ((0, 1, 2, 3, 4, 6, 8, 12, 16) if os.environ.get('KERNEL', '0') != '2' else (0, 2, 4, 7, 9, 14, 28)):
+    for splits in (0, 1, 2, 3, 4, 6, 8, 12, 16):
         def run():
-            _lib.check(lib.msmd_gemm_tn(p(a), p(b), p(c), p(cs), M, N, K, N, K, K, 1, 0, 0, N * K, 0, 0, 1 | (splits << 8) | (int(os.environ.get('KERNEL', '0')) << 16), p(ws),
+            _lib.check(lib.msmd_gemm_tn(p(a), p(b), p(c), p(cs), M, N, K, N, K, K, 1, 0, 0, N * K, 0, 0, 1 | (splits << 8), p(ws),
                                         ws.numel(), st), "msmd_gemm_tn")
         for _ in range(3):
             run()

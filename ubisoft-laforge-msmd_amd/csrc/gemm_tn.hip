@@ -257,264 +257,13 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const TnArgs p) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// gemm_tn8_kernel (round 6): the weight-gradient contraction on 256 x 256 output tiles with the 8-phase schedule of
-// gemm.hip's gemm8_kernel (cdna_hip_programming.md section 5, "The 256^2 8-phase template"): one 8-wave workgroup per CU, 128 KB
-// ring of two K tiles (64 contraction rows each) x {A0 A1 B0 B1} half-tiles, counted vmcnt once per K tile, the two wave rows one
-// barrier apart.  Why: the 128 x 128 kernel above is bound by LDS, not by the matrix pipe -- per 64-row stage a workgroup's eight
-// waves read 98 KB of fragments and take in 32 KB by LDS-DMA for 512 MFMA cycles (270-630 TFLOP/s); a 256 x 256 tile halves
-// the bytes per MFMA.  A half-tile = 64 contraction rows x 128 columns = exactly the operand image of the kernel above (256-byte
-// rows, 32-byte column blocks XOR-swizzled by row & 7 on the DMA's source side, fragments by ds_read_b64_tr_b16): its address
-// maths is reused per half.  waves: 2 (wr: 64 n-columns of each A half) x 4 (wc: 32 k-columns of each B half); quadrant (h, g)
-// = A half h x B half g = 4 x 2 fragment pairs x 2 k-steps = 16 MFMAs = one phase.
-//   ph1: tr-reads B0 (8, first) + A0 (16), lgkmcnt(15) retires the B0 reads; quadrant (0,0); stages A1(t+1)
-//   ph2: reads B1 (8);                                                      quadrant (0,1); stages B0(t+2)
-//   ph3: reads A1 (16);                                                     quadrant (1,1); stages A0(t+2)
-//   ph4: vmcnt(6) -> K tile t+1 has landed;                                 quadrant (1,0); stages B1(t+2)
-// Work item = (split of the contraction, output tile), split-major: the tiles of one contraction range share their operand
-// rows in one XCD's L2.  Partial tiles go to the caller's slabs (tn_reduce_kernel sums them).  Bias gradient: wave column wc adds
-// ones . A-fragment wc of its wave row in the k-tile-0 items (2 extra MFMAs in phases 1 and 3).  Plain (unwindowed) B only.
-template <int XN>
-__device__ __forceinline__ void tn8_wait_x(u32x2 (&f)[2][4][2]) {
-  asm volatile("s_waitcnt lgkmcnt(%16)"
-               : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]), "+v"(f[0][2][0]), "+v"(f[0][2][1]),
-                 "+v"(f[0][3][0]), "+v"(f[0][3][1]), "+v"(f[1][0][0]), "+v"(f[1][0][1]), "+v"(f[1][1][0]), "+v"(f[1][1][1]),
-                 "+v"(f[1][2][0]), "+v"(f[1][2][1]), "+v"(f[1][3][0]), "+v"(f[1][3][1])
-               : "n"(XN)
-               : "memory");
-}
-template <int XN>
-__device__ __forceinline__ void tn8_wait_w(u32x2 (&f)[2][2][2]) {
-  asm volatile("s_waitcnt lgkmcnt(%8)"
-               : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]), "+v"(f[1][0][0]), "+v"(f[1][0][1]),
-                 "+v"(f[1][1][0]), "+v"(f[1][1][1])
-               : "n"(XN)
-               : "memory");
-}
-
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn8_kernel(const TnArgs p) {
-  constexpr int HALF = 64 * 256;   // bytes of one half-tile: 64 contraction rows x 128 columns
-  constexpr int BUF = 4 * HALF;    // A0 A1 B0 B1
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wid >> 2, wc = wid & 3;
-  const int tiles = p.nt_n * p.nt_k, items = tiles * p.splits;
-  const int per_xcd = (items + 7) >> 3;
-  const int lin = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-  if (lin >= items || (int)(blockIdx.x >> 3) >= per_xcd) return;
-  const int split = lin / tiles, t_ = lin - split * tiles;
-  const int n_tile = t_ / p.nt_k, k_tile = t_ - n_tile * p.nt_k;
-  const int n0 = n_tile * 256, k0 = k_tile * 256;
-  const int nk_total = (p.M + 63) / 64;
-  const int kt_begin = split * p.steps_per_split;
-  const int nk = min(nk_total, kt_begin + p.steps_per_split) - kt_begin;     // >= 2 (launcher)
-  const char* __restrict__ A = (const char*)p.A;
-  const char* __restrict__ B = (const char*)p.B;
-
-  // LDS-DMA: piece i (0, 1) of this wave inside a half-tile = its 1 KB chunk i * 8 + wid = contraction rows 4 chunk .. + 3
-  unsigned src[4][2];      // [A0 A1 B0 B1][piece]: byte offset of (row of K tile 0, this lane's 16-byte column chunk)
-  unsigned srow[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (i * 8 + wid) * 4 + (lane >> 4), phys = lane & 15;
-    const int c = ((((phys >> 1) ^ (row & 7)) << 1) | (phys & 1));
-    srow[i] = row;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      src[h][i] = (unsigned)(min(n0 + h * 128 + c * 8, p.N - 8) * 2);
-      src[2 + h][i] = (unsigned)(min(k0 + h * 128 + c * 8, p.K - 8) * 2);
-    }
-  }
-  const unsigned dma_base = wid * 1024;
-  const unsigned lda2 = (unsigned)p.lda * 2u, ldb2 = (unsigned)p.ldb * 2u;
-  auto stage = [&](int which, int kt, unsigned bufoff) {      // kt: K tile of this item (0 ..)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const unsigned r = (unsigned)min((kt_begin + kt) * 64 + (int)srow[i], p.M - 1);
-      const unsigned off = r * (which < 2 ? lda2 : ldb2) + src[which][i];
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)((which < 2 ? A : B) + (size_t)off),
-                                       (lds_void_t*)(smem + (dma_base + bufoff + which * HALF + i * 8192)), 16, 0, 0);
-    }
-  };
-
-  const int fr = lane & 15, fq = lane >> 4;
-  const int qp = fr >> 2, pp = fr & 3;
-  const int rr = 4 * fq + qp;
-  const unsigned lds0 = (unsigned)(uintptr_t)smem;
-  unsigned aa[4], ab[2];       // fragment addresses inside buffer 0 (k-step / row-half / half-tile offsets are immediates)
-#pragma unroll
-  for (int j = 0; j < 4; ++j) aa[j] = lds0 + rr * 256 + (((wr * 4 + j) ^ (rr & 7)) << 5) + pp * 8;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) ab[i] = lds0 + 2 * HALF + rr * 256 + (((wc * 2 + i) ^ (rr & 7)) << 5) + pp * 8;
-
-  f32x4 acc[2][2][2][4];       // [h (A half)][g (B half)][i (k fragment)][j (n fragment)]
-  f32x4 acs[2];                // bias gradient: column sums of A fragment j = wc of half h
-  u32x2 fx[2][4][2], fw0[2][2][2], fw1[2][2][2];   // [k-step][fragment][row half]
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    acs[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[h][g][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  const bool do_cs = p.colsum != nullptr && k_tile == 0;
-  const bf16x8 ones = bf16x8{(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
-
-#define TN8_RX(H)                                                                   \
-  do {                                                                              \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                  \
-      fx[0][j][0] = tr_read<(H) * HALF>(aa[j]);                                      \
-      fx[0][j][1] = tr_read<(H) * HALF + 4096>(aa[j]);                               \
-      fx[1][j][0] = tr_read<(H) * HALF + 8192>(aa[j]);                               \
-      fx[1][j][1] = tr_read<(H) * HALF + 8192 + 4096>(aa[j]);                        \
-    }                                                                               \
-  } while (0)
-#define TN8_RW(G, FW)                                                               \
-  do {                                                                              \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                  \
-      FW[0][i][0] = tr_read<(G) * HALF>(ab[i]);                                      \
-      FW[0][i][1] = tr_read<(G) * HALF + 4096>(ab[i]);                               \
-      FW[1][i][0] = tr_read<(G) * HALF + 8192>(ab[i]);                               \
-      FW[1][i][1] = tr_read<(G) * HALF + 8192 + 4096>(ab[i]);                        \
-    }                                                                               \
-  } while (0)
-  // contraction rows >= M of the last K tile were clamped duplicates: zeroed in the A fragments (m_base = row of k-step 0)
-  auto zero_tail = [&](int m_base) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        s16x4 lo = __builtin_bit_cast(s16x4, fx[ks][j][0]), hi = __builtin_bit_cast(s16x4, fx[ks][j][1]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (m_base + ks * 32 + 4 * fq + e >= p.M) lo[e] = 0;
-          if (m_base + ks * 32 + 4 * fq + 16 + e >= p.M) hi[e] = 0;
-        }
-        fx[ks][j][0] = __builtin_bit_cast(u32x2, lo); fx[ks][j][1] = __builtin_bit_cast(u32x2, hi);
-      }
-  };
-  auto quadrant = [&](f32x4 (&a)[2][4], const u32x2 (&fw)[2][2][2], f32x4& cs, const bool with_cs) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          a[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag8(fw[ks][i][0], fw[ks][i][1]), frag8(fx[ks][j][0], fx[ks][j][1]), a[i][j], 0, 0, 0);
-      if (with_cs) {            // wave-uniform
-        // fragment j = wc by four wave-uniform branches: a select chain on wc is turned into a runtime index into fx and puts
-        // the fragment arrays in scratch (144 bytes, inside the K loop: the counted vmcnt would no longer hold)
-        if (wc == 0) cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, frag8(fx[ks][0][0], fx[ks][0][1]), cs, 0, 0, 0);
-        else if (wc == 1) cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, frag8(fx[ks][1][0], fx[ks][1][1]), cs, 0, 0, 0);
-        else if (wc == 2) cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, frag8(fx[ks][2][0], fx[ks][2][1]), cs, 0, 0, 0);
-        else cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, frag8(fx[ks][3][0], fx[ks][3][1]), cs, 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_s_setprio(0);
-  };
-#define TN8_BAR()                       \
-  do {                                  \
-    __builtin_amdgcn_sched_barrier(0);  \
-    __builtin_amdgcn_s_barrier();       \
-    __builtin_amdgcn_sched_barrier(0);  \
-  } while (0)
-
-  // prologue: K tile 0 whole, K tile 1 except A1 (which phase 1 of tile 0 stages)
-  stage(2, 0, 0); stage(0, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
-  stage(2, 1, BUF); stage(0, 1, BUF); stage(3, 1, BUF);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();     // stagger: wave row 1 runs one barrier behind row 0
-  unsigned cur = 0;
-  const bool tail = (p.M & 63) != 0 && kt_begin + nk == nk_total;
-  auto ktile = [&](int t, auto MODE_) {
-    constexpr int MODE = decltype(MODE_)::value;   // 0: steady state; 1: K tile nk - 2; 2: the last K tile
-    // ---- phase 1
-    TN8_RW(0, fw0);
-    __builtin_amdgcn_sched_barrier(0);
-    TN8_RX(0);
-    if (MODE <= 1) stage(1, t + 1, cur ^ BUF);
-    tn8_wait_w<15>(fw0);                           // 24 reads issued, at most 15 outstanding: the eight B0 reads have returned
-    TN8_BAR();
-    tn8_wait_x<0>(fx);
-    if (MODE == 2 && tail) zero_tail((kt_begin + t) * 64);
-    quadrant(acc[0][0], fw0, acs[0], do_cs);
-    TN8_BAR();
-    // ---- phase 2
-    TN8_RW(1, fw1);
-    if (MODE == 0) stage(2, t + 2, cur);
-    TN8_BAR();
-    tn8_wait_w<0>(fw1);
-    quadrant(acc[0][1], fw1, acs[0], false);
-    TN8_BAR();
-    // ---- phase 3
-    TN8_RX(1);
-    if (MODE == 0) stage(0, t + 2, cur);
-    TN8_BAR();
-    tn8_wait_x<0>(fx);
-    if (MODE == 2 && tail) zero_tail((kt_begin + t) * 64);
-    quadrant(acc[1][1], fw1, acs[1], do_cs);
-    TN8_BAR();
-    // ---- phase 4
-    if (MODE == 0) stage(3, t + 2, cur);
-    if (MODE == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    if (MODE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TN8_BAR();
-    quadrant(acc[1][0], fw0, acs[1], false);
-    TN8_BAR();
-    cur ^= BUF;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) aa[j] ^= BUF;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) ab[i] ^= BUF;
-  };
-  for (int t = 0; t < nk - 2; ++t) ktile(t, std::integral_constant<int, 0>{});
-  ktile(nk - 2, std::integral_constant<int, 1>{});
-  ktile(nk - 1, std::integral_constant<int, 2>{});
-#undef TN8_BAR
-#undef TN8_RX
-#undef TN8_RW
-
-  // epilogue: acc[h][g][i][j][e] = C[n = n0 + 128 h + 64 wr + 16 j + fr][k = k0 + 128 g + 32 wc + 16 i + 4 fq + e]
-  const bool partial = p.splits > 1;
-  float* __restrict__ C = partial ? p.ws + split * p.slab : p.C;
-  const long ldc = partial ? p.K : p.ldc;
-  const bool add = p.accumulate && !partial;
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + 128 * h + 64 * wr + 16 * j + fr;
-      if (n < p.N) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const int k = k0 + 128 * g + 32 * wc + 16 * i + 4 * fq;
-            if (k < p.K) {     // K % 8 == 0 and 16-byte aligned rows (launcher): whole quads
-              float* dst = C + (long)n * ldc + k;
-              *(f32x4*)dst = add ? *(const f32x4*)dst + acc[h][g][i][j] : acc[h][g][i][j];
-            }
-          }
-      }
-    }
-  if (do_cs && fq == 0) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int n = n0 + 128 * h + 64 * wr + 16 * wc + fr;
-      if (n < p.N) {
-        if (partial || p.accumulate) atomicAdd(p.colsum + n, acs[h][0]);
-        else p.colsum[n] = acs[h][0];
-      }
-    }
-  }
-}
-
+// (Round 6 built this contraction on 256 x 256 output tiles with gemm.hip's 8-phase schedule -- gemm_tn8_kernel, commit fbbdd5f:
+// correct on every test, no scratch, 229 registers -- and removed it: one workgroup per CU needs 7-28 contraction splits to fill
+// the chip where this kernel takes 4-6, so the partial slabs double (64 MB written and read back per weight gradient), and its K
+// tile ran at 1.8 us per workgroup against the 1.0 us of a saturated matrix pipe (48 transposed 8-byte LDS reads per phase where
+// the forward kernel issues 24 of 16 bytes).  us per call with the slab reduction, M = 12800: 768 x 768 35.6 -> 39.6,
+// 2304 x 768 69.4 -> 69.3, 3072 x 768 82.5 -> 81.4, 768 x 3072 82.8 -> 83.6; M = 7040 decoder shapes 20-34 -> 32-40.  What the
+// numbers ask for instead is one GROUPED launch per layer's four weight gradients -- 108 tiles, two splits -- DESIGN.md section 5.)
 // C[z][n][k] = sum_s ws[s][z][n][k]
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int splits,
                                                         long slab, int N, int K, long ldc, long strideC, int accumulate) {
@@ -553,28 +302,11 @@ static long tn_auto_splits(long tiles, long nk_elems) {
 // accumulate: C += product and colsum += sums instead of overwriting (gradient accumulation into .grad).
 // ws / ws_bytes: optional workspace for split-contraction partial slabs (msmd_gemm_tn_workspace gives the
 // size that lets the launch fill the chip; smaller or NULL just means fewer / no splits).
-// gemm_tn8_kernel: the calls it takes and its contraction split count (one workgroup per CU: 256 items fill the chip).
-static bool tn8_takes(int M, int N, int K, int batch, int b_rpw) {
-  return batch == 1 && b_rpw == 0 && N >= 256 && K >= 256 && M >= 1024;
-}
-static long tn8_splits(int M, int N, int K) {
-  const long tiles = (long)((N + 255) / 256) * ((K + 255) / 256);
-  const int nk = (M + 63) / 64;
-  return max(1L, min(256 / max(tiles, 1L), (long)(nk / 4)));      // >= 4 K tiles per item
-}
-// ... and when the library picks it (tools/bench_gemm_tn.py SHAPES=train2, us per call with the slab reduction, 128 x 128 kernel ->
-// this one): see tn8_wins() at the launch below.
-static bool tn8_wins(int M, int N, int K) {
-  const long tiles = (long)((N + 255) / 256) * ((K + 255) / 256);
-  return M >= 4096 && tiles >= 4;
-}
-
 extern "C" long msmd_gemm_tn_workspace(int M, int N, int K, int batch) {
   const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128) * batch;
   const int nk = (M + 63) / 64;
   long splits = tn_auto_splits(tiles, (long)N * K);
   splits = max(1L, min(splits, (long)max(1, nk / 4)));
-  if (tn8_takes(M, N, K, batch, 0)) splits = max(splits, tn8_splits(M, N, K));
   return splits > 1 ? splits * batch * (long)N * K * (long)sizeof(float) : 0;
 }
 
@@ -595,48 +327,7 @@ extern "C" int msmd_gemm_tn(const void* A, const void* B, float* C, float* colsu
   const int nk = (M + 63) / 64;
   long splits = tn_auto_splits(tiles, (long)N * K);
   const int forced = (accumulate >> 8) & 0xff;   // per-call override of the contraction split count (tests, tuning)
-  const int kernel_hint = (accumulate >> 16) & 3;   // 0 = the library's choice, 1 = the 128 x 128 kernel, 2 = the 256 x 256 kernel (A/B, tests)
   accumulate &= 1;
-  const int rpw = (b_rows_per_window > 0 && b_rows_per_window < M) ? b_rows_per_window : 0;
-  if (kernel_hint != 1 && ws && tn8_takes(M, N, K, batch, rpw) && (kernel_hint == 2 || tn8_wins(M, N, K))) {
-    const int nk8 = (M + 63) / 64;
-    long s8 = forced > 0 ? forced : tn8_splits(M, N, K);
-    s8 = max(1L, min(s8, (long)(nk8 / 2)));
-    s8 = min(s8, ws_bytes / ((long)N * K * (long)sizeof(float)));
-    if (s8 >= 1) {
-      p.nt_n = (N + 255) / 256; p.nt_k = (K + 255) / 256;
-      p.steps_per_split = (int)((nk8 + s8 - 1) / s8);
-      if (p.steps_per_split < 2) p.steps_per_split = 2;
-      p.splits = (nk8 + p.steps_per_split - 1) / p.steps_per_split;
-      if (nk8 - (p.splits - 1) * p.steps_per_split < 2) {      // the last item needs two K tiles too
-        p.steps_per_split += 1;
-        p.splits = (nk8 + p.steps_per_split - 1) / p.steps_per_split;
-      }
-      if (nk8 - (p.splits - 1) * p.steps_per_split >= 2 && nk8 >= 2) {
-        p.ws = (float*)ws; p.slab = (long)N * K;
-        p.b_rpw = 0; p.b_wstride = 0; p.inv_rpw = 0.f; p.accumulate = accumulate ? 1 : 0; p.plain_order = 0;
-        if (p.splits > 1 && colsum && !accumulate) {
-          hipError_t e = msmd_zero_async(colsum, sizeof(float) * N, st);
-          if (e != hipSuccess) return (int)e;
-        }
-        constexpr int lds8 = 2 * 4 * 64 * 256;
-        static bool attr8 = false;
-        if (!attr8) {
-          (void)hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds8);
-          attr8 = true;
-        }
-        const int items = p.nt_n * p.nt_k * p.splits;
-        hipLaunchKernelGGL(gemm_tn8_kernel, dim3(((items + 7) / 8) * 8), dim3(512), lds8, st, p);
-        if (p.splits > 1) {
-          const long quads = (long)N * (K / 4);
-          hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((quads + 255) / 256), 1), dim3(256), 0, st, p.ws, C,
-                             p.splits, p.slab, N, K, ldc, strideC, p.accumulate);
-        }
-        MSMD_RETURN_LAST();
-      }
-      p.nt_n = (N + 127) / 128; p.nt_k = (K + 127) / 128;      // (fall through to the 128 x 128 kernel)
-    }
-  }
   if (forced > 0) splits = forced;
   if (MSMD_TUNE(2) > 0) splits = MSMD_TUNE(2);
   splits = max(1L, min(splits, (long)max(1, nk / 4)));

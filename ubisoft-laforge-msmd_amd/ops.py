@@ -439,10 +439,9 @@ g_tn_split = True
 
 
 def gemm_tn(a, b, want_colsum=False, *, M=None, N=None, K=None, lda=None, ldb=None, batch=1, strideA=0, strideB=0,
-            b_rows_per_window=0, b_window_stride=0, out=None, colsum_out=None, accumulate=False, splits=0, kernel=0):
+            b_rows_per_window=0, b_window_stride=0, out=None, colsum_out=None, accumulate=False, splits=0):
     """C (N, K) fp32 = a^T @ b for bf16 a (M, N), b (M, K) (contraction over rows: the weight-gradient product, no
-    transposes).  Returns C, or (C, colsum) with colsum[n] = sum_m a[m, n] (the bias gradient) when asked.
-    kernel: 0 = the library's choice, 1 = the 128 x 128-tile kernel, 2 = the 256 x 256-tile 8-phase kernel (A/B, tests)."""
+    transposes).  Returns C, or (C, colsum) with colsum[n] = sum_m a[m, n] (the bias gradient) when asked."""
     _need_cuda(a, b)
     if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
         raise TypeError("gemm_tn takes bf16 operands")
@@ -461,7 +460,7 @@ def gemm_tn(a, b, want_colsum=False, *, M=None, N=None, K=None, lda=None, ldb=No
     nws = lib.msmd_gemm_tn_workspace(M, N, K, batch) if g_tn_split else 0
     ws = torch.empty(nws, device=a.device, dtype=torch.uint8) if nws > 0 else None
     _lib.check(lib.msmd_gemm_tn(_p(a), _p(b), _p(out), _p(cs), M, N, K, lda, ldb, K, batch, strideA, strideB, N * K,
-                                b_rows_per_window, b_window_stride, int(bool(accumulate)) | (int(splits) << 8) | (int(kernel) << 16), _p(ws), nws,
+                                b_rows_per_window, b_window_stride, int(bool(accumulate)) | (int(splits) << 8), _p(ws), nws,
                                 _stream()), "msmd_gemm_tn")
     return (out, cs) if (want_colsum or colsum_out is not None) else out
 
