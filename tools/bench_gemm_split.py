@@ -20,6 +20,8 @@ decoder = [("d_qkv", 3552, 1536, 512), ("d_out", 3552, 512, 512), ("d_ffn1", 355
 large = [("hl_qkv", 15968, 3072, 1024), ("hl_out", 15968, 1024, 1024), ("hl_ffn1", 15968, 4096, 1024), ("hl_ffn2", 15968, 1024, 4096),
          ("big", 16384, 4096, 3072)]
 shapes = {"conv": conv, "encoder": encoder, "decoder": decoder, "large": large}.get(os.environ.get("SHAPES", ""), conv + encoder + decoder)
+if ":" in os.environ.get("SHAPES", ""):        # SHAPES=name:M:N:K,name:M:N:K
+    shapes = [(n, int(m), int(nn), int(k)) for n, m, nn, k in (t.split(":") for t in os.environ["SHAPES"].split(","))]
 g = torch.Generator(device="cuda").manual_seed(0)
 for name, M, N, K in shapes:
     a32 = torch.randn(M, K, device="cuda", generator=g)
