@@ -497,7 +497,8 @@ def leg_lbs(device, frames_list=(6400, 25600)):
         bpf = 4 * 165 + 2 * 3 * 5024
         out["lbs_25600_fp16_vertices"] = dict(ms=round(ms, 4), frames_per_s=round(n / ms * 1e3), gb_per_s=round(n * bpf / ms / 1e6, 1),
                                               hbm_frac=round(n * bpf / ms / 1e6 / PEAK_HBM_GBS, 4), bytes_per_frame=bpf,
-                                              bound="|v16 - v32| <= 2^-11 |v32| (one fp16 rounding of the fp32 kernel's vertex)",
+                                              bound="|v16 - v32| <= 2^-11 |v32| + 2^-10 sum_k |coef_k dirs_k| (fp16 operand planes: one MFMA per K group; "
+                                                    "FLAME.vertex_exact = True gives the fp32 kernel's vertex rounded once, slower)",
                                               inputs="as lbs_25600; vertices stored as fp16 in rows of 5024 x 3 (opt-in FLAME.vertex_dtype)")
     if only in ("6400", "25600", "25600_fp16"):
         return out

@@ -423,12 +423,19 @@ int msmd_lbs_skin_v2(const void* skin_tiles, const float* v_template, const void
 
 /* msmd_lbs_skin_v2 with fp16 vertices (opt-in; BASELINE configs[4] names the fp16 LBS pass): verts16 (B, V_ld, 3) fp16, V_ld
  * even and >= V (rows of V * 3 halves would put every other frame on a 2-byte boundary; slot V of a row receives a copy of
- * vertex V - 1).  Same arithmetic, fp32 until the store: |error| <= 2^-11 relative to the fp32 kernel's vertex.  Half the
- * store stream that bounds the fp32 kernel: 30 144 + 660 algorithmic bytes per frame at V = 5023.  Reference:
- * utils/lbs.py:210-221 (fp32 there). */
-int msmd_lbs_skin_v2_f16(const void* skin_tiles, const float* v_template, const void* dirs_hl, const float* lbs_weights,
+ * vertex V - 1).  Half the store stream that bounds the fp32 kernel: 30 144 + 660 algorithmic bytes per frame at V = 5023.
+ *   single_plane == 0: skin_tiles / dirs = msmd_lbs_skin_v2's operands (18 KB records, dirs_hl): the fp32 kernel's arithmetic
+ *     with one fp16 rounding at the store (equal to its output rounded once);
+ *   single_plane != 0: skin_tiles = the 12 KB records of msmd_lbs_tiles_f16, dirs = ONE fp16 plane (3, Kp / 8, Vp, 8) of the
+ *     blendshape directions: one MFMA per K group and coordinate instead of three; |error| <= 2^-11 |v| + 2^-10 sum_k
+ *     |coef_k| |dirs_k| (the operands' own fp16 rounding, on the un-skinned blendshape offset) + the fp32 kernel's 5e-6.
+ * Reference: utils/lbs.py:210-221 (fp32 there). */
+int msmd_lbs_skin_v2_f16(const void* skin_tiles, const float* v_template, const void* dirs, const float* lbs_weights,
                          void* verts16, int B, int J, int V, int V_ld, int Vp, int Kp, const int* shape_varies,
-                         const float* v_template_folded, msmd_stream_t stream);
+                         const float* v_template_folded, int single_plane, msmd_stream_t stream);
+/* msmd_lbs_skin_v2's tile records (18 432 bytes per 16 frames) -> the single-plane form's (12 288 bytes: coefficients hi + lo
+ * as one fp16 number [k / 8][frame % 16][k % 8], then the blend rows). */
+int msmd_lbs_tiles_f16(const void* skin_tiles, void* tiles16, int B, msmd_stream_t stream);
 
 /* Training through FLAME (the reference's use_vertex_space branch: training_script.py:167-176 -> utils/common.py:486-513
  * -> utils/lbs.py:141-223, differentiated by autograd there).

@@ -28,6 +28,7 @@ by_line = collections.Counter()
 REDUCE = ("sum", "mean", "var", "var_mean", "std", "norm", "linalg_vector_norm", "amax", "amin", "max", "min", "all", "any", "prod",
           "logsumexp", "_softmax", "count_nonzero", "cumsum", "argmax")
 reductions = collections.Counter()   # (op, input shape, outputs, elements reduced per output, calling line)
+engine = collections.Counter()
 slow = collections.Counter()      # ops with a non-contiguous (s) or broadcast operand: the generic strided elementwise kernels
 
 
@@ -60,6 +61,8 @@ class Count(TorchDispatchMode):
                 break
         by_line[(where, name)] += 1
         ts = [a for a in list(args) + list((kwargs or {}).values()) if torch.is_tensor(a)]
+        if where.startswith("autograd engine"):
+            engine[(where, name, " ".join(str(tuple(a.shape)) + ("" if a.is_contiguous() else "s") for a in ts)[:60])] += 1
         if any(not a.is_contiguous() for a in ts) or len({tuple(a.shape) for a in ts if a.dim() > 0}) > 1:
             slow[(where, name, " ".join(str(tuple(a.shape)) + ("" if a.is_contiguous() else "s") for a in ts))] += 1
         if t is not None:
@@ -79,6 +82,12 @@ print("by op:", by_name.most_common(25))
 print("by calling line of this package (top 60):")
 for (w, n), c in by_line.most_common(60):
     print(f"  {w:44s} {n:28s} x{c}")
+print("ops issued by the autograd engine (backward of torch ops in the glue code), by op and first-operand shape:")
+eng = collections.Counter()
+for (w, n, shp), c in engine.items():
+    eng[(n, shp)] += c
+for (n, shp), c in eng.most_common(60):
+    print(f"  {n:28s} {shp:60s} x{c}")
 print(f"ops with a strided (s) or broadcast operand: {sum(slow.values())}")
 for (w, n, shp), c in slow.most_common(70):
     print(f"  {w:44s} {n:24s} x{c:3d}  {shp[:90]}")

@@ -555,7 +555,11 @@ __device__ __forceinline__ void vm_wait_n(int n) {   // n = (pieces per load gro
 // 12 contiguous bytes [x y z x y z] of its vertex PAIR for two of the tile's four frames: 2 store instructions of 96-byte runs
 // per 8 lanes instead of 4 of 192-byte runs per 16.  (V = 5023 is odd: a row of V * 3 halves would put every other frame on a
 // 2-byte boundary; hence the padded row.  Slot V of a row receives a copy of vertex V - 1.)
-template <int KG, int NS, int NWV, int ABL = 0, bool WP = false, int RB = 0, bool OUT16 = false>
+// F16P (with OUT16; msmd_lbs_skin_v2_f16's default form): fp16 vertices do not need 16-bit-split operands -- the blendshape
+// product runs on ONE fp16 plane of `dirs` (72 registers instead of 144) and ONE fp16 coefficient plane (12 KB tile records
+// [coef fp16 6 KB | blend rows 6 KB] written by msmd_lbs_tiles_f16): 1 MFMA per K group and coordinate instead of 3.  The
+// operands' own rounding (2^-12 relative on offsets of <= ~0.03) stays under the fp16 step of the stored vertex.
+template <int KG, int NS, int NWV, int ABL = 0, bool WP = false, int RB = 0, bool OUT16 = false, bool F16P = false>
 __global__ __launch_bounds__(64 * NWV) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void lbs_skin_v2_kernel(const unsigned char* __restrict__ tiles,
                         const float* __restrict__ tmpl, const bf16_t* __restrict__ dirs_hl,
@@ -569,13 +573,14 @@ void lbs_skin_v2_kernel(const unsigned char* __restrict__ tiles,
   const bool uni = shape_varies != nullptr && tmpl_folded != nullptr && *shape_varies == 0;
   const int g_first = uni ? LBS_KFOLD / 32 : 0;
   if (uni) tmpl = tmpl_folded;
+  static_assert(!F16P || OUT16, "the single-plane form is for fp16 vertices");
   constexpr int Kp = KG * 32, J = 5, VPB = 16 * NWV;
-  constexpr int NCH = 2 * Kp / 8;            // 16-byte chunks per frame of coef_hl (hi then lo)
+  constexpr int NCH = (F16P ? 1 : 2) * Kp / 8;   // 16-byte chunks per frame of the coefficients (hi then lo; F16P: one fp16 plane)
   constexpr int COEF_BYTES = NCH * 256;      // [chunk][frame] 16 B
   constexpr int AT_BYTES = 12 * 2 * 256;     // [m][slot octet][frame] 16 B
   constexpr int STAGE = COEF_BYTES + AT_BYTES;
-  constexpr int NP = STAGE / 1024;           // 18 one-KiB LDS-DMA pieces per tile
-  static_assert(COEF_BYTES == 12 * 1024 && AT_BYTES == 6 * 1024, "piece map below");
+  constexpr int NP = STAGE / 1024;           // 18 (F16P: 12) one-KiB LDS-DMA pieces per tile
+  static_assert(COEF_BYTES == (F16P ? 6 : 12) * 1024 && AT_BYTES == 6 * 1024, "piece map below");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -593,14 +598,14 @@ void lbs_skin_v2_kernel(const unsigned char* __restrict__ tiles,
   const int ntiles = (f_end - f_begin + 15) >> 4;
   const int ve = min(v_tile * VPB + wid * 16 + i, V - 1);
 
-  u32x4 dh[3][KG], dl[3][KG];
+  u32x4 dh[3][KG], dl[3][F16P ? 1 : KG];     // F16P: dirs_hl points at the ONE fp16 plane (3, Kp / 8, Vp, 8)
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
       const long off = (((long)c * (Kp / 8) + 4 * g + q) * Vp + ve) * 8;
       dh[c][g] = *(const u32x4*)(dirs_hl + off);
-      dl[c][g] = *(const u32x4*)(dirs_hl + (long)3 * (Kp / 8) * Vp * 8 + off);
+      if constexpr (!F16P) dl[c][g] = *(const u32x4*)(dirs_hl + (long)3 * (Kp / 8) * Vp * 8 + off);
     }
   float t3[3];
 #pragma unroll
@@ -648,16 +653,23 @@ void lbs_skin_v2_kernel(const unsigned char* __restrict__ tiles,
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
       if (g < g_first) continue;   // wave-uniform
+      if constexpr (F16P) {
+        const f16x8 a16 = __builtin_bit_cast(f16x8, *(const u32x4*)(sc + ((4 * g + q) * 16 + i) * 16));
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          accp[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16, __builtin_bit_cast(f16x8, dh[c][g]), accp[c], 0, 0, 0);
+        continue;
+      }
       const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4*)(sc + ((4 * g + q) * 16 + i) * 16));
-      const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4*)(sc + ((Kp / 8 + 4 * g + q) * 16 + i) * 16));
+      const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4*)(sc + (((F16P ? 0 : Kp / 8) + 4 * g + q) * 16 + i) * 16));
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         if constexpr (ABL & 4) {
           if (g == 0) accp[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8, dh[c][g]), accp[c], 0, 0, 0);
-          asm volatile("" :: "v"(dh[c][g]), "v"(dl[c][g]), "v"(ah), "v"(al));
+          asm volatile("" :: "v"(dh[c][g]), "v"(dl[c][F16P ? 0 : g]), "v"(ah), "v"(al));
         } else {
           accp[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8, dh[c][g]), accp[c], 0, 0, 0);
-          accp[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, dl[c][g]), accp[c], 0, 0, 0);
+          accp[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, dl[c][F16P ? 0 : g]), accp[c], 0, 0, 0);
           accp[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, dh[c][g]), accp[c], 0, 0, 0);
         }
       }
@@ -771,7 +783,7 @@ void lbs_skin_v2_kernel(const unsigned char* __restrict__ tiles,
 static int lbs_skin_v2_impl(const void* skin_tiles, const float* v_template, const void* dirs_hl,
                             const float* lbs_weights, float* verts, float* vposed, int B, int J, int V, int Vp, int Kp,
                             msmd_stream_t stream, const int* shape_varies = nullptr, const float* tmpl_folded = nullptr,
-                            int V_ld16 = 0) {
+                            int V_ld16 = 0, bool single_plane = false) {
   if (B <= 0 || V <= 0 || Vp < V || J != 5 || Kp != 192 || !skin_tiles) return 1;
   if (V_ld16 && (V_ld16 < V || (V_ld16 & 1) || vposed || ((uintptr_t)verts & 3))) return 1;
   // tuning key 9: 1 = two 4-wave workgroups per CU (64 vertices each, 3-stage rings) instead of one 8-wave workgroup
@@ -815,6 +827,16 @@ static int lbs_skin_v2_impl(const void* skin_tiles, const float* v_template, con
       default: LBS_V2_LAUNCH(4, 8, 0); break;         // 100: one barrier per tile (the round-2a schedule)
     }
 #endif
+  } else if (V_ld16 && single_plane) {
+    // (143 registers.  Twelve-wave workgroups of 192 vertices at three waves per SIMD measured the same as these eight-wave ones:
+    // 0.387-0.392 against 0.388-0.394 ms at 25 600 frames; two 8-wave workgroups per CU need 128 registers and spilled 24 bytes
+    // into the counted-vmcnt loop.)
+    constexpr int lds = 4 * 12 * 1024;
+    auto kfn = lbs_skin_v2_kernel<6, 4, 8, 0, false, 2, true, true>;
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, (hipStream_t)stream, (const unsigned char*)skin_tiles, v_template,
+                       (const bf16_t*)dirs_hl, lbs_weights, verts, B, V, Vp, fpb, vt, (float*)nullptr, xcd_adj, shape_varies,
+                       tmpl_folded, V_ld16);
   } else if (V_ld16) {
     constexpr int lds = 4 * 18 * 1024;
     auto kfn = lbs_skin_v2_kernel<6, 4, 8, 0, false, 2, true>;
@@ -836,12 +858,35 @@ extern "C" int msmd_lbs_skin_v2(const void* skin_tiles, const float* v_template,
                           shape_varies, v_template_folded);
 }
 
-extern "C" int msmd_lbs_skin_v2_f16(const void* skin_tiles, const float* v_template, const void* dirs_hl,
-                                    const float* lbs_weights, void* verts16, int B, int J, int V, int V_ld, int Vp, int Kp,
-                                    const int* shape_varies, const float* v_template_folded, msmd_stream_t stream) {
+extern "C" int msmd_lbs_skin_v2_f16(const void* skin_tiles, const float* v_template, const void* dirs, const float* lbs_weights,
+                                    void* verts16, int B, int J, int V, int V_ld, int Vp, int Kp, const int* shape_varies,
+                                    const float* v_template_folded, int single_plane, msmd_stream_t stream) {
   if (V_ld <= 0) return 1;
-  return lbs_skin_v2_impl(skin_tiles, v_template, dirs_hl, lbs_weights, (float*)verts16, nullptr, B, J, V, Vp, Kp, stream,
-                          shape_varies, v_template_folded, V_ld);
+  return lbs_skin_v2_impl(skin_tiles, v_template, dirs, lbs_weights, (float*)verts16, nullptr, B, J, V, Vp, Kp, stream,
+                          shape_varies, v_template_folded, V_ld, single_plane != 0);
+}
+
+// msmd_lbs_skin_v2's 18 KB tile records -> the 12 KB records of its single-plane fp16 form: coefficients hi + lo as ONE fp16
+// number, [chunk = k / 8][frame % 16][k % 8] (6 KB), then the blend rows unchanged (6 KB).  One workgroup per tile.
+__global__ __launch_bounds__(256) void lbs_tiles_f16_kernel(const unsigned char* __restrict__ tiles, unsigned char* __restrict__ out) {
+  const unsigned char* src = tiles + (long)blockIdx.x * LBS_TILE_BYTES;
+  unsigned char* dst = out + (long)blockIdx.x * 12288;
+  for (int id = threadIdx.x; id < 24 * 16; id += 256) {       // one 16-byte chunk = 8 coefficients of one frame
+    const bf16x8 h = *(const bf16x8*)(src + id * 16), l = *(const bf16x8*)(src + (24 * 16 + id) * 16);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16_t)((float)h[e] + (float)l[e]);
+    *(f16x8*)(dst + id * 16) = o;
+  }
+  for (int id = threadIdx.x; id < 6144 / 16; id += 256)
+    *(u32x4*)(dst + 6144 + id * 16) = *(const u32x4*)(src + LBS_TILE_COEF_BYTES + id * 16);
+}
+
+extern "C" int msmd_lbs_tiles_f16(const void* skin_tiles, void* tiles16, int B, msmd_stream_t stream) {
+  if (B <= 0 || !skin_tiles || !tiles16 || ((uintptr_t)skin_tiles & 15) || ((uintptr_t)tiles16 & 15)) return 1;
+  hipLaunchKernelGGL(lbs_tiles_f16_kernel, dim3((B + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)skin_tiles,
+                     (unsigned char*)tiles16);
+  MSMD_RETURN_LAST();
 }
 
 // Training form: the same kernel, additionally writing the un-skinned vertices v_posed (B, V, 3) for msmd_lbs_skin_bwd.

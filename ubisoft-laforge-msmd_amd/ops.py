@@ -824,9 +824,12 @@ def lbs_skin_bf16x3(coef_hl, A, v_template_planes, dirs_hl, weight_planes, V):
 
 
 def lbs_skin_v2(skin_tiles, B, v_template_planes, dirs_hl, weight_planes, V, Kp=192, shape_varies=None, folded=None,
-                out_dtype=torch.float32):
+                out_dtype=torch.float32, dirs_f16=None):
     """out_dtype=torch.float16 (opt-in, msmd_lbs_skin_v2_f16): the vertices as fp16 -- a (B, V, 3) VIEW of rows padded to an
-    even vertex count (row stride (V + V % 2) * 3); half the store stream that bounds the kernel."""
+    even vertex count (row stride (V + V % 2) * 3); half the store stream.  With dirs_f16 (ONE fp16 plane of the blendshape
+    directions, LbsConstants.dirs_f16) the product runs on fp16 operand planes (1 MFMA per K group instead of 3; the tile
+    records are converted by msmd_lbs_tiles_f16 first): |error| <= 2^-11 |v| + 2^-10 sum_k |coef_k| |dirs_k|; without it the fp32 kernel's arithmetic,
+    rounded once at the store."""
     lib = _lib.load()
     assert skin_tiles.numel() * skin_tiles.element_size() == ((B + 15) // 16) * SKIN_TILE_BYTES
     J = weight_planes.shape[0]
@@ -834,8 +837,13 @@ def lbs_skin_v2(skin_tiles, B, v_template_planes, dirs_hl, weight_planes, V, Kp=
     if out_dtype == torch.float16:
         V_ld = V + (V & 1)
         v16 = torch.empty(B, V_ld, 3, device=skin_tiles.device, dtype=torch.float16)
-        _lib.check(lib.msmd_lbs_skin_v2_f16(_p(skin_tiles), _p(v_template_planes), _p(dirs_hl), _p(weight_planes), _p(v16), B, J, V,
-                                            V_ld, Vp, Kp, _p(shape_varies), _p(folded), _stream()), "msmd_lbs_skin_v2_f16")
+        tiles, dirs, single = skin_tiles, dirs_hl, 0
+        if dirs_f16 is not None:
+            tiles = torch.empty((B + 15) // 16, 12288 // 2, device=skin_tiles.device, dtype=torch.float16)
+            _lib.check(lib.msmd_lbs_tiles_f16(_p(skin_tiles), _p(tiles), B, _stream()), "msmd_lbs_tiles_f16")
+            dirs, single = dirs_f16, 1
+        _lib.check(lib.msmd_lbs_skin_v2_f16(_p(tiles), _p(v_template_planes), _p(dirs), _p(weight_planes), _p(v16), B, J, V,
+                                            V_ld, Vp, Kp, _p(shape_varies), _p(folded), single, _stream()), "msmd_lbs_skin_v2_f16")
         return v16[:, :V]
     if out_dtype != torch.float32:
         raise TypeError("lbs_skin_v2: fp32 or fp16 vertices")

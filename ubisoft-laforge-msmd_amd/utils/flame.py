@@ -140,8 +140,10 @@ class FLAME(nn.Module):
                                                       c.template_planes)
             # vertex_dtype = torch.float16 (opt-in attribute; BASELINE configs[4]'s fp16 LBS pass): fp16 vertices, half the stores
             vd = getattr(self, "vertex_dtype", torch.float32)
+            # fp16 vertices: on fp16 operand planes by default (vertex_exact = True: the fp32 kernel's arithmetic, rounded once)
             vertices = ops.lbs_skin_v2(tiles, B, c.template_planes, c.dirs_hl, c.weight_planes, c.V, shape_varies=varies,
-                                       folded=folded, out_dtype=vd)
+                                       folded=folded, out_dtype=vd,
+                                       dirs_f16=c.dirs_f16 if (vd == torch.float16 and not getattr(self, "vertex_exact", False)) else None)
             landmarks3d = None
             if return_lm3d:
                 landmarks3d = ops.landmarks(vertices if vd == torch.float32 else vertices.float().contiguous(), p["faces"],

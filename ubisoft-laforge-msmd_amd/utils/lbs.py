@@ -41,6 +41,7 @@ class LbsConstants:
         lo = (dirs - hi.float()).to(torch.bfloat16)
         oct_ = lambda t: t.reshape(3, KP // 8, 8, Vp).permute(0, 1, 3, 2)
         self.dirs_hl = torch.stack([oct_(hi), oct_(lo)], 0).contiguous()
+        self.dirs_f16 = oct_(dirs.to(torch.float16)).contiguous()      # ONE fp16 plane: the operand of the fp16-vertex form (ops.lbs_skin_v2)
         tp = torch.zeros(3, Vp, device=dev, dtype=torch.float32)
         tp[:, :V] = vt.t()
         self.template_planes = tp.contiguous()
