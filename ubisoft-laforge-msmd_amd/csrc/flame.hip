@@ -52,7 +52,7 @@ extern "C" int msmd_batch_rodrigues(const float* rot_vecs, float* R, int N, msmd
 // workgroup per frame with the joint chain serial in lane 0: latency bound, 110 us for 25 600 frames -- a sixth of the
 // whole FLAME pass.)  The joint-regression table (9 KB) is staged in LDS once per workgroup and shared by its frames;
 // the kinematic chain runs joint by joint (parents[i] < i) with 12 lanes computing the 3x4 entries of a transform.
-#define LBS_MAXJ 8
+#define LBS_MAXJ 5     // the launchers take J <= 5 (FLAME: 5 joints)
 #define LBS_FPB 16
 #define LBS_TILE_COEF_BYTES 12288   // 2 (hi, lo) x 192 K x 16 frames x 2 B
 #define LBS_TILE_BYTES 18432        // + 12 components x 16 slots x 16 frames x 2 B of blend rows
@@ -69,12 +69,19 @@ __global__ __launch_bounds__(256) void lbs_prepare_kernel(const float* __restric
   // betas2 != NULL: the coefficient row is [betas (B, NB1) | betas2 (B, NB - NB1)] (FLAME's shape | expression, no
   // concatenated copy).  pose_mode 1 / 2: `pose` is FLAME's (B, 6) [global | jaw] axis-angle input, the neck is the
   // identity, `eye` (B, 6) or NULL = identity; 2 also ignores the global rotation (utils/flame.py:199-207).
-  __shared__ float sJS[257 * 15];
-  __shared__ float sB[LBS_FPB][260];
-  __shared__ float sJ[LBS_FPB][16];
-  __shared__ float sR[LBS_FPB][LBS_MAXJ * 9];
-  __shared__ float sT[LBS_FPB][LBS_MAXJ * 12];
-  __shared__ float sAo[LBS_FPB][LBS_MAXJ * 12];
+  // LDS sized by the launcher for THIS model (lbs_prepare_lds): round 6 found the static arrays for the largest admissible one
+  // (NB = 256, J = 8: 49.8 KB) held the launch to three workgroups per CU -- three rounds at 25 600 frames, 58 us of latency.
+  // The joint-regression table is dead once the joints are known: the chain's transforms sT / sAo live in its space.
+  extern __shared__ __attribute__((aligned(16))) float lbs_prep_smem[];
+  const int nbp = NB + 4;
+  float* sJS = lbs_prep_smem;                                          // (NB + 1) x 3 J, later sT | sAo
+  const int region0 = max((NB + 1) * J * 3, 2 * LBS_FPB * LBS_MAXJ * 12);
+  float (*sT)[LBS_MAXJ * 12] = (float (*)[LBS_MAXJ * 12])lbs_prep_smem;
+  float (*sAo)[LBS_MAXJ * 12] = (float (*)[LBS_MAXJ * 12])(lbs_prep_smem + LBS_FPB * LBS_MAXJ * 12);
+  float* sBf = lbs_prep_smem + region0;                                // [frame][NB + 4]
+  float (*sJ)[16] = (float (*)[16])(sBf + LBS_FPB * nbp);
+  float (*sR)[LBS_MAXJ * 9] = (float (*)[LBS_MAXJ * 9])(sBf + LBS_FPB * nbp + LBS_FPB * 16);
+#define sB(f, k) sBf[(f) * nbp + (k)]
   const int tid = threadIdx.x, fl = tid >> 4, ln = tid & 15;
   const int b = blockIdx.x * LBS_FPB + fl;
   const bool valid = b < B;
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(256) void lbs_prepare_kernel(const float* __restric
   if (betas2) {
     const float* b1 = betas + (long)bb * NB1;
     const float* b2 = betas2 + (long)bb * (NB - NB1);
-    for (int k = ln; k < NB; k += 16) sB[fl][k] = k < NB1 ? b1[k] : b2[k - NB1];
+    for (int k = ln; k < NB; k += 16) sB(fl, k) = k < NB1 ? b1[k] : b2[k - NB1];
     if (shape_varies) {   // do the first kfold shape coefficients of this frame differ from frame 0's?  (see lbs_shape_fold)
       bool diff = false;
       for (int k = ln; k < kfold; k += 16) diff |= b1[k] != betas[k];
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(256) void lbs_prepare_kernel(const float* __restric
     }
   } else {
     const float* be = betas + (long)bb * NB;
-    for (int k = ln; k < NB; k += 16) sB[fl][k] = be[k];
+    for (int k = ln; k < NB; k += 16) sB(fl, k) = be[k];
   }
   if (ln < J) {
     float R[9];
@@ -120,10 +127,10 @@ __global__ __launch_bounds__(256) void lbs_prepare_kernel(const float* __restric
     float a0 = sJS[ln], a1 = 0.f;
     int l = 0;
     for (; l + 1 < NB; l += 2) {
-      a0 = fmaf(sB[fl][l], sJS[(1 + l) * J3 + ln], a0);
-      a1 = fmaf(sB[fl][l + 1], sJS[(2 + l) * J3 + ln], a1);
+      a0 = fmaf(sB(fl, l), sJS[(1 + l) * J3 + ln], a0);
+      a1 = fmaf(sB(fl, l + 1), sJS[(2 + l) * J3 + ln], a1);
     }
-    if (l < NB) a0 = fmaf(sB[fl][l], sJS[(1 + l) * J3 + ln], a0);
+    if (l < NB) a0 = fmaf(sB(fl, l), sJS[(1 + l) * J3 + ln], a0);
     sJ[fl][ln] = a0 + a1;
   }
   __syncthreads();
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(256) void lbs_prepare_kernel(const float* __restric
     float* crow = coef + (long)b * Kp;
     for (int k = ln; k < Kp; k += 16) {
       float v = 0.f;
-      if (k < NB) v = sB[fl][k];
+      if (k < NB) v = sB(fl, k);
       else if (k < NB + (J - 1) * 9) {
         const int pf = k - NB, jj = 1 + pf / 9, rc = pf % 9;
         v = sR[fl][jj * 9 + rc] - ((rc == 0 || rc == 4 || rc == 8) ? 1.0f : 0.0f);
@@ -206,12 +213,17 @@ __global__ __launch_bounds__(256) void lbs_prepare_kernel(const float* __restric
     }
   }
 }
+#undef sB
+static size_t lbs_prepare_lds(int NB, int J) {
+  const int region0 = max((NB + 1) * J * 3, 2 * LBS_FPB * LBS_MAXJ * 12);
+  return sizeof(float) * (size_t)(region0 + LBS_FPB * (NB + 4) + LBS_FPB * 16 + LBS_FPB * LBS_MAXJ * 9);
+}
 
 extern "C" int msmd_lbs_prepare(const float* betas, const float* pose, const float* JS, const int* parents,
                                 float* coef, void* coef_hl, float* A, float* joints, void* at_tiles, int B, int NB, int J,
                                 int Kp, int pose_is_matrix, msmd_stream_t stream) {
   if (B <= 0 || NB <= 0 || NB > 256 || J <= 0 || J > 5 || Kp < NB + (J - 1) * 9 || (at_tiles && (J != 5 || Kp != 192))) return 1;
-  hipLaunchKernelGGL(lbs_prepare_kernel, dim3((B + LBS_FPB - 1) / LBS_FPB), dim3(256), 0, (hipStream_t)stream, betas, pose,
+  hipLaunchKernelGGL(lbs_prepare_kernel, dim3((B + LBS_FPB - 1) / LBS_FPB), dim3(256), lbs_prepare_lds(NB, J), (hipStream_t)stream, betas, pose,
                      JS, parents, coef, (bf16_t*)coef_hl, A, joints, NB, J, Kp, pose_is_matrix, (f16_t*)at_tiles, B);
   MSMD_RETURN_LAST();
 }
@@ -336,7 +348,7 @@ extern "C" int msmd_flame_prepare(const float* shape, const float* expr, const f
     hipError_t e = msmd_zero_async(shape_varies, sizeof(int), st);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(lbs_prepare_kernel, dim3((B + LBS_FPB - 1) / LBS_FPB), dim3(256), 0, st, shape, pose6,
+  hipLaunchKernelGGL(lbs_prepare_kernel, dim3((B + LBS_FPB - 1) / LBS_FPB), dim3(256), lbs_prepare_lds(NB, J), st, shape, pose6,
                      JS, parents, coef, (bf16_t*)nullptr, A, joints, NB, J, Kp, 0, (f16_t*)skin_tiles, B, expr, NS, eye,
                      ignore_global_rot ? 2 : 1, fold ? shape_varies : (int*)nullptr, LBS_KFOLD);
   if (fold)
