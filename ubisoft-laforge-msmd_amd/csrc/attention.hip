@@ -291,7 +291,8 @@ __global__ __launch_bounds__(64 * NW) void attn_kernel(const AttnArgs p) {
 constexpr int ATTN_WHOLE_NF = 13;   // key fragments of 16 of the default instantiation: Tk <= 208 (52 KB: three workgroups per CU)
 // NF = 17 (Tk <= 272: the decoder at n_motions = 250; 68 KB, two workgroups per CU) takes the same kernel: 25 us against 39 for the
 // tiled kernel.  NF = 32 (Tk <= 512: HuBERT-large's 10 s clips; 128 KB, ONE workgroup per CU, 152 registers) was built and
-// measured: 118 us against the tiled kernel's 85 -- not kept.
+// measured: 118 us against the tiled kernel's 85 -- not kept.  (Round 6: the 13-wave form forced to 72 registers so that TWO workgroups
+// share a CU -- 384 workgroups in one round instead of 1.5 -- spilled 28 bytes and ran 18.9 us against 16.3: not kept either.)
 
 template <typename T, int NW, int NF = ATTN_WHOLE_NF>
 __global__ __launch_bounds__(64 * NW) void attn_whole_kernel(const AttnArgs p) {
